@@ -1,0 +1,142 @@
+// TEST INFRASTRUCTURE ONLY — never linked into the product library.
+//
+// C-callable wrappers around the *reference's own* compiled functions (rcedgar/muscle, built
+// from /root/reference/src by oracle/build_ref.sh into oracle/_ref/libmuscle_ref.so).
+// Used (a) to pin oracle/mpc_oracle.c against the real reference, (b) to generate the golden
+// fixtures under tests/golden/ (tests/golden/make_golden.py), (c) optionally as bench.py's
+// cpu_baseline kind="reference".  This file contains NO restated numerics: every number comes
+// out of a reference function, cited below.
+#include "muscle.h"      // reference header (-I/root/reference/src)
+#include "mpcflat.h"
+#include "pairhmm.h"
+#include "hmmparams.h"
+#include <cstring>
+
+string g_Arg1; // normally defined in main.cpp:4 (main.o is not linked)
+
+float CalcAlnScoreFlat(const float *Post, uint LX, uint LY, float *DPRows); // calcalnscoreflat.cpp:4
+void CalcPostFlat(const float *FlatFwd, const float *FlatBwd, uint LX, uint LY, float *Post); // calcposteriorflat.cpp:4
+
+extern "C" {
+
+// HMMParams::FromDefaults/PerturbProbs/ToPairHMM (hmmparams.cpp:273,298; perturbhmm.cpp:15)
+// -> fills the process-global PairHMM tables (pairhmm.h:23-29).
+void ref_init_hmm(int nucleo, unsigned perturb_seed)
+	{
+	opt_quiet = true; optset_quiet = true;
+	HMMParams HP;
+	HP.FromDefaults(nucleo != 0);
+	if (perturb_seed != 0)
+		HP.PerturbProbs(perturb_seed);
+	HP.ToPairHMM();
+	}
+
+void ref_set_threads(unsigned n)
+	{
+	opt_threads = n; optset_threads = true;
+	}
+
+// Copies of the PairHMM statics (pairhmm.h:23-29): start[5], trans[25], match[256*256], ins[256]
+void ref_get_hmm(float *start, float *trans, float *match, float *ins)
+	{
+	memcpy(start, PairHMM::m_StartScore, sizeof(float)*5);
+	memcpy(trans, PairHMM::m_TransScore, sizeof(float)*25);
+	memcpy(match, PairHMM::m_MatchScore, sizeof(float)*256*256);
+	memcpy(ins, PairHMM::m_InsScore, sizeof(float)*256);
+	}
+
+float ref_min_sparse_score() { return MIN_SPARSE_SCORE; } // mysparsemx.h:4 (host logf)
+
+// fwdflat3.cpp:12 / bwdflat3.cpp:10 ; Flat has 5*(LX+1)*(LY+1) floats
+void ref_fwd(const byte *X, uint LX, const byte *Y, uint LY, float *Flat) { CalcFwdFlat(X, LX, Y, LY, Flat); }
+void ref_bwd(const byte *X, uint LX, const byte *Y, uint LY, float *Flat) { CalcBwdFlat(X, LX, Y, LY, Flat); }
+// totalprobflat.cpp:3
+float ref_total(const float *Fwd, const float *Bwd, uint LX, uint LY) { return CalcTotalProbFlat(Fwd, Bwd, LX, LY); }
+// calcposteriorflat.cpp:4 ; Post has LX*LY floats
+void ref_post(const float *Fwd, const float *Bwd, uint LX, uint LY, float *Post) { CalcPostFlat(Fwd, Bwd, LX, LY, Post); }
+// calcalnscoreflat.cpp:4
+float ref_aln_score(const float *Post, uint LX, uint LY)
+	{
+	float *DPRows = AllocDPRows(LX, LY);
+	float s = CalcAlnScoreFlat(Post, LX, LY, DPRows);
+	myfree(DPRows);
+	return s;
+	}
+// calcalnflat.cpp:6 + tracebackflat.cpp:3 ; path must hold LX+LY+1 chars; returns score
+float ref_calc_aln(const float *Post, uint LX, uint LY, char *path, uint *pathlen)
+	{
+	float *DPRows = AllocDPRows(LX, LY);
+	char *TB = AllocTB(LX, LY);
+	string Path;
+	float s = CalcAlnFlat(Post, LX, LY, DPRows, TB, Path);
+	myfree(DPRows); myfree(TB);
+	memcpy(path, Path.c_str(), Path.size());
+	*pathlen = (uint) Path.size();
+	return s;
+	}
+
+// MySparseMx::FromPost (mysparsemx.cpp:115). offsets: LX+1 uints; values: LX*LY*8 bytes max.
+uint ref_sparse_from_post(const float *Post, uint LX, uint LY, uint *offsets, byte *values)
+	{
+	MySparseMx M;
+	M.FromPost(Post, LX, LY);
+	memcpy(offsets, M.m_Offsets, sizeof(uint)*(LX+1));
+	memcpy(values, M.m_ValueVec, 8*(size_t)M.m_VecSize);
+	return M.m_VecSize;
+	}
+
+// ---------------------------------------------------------------------------------------
+// Whole stage through the reference's own orchestrator. ONE call per process: the global
+// input registry can only be set once (globalinputms.cpp:70 asserta(g_GlobalMS == 0)).
+// Follows MPCFlat::Run_Super4 (mpcflat.cpp:266-283) minus CalcGuideTree:
+//   AllocPairCount, InitSeqs, InitPairs, InitDistMx, CalcPosteriors, ConsIter x iters.
+// Snapshots of the sparse store are copied out after CalcPosteriors (stage 0) and after each
+// ConsIter (stage 1..iters) through the callback-free "query" functions below.
+static MPCFlat *g_M = 0;
+static MultiSequence *g_MS = 0;
+
+int ref_mpc_begin(uint n, const char **seqs, uint threads)
+	{
+	if (g_M != 0)
+		return -1;
+	opt_quiet = true; optset_quiet = true;
+	if (threads > 0)
+		ref_set_threads(threads);
+	vector<string> Labels, Seqs;
+	for (uint i = 0; i < n; ++i)
+		{
+		char tmp[32];
+		snprintf(tmp, sizeof(tmp), "s%u", i);
+		Labels.push_back(tmp);
+		Seqs.push_back(seqs[i]);
+		}
+	g_MS = new MultiSequence;
+	g_MS->FromStrings(Labels, Seqs);
+	SetGlobalInputMS(*g_MS);
+	g_M = new MPCFlat;
+	MPCFlat &M = *g_M;
+	M.Clear();
+	M.AllocPairCount((n*(n-1))/2);
+	M.InitSeqs(g_MS);
+	M.InitPairs();
+	M.InitDistMx();
+	M.m_Weights.assign(n, 1.0f); // read (then overwritten by 1.0f) at conspairflat.cpp:41-42
+	return 0;
+	}
+
+void ref_mpc_calc_posteriors() { g_M->CalcPosteriors(); }     // mpcflat.cpp:214
+void ref_mpc_cons_iter(uint iter) { g_M->ConsIter(iter); }     // consflat.cpp:5
+uint ref_mpc_pair_count() { return (uint) g_M->m_Pairs.size(); }
+void ref_mpc_pair(uint k, uint *i, uint *j) { *i = g_M->m_Pairs[k].first; *j = g_M->m_Pairs[k].second; }
+float ref_mpc_ea(uint i, uint j) { return g_M->m_DistMx[i][j]; }
+// NB: MySparseMx::UpdateFromPost (mysparsemx.cpp:87-113) never sets m_VecSize on the updated matrix,
+// so the entry count is read from m_Offsets[m_LX] instead.
+uint ref_mpc_nnz(uint k) { const MySparseMx &S = g_M->GetSparsePost(k); return S.m_Offsets[S.m_LX]; }
+void ref_mpc_sparse(uint k, uint *offsets, byte *values)
+	{
+	const MySparseMx &S = g_M->GetSparsePost(k);
+	memcpy(offsets, S.m_Offsets, sizeof(uint)*(S.m_LX+1));
+	memcpy(values, S.m_ValueVec, 8*(size_t)S.m_Offsets[S.m_LX]);
+	}
+
+} // extern "C"

@@ -1,0 +1,59 @@
+"""Loaders for the committed fixtures in tests/golden/ (made by tests/golden/make_golden.py)."""
+import hashlib
+import os
+
+import numpy as np
+
+GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GDIR, name + ".npz"), allow_pickle=False)
+
+
+def hmm_tables(name="hmm_amino"):
+    z = load(name)
+    return z["start"], z["trans"], z["match"], z["ins"], np.float32(z["min_sparse_score"])
+
+
+def sha(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def stage_digest(stage):
+    h = hashlib.sha256()
+    for off, val in stage:
+        h.update(np.ascontiguousarray(off, np.uint32).tobytes())
+        h.update(np.ascontiguousarray(val, np.uint32).tobytes())
+    return h.hexdigest()
+
+
+MPC_SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "bb11001", "n32_L150", "bb11005", "n48_L260"]
+
+
+def mpc(name):
+    """-> dict(seqs, ea, nstages, digest[s], nnz[s], and stage[s] = [(off,val)...] when stored in full)"""
+    z = load("mpc_" + name)
+    seqs = [str(s) for s in z["seqs"]]
+    n = len(seqs)
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    out = {"seqs": seqs, "ea": z["ea"], "nstages": int(z["nstages"]), "digest": [], "nnz": [], "stage": []}
+    for s in range(out["nstages"]):
+        out["digest"].append(str(z["digest%d" % s]))
+        nnz = z["nnz%d" % s]
+        out["nnz"].append(nnz)
+        if ("off%d" % s) in z.files:
+            offs, vals = z["off%d" % s], z["val%d" % s]
+            st, po, pv = [], 0, 0
+            for k, (i, j) in enumerate(pairs):
+                L = len(seqs[i]) + 1
+                st.append((offs[po:po + L], vals[pv:pv + 2 * int(nnz[k])]))
+                po += L
+                pv += 2 * int(nnz[k])
+            out["stage"].append(st)
+        else:
+            out["stage"].append(None)
+    return out

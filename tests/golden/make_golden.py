@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in tests/golden/ FROM THE COMPILED REFERENCE
+(oracle/_ref/libmuscle_ref.so, built from /root/reference/src by oracle/build_ref.sh).
+
+Run here (the container that has /root/reference):   python tests/golden/make_golden.py
+The GPU box has no /root/reference; it only reads the committed .npz files.
+
+Fixtures
+  hmm_amino.npz / hmm_nucleo.npz : PairHMM tables after HMMParams::FromDefaults + ToPairHMM
+                                   (hmmparams.cpp:273,298) and MIN_SPARSE_SCORE (mysparsemx.h:4)
+  pairs_small.npz                : per-pair outputs of CalcFwdFlat/CalcBwdFlat/CalcTotalProbFlat/
+                                   CalcPostFlat/FromPost/CalcAlnScoreFlat/CalcAlnFlat for the short
+                                   pairs of the reference's disabled unit test (testfb.cpp:369-375)
+                                   and edge cases; F/B M-planes in full, sha256 of the full 5-state arrays
+  mpc_<name>.npz                 : whole stage through the reference's MPCFlat::CalcPosteriors +
+                                   ConsIter x2 (one subprocess per data set): EA per pair and, per
+                                   stage, the MySparseMx arrays in full (small sets) or their sha256
+                                   digests (larger sets)
+"""
+import hashlib
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SHORT = [("MQTIF", "MSIF"), ("GATTACA", "MQTIF"), ("ABC", "DEF"),
+         ("LQNGSEQVENCE", "QTHERSEQVENCEINSERT")]
+EDGE = [("A", "A"), ("A", "ACDEFGHIKL"), ("ACDEFGHIKLMNPQRSTVWY" * 3, "W"), ("XXBZ", "AXCB"),
+        ("acdef", "ACDEF"), ("MKV", "MKV")]
+
+
+def sha(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def stage_digest(stage):
+    h = hashlib.sha256()
+    for off, val in stage:
+        h.update(off.tobytes())
+        h.update(val.tobytes())
+    return h.hexdigest()
+
+
+def gen_hmm():
+    import _ref as R
+    for name, nuc in (("hmm_amino", False), ("hmm_nucleo", True)):
+        R.init_hmm(nuc, 0)
+        start, trans, match, ins = R.get_hmm()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), start=start, trans=trans,
+                            match=match.reshape(256, 256), ins=ins,
+                            min_sparse_score=np.float32(R.lib().ref_min_sparse_score()))
+    R.init_hmm(False, 0)
+
+
+def gen_pairs_small():
+    import _ref as R
+    from muscle_amd.synth import make_family
+    R.init_hmm(False, 0)
+    fam = make_family(4, 70, seed=11)
+    pairs = SHORT + EDGE + [(fam[0], fam[1]), (fam[2], fam[3])]
+    d = {"n": np.int32(len(pairs))}
+    for k, (x, y) in enumerate(pairs):
+        LX, LY = len(x), len(y)
+        F, B = R.fwd(x, y), R.bwd(x, y)
+        P = R.post(F, B, LX, LY)
+        off, val = R.sparse_from_post(P)
+        sc, path = R.calc_aln(P)
+        d["x%d" % k] = np.frombuffer(x.encode(), np.uint8)
+        d["y%d" % k] = np.frombuffer(y.encode(), np.uint8)
+        d["FM%d" % k] = F.reshape(LX + 1, LY + 1, 5)[:, :, 0].copy()
+        d["BM%d" % k] = B.reshape(LX + 1, LY + 1, 5)[:, :, 0].copy()
+        d["Fsha%d" % k] = np.array(sha(F))
+        d["Bsha%d" % k] = np.array(sha(B))
+        d["total%d" % k] = np.float32(R.total(F, B, LX, LY))
+        d["post%d" % k] = P
+        d["off%d" % k] = off
+        d["val%d" % k] = val
+        d["alnscore%d" % k] = np.float32(R.aln_score(P))
+        d["calcaln_score%d" % k] = np.float32(sc)
+        d["path%d" % k] = np.array(path)
+    np.savez_compressed(os.path.join(HERE, "pairs_small.npz"), **d)
+
+
+def read_fasta(path):
+    seqs, cur = [], []
+    for line in open(path):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur:
+                seqs.append("".join(cur))
+            cur = []
+        elif line:
+            cur.append(line.upper())  # sequence.cpp:87-88 upper-cases at load
+    if cur:
+        seqs.append("".join(cur))
+    return seqs
+
+
+def _mpc_worker(args):
+    name, seqs, full = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _ref as R
+    stages, ea = R.mpc_run(seqs, iters=2, threads=0)
+    d = {"seqs": np.array(seqs), "ea": ea, "nstages": np.int32(len(stages))}
+    for s, st in enumerate(stages):
+        d["digest%d" % s] = np.array(stage_digest(st))
+        d["nnz%d" % s] = np.array([len(v) // 2 for _, v in st], np.uint32)
+        if full:
+            d["off%d" % s] = np.concatenate([o for o, _ in st])
+            d["val%d" % s] = np.concatenate([v for _, v in st]) if st else np.zeros(0, np.uint32)
+    np.savez_compressed(os.path.join(HERE, "mpc_%s.npz" % name), **d)
+    return name, len(seqs), [int(sum(len(v) // 2 for _, v in st)) for st in stages]
+
+
+def gen_mpc():
+    from muscle_amd.synth import make_family
+    jobs = [
+        ("n2_L40", make_family(2, 40, seed=5), True),       # N<3: consistency skipped (mpcflat.cpp:176)
+        ("n3_L30", make_family(3, 30, seed=6), True),
+        ("n8_L60", make_family(8, 60, seed=2), True),
+        ("ragged", ["M", "MKVLA", make_family(1, 90, seed=9)[0], "ACDEFGHIKLMNPQRSTVWY" * 2,
+                    make_family(1, 33, seed=10)[0], "WWWWWWWW"], True),
+        ("n32_L150", make_family(32, 150, seed=1), False),  # BASELINE config 0 shape
+        ("n48_L260", make_family(48, 260, seed=1), False),
+    ]
+    bb = "/root/reference/test_data/fa/BB11001"
+    if os.path.exists(bb):
+        jobs.append(("bb11001", read_fasta(bb), True))
+    bb5 = "/root/reference/test_data/fa/BB11005"
+    if os.path.exists(bb5):
+        jobs.append(("bb11005", read_fasta(bb5), False))
+    ctx = mp.get_context("spawn")
+    for job in jobs:  # one process per data set: SetGlobalInputMS is once-per-process
+        with ctx.Pool(1) as pool:
+            print(pool.map(_mpc_worker, [job])[0])
+
+
+if __name__ == "__main__":
+    gen_hmm()
+    gen_pairs_small()
+    gen_mpc()
+    print("golden fixtures written to", HERE)

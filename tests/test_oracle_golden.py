@@ -1,0 +1,68 @@
+"""Pins the CPU oracle against the committed golden fixtures (outputs of the compiled reference,
+tests/golden/make_golden.py). Runs anywhere — this is the oracle's pin on the GPU box."""
+import numpy as np
+import pytest
+
+import _golden as G
+import _oracle as O
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def hmm():
+    s, t, m, i, thr = G.hmm_tables()
+    assert bits(O.lib().orc_min_sparse_score()) == bits(thr)
+    return O.make_hmm(s, t, m, i)
+
+
+def test_pairs_small(hmm):
+    z = G.load("pairs_small")
+    for k in range(int(z["n"])):
+        x, y = z["x%d" % k].tobytes(), z["y%d" % k].tobytes()
+        LX, LY = len(x), len(y)
+        F, B = O.fwd(hmm, x, y), O.bwd(hmm, x, y)
+        assert G.sha(F) == str(z["Fsha%d" % k]) and G.sha(B) == str(z["Bsha%d" % k])
+        assert np.array_equal(bits(F.reshape(LX + 1, LY + 1, 5)[:, :, 0]), bits(z["FM%d" % k]))
+        assert bits(O.total(F, B, LX, LY)) == bits(z["total%d" % k])
+        P = O.post(F, B, LX, LY)
+        assert np.array_equal(bits(P), bits(z["post%d" % k]))
+        off, val = O.sparse_from_post(P)
+        assert np.array_equal(off, z["off%d" % k]) and np.array_equal(val, z["val%d" % k])
+        assert bits(O.aln_score(P)) == bits(z["alnscore%d" % k])
+        sc, path = O.calc_aln(P)
+        assert path == str(z["path%d" % k]) and bits(sc) == bits(z["calcaln_score%d" % k])
+
+
+@pytest.mark.parametrize("name", G.MPC_SETS)
+def test_mpc_stage(hmm, name):
+    g = G.mpc(name)
+    st = O.Store(g["seqs"])
+    ea = st.calc_posteriors(hmm)
+    assert np.array_equal(bits(ea), bits(g["ea"]))
+    cur = st
+    for s in range(g["nstages"]):
+        if s > 0:
+            cur = cur.cons_iter()
+        stage = [cur.get(k) for k in range(st.npairs)]
+        assert G.stage_digest(stage) == g["digest"][s], "stage %d" % s
+        if g["stage"][s] is not None:
+            for (o1, v1), (o2, v2) in zip(stage, g["stage"][s]):
+                assert np.array_equal(o1, o2) and np.array_equal(v1, v2)
+
+
+def test_expf_emulation_matches_libm():
+    """The glibc-2.35 expf restatement (both ifunc variants) vs this host's libm over the only
+    range the path uses, [logf(0.01f), 0): the variant the host resolves to must be bit-identical."""
+    L = O.lib()
+    use_fma = L.orc_host_expf_uses_fma()
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-4.7, 0.0, 200000).astype(np.float32),
+                         np.float32([-4.6051702, -4.605170, -1e-7, -0.5, -1, -2, -3, -4])])
+    bad = 0
+    for x in xs:
+        if bits(L.orc_expf_emul(float(x), use_fma)) != bits(L.orc_libm_expf(float(x))):
+            bad += 1
+    assert bad == 0, "%d mismatches (use_fma=%d)" % (bad, use_fma)
