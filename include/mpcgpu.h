@@ -1,0 +1,129 @@
+/*
+ * mpcgpu.h — C ABI of libmpcgpu.so: the MI355X (gfx950) implementation of MUSCLE5's MPCFlat
+ * all-pairs posterior stage. Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference (rcedgar/muscle 5.3) has no plugin/FFI API: its seam is C++ link time, one
+ * numeric function per translation unit. Each entry point below names the
+ * reference interface it replaces (paths relative to the reference's src/). The C++ drop-in
+ * translation units that bind these into an unmodified mpcflat.{h,cpp} are in hostcxx/ and
+ * described in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; mpcgpu_last_error() then holds a
+ *    message (the reference has no error codes: fatal -> Die(), myutils.cpp:883; the C++ shim
+ *    converts non-zero into Die()).
+ *  - pair index k enumerates (i<j) row-major over the n sequences, exactly MPCFlat::InitPairs
+ *    (mpcflat.cpp:139-159); "pair range [k0,k1)" arguments select a contiguous shard of it.
+ *  - sparse posterior matrices cross the boundary in MySparseMx's own layout
+ *    (mysparsemx.h:6-98): uint32 offsets[LX+1] and nnz 8-byte entries {float P; uint32 col},
+ *    rows ascending, columns ascending.
+ *  - the library never falls back to a CPU implementation: without a usable gfx950 device
+ *    mpcgpu_create() fails.
+ */
+#ifndef MPCGPU_H
+#define MPCGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpcgpu_ctx mpcgpu_ctx;
+
+/* Library / device lifetime. One context = one GPU = one MPCFlat::Run at a time
+ * (device buffers live for one Run: mpcflat.cpp:285-337). */
+int mpcgpu_create(mpcgpu_ctx **out, int device_ordinal);
+void mpcgpu_destroy(mpcgpu_ctx *ctx);
+const char *mpcgpu_last_error(const mpcgpu_ctx *ctx); /* ctx may be NULL: last create() error */
+const char *mpcgpu_version(void);
+
+/* Kernel constants. Replaces the process-global PairHMM::m_StartScore[5] / m_TransScore[5][5] /
+ * m_MatchScore[256][256] / m_InsScore[256] (pairhmm.h:23-29; filled by HMMParams::ToPairHMM,
+ * hmmparams.cpp:298-409; bound inside every DP function by hmmscores.h:1-16). The tables can
+ * change between replicates (align.cpp:35-40) so this is called once per Run.
+ * min_sparse_score = MIN_SPARSE_SCORE = logf(0.01f) as evaluated by the host (mysparsemx.h:4).
+ * expf_variant selects which glibc expf build the device reproduces for calcposteriorflat.cpp:20:
+ *   0 = baseline (separate mul/add), 1 = FMA build, -1 = whatever this host's libm resolves to. */
+int mpcgpu_set_hmm(mpcgpu_ctx *ctx, const float start[5], const float trans[25],
+                   const float match[256 * 256], const float ins[256],
+                   float min_sparse_score, int expf_variant);
+
+/* Input sequences. Replaces MPCFlat::InitSeqs + GetBytePtr/GetSeqLength (mpcflat.cpp:41-57,
+ * 121-137): n raw ASCII byte strings (already upper-cased by the loader, sequence.cpp:87-88).
+ * The bytes are copied; at most 64 distinct byte values may occur over all sequences.
+ * Also performs MPCFlat::InitPairs (all i<j pairs). Length overflow check of
+ * calcposteriorflat.cpp:54-61 (LX*LY*5+100 > INT_MAX) is preserved as an error. */
+int mpcgpu_set_seqs(mpcgpu_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens);
+
+uint64_t mpcgpu_pair_count(const mpcgpu_ctx *ctx); /* n(n-1)/2 */
+
+/* Stage A for the pair range [k0,k1): replaces MPCFlat::CalcPosteriors' OpenMP loop
+ * (mpcflat.cpp:239-251) over MPCFlat::CalcPosterior (calcposteriorflat.cpp:45-92), i.e.
+ * CalcFwdFlat (fwdflat3.cpp:12) + CalcBwdFlat (bwdflat3.cpp:10) + CalcTotalProbFlat
+ * (totalprobflat.cpp:3) + CalcPostFlat (calcposteriorflat.cpp:4) + MySparseMx::FromPost
+ * (mysparsemx.cpp:115) + CalcAlnScoreFlat (calcalnscoreflat.cpp:4) + EA = Score/min(LX,LY).
+ * Results stay on the device ("packed shard"). */
+int mpcgpu_calc_posteriors(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1);
+
+/* Builds the device-resident all-pairs store the relax kernel reads, from this context's own
+ * shard. Only valid when the shard is the full range [0, pair_count) (single GPU). */
+int mpcgpu_build_store(mpcgpu_ctx *ctx);
+
+/* ---- multi-GPU exchange (one process per GPU; the collective itself is the caller's RCCL
+ * all-gather over xGMI on these device pointers — SURVEY.md §8e) --------------------------- */
+/* Size in bytes and device address of this context's packed shard (valid after calc_posteriors). */
+int mpcgpu_shard_info(mpcgpu_ctx *ctx, uint64_t *bytes, void **dev_ptr);
+/* Build the all-pairs store from nshards packed shards laid out back to back in device memory
+ * (dev_all; shard s occupies bytes[s] bytes, covers pairs [k0[s],k1[s]), ascending, contiguous,
+ * covering [0,pair_count)). dev_all must stay valid until the next set_seqs/destroy. */
+int mpcgpu_store_import(mpcgpu_ctx *ctx, uint32_t nshards, const uint64_t *k0, const uint64_t *k1,
+                        const uint64_t *bytes, const void *dev_all);
+/* Device address + element count of the float array holding the next-iteration probabilities of
+ * ALL pairs in canonical order (pair ascending, entries row-major), and the [first, first+count)
+ * slice that cons_iter(k0,k1) writes. The caller all-gathers the slices in place, then commits. */
+int mpcgpu_values_info(mpcgpu_ctx *ctx, void **dev_ptr, uint64_t *total_count);
+int mpcgpu_values_slice(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1, uint64_t *first, uint64_t *count);
+
+/* One consistency iteration for the pair range [k0,k1): replaces MPCFlat::ConsIter
+ * (consflat.cpp:5-23) -> ConsPair (conspairflat.cpp:10-110) -> RelaxFlat_{XZ_ZY,ZX_ZY,XZ_YZ}
+ * (relaxflat.cpp:4-94) -> MySparseMx::UpdateFromPost (mysparsemx.cpp:87-113). Jacobi: reads the
+ * current store, writes the "values" array; mpcgpu_cons_commit makes them current (the buffer
+ * swap of consflat.cpp:22). */
+int mpcgpu_cons_iter(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1);
+int mpcgpu_cons_commit(mpcgpu_ctx *ctx);
+
+/* ---- results back to the host (the reference's in-memory formats) ------------------------- */
+/* EA per pair: what calcposteriorflat.cpp:89-91 stores in m_DistMx[i][j]. Valid for own shard
+ * after calc_posteriors, for all pairs after build_store/store_import. */
+int mpcgpu_get_ea(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1, float *ea);
+/* nnz per pair (MySparseMx::m_VecSize). */
+int mpcgpu_get_nnz(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1, uint32_t *nnz);
+/* Current sparse matrix of pair k in MySparseMx layout: offsets[LX+1], values[8*nnz bytes]. */
+int mpcgpu_get_sparse(mpcgpu_ctx *ctx, uint64_t k, uint32_t *offsets, void *values);
+/* Bulk form for [k0,k1): offsets concatenated (sum of LX+1 uint32), values concatenated
+ * (8*sum nnz bytes). Sizes via mpcgpu_get_nnz and the sequence lengths. */
+int mpcgpu_get_sparse_range(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1, uint32_t *offsets, void *values);
+
+/* Posterior-DP alignment of one dense LX x LY matrix resident in HOST memory: replaces
+ * CalcAlnFlat (calcalnflat.cpp:6-46) + TraceBackFlat (tracebackflat.cpp:3-37), tie order of
+ * best3.h:5-28. path receives the B/X/Y string (capacity >= LX+LY), not NUL-terminated. */
+int mpcgpu_calc_aln(mpcgpu_ctx *ctx, const float *post, uint32_t LX, uint32_t LY,
+                    char *path, uint32_t *pathlen, float *score);
+
+/* ---- measurement hooks (bench.py) --------------------------------------------------------- */
+/* Kernel time in ms measured with hipEvents on the library's own stream, accumulated since the
+ * last reset, per kernel family: 0 = fwd/bwd (fb), 1 = posterior finish (sort/EA/pack),
+ * 2 = store build, 3 = relax, 4 = commit/scatter; and launches counted per family. */
+#define MPCGPU_NKERNELS 5
+int mpcgpu_timers_reset(mpcgpu_ctx *ctx);
+int mpcgpu_timers_get(mpcgpu_ctx *ctx, float ms[MPCGPU_NKERNELS], uint64_t launches[MPCGPU_NKERNELS]);
+/* Algorithmic work of the last calc_posteriors call: DP cells summed over pairs
+ * (sum (LX+1)(LY+1)) and of the last cons_iter: (pair,Z) triples and stored entries. */
+int mpcgpu_work_get(mpcgpu_ctx *ctx, uint64_t *dp_cells, uint64_t *relax_entry_z, uint64_t *store_entries);
+int mpcgpu_synchronize(mpcgpu_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCGPU_H */

@@ -1,0 +1,202 @@
+"""ctypes binding of the C ABI in include/mpcgpu.h (muscle_amd/csrc/libmpcgpu.so).
+
+Plumbing only. There is no CPU fallback: if the HIP library is missing or no GPU is present the
+calls raise. (`lib_path` exists so the test-suite can point the same binding at the SIMT-emulator
+build of the same sources, tests/emu/libmpcgpu_emu.so, to check kernel logic without a GPU.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "csrc", "libmpcgpu.so")
+NKERNELS = 5
+KERNEL_FAMILIES = ["fb", "post", "store_build", "relax", "commit"]
+
+SYMBOLS = [
+    "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_version", "mpcgpu_set_hmm",
+    "mpcgpu_set_seqs", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
+    "mpcgpu_shard_info", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice",
+    "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
+    "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_timers_reset", "mpcgpu_timers_get",
+    "mpcgpu_work_get", "mpcgpu_synchronize",
+]
+
+
+class MpcGpuError(RuntimeError):
+    pass
+
+
+_libs = {}
+
+
+def load(lib_path=None):
+    path = lib_path or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise MpcGpuError("HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C muscle_amd/csrc`); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.mpcgpu_create.argtypes = [C.POINTER(vp), i32]
+    L.mpcgpu_destroy.argtypes = [vp]
+    L.mpcgpu_destroy.restype = None
+    L.mpcgpu_last_error.argtypes = [vp]
+    L.mpcgpu_last_error.restype = C.c_char_p
+    L.mpcgpu_version.restype = C.c_char_p
+    L.mpcgpu_set_hmm.argtypes = [vp, vp, vp, vp, vp, C.c_float, i32]
+    L.mpcgpu_set_seqs.argtypes = [vp, u32, vp, vp]
+    L.mpcgpu_pair_count.argtypes = [vp]
+    L.mpcgpu_pair_count.restype = u64
+    L.mpcgpu_calc_posteriors.argtypes = [vp, u64, u64]
+    L.mpcgpu_build_store.argtypes = [vp]
+    L.mpcgpu_shard_info.argtypes = [vp, C.POINTER(u64), C.POINTER(vp)]
+    L.mpcgpu_store_import.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.mpcgpu_values_info.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.mpcgpu_values_slice.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.mpcgpu_cons_iter.argtypes = [vp, u64, u64]
+    L.mpcgpu_cons_commit.argtypes = [vp]
+    L.mpcgpu_get_ea.argtypes = [vp, u64, u64, vp]
+    L.mpcgpu_get_nnz.argtypes = [vp, u64, u64, vp]
+    L.mpcgpu_get_sparse.argtypes = [vp, u64, vp, vp]
+    L.mpcgpu_get_sparse_range.argtypes = [vp, u64, u64, vp, vp]
+    L.mpcgpu_calc_aln.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
+    L.mpcgpu_timers_reset.argtypes = [vp]
+    L.mpcgpu_timers_get.argtypes = [vp, vp, vp]
+    L.mpcgpu_work_get.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.mpcgpu_synchronize.argtypes = [vp]
+    _libs[path] = L
+    return L
+
+
+class MpcGpu:
+    """One context = one GPU = one MPCFlat run (mirrors the members of class MPCFlat that the
+    hot path touches: InitSeqs/InitPairs, CalcPosteriors, ConsIter, m_DistMx, m_SparsePosts)."""
+
+    def __init__(self, device=0, lib_path=None):
+        self.L = load(lib_path)
+        h = C.c_void_p()
+        if self.L.mpcgpu_create(C.byref(h), device) != 0:
+            raise MpcGpuError(self.L.mpcgpu_last_error(None).decode())
+        self.h = h
+        self.n = 0
+        self.lens = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mpcgpu_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MpcGpuError(self.L.mpcgpu_last_error(self.h).decode())
+
+    def version(self):
+        return self.L.mpcgpu_version().decode()
+
+    def set_hmm(self, start, trans, match, ins, min_sparse_score, expf_variant=-1):
+        a = [np.ascontiguousarray(x, np.float32) for x in (start, trans, match, ins)]
+        assert a[0].size == 5 and a[1].size == 25 and a[2].size == 65536 and a[3].size == 256
+        self._ck(self.L.mpcgpu_set_hmm(self.h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+                                        a[3].ctypes.data, float(min_sparse_score), expf_variant))
+
+    def set_seqs(self, seqs):
+        bufs = [np.frombuffer(s.encode() if isinstance(s, str) else bytes(s), np.uint8).copy() for s in seqs]
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        lens = np.array([len(b) for b in bufs], np.uint32)
+        self._ck(self.L.mpcgpu_set_seqs(self.h, len(bufs), ptrs, lens.ctypes.data))
+        self.n = len(bufs)
+        self.lens = lens
+        self.pairs = [(i, j) for i in range(self.n) for j in range(i + 1, self.n)] if self.n <= 4096 else None
+
+    @property
+    def npairs(self):
+        return int(self.L.mpcgpu_pair_count(self.h))
+
+    def calc_posteriors(self, k0=0, k1=None):
+        self._ck(self.L.mpcgpu_calc_posteriors(self.h, k0, self.npairs if k1 is None else k1))
+
+    def build_store(self):
+        self._ck(self.L.mpcgpu_build_store(self.h))
+
+    def shard_info(self):
+        b, p = C.c_uint64(), C.c_void_p()
+        self._ck(self.L.mpcgpu_shard_info(self.h, C.byref(b), C.byref(p)))
+        return b.value, p.value
+
+    def store_import(self, k0s, k1s, nbytes, dev_ptr):
+        a, b, c = (np.ascontiguousarray(x, np.uint64) for x in (k0s, k1s, nbytes))
+        self._ck(self.L.mpcgpu_store_import(self.h, len(a), a.ctypes.data, b.ctypes.data, c.ctypes.data, dev_ptr))
+
+    def values_info(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._ck(self.L.mpcgpu_values_info(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def values_slice(self, k0, k1):
+        f, n = C.c_uint64(), C.c_uint64()
+        self._ck(self.L.mpcgpu_values_slice(self.h, k0, k1, C.byref(f), C.byref(n)))
+        return f.value, n.value
+
+    def cons_iter(self, k0=0, k1=None):
+        self._ck(self.L.mpcgpu_cons_iter(self.h, k0, self.npairs if k1 is None else k1))
+
+    def cons_commit(self):
+        self._ck(self.L.mpcgpu_cons_commit(self.h))
+
+    def synchronize(self):
+        self._ck(self.L.mpcgpu_synchronize(self.h))
+
+    def get_ea(self, k0=0, k1=None):
+        k1 = self.npairs if k1 is None else k1
+        out = np.empty(max(k1 - k0, 1), np.float32)
+        self._ck(self.L.mpcgpu_get_ea(self.h, k0, k1, out.ctypes.data))
+        return out[:k1 - k0]
+
+    def get_nnz(self, k0=0, k1=None):
+        k1 = self.npairs if k1 is None else k1
+        out = np.empty(max(k1 - k0, 1), np.uint32)
+        self._ck(self.L.mpcgpu_get_nnz(self.h, k0, k1, out.ctypes.data))
+        return out[:k1 - k0]
+
+    def _pair(self, k):
+        if self.pairs is not None:
+            return self.pairs[k]
+        n, i = self.n, 0
+        while k >= n - 1 - i:
+            k -= n - 1 - i
+            i += 1
+        return i, i + 1 + k
+
+    def get_sparse_range(self, k0=0, k1=None):
+        """-> list of (offsets u32[LX+1], values u32[2*nnz] = interleaved {P bits, col}) per pair"""
+        k1 = self.npairs if k1 is None else k1
+        nnz = self.get_nnz(k0, k1).astype(np.int64)
+        lx = np.array([int(self.lens[self._pair(k)[0]]) + 1 for k in range(k0, k1)], np.int64)
+        off = np.empty(max(int(lx.sum()), 1), np.uint32)
+        val = np.empty(max(int(nnz.sum()) * 2, 1), np.uint32)
+        self._ck(self.L.mpcgpu_get_sparse_range(self.h, k0, k1, off.ctypes.data, val.ctypes.data))
+        out, po, pv = [], 0, 0
+        for q in range(k1 - k0):
+            out.append((off[po:po + lx[q]], val[pv:pv + 2 * nnz[q]]))
+            po += lx[q]
+            pv += 2 * nnz[q]
+        return out
+
+    def timers_reset(self):
+        self._ck(self.L.mpcgpu_timers_reset(self.h))
+
+    def timers_get(self):
+        ms = np.zeros(NKERNELS, np.float32)
+        ln = np.zeros(NKERNELS, np.uint64)
+        self._ck(self.L.mpcgpu_timers_get(self.h, ms.ctypes.data, ln.ctypes.data))
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(KERNEL_FAMILIES)}
+
+    def work_get(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ck(self.L.mpcgpu_work_get(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"dp_cells": a.value, "relax_entry_z": b.value, "store_entries": c.value}

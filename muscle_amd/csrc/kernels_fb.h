@@ -1,0 +1,267 @@
+// kernels_fb.h — pair-HMM forward + backward + posterior thresholding, one wavefront per pair.
+//
+// Replaces CalcFwdFlat (fwdflat3.cpp:12-153), CalcBwdFlat (bwdflat3.cpp:10-184),
+// CalcTotalProbFlat (totalprobflat.cpp:3-16) and the Score/threshold half of CalcPostFlat
+// (calcposteriorflat.cpp:9-26) of the reference; the exp/sort/sparsify half is kernels_post.h.
+//
+// Mapping (CDNA4, 64-wide wavefront): lane t owns H consecutive rows of X (i = t*H+1 .. t*H+H,
+// H = ceil(LX/64) <= MPC_HMAX) and sweeps the columns of Y as a systolic array: at step s lane t
+// computes column j = s - t, so the three DP neighbours (i-1,j-1), (i-1,j), (i,j-1) are either in
+// the lane's own registers or in lane t-1's registers from the previous step (one wave shift of
+// 5 floats + the Y letter per step). All 5H state values live in VGPRs; LDS only holds the
+// compacted emission tables (A*A match + A insert scores). Only the forward M plane ever touches
+// HBM: it is written step-major [(step*H + r)*64 + lane] so both the forward store and the
+// backward load (which visits the same (lane,row,column) at forward-step index j+t, uniform over
+// the wave) are fully coalesced 256-byte rows. The backward sweep mirrors the schedule (lane T-1
+// leads, data flows t+1 -> t) and emits every cell with Score >= MIN_SPARSE_SCORE as an 8-byte
+// candidate {flat index, score} through a wave-aggregated append.
+//
+// Every cell value is a fixed expression of its three neighbours, so the wavefront order does
+// not change results: outputs are bit-identical to the row-major CPU sweep (given no FMA
+// contraction, -ffp-contract=off). Border handling: the reference's special-cased border
+// formulas are reproduced by the generic recurrences over virtual LOG_ZERO neighbours
+// (LOG_ZERO + score == LOG_ZERO exactly, LOG_ADD(LOG_ZERO, v) == v) plus the few genuinely special
+// cells, each cited below.
+#pragma once
+#include "device_math.h"
+
+#define MPC_HMAX 16
+
+struct FbParams {
+	// sequences (compact alphabet codes 0..A-1)
+	const u8 *seq_code;
+	const u64 *seq_off;
+	const u32 *seq_len;
+	// PairHMM constants (hmmscores.h:1-16 names)
+	float tSM, tSI, tSJ, tMM, tMI, tMJ, tII, tIM, tJJ, tJM;
+	float thr; // MIN_SPARSE_SCORE
+	int A;     // alphabet size
+	const float *match; // A*A
+	const float *ins;   // A
+	// work list of this launch
+	const u32 *pair_x, *pair_y; // per batch-local pair: sequence indices
+	const u32 *order;           // batch-local pair ids handled by this launch (same H for all)
+	u32 count;
+	u32 *queue; // work-queue head (zeroed before launch)
+	// scratch / outputs
+	float *fm_scratch; // forward M plane, one slot per resident wave
+	u64 fm_stride;     // floats per slot
+	u64 *cand;         // candidates, capc per batch-local pair: (flat index << 32) | score bits
+	u32 capc;
+	u32 *cand_cnt; // per batch-local pair (may exceed capc: overflow, detected by the host)
+	float *total;  // per batch-local pair: log total probability (diagnostic / tests)
+};
+
+template <int H>
+__global__ void __launch_bounds__(256) fb_kernel(FbParams p)
+{
+	MPC_DYN_SMEM(smem_raw);
+	float *s_match = (float *)smem_raw; // A*A
+	float *s_ins = s_match + p.A * p.A; // A
+	for (int q = threadIdx.x; q < p.A * p.A; q += blockDim.x)
+		s_match[q] = p.match[q];
+	for (int q = threadIdx.x; q < p.A; q += blockDim.x)
+		s_ins[q] = p.ins[q];
+	__syncthreads();
+
+	const int t = threadIdx.x & 63;
+	const u32 waves_per_block = blockDim.x >> 6;
+	const u32 slot = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+	float *fm = p.fm_scratch + (u64)slot * p.fm_stride;
+	const float LZ = MPC_LOG_ZERO;
+	const float tSM = p.tSM, tSI = p.tSI, tSJ = p.tSJ, tMM = p.tMM, tMI = p.tMI, tMJ = p.tMJ;
+	const float tII = p.tII, tIM = p.tIM, tJJ = p.tJJ, tJM = p.tJM;
+	const int A = p.A;
+
+	for (;;) {
+		u32 qi = 0;
+		if (t == 0)
+			qi = atomicAdd(p.queue, 1u);
+		qi = __shfl(qi, 0);
+		if (qi >= p.count)
+			break;
+		const u32 pid = p.order[qi];
+		const u32 sx = p.pair_x[pid], sy = p.pair_y[pid];
+		const int LX = (int)p.seq_len[sx], LY = (int)p.seq_len[sy];
+		const u8 *X = p.seq_code + p.seq_off[sx];
+		const u8 *Y = p.seq_code + p.seq_off[sy];
+		const int T = (LX + H - 1) / H; // lanes that own at least one row
+
+		// ------------------------------------------------------------------ forward
+		float cM[H], cIX[H], cJX[H], cIY[H], cJY[H]; // own rows at the previous column
+		float insx[H];
+		int mrow[H];
+#pragma unroll
+		for (int r = 0; r < H; ++r) {
+			const int i = t * H + r + 1;
+			const int xc = (i <= LX) ? (int)X[i - 1] : 0;
+			insx[r] = s_ins[xc];
+			mrow[r] = xc * A;
+			cM[r] = cIX[r] = cJX[r] = cIY[r] = cJY[r] = LZ;
+		}
+		float uM = LZ, uIX = LZ, uJX = LZ, uIY = LZ, uJY = LZ; // row t*H at column j-1 (diagonal of r=0)
+		float gIY = LZ, gJY = LZ;                              // lane 0: row-0 chain (fwdflat3.cpp:81-93)
+		int yprev = 0;
+		const int nsteps = LY + T;
+		for (int s = 0; s < nsteps; ++s) {
+			const int j = s - t;
+			// row t*H at column j comes from lane t-1's last row of the previous step
+			float nM = __shfl_up(cM[H - 1], 1);
+			float nIX = __shfl_up(cIX[H - 1], 1);
+			float nJX = __shfl_up(cJX[H - 1], 1);
+			float nIY = __shfl_up(cIY[H - 1], 1);
+			float nJY = __shfl_up(cJY[H - 1], 1);
+			int yc = __shfl_up(yprev, 1);
+			const int yload = (s >= 1 && s <= LY) ? (int)Y[s - 1] : 0; // lane 0: letter of column j = s
+			if (t == 0)
+				yc = yload;
+			const float insy = s_ins[yc];
+			if (t == 0) {
+				// row 0 (fwdflat3.cpp:35-39, :44-45, :57-65, :81-93): M=IX=JX=LOG_ZERO,
+				// IY(0,1)=tSI+Ins(y1), IY(0,j)=IY(0,j-1)+tII+Ins(yj)
+				nM = LZ; nIX = LZ; nJX = LZ;
+				if (j <= 0) { nIY = LZ; nJY = LZ; }
+				else if (j == 1) { nIY = tSI + insy; nJY = tSJ + insy; }
+				else { nIY = gIY + tII + insy; nJY = gJY + tJJ + insy; }
+				gIY = nIY; gJY = nJY;
+			}
+			float dM = uM, dIX = uIX, dJX = uJX, dIY = uIY, dJY = uJY; // (i-1, j-1)
+			float upM = nM, upIX = nIX, upJX = nJX;                     // (i-1, j)
+			float *fmrow = fm + ((u64)s * H) * 64 + t;
+#pragma unroll
+			for (int r = 0; r < H; ++r) {
+				const int i = t * H + r + 1;
+				const float oM = cM[r], oIX = cIX[r], oJX = cJX[r], oIY = cIY[r], oJY = cJY[r]; // (i, j-1)
+				const float m = s_match[mrow[r] + yc];
+				// fwdflat3.cpp:116-145
+				float vM = mpc_la5(dM + tMM, dIX + tIM, dJX + tJM, dIY + tIM, dJY + tJM) + m;
+				float vIX = mpc_la2(upIX + tII, upM + tMI) + insx[r];
+				float vJX = mpc_la2(upJX + tJJ, upM + tMJ) + insx[r];
+				float vIY = mpc_la2(oIY + tII, oM + tMI) + insy;
+				float vJY = mpc_la2(oJY + tJJ, oM + tMJ) + insy;
+				if (j <= 0) { // column 0 (fwdflat3.cpp:42-43, :48-55, :67-79); j<0: lane not started yet
+					vM = LZ; vIY = LZ; vJY = LZ;
+					if (i == 1) { vIX = tSI + insx[r]; vJX = tSJ + insx[r]; }
+				}
+				if (j == 1 && i == 1) // fwdflat3.cpp:111-112
+					vM = tSM + m;
+				cM[r] = vM; cIX[r] = vIX; cJX[r] = vJX; cIY[r] = vIY; cJY[r] = vJY;
+				fmrow[r * 64] = vM;
+				dM = oM; dIX = oIX; dJX = oJX; dIY = oIY; dJY = oJY;
+				upM = vM; upIX = vIX; upJX = vJX;
+			}
+			uM = nM; uIX = nIX; uJX = nJX; uIY = nIY; uJY = nJY;
+			yprev = yc;
+		}
+		// F(LX,LY,*) sits in lane T-1, row (LX-1)%H, after its last step (column LY).
+		float eM = LZ, eIX = LZ, eJX = LZ, eIY = LZ, eJY = LZ;
+		{
+			const int rl = (LX - 1) % H;
+#pragma unroll
+			for (int r = 0; r < H; ++r)
+				if (r == rl) { eM = cM[r]; eIX = cIX[r]; eJX = cJX[r]; eIY = cIY[r]; eJY = cJY[r]; }
+			eM = __shfl(eM, T - 1); eIX = __shfl(eIX, T - 1); eJX = __shfl(eJX, T - 1);
+			eIY = __shfl(eIY, T - 1); eJY = __shfl(eJY, T - 1);
+		}
+		// totalprobflat.cpp:3-16 with B(LX,LY,*) = start scores (bwdflat3.cpp:53-61); state order
+		// M, IX, IY, JX, JY (pairhmm.h:11-19), left fold from LOG_ZERO.
+		float total = LZ;
+		total = mpc_la2(total, eM + tSM);
+		total = mpc_la2(total, eIX + tSI);
+		total = mpc_la2(total, eIY + tSI);
+		total = mpc_la2(total, eJX + tSJ);
+		total = mpc_la2(total, eJY + tSJ);
+		if (t == 0)
+			p.total[pid] = total;
+
+		// ------------------------------------------------------------------ backward + posterior
+		// Row i uses the emissions of x_{i+1}=X[i] and y_{j+1}=Y[j] (bwdflat3.cpp:46,64).
+#pragma unroll
+		for (int r = 0; r < H; ++r) {
+			const int i = t * H + r + 1;
+			const int xc = (i < LX) ? (int)X[i] : 0;
+			insx[r] = s_ins[xc];
+			mrow[r] = xc * A;
+			cM[r] = cIX[r] = cJX[r] = cIY[r] = cJY[r] = LZ; // virtual column LY+1
+		}
+		float gM = LZ; // row (t+1)*H+1 at column j+1: diagonal of r=H-1
+		u64 *cand = p.cand + (u64)pid * p.capc;
+		u32 ncand = 0;
+		int ynext_prev = 0;
+		const int bsteps = LY + T - 1;
+		for (int s = 0; s < bsteps; ++s) {
+			const int j = LY - s + (T - 1 - t);
+			// row (t+1)*H+1 at column j: lane t+1's first row from the previous step
+			float nM = __shfl_down(cM[0], 1);
+			float nIX = __shfl_down(cIX[0], 1);
+			float nJX = __shfl_down(cJX[0], 1);
+			if (t == 63) { nM = LZ; nIX = LZ; nJX = LZ; } // nothing below the wave: virtual row
+			int yc = __shfl_down(ynext_prev, 1);
+			const int jl = LY - s; // column of the leading lane T-1
+			const int yload = (jl >= 0 && jl < LY) ? (int)Y[jl] : 0;
+			if (t >= T - 1)
+				yc = yload; // leading lane (and idle lanes beyond it)
+			const float insy = s_ins[yc];
+			const int sf = j + t; // forward step that stored column j of this lane (uniform: LY-s+T-1)
+			const float *fmrow = fm + ((u64)(sf < 0 ? 0 : sf) * H) * 64 + t;
+			float dgM = gM;                           // M(i+1, j+1)
+			float dnIX = nIX, dnJX = nJX;             // (i+1, j)
+			float newfirstM = LZ;
+			bool anyhit = false;
+			float sc[H];
+#pragma unroll
+			for (int r = H - 1; r >= 0; --r) {
+				const int i = t * H + r + 1;
+				const float oM = cM[r], oIY = cIY[r], oJY = cJY[r]; // (i, j+1)
+				// bwdflat3.cpp:75-79
+				const float xM = dgM + s_match[mrow[r] + yc];
+				const float xIX = dnIX + insx[r];
+				const float xJX = dnJX + insx[r];
+				const float xIY = oIY + insy;
+				const float xJY = oJY + insy;
+				// bwdflat3.cpp:81-118 (interior); the right column (:132-153) and bottom row (:155-176)
+				// formulas fall out of the same expressions over LOG_ZERO virtual neighbours.
+				float vM = mpc_la5(tMM + xM, tMI + xIX, tMJ + xJX, tMI + xIY, tMJ + xJY);
+				float vIX = mpc_la2(tII + xIX, tIM + xM);
+				float vJX = mpc_la2(tJJ + xJX, tJM + xM);
+				float vIY = mpc_la2(tII + xIY, tIM + xM);
+				float vJY = mpc_la2(tJJ + xJY, tJM + xM);
+				if (i == LX && j == LY) { // bwdflat3.cpp:53-61
+					vM = tSM; vIX = tSI; vIY = tSI; vJX = tSJ; vJY = tSJ;
+				}
+				const bool live = (i <= LX) && (j >= 1) && (j <= LY);
+				if (!live) { vM = LZ; vIX = LZ; vJX = LZ; vIY = LZ; vJY = LZ; }
+				// calcposteriorflat.cpp:14: Score = F_M + B_M - Total
+				const float f = fmrow[r * 64];
+				const float score = (f + vM) - total;
+				sc[r] = score;
+				anyhit = anyhit || (live && score >= p.thr);
+				dgM = oM; // becomes M(i, j+1) = diagonal of row i-1
+				cM[r] = vM; cIX[r] = vIX; cJX[r] = vJX; cIY[r] = vIY; cJY[r] = vJY;
+				dnIX = vIX; dnJX = vJX;
+				if (r == 0) newfirstM = vM;
+			}
+			(void)newfirstM;
+			gM = nM;
+			ynext_prev = yc;
+			if (__ballot(anyhit)) {
+#pragma unroll
+				for (int r = 0; r < H; ++r) {
+					const int i = t * H + r + 1;
+					const bool hit = (i <= LX) && (j >= 1) && (j <= LY) && (sc[r] >= p.thr);
+					const u64 bal = __ballot(hit);
+					if (bal) {
+						const u32 pos = ncand + (u32)__popcll(bal & ((1ull << t) - 1ull));
+						if (hit && pos < p.capc) {
+							const u32 idx = (u32)(i - 1) * (u32)LY + (u32)(j - 1);
+							cand[pos] = ((u64)idx << 32) | (u64)__float_as_uint(sc[r]);
+						}
+						ncand += (u32)__popcll(bal);
+					}
+				}
+			}
+		}
+		if (t == 0)
+			p.cand_cnt[pid] = ncand;
+	}
+}

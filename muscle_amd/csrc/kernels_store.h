@@ -1,0 +1,211 @@
+// kernels_store.h — device-resident all-pairs sparse posterior store, relax, commit, export.
+//
+// Layout in HBM. The reference keeps one MySparseMx per unordered pair and reaches
+// P_YZ(y,z) for Z>Y through a column->row range search (relaxflat.cpp:62-94, mysparsemx.cpp:238).
+// Here every ORDERED pair (A,Z) gets a row-major CSR matrix M(A,Z) (rows = positions of A, cols =
+// positions of Z; the transposed copies carry bit-identical floats), grouped into one "slab" per
+// sequence A with Z ascending and an empty matrix at Z == A:
+//     rp  [rp_base[A] + Z*(L_A+1) + a]   u32  entry offset of row a of M(A,Z), relative to slab A
+//     ent [ent_base[A] + offset]         {P bits, col} 8 bytes
+// With that, ConsPair (conspairflat.cpp:10-110) for one stored cell (x,y) of pair (X,Y) is
+//     acc = 2*P_XY(x,y);  for Z = 0..N-1:  acc += sum_z  M(X,Z)(x,z) * M(Y,Z)(y,z)   (z ascending)
+//     P'  = acc / N
+// i.e. a merge of two short sorted rows per Z; rows x..x+k of M(X,Z) are contiguous, so a wave of
+// consecutive cells reads a few contiguous cache lines per Z. The three RelaxFlat_* variants
+// (relaxflat.cpp:4-94) collapse into this one form because both factors are always read by row; the
+// accumulation order per cell (Z ascending, then z ascending; product rounded, then added — no FMA)
+// is the reference's, so results are bit-identical. Z == X and Z == Y contribute nothing because
+// M(X,X) and M(Y,Y) are empty, matching the `continue` at conspairflat.cpp:39-40.
+#pragma once
+#include "device_math.h"
+
+struct MpcEnt { u32 p; u32 c; }; // {float bits, column}: MySparseMx entry layout (mysparsemx.h:56-82)
+
+struct StoreParams {
+	u32 n;
+	const u32 *seq_len;
+	u64 npairs;
+	const u32 *pair_x, *pair_y; // all pairs (InitPairs order)
+	// packed records of all pairs (kernels_post.h layout) and their bases
+	u32 *packed;
+	const u64 *pbase; // npairs+1, word offsets into packed
+	const u64 *vbase; // npairs+1, canonical entry index of the pair's first entry
+	// slabs
+	u32 *rp;
+	const u64 *rp_base; // n+1
+	MpcEnt *ent;
+	const u64 *ent_base; // n+1
+	const u32 *mbase;    // n*n, entry offset of M(A,Z) inside slab A
+	// values of the next iteration, canonical order
+	float *vnext;
+};
+
+__device__ __forceinline__ u64 mpc_pair_index(u32 n, u32 i, u32 j) // i<j, mpcflat.cpp:145-155 order
+{
+	return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1);
+}
+
+// One 64-thread workgroup per ordered pair (A,Z): row pointers (exclusive scan of the per-row or
+// per-column counts) and entries (row-major copy, or column-major through tperm).
+__global__ void __launch_bounds__(64) slab_build_kernel(StoreParams s)
+{
+	const int t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		const u32 LA = s.seq_len[A];
+		u32 *rp = s.rp + s.rp_base[A] + (u64)Z * (LA + 1);
+		const u32 mb = s.mbase[(u64)A * s.n + Z];
+		if (A == Z) {
+			for (u32 a = t; a <= LA; a += 64) rp[a] = mb;
+			continue;
+		}
+		const bool fwd = A < Z;
+		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 LX = fwd ? LA : s.seq_len[Z]; // rows of the stored (unordered) pair
+		const u32 LY = fwd ? s.seq_len[Z] : LA;
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		const u32 *cnt = fwd ? rec : rec + LX; // rowcnt or colcnt, LA entries
+		u32 carry = mb;
+		for (u32 a0 = 0; a0 <= LA; a0 += 64) {
+			const u32 a = a0 + t;
+			const u32 v = (a < LA) ? cnt[a] : 0;
+			u32 incl = v;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d);
+				if (t >= d) incl += o;
+			}
+			if (a <= LA) rp[a] = carry + incl - v;
+			carry += __shfl(incl, 63);
+		}
+		const u32 *e = rec + LX + LY;
+		const u32 *rowv = e + 2 * (u64)nnz;
+		const u32 *tperm = rowv + nnz;
+		MpcEnt *dst = s.ent + s.ent_base[A] + mb;
+		for (u32 q = t; q < nnz; q += 64) {
+			MpcEnt v;
+			v.p = e[2 * (u64)q];
+			if (fwd) { v.c = e[2 * (u64)q + 1]; dst[q] = v; }
+			else { v.c = rowv[q]; dst[tperm[q]] = v; }
+		}
+	}
+}
+
+__device__ __forceinline__ u64 mpc_find_pair(const u64 *vbase, u64 lo, u64 hi, u64 e)
+{
+	// largest k in [lo,hi) with vbase[k] <= e (pairs without entries are skipped naturally)
+	while (hi - lo > 1) {
+		const u64 mid = (lo + hi) >> 1;
+		if (vbase[mid] <= e) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+// One thread per stored cell of the pairs [k0,k1).
+__global__ void __launch_bounds__(256) relax_kernel(StoreParams s, u64 k0, u64 k1)
+{
+	const u64 first = s.vbase[k0], last = s.vbase[k1];
+	const u32 n = s.n;
+	for (u64 e = first + (u64)blockIdx.x * blockDim.x + threadIdx.x; e < last; e += (u64)gridDim.x * blockDim.x) {
+		const u64 k = mpc_find_pair(s.vbase, k0, k1, e);
+		const u32 X = s.pair_x[k], Y = s.pair_y[k];
+		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		const u32 idx = (u32)(e - s.vbase[k]);
+		const u32 *ent = rec + LX + LY;
+		const float pxy = __uint_as_float(ent[2 * (u64)idx]);
+		const u32 y = ent[2 * (u64)idx + 1];
+		const u32 x = ent[2 * (u64)nnz + idx];
+		float acc = pxy * 2.0f; // conspairflat.cpp:29-30
+		const u32 *rpx = s.rp + s.rp_base[X] + x;
+		const u32 *rpy = s.rp + s.rp_base[Y] + y;
+		const MpcEnt *ex = s.ent + s.ent_base[X];
+		const MpcEnt *ey = s.ent + s.ent_base[Y];
+		const u32 sxs = LX + 1, sys = LY + 1;
+		for (u32 Z = 0; Z < n; ++Z) {
+			u32 a = rpx[0], a1 = rpx[1];
+			u32 b = rpy[0], b1 = rpy[1];
+			rpx += sxs; rpy += sys;
+			if (a == a1 || b == b1) continue;
+			MpcEnt va = ex[a], vb = ey[b];
+			for (;;) {
+				if (va.c == vb.c) {
+					acc += __uint_as_float(va.p) * __uint_as_float(vb.p); // relaxflat.cpp:27 (w == 1.0f)
+					if (++a == a1 || ++b == b1) break;
+					va = ex[a]; vb = ey[b];
+				} else if (va.c < vb.c) {
+					if (++a == a1) break;
+					va = ex[a];
+				} else {
+					if (++b == b1) break;
+					vb = ey[b];
+				}
+			}
+		}
+		s.vnext[e] = acc / (float)n; // mysparsemx.cpp:108 (uint -> float, IEEE divide)
+	}
+}
+
+// Make vnext current everywhere it is stored: both slab orientations and the packed record
+// (the swap of consflat.cpp:22). One thread per stored cell of ALL pairs.
+__global__ void __launch_bounds__(256) commit_kernel(StoreParams s)
+{
+	const u64 last = s.vbase[s.npairs];
+	for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < last; e += (u64)gridDim.x * blockDim.x) {
+		const u64 k = mpc_find_pair(s.vbase, 0, s.npairs, e);
+		const u32 X = s.pair_x[k], Y = s.pair_y[k];
+		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];
+		u32 *rec = s.packed + s.pbase[k];
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		const u32 idx = (u32)(e - s.vbase[k]);
+		u32 *ent = rec + LX + LY;
+		const u32 pb = __float_as_uint(s.vnext[e]);
+		const u32 tq = ent[3 * (u64)nnz + idx];
+		ent[2 * (u64)idx] = pb;
+		s.ent[s.ent_base[X] + s.mbase[(u64)X * s.n + Y] + idx].p = pb;
+		s.ent[s.ent_base[Y] + s.mbase[(u64)Y * s.n + X] + tq].p = pb;
+	}
+}
+
+// Pack one batch of post_kernel records (fixed stride) into the packed buffer.
+__global__ void __launch_bounds__(256) pack_kernel(const u32 *res, u64 res_stride, const u64 *dst_base,
+	const u64 *rec_words, u32 *packed, u32 count)
+{
+	for (u32 pid = blockIdx.x; pid < count; pid += gridDim.x) {
+		const u32 *src = res + (u64)pid * res_stride;
+		u32 *dst = packed + dst_base[pid];
+		const u64 w = rec_words[pid];
+		for (u64 q = threadIdx.x; q < w; q += blockDim.x) dst[q] = src[q];
+	}
+}
+
+// Export pairs [k0,k1) in MySparseMx layout: offsets (LX+1 per pair, exclusive scan of rowcnt) and
+// values ({P,col} per entry) into two contiguous staging arrays.
+__global__ void __launch_bounds__(64) export_kernel(StoreParams s, u64 k0, u64 k1, const u64 *off_base,
+	u32 *out_off, u32 *out_val)
+{
+	const int t = threadIdx.x;
+	for (u64 k = k0 + blockIdx.x; k < k1; k += gridDim.x) {
+		const u32 LX = s.seq_len[s.pair_x[k]], LY = s.seq_len[s.pair_y[k]];
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		u32 *oo = out_off + off_base[k - k0];
+		u32 carry = 0;
+		for (u32 a0 = 0; a0 <= LX; a0 += 64) {
+			const u32 a = a0 + t;
+			const u32 v = (a < LX) ? rec[a] : 0;
+			u32 incl = v;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d);
+				if (t >= d) incl += o;
+			}
+			if (a <= LX) oo[a] = carry + incl - v;
+			carry += __shfl(incl, 63);
+		}
+		const u32 *ent = rec + LX + LY;
+		u32 *ov = out_val + 2 * (s.vbase[k] - s.vbase[k0]);
+		for (u32 q = t; q < 2 * nnz; q += 64) ov[q] = ent[q];
+	}
+}

@@ -1,0 +1,785 @@
+// mpcgpu.cpp — host side of libmpcgpu.so: the C ABI of include/mpcgpu.h over the HIP kernels in
+// kernels_fb.h / kernels_post.h / kernels_store.h. Built by hipcc (-x hip) for gfx950. There is
+// no CPU implementation behind this API: without a HIP device mpcgpu_create() fails.
+#include "../../include/mpcgpu.h"
+#include "kernels_fb.h"
+#include "kernels_post.h"
+#include "kernels_store.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_err;
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	hipError_t ensure(size_t bytes, bool keep = false, hipStream_t st = nullptr)
+	{
+		if (bytes <= cap) return hipSuccess;
+		size_t ncap = keep ? std::max(bytes, cap + cap / 2) : bytes;
+		void *np = nullptr;
+		hipError_t e = hipMalloc(&np, ncap ? ncap : 1);
+		if (e != hipSuccess) return e;
+		if (keep && p && cap) {
+			e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st);
+			if (e != hipSuccess) return e;
+			e = hipStreamSynchronize(st);
+			if (e != hipSuccess) return e;
+		}
+		if (p) (void)hipFree(p);
+		p = np;
+		cap = ncap;
+		return hipSuccess;
+	}
+	void release()
+	{
+		if (p) (void)hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+	template <class T> T *as() const { return (T *)p; }
+};
+
+struct TimedSpan { hipEvent_t a, b; int fam; };
+
+} // namespace
+
+struct mpcgpu_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipDeviceProp_t prop;
+	std::string err;
+
+	// HMM (row 0)
+	bool have_hmm = false;
+	float start[5], trans[25], thr = 0;
+	std::vector<float> match256, ins256;
+	int use_fma = 1;
+
+	// sequences
+	u32 n = 0;
+	std::vector<std::vector<u8>> raw;
+	std::vector<u32> len;
+	int A = 0;
+	int code_of[256];
+	DevBuf d_seq_code, d_seq_off, d_seq_len, d_match, d_ins;
+	u64 npairs = 0;
+	DevBuf d_pair_x, d_pair_y; // all pairs
+	std::vector<u32> h_pair_x, h_pair_y;
+
+	// shard state (stage A output of this context)
+	bool have_shard = false;
+	u64 sh_k0 = 0, sh_k1 = 0;
+	DevBuf d_shard;             // [header][records]
+	u64 shard_bytes = 0;
+	std::vector<u32> sh_nnz;
+	std::vector<float> sh_ea;
+
+	// store state (all pairs)
+	bool have_store = false;
+	const u32 *st_packed = nullptr; // device: words base that pbase refers to
+	std::vector<u64> h_pbase, h_vbase;
+	std::vector<u32> all_nnz;
+	std::vector<float> all_ea;
+	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
+	u64 total_entries = 0;
+
+	// scratch
+	DevBuf d_queue, d_order, d_bx, d_by, d_fm, d_cand, d_cand_cnt, d_total, d_res, d_nnz, d_ea, d_flags,
+		d_sort_scratch, d_srow_scratch, d_dstbase, d_recwords, d_exp_off, d_exp_val, d_exp_offbase;
+
+	// measurement
+	std::vector<TimedSpan> spans;
+	float ms[MPCGPU_NKERNELS] = {0, 0, 0, 0, 0};
+	u64 launches[MPCGPU_NKERNELS] = {0, 0, 0, 0, 0};
+	u64 work_cells = 0, work_entry_z = 0;
+};
+
+namespace {
+
+int fail(mpcgpu_ctx *c, const char *fmt, ...)
+{
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	if (c) c->err = buf; else g_create_err = buf;
+	return 1;
+}
+
+#define HIPCHK(c, call)                                                                          \
+	do {                                                                                         \
+		hipError_t e_ = (call);                                                                  \
+		if (e_ != hipSuccess)                                                                    \
+			return fail((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+int span_begin(mpcgpu_ctx *c, int fam, TimedSpan *sp)
+{
+	sp->fam = fam;
+	HIPCHK(c, hipEventCreate(&sp->a));
+	HIPCHK(c, hipEventCreate(&sp->b));
+	HIPCHK(c, hipEventRecord(sp->a, c->stream));
+	return 0;
+}
+int span_end(mpcgpu_ctx *c, TimedSpan *sp)
+{
+	HIPCHK(c, hipEventRecord(sp->b, c->stream));
+	c->spans.push_back(*sp);
+	c->launches[sp->fam] += 1;
+	return 0;
+}
+int spans_collect(mpcgpu_ctx *c)
+{
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	for (auto &sp : c->spans) {
+		float t = 0;
+		HIPCHK(c, hipEventElapsedTime(&t, sp.a, sp.b));
+		c->ms[sp.fam] += t;
+		(void)hipEventDestroy(sp.a);
+		(void)hipEventDestroy(sp.b);
+	}
+	c->spans.clear();
+	return 0;
+}
+
+template <class T> int upload(mpcgpu_ctx *c, DevBuf &b, const std::vector<T> &v)
+{
+	HIPCHK(c, b.ensure(std::max<size_t>(v.size(), 1) * sizeof(T)));
+	if (!v.empty())
+		HIPCHK(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+	return 0;
+}
+
+u32 next_pow2(u32 v)
+{
+	u32 p = 1;
+	while (p < v) p <<= 1;
+	return p;
+}
+
+int env_int(const char *name, int dflt)
+{
+	const char *s = getenv(name);
+	return (s && *s) ? atoi(s) : dflt;
+}
+
+template <int H> void launch_fb(const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+{
+	MPC_LAUNCH(HIP_KERNEL_NAME(fb_kernel<H>), grid, block, smem, st, p);
+}
+
+void launch_fb_h(int H, const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+{
+	switch (H) {
+#define MPC_CASE(h) case h: launch_fb<h>(p, grid, block, smem, st); break;
+	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
+	MPC_CASE(9) MPC_CASE(10) MPC_CASE(11) MPC_CASE(12) MPC_CASE(13) MPC_CASE(14) MPC_CASE(15) MPC_CASE(16)
+#undef MPC_CASE
+	default: break;
+	}
+}
+
+// shard buffer layout: [u64 npairs][u64 record_words_total][u32 nnz[np]][f32 ea[np]] pad to 8 | records
+u64 shard_header_bytes(u64 np) { return ((16 + np * 8 + 7) / 8) * 8; }
+u64 rec_words(u32 LX, u32 LY, u32 nnz) { return (u64)LX + LY + 4 * (u64)nnz; }
+
+void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
+{
+	s.n = c->n;
+	s.seq_len = c->d_seq_len.as<u32>();
+	s.npairs = c->npairs;
+	s.pair_x = c->d_pair_x.as<u32>();
+	s.pair_y = c->d_pair_y.as<u32>();
+	s.packed = (u32 *)c->st_packed;
+	s.pbase = c->d_pbase.as<u64>();
+	s.vbase = c->d_vbase.as<u64>();
+	s.rp = c->d_rp.as<u32>();
+	s.rp_base = c->d_rp_base.as<u64>();
+	s.ent = c->d_ent.as<MpcEnt>();
+	s.ent_base = c->d_ent_base.as<u64>();
+	s.mbase = c->d_mbase.as<u32>();
+	s.vnext = c->d_vnext.as<float>();
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mpcgpu_version(void)
+{
+#ifdef MPC_EMU
+	return "mpcgpu 0.1 (SIMT emulator build: tests only)";
+#else
+	return "mpcgpu 0.1 (HIP gfx950)";
+#endif
+}
+
+const char *mpcgpu_last_error(const mpcgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int mpcgpu_create(mpcgpu_ctx **out, int device_ordinal)
+{
+	if (!out) return fail(nullptr, "mpcgpu_create: out is NULL");
+	*out = nullptr;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev <= 0)
+		return fail(nullptr, "mpcgpu_create: no HIP device available (%s); this library has no CPU path",
+			e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+	if (device_ordinal < 0 || device_ordinal >= ndev)
+		return fail(nullptr, "mpcgpu_create: device %d out of range (have %d)", device_ordinal, ndev);
+	mpcgpu_ctx *c = new mpcgpu_ctx;
+	c->device = device_ordinal;
+	if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess ||
+		hipStreamCreate(&c->stream) != hipSuccess) {
+		delete c;
+		return fail(nullptr, "mpcgpu_create: cannot initialise device %d", device_ordinal);
+	}
+	for (int i = 0; i < 256; ++i) c->code_of[i] = -1;
+	*out = c;
+	return 0;
+}
+
+void mpcgpu_destroy(mpcgpu_ctx *c)
+{
+	if (!c) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (auto &sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+	DevBuf *all[] = {&c->d_seq_code, &c->d_seq_off, &c->d_seq_len, &c->d_match, &c->d_ins, &c->d_pair_x, &c->d_pair_y,
+		&c->d_shard, &c->d_pbase, &c->d_vbase, &c->d_rp, &c->d_rp_base, &c->d_ent, &c->d_ent_base, &c->d_mbase,
+		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
+		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
+		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase};
+	for (DevBuf *b : all) b->release();
+	(void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int mpcgpu_synchronize(mpcgpu_ctx *c)
+{
+	if (!c) return 1;
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+int mpcgpu_set_hmm(mpcgpu_ctx *c, const float start[5], const float trans[25], const float match[65536],
+	const float ins[256], float min_sparse_score, int expf_variant)
+{
+	if (!c) return 1;
+	if (!start || !trans || !match || !ins) return fail(c, "mpcgpu_set_hmm: NULL table");
+	memcpy(c->start, start, sizeof(c->start));
+	memcpy(c->trans, trans, sizeof(c->trans));
+	c->match256.assign(match, match + 65536);
+	c->ins256.assign(ins, ins + 256);
+	c->thr = min_sparse_score;
+	if (expf_variant < 0) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+		__builtin_cpu_init();
+		c->use_fma = (__builtin_cpu_supports("fma") && __builtin_cpu_supports("avx2")) ? 1 : 0; // glibc ifunc-fma.h
+#else
+		c->use_fma = 0;
+#endif
+	} else
+		c->use_fma = expf_variant ? 1 : 0;
+	c->have_hmm = true;
+	c->have_shard = c->have_store = false;
+	return 0;
+}
+
+int mpcgpu_set_seqs(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens)
+{
+	if (!c) return 1;
+	if (!c->have_hmm) return fail(c, "mpcgpu_set_seqs: call mpcgpu_set_hmm first");
+	if (n < 2) return fail(c, "mpcgpu_set_seqs: need at least 2 sequences (got %u)", n);
+	if ((u64)n * n > 0xffffffffull) return fail(c, "mpcgpu_set_seqs: too many sequences (%u)", n);
+	HIPCHK(c, hipSetDevice(c->device));
+	c->have_shard = c->have_store = false;
+	c->n = n;
+	c->raw.assign(n, {});
+	c->len.assign(lens, lens + n);
+	for (int i = 0; i < 256; ++i) c->code_of[i] = -1;
+	c->A = 0;
+	u32 maxl = 0, max2 = 0;
+	for (u32 i = 0; i < n; ++i) {
+		if (lens[i] == 0) return fail(c, "mpcgpu_set_seqs: sequence %u is empty", i);
+		c->raw[i].assign(seqs[i], seqs[i] + lens[i]);
+		for (u8 b : c->raw[i]) {
+			if (b >= 128) return fail(c, "mpcgpu_set_seqs: sequence %u holds non-ASCII byte %u", i, (unsigned)b);
+			if (c->code_of[b] < 0) c->code_of[b] = c->A++;
+		}
+		if (lens[i] > maxl) { max2 = maxl; maxl = lens[i]; } else if (lens[i] > max2) max2 = lens[i];
+	}
+	if (c->A > 64) return fail(c, "mpcgpu_set_seqs: %d distinct letters; this build supports at most 64", c->A);
+	// calcposteriorflat.cpp:54-61
+	if (double(maxl) * double(max2) * 5 + 100 > double(INT_MAX))
+		return fail(c, "HMM overflow, sequence lengths %u, %u (max ~21k)", maxl, max2);
+	std::vector<u8> code;
+	std::vector<u64> off(n + 1, 0);
+	for (u32 i = 0; i < n; ++i) {
+		off[i] = code.size();
+		for (u8 b : c->raw[i]) code.push_back((u8)c->code_of[b]);
+	}
+	off[n] = code.size();
+	std::vector<float> cm((size_t)c->A * c->A), ci(c->A);
+	int byte_of[64];
+	for (int b = 0; b < 256; ++b) if (c->code_of[b] >= 0) byte_of[c->code_of[b]] = b;
+	for (int a = 0; a < c->A; ++a) {
+		ci[a] = c->ins256[byte_of[a]];
+		for (int b = 0; b < c->A; ++b) cm[(size_t)a * c->A + b] = c->match256[(size_t)byte_of[a] * 256 + byte_of[b]];
+	}
+	if (upload(c, c->d_seq_code, code) || upload(c, c->d_seq_off, off) || upload(c, c->d_seq_len, c->len) ||
+		upload(c, c->d_match, cm) || upload(c, c->d_ins, ci))
+		return 1;
+	// MPCFlat::InitPairs (mpcflat.cpp:139-159)
+	c->npairs = (u64)n * (n - 1) / 2;
+	c->h_pair_x.resize(c->npairs);
+	c->h_pair_y.resize(c->npairs);
+	u64 k = 0;
+	for (u32 i = 0; i < n; ++i)
+		for (u32 j = i + 1; j < n; ++j) { c->h_pair_x[k] = i; c->h_pair_y[k] = j; ++k; }
+	if (upload(c, c->d_pair_x, c->h_pair_x) || upload(c, c->d_pair_y, c->h_pair_y)) return 1;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+uint64_t mpcgpu_pair_count(const mpcgpu_ctx *c) { return c ? c->npairs : 0; }
+
+int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
+{
+	if (!c) return 1;
+	if (c->n == 0) return fail(c, "mpcgpu_calc_posteriors: call mpcgpu_set_seqs first");
+	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_calc_posteriors: bad pair range [%llu,%llu)", (u64)k0, (u64)k1);
+	HIPCHK(c, hipSetDevice(c->device));
+	c->have_shard = c->have_store = false;
+	const u64 np = k1 - k0;
+	c->sh_k0 = k0; c->sh_k1 = k1;
+	c->sh_nnz.assign(np, 0);
+	c->sh_ea.assign(np, 0.0f);
+	c->work_cells = 0;
+	const u64 hdr = shard_header_bytes(np);
+	if (np == 0) {
+		HIPCHK(c, c->d_shard.ensure(hdr));
+		u64 h2[2] = {0, 0};
+		HIPCHK(c, hipMemcpyAsync(c->d_shard.p, h2, 16, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		c->shard_bytes = hdr;
+		c->have_shard = true;
+		return 0;
+	}
+	// geometry of the shard
+	u32 LXmax = 0, LYmax = 0;
+	for (u64 k = k0; k < k1; ++k) {
+		const u32 LX = c->len[c->h_pair_x[k]], LY = c->len[c->h_pair_y[k]];
+		LXmax = std::max(LXmax, LX); LYmax = std::max(LYmax, LY);
+		c->work_cells += (u64)(LX + 1) * (LY + 1);
+	}
+	if (LXmax > 64u * MPC_HMAX)
+		return fail(c, "mpcgpu_calc_posteriors: row sequence length %u exceeds %u (row-block tiling for longer "
+			"sequences is not implemented in this build)", LXmax, 64u * MPC_HMAX);
+	const u32 Lmax = std::max(LXmax, LYmax);
+	u32 capc = (u32)std::max(env_int("MPCGPU_CAND_PER_ROW", 12), 1) * Lmax;
+	capc = std::max(capc, 1024u);
+	const int waves_per_block = 4, block = 64 * waves_per_block;
+	const u32 cus = (u32)c->prop.multiProcessorCount;
+	const size_t fb_smem = ((size_t)c->A * c->A + c->A) * sizeof(float);
+
+	u64 words_done = 0; // record words packed so far
+	u64 done = 0;
+	while (done < np) {
+		// ---- batch sizing: candidates + fixed-stride records per pair
+		const u64 res_stride = (u64)LXmax + LYmax + 4 * (u64)capc;
+		const u64 per_pair = (u64)capc * 8 + res_stride * 4 + 64;
+		size_t freeb = 0, totb = 0;
+		HIPCHK(c, hipMemGetInfo(&freeb, &totb));
+		u64 budget = std::min<u64>((u64)env_int("MPCGPU_SCRATCH_GB", 16) << 30, (u64)(freeb * 0.4));
+		u64 B = std::max<u64>(1, std::min<u64>(np - done, budget / per_pair));
+		B = std::min<u64>(B, 1u << 22);
+		const u64 b0 = k0 + done;
+		// ---- bin by H, order by work (longest first)
+		std::vector<u32> bx(B), by(B), hh(B);
+		std::vector<u32> order(B);
+		std::vector<u64> wk(B);
+		u32 hcount[MPC_HMAX + 1] = {0};
+		for (u64 q = 0; q < B; ++q) {
+			bx[q] = c->h_pair_x[b0 + q]; by[q] = c->h_pair_y[b0 + q];
+			const u32 LX = c->len[bx[q]], LY = c->len[by[q]];
+			const u32 H = (LX + 63) / 64;
+			hh[q] = H; hcount[H]++;
+			wk[q] = (u64)(LY + (LX + H - 1) / H) * H;
+			order[q] = (u32)q;
+		}
+		std::sort(order.begin(), order.end(), [&](u32 a, u32 b) {
+			if (hh[a] != hh[b]) return hh[a] < hh[b];
+			if (wk[a] != wk[b]) return wk[a] > wk[b];
+			return a < b;
+		});
+		if (upload(c, c->d_bx, bx) || upload(c, c->d_by, by) || upload(c, c->d_order, order)) return 1;
+		HIPCHK(c, c->d_cand.ensure(B * capc * 8));
+		HIPCHK(c, c->d_cand_cnt.ensure(B * 4));
+		HIPCHK(c, c->d_total.ensure(B * 4));
+		HIPCHK(c, c->d_res.ensure(B * res_stride * 4));
+		HIPCHK(c, c->d_nnz.ensure(B * 4));
+		HIPCHK(c, c->d_ea.ensure(B * 4));
+		HIPCHK(c, c->d_flags.ensure(B * 4));
+		HIPCHK(c, c->d_queue.ensure(4 * (MPC_HMAX + 1)));
+		HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (MPC_HMAX + 1), c->stream));
+
+		FbParams fp;
+		fp.seq_code = c->d_seq_code.as<u8>(); fp.seq_off = c->d_seq_off.as<u64>(); fp.seq_len = c->d_seq_len.as<u32>();
+		fp.tSM = c->start[0]; fp.tSI = c->start[1]; fp.tSJ = c->start[3]; // pairhmm.h:11-19: M,IX,IY,JX,JY
+		fp.tMM = c->trans[0 * 5 + 0]; fp.tMI = c->trans[0 * 5 + 1]; fp.tMJ = c->trans[0 * 5 + 3];
+		fp.tII = c->trans[1 * 5 + 1]; fp.tIM = c->trans[1 * 5 + 0];
+		fp.tJJ = c->trans[3 * 5 + 3]; fp.tJM = c->trans[3 * 5 + 0];
+		fp.thr = c->thr; fp.A = c->A; fp.match = c->d_match.as<float>(); fp.ins = c->d_ins.as<float>();
+		fp.pair_x = c->d_bx.as<u32>(); fp.pair_y = c->d_by.as<u32>();
+		fp.cand = c->d_cand.as<u64>(); fp.capc = capc; fp.cand_cnt = c->d_cand_cnt.as<u32>();
+		fp.total = c->d_total.as<float>();
+
+		TimedSpan sp;
+		u32 pos = 0;
+		for (u32 H = 1; H <= MPC_HMAX; ++H) {
+			if (!hcount[H]) continue;
+			const u32 cnt = hcount[H];
+			// resident waves: enough slots to fill the chip (VGPR-limited: ~8 waves/SIMD for small H)
+			const u32 waves_per_cu = H <= 4 ? 32 : (H <= 8 ? 20 : 12);
+			u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block,
+				cus * std::max(1u, waves_per_cu / waves_per_block));
+			grid = std::max(grid, 1u);
+			const u64 fm_stride = (u64)(LYmax + 64) * H * 64;
+			HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
+			fp.order = c->d_order.as<u32>() + pos; fp.count = cnt;
+			fp.queue = c->d_queue.as<u32>() + H;
+			fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride;
+			if (span_begin(c, 0, &sp)) return 1;
+			launch_fb_h((int)H, fp, grid, block, fb_smem, c->stream);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &sp)) return 1;
+			pos += cnt;
+		}
+		// ---- finish: probabilities, sort, EA, sparsify
+		PostParams pp;
+		pp.pair_x = c->d_bx.as<u32>(); pp.pair_y = c->d_by.as<u32>(); pp.seq_len = c->d_seq_len.as<u32>();
+		pp.cand = c->d_cand.as<u64>(); pp.capc = capc; pp.cand_cnt = c->d_cand_cnt.as<u32>();
+		pp.use_fma = c->use_fma;
+		pp.sort_cap = std::min<u32>(next_pow2(capc), 2048u);
+		pp.srow_cap = std::min<u32>(LYmax + 1, 2048u);
+		const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * 8);
+		pp.sort_stride = next_pow2(capc);
+		pp.srow_stride = 2 * ((u64)LYmax + 1);
+		const bool need_sort_scr = next_pow2(capc) > pp.sort_cap, need_srow_scr = LYmax + 1 > pp.srow_cap;
+		HIPCHK(c, c->d_sort_scratch.ensure(need_sort_scr ? (u64)pgrid * pp.sort_stride * 8 : 8));
+		HIPCHK(c, c->d_srow_scratch.ensure(need_srow_scr ? (u64)pgrid * pp.srow_stride * 4 : 8));
+		pp.sort_scratch = c->d_sort_scratch.as<u64>(); pp.srow_scratch = c->d_srow_scratch.as<float>();
+		pp.res = c->d_res.as<u32>(); pp.res_stride = res_stride;
+		pp.nnz = c->d_nnz.as<u32>(); pp.ea = c->d_ea.as<float>(); pp.flags = c->d_flags.as<u32>();
+		pp.count = (u32)B;
+		const size_t psmem = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
+		if (span_begin(c, 1, &sp)) return 1;
+		MPC_LAUNCH(post_kernel, pgrid, 64, psmem, c->stream, pp);
+		HIPCHK(c, hipGetLastError());
+		if (span_end(c, &sp)) return 1;
+		// ---- sizes back, overflow check, pack
+		std::vector<u32> flags(B);
+		HIPCHK(c, hipMemcpyAsync(&c->sh_nnz[done], c->d_nnz.p, B * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(&c->sh_ea[done], c->d_ea.p, B * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(flags.data(), c->d_flags.p, B * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		bool overflow = false;
+		for (u64 q = 0; q < B; ++q) overflow = overflow || (flags[q] & 1u);
+		if (overflow) {
+			if (capc >= LXmax * (u64)LYmax)
+				return fail(c, "mpcgpu_calc_posteriors: candidate overflow at full capacity (internal error)");
+			capc = (u32)std::min<u64>((u64)capc * 2, (u64)LXmax * LYmax);
+			continue; // redo this batch with a larger candidate capacity
+		}
+		std::vector<u64> dstbase(B), recw(B);
+		u64 w = words_done;
+		for (u64 q = 0; q < B; ++q) {
+			recw[q] = rec_words(c->len[bx[q]], c->len[by[q]], c->sh_nnz[done + q]);
+			dstbase[q] = hdr / 4 + w;
+			w += recw[q];
+		}
+		// capacity estimate for the whole shard from the words seen so far
+		const double per = double(w) / double(done + B);
+		const u64 est = hdr + (u64)(per * 1.05 * double(np) + 1024) * 4;
+		HIPCHK(c, c->d_shard.ensure(std::max<u64>(est, hdr + w * 4), true, c->stream));
+		if (upload(c, c->d_dstbase, dstbase) || upload(c, c->d_recwords, recw)) return 1;
+		if (span_begin(c, 1, &sp)) return 1;
+		MPC_LAUNCH(pack_kernel, (u32)std::min<u64>(B, (u64)cus * 8), 256, 0, c->stream, c->d_res.as<u32>(), res_stride,
+			c->d_dstbase.as<u64>(), c->d_recwords.as<u64>(), c->d_shard.as<u32>(), (u32)B);
+		HIPCHK(c, hipGetLastError());
+		if (span_end(c, &sp)) return 1;
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		words_done = w;
+		done += B;
+	}
+	// header
+	std::vector<u8> h(hdr, 0);
+	u64 h2[2] = {np, words_done};
+	memcpy(h.data(), h2, 16);
+	memcpy(h.data() + 16, c->sh_nnz.data(), np * 4);
+	memcpy(h.data() + 16 + np * 4, c->sh_ea.data(), np * 4);
+	HIPCHK(c, hipMemcpyAsync(c->d_shard.p, h.data(), hdr, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->shard_bytes = hdr + words_done * 4;
+	c->have_shard = true;
+	return 0;
+}
+
+int mpcgpu_shard_info(mpcgpu_ctx *c, uint64_t *bytes, void **dev_ptr)
+{
+	if (!c) return 1;
+	if (!c->have_shard) return fail(c, "mpcgpu_shard_info: no shard (call mpcgpu_calc_posteriors)");
+	if (bytes) *bytes = c->shard_bytes;
+	if (dev_ptr) *dev_ptr = c->d_shard.p;
+	return 0;
+}
+
+int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, const uint64_t *k1,
+	const uint64_t *bytes, const void *dev_all)
+{
+	if (!c) return 1;
+	if (c->n == 0) return fail(c, "mpcgpu_store_import: call mpcgpu_set_seqs first");
+	HIPCHK(c, hipSetDevice(c->device));
+	c->have_store = false;
+	const u32 n = c->n;
+	// ---- read shard headers, check coverage
+	c->all_nnz.assign(c->npairs, 0);
+	c->all_ea.assign(c->npairs, 0.0f);
+	c->h_pbase.assign(c->npairs + 1, 0);
+	c->h_vbase.assign(c->npairs + 1, 0);
+	u64 expect = 0, byte_off = 0;
+	for (u32 s = 0; s < nshards; ++s) {
+		if (k0[s] != expect || k1[s] < k0[s] || k1[s] > c->npairs)
+			return fail(c, "mpcgpu_store_import: shards must tile [0,%llu) in order (shard %u is [%llu,%llu))",
+				(u64)c->npairs, s, (u64)k0[s], (u64)k1[s]);
+		const u64 np = k1[s] - k0[s];
+		const u64 hdr = shard_header_bytes(np);
+		if (bytes[s] < hdr) return fail(c, "mpcgpu_store_import: shard %u too small", s);
+		std::vector<u8> h(hdr);
+		HIPCHK(c, hipMemcpyAsync(h.data(), (const u8 *)dev_all + byte_off, hdr, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		u64 h2[2];
+		memcpy(h2, h.data(), 16);
+		if (h2[0] != np || hdr + h2[1] * 4 != bytes[s])
+			return fail(c, "mpcgpu_store_import: shard %u header mismatch (pairs %llu vs %llu, bytes %llu vs %llu)", s,
+				(u64)h2[0], (u64)np, (u64)(hdr + h2[1] * 4), (u64)bytes[s]);
+		memcpy(&c->all_nnz[k0[s]], h.data() + 16, np * 4);
+		memcpy(&c->all_ea[k0[s]], h.data() + 16 + np * 4, np * 4);
+		u64 w = (byte_off + hdr) / 4;
+		for (u64 k = k0[s]; k < k1[s]; ++k) {
+			c->h_pbase[k] = w;
+			w += rec_words(c->len[c->h_pair_x[k]], c->len[c->h_pair_y[k]], c->all_nnz[k]);
+		}
+		if (w * 4 != byte_off + bytes[s]) return fail(c, "mpcgpu_store_import: shard %u record sizes do not add up", s);
+		byte_off += bytes[s];
+		expect = k1[s];
+	}
+	if (expect != c->npairs) return fail(c, "mpcgpu_store_import: shards cover %llu of %llu pairs", (u64)expect, (u64)c->npairs);
+	c->h_pbase[c->npairs] = byte_off / 4;
+	for (u64 k = 0; k < c->npairs; ++k) c->h_vbase[k + 1] = c->h_vbase[k] + c->all_nnz[k];
+	c->total_entries = c->h_vbase[c->npairs];
+	c->st_packed = (const u32 *)dev_all;
+	// ---- slab geometry: per ordered pair entry counts -> mbase (within slab), slab bases
+	std::vector<u32> mbase((size_t)n * n, 0);
+	std::vector<u64> ent_base(n + 1, 0), rp_base(n + 1, 0);
+	{
+		std::vector<u64> slab(n, 0);
+		// nnz(A,Z) = nnz of the unordered pair
+		for (u32 A = 0; A < n; ++A) {
+			u64 run = 0;
+			for (u32 Z = 0; Z < n; ++Z) {
+				if (run > 0xffffffffull) return fail(c, "mpcgpu_store_import: slab of sequence %u exceeds 2^32 entries", A);
+				mbase[(size_t)A * n + Z] = (u32)run;
+				if (Z != A) {
+					const u64 k = A < Z ? (u64)A * n - ((u64)A * (A + 1)) / 2 + (Z - A - 1)
+					                    : (u64)Z * n - ((u64)Z * (Z + 1)) / 2 + (A - Z - 1);
+					run += c->all_nnz[k];
+				}
+			}
+			slab[A] = run;
+		}
+		for (u32 A = 0; A < n; ++A) {
+			ent_base[A + 1] = ent_base[A] + slab[A];
+			rp_base[A + 1] = rp_base[A] + (u64)n * (c->len[A] + 1);
+		}
+	}
+	HIPCHK(c, c->d_rp.ensure(rp_base[n] * 4));
+	HIPCHK(c, c->d_ent.ensure(std::max<u64>(ent_base[n], 1) * 8));
+	HIPCHK(c, c->d_vnext.ensure(std::max<u64>(c->total_entries, 1) * 4));
+	if (upload(c, c->d_pbase, c->h_pbase) || upload(c, c->d_vbase, c->h_vbase) || upload(c, c->d_mbase, mbase) ||
+		upload(c, c->d_ent_base, ent_base) || upload(c, c->d_rp_base, rp_base))
+		return 1;
+	StoreParams sp;
+	fill_store_params(c, sp);
+	TimedSpan ts;
+	if (span_begin(c, 2, &ts)) return 1;
+	const u64 blocks = (u64)n * n;
+	MPC_LAUNCH(slab_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp);
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts)) return 1;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->have_store = true;
+	return 0;
+}
+
+int mpcgpu_build_store(mpcgpu_ctx *c)
+{
+	if (!c) return 1;
+	if (!c->have_shard || c->sh_k0 != 0 || c->sh_k1 != c->npairs)
+		return fail(c, "mpcgpu_build_store: needs this context's shard to cover all pairs "
+			"(multi-GPU callers use mpcgpu_store_import)");
+	const uint64_t k0 = 0, k1 = c->npairs, bytes = c->shard_bytes;
+	return mpcgpu_store_import(c, 1, &k0, &k1, &bytes, c->d_shard.p);
+}
+
+int mpcgpu_values_info(mpcgpu_ctx *c, void **dev_ptr, uint64_t *total_count)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_values_info: no store");
+	if (dev_ptr) *dev_ptr = c->d_vnext.p;
+	if (total_count) *total_count = c->total_entries;
+	return 0;
+}
+
+int mpcgpu_values_slice(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, uint64_t *first, uint64_t *count)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_values_slice: no store");
+	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_values_slice: bad pair range");
+	if (first) *first = c->h_vbase[k0];
+	if (count) *count = c->h_vbase[k1] - c->h_vbase[k0];
+	return 0;
+}
+
+int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_cons_iter: no store (call mpcgpu_build_store / mpcgpu_store_import)");
+	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_cons_iter: bad pair range");
+	HIPCHK(c, hipSetDevice(c->device));
+	const u64 cnt = c->h_vbase[k1] - c->h_vbase[k0];
+	c->work_entry_z = cnt * c->n;
+	if (cnt == 0) return 0;
+	StoreParams sp;
+	fill_store_params(c, sp);
+	TimedSpan ts;
+	if (span_begin(c, 3, &ts)) return 1;
+	const u32 block = 256;
+	const u64 blocks = (cnt + block - 1) / block;
+	MPC_LAUNCH(relax_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64), block, 0, c->stream, sp,
+		(u64)k0, (u64)k1);
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts)) return 1;
+	return 0;
+}
+
+int mpcgpu_cons_commit(mpcgpu_ctx *c)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_cons_commit: no store");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (c->total_entries == 0) return 0;
+	StoreParams sp;
+	fill_store_params(c, sp);
+	TimedSpan ts;
+	if (span_begin(c, 4, &ts)) return 1;
+	const u32 block = 256;
+	const u64 blocks = (c->total_entries + block - 1) / block;
+	MPC_LAUNCH(commit_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64), block, 0, c->stream, sp);
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts)) return 1;
+	return 0;
+}
+
+int mpcgpu_get_ea(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, float *ea)
+{
+	if (!c) return 1;
+	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_get_ea: bad pair range");
+	if (c->have_store) { memcpy(ea, &c->all_ea[k0], (k1 - k0) * 4); return 0; }
+	if (c->have_shard && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(ea, &c->sh_ea[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
+	return fail(c, "mpcgpu_get_ea: range [%llu,%llu) not available", (u64)k0, (u64)k1);
+}
+
+int mpcgpu_get_nnz(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, uint32_t *nnz)
+{
+	if (!c) return 1;
+	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_get_nnz: bad pair range");
+	if (c->have_store) { memcpy(nnz, &c->all_nnz[k0], (k1 - k0) * 4); return 0; }
+	if (c->have_shard && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(nnz, &c->sh_nnz[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
+	return fail(c, "mpcgpu_get_nnz: range [%llu,%llu) not available", (u64)k0, (u64)k1);
+}
+
+int mpcgpu_get_sparse_range(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, uint32_t *offsets, void *values)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_get_sparse_range: no store (call mpcgpu_build_store / mpcgpu_store_import)");
+	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_get_sparse_range: bad pair range");
+	if (k0 == k1) return 0;
+	HIPCHK(c, hipSetDevice(c->device));
+	std::vector<u64> offbase(k1 - k0);
+	u64 o = 0;
+	for (u64 k = k0; k < k1; ++k) { offbase[k - k0] = o; o += c->len[c->h_pair_x[k]] + 1; }
+	const u64 nval = c->h_vbase[k1] - c->h_vbase[k0];
+	HIPCHK(c, c->d_exp_off.ensure(o * 4));
+	HIPCHK(c, c->d_exp_val.ensure(std::max<u64>(nval, 1) * 8));
+	if (upload(c, c->d_exp_offbase, offbase)) return 1;
+	StoreParams sp;
+	fill_store_params(c, sp);
+	MPC_LAUNCH(export_kernel, (u32)std::min<u64>(k1 - k0, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp,
+		(u64)k0, (u64)k1, c->d_exp_offbase.as<u64>(), c->d_exp_off.as<u32>(), c->d_exp_val.as<u32>());
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemcpyAsync(offsets, c->d_exp_off.p, o * 4, hipMemcpyDeviceToHost, c->stream));
+	if (nval) HIPCHK(c, hipMemcpyAsync(values, c->d_exp_val.p, nval * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+int mpcgpu_get_sparse(mpcgpu_ctx *c, uint64_t k, uint32_t *offsets, void *values)
+{
+	return mpcgpu_get_sparse_range(c, k, k + 1, offsets, values);
+}
+
+int mpcgpu_calc_aln(mpcgpu_ctx *c, const float *, uint32_t, uint32_t, char *, uint32_t *, float *)
+{
+	return fail(c, "mpcgpu_calc_aln: not implemented in this build");
+}
+
+int mpcgpu_timers_reset(mpcgpu_ctx *c)
+{
+	if (!c) return 1;
+	if (spans_collect(c)) return 1;
+	for (int i = 0; i < MPCGPU_NKERNELS; ++i) { c->ms[i] = 0; c->launches[i] = 0; }
+	return 0;
+}
+
+int mpcgpu_timers_get(mpcgpu_ctx *c, float ms[MPCGPU_NKERNELS], uint64_t launches[MPCGPU_NKERNELS])
+{
+	if (!c) return 1;
+	if (spans_collect(c)) return 1;
+	for (int i = 0; i < MPCGPU_NKERNELS; ++i) { ms[i] = c->ms[i]; launches[i] = c->launches[i]; }
+	return 0;
+}
+
+int mpcgpu_work_get(mpcgpu_ctx *c, uint64_t *dp_cells, uint64_t *relax_entry_z, uint64_t *store_entries)
+{
+	if (!c) return 1;
+	if (dp_cells) *dp_cells = c->work_cells;
+	if (relax_entry_z) *relax_entry_z = c->work_entry_z;
+	if (store_entries) *store_entries = c->total_entries;
+	return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,156 @@
+// tests/emu/hip_emu.h — TEST INFRASTRUCTURE ONLY (never part of the product library).
+//
+// A tiny SIMT emulator: just enough of the HIP runtime + device intrinsics for the sources in
+// muscle_amd/csrc to be compiled by g++ (-DMPC_EMU) into tests/emu/libmpcgpu_emu.so, so kernel
+// logic (indexing, skew schedules, boundary cases, orchestration, buffer sizing) can be checked
+// against the oracle in this GPU-less container BEFORE a gpurun call is spent. One OS thread per
+// GPU thread of the running block; wave collectives (shuffles, ballot) and __syncthreads are
+// pthread barriers; blocks run one after another. Slow by design: tiny inputs only.
+// The product path (muscle_amd/csrc/libmpcgpu.so, hipcc --offload-arch=gfx950) never sees this.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <pthread.h>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+struct dim3 {
+	unsigned x, y, z;
+	dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace emu {
+struct WaveState {
+	pthread_barrier_t bar;
+	uint64_t xbuf[64];
+	int nthreads;
+};
+struct BlockState {
+	pthread_barrier_t bar;
+	std::vector<WaveState *> waves;
+	unsigned char *dyn_smem;
+};
+extern BlockState *g_block;
+extern thread_local WaveState *t_wave;
+extern thread_local unsigned t_lane;
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()> &body);
+} // namespace emu
+
+extern thread_local dim3 threadIdx;
+extern thread_local dim3 blockIdx;
+extern dim3 blockDim;
+extern dim3 gridDim;
+
+#define MPC_LAUNCH(kern, grid, block, smem, stream, ...) \
+	emu::launch(dim3(grid), dim3(block), (smem), [=]() { kern(__VA_ARGS__); })
+#define MPC_DYN_SMEM(name) unsigned char *name = emu::g_block->dyn_smem
+
+// ---- device intrinsics -------------------------------------------------------------------
+static inline void __syncthreads() { pthread_barrier_wait(&emu::g_block->bar); }
+
+template <class T> static inline T emu_xchg(T v, int src_lane_delta, bool absolute)
+{
+	static_assert(sizeof(T) <= 8, "emu shuffle: <= 8 bytes");
+	emu::WaveState *w = emu::t_wave;
+	uint64_t raw = 0;
+	memcpy(&raw, &v, sizeof(T));
+	w->xbuf[emu::t_lane] = raw;
+	pthread_barrier_wait(&w->bar);
+	int src = absolute ? src_lane_delta : (int)emu::t_lane + src_lane_delta;
+	T r = v;
+	if (src >= 0 && src < w->nthreads)
+		memcpy(&r, &w->xbuf[src], sizeof(T));
+	pthread_barrier_wait(&w->bar);
+	return r;
+}
+template <class T> static inline T __shfl_up(T v, unsigned d) { return emu_xchg(v, -(int)d, false); }
+template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xchg(v, (int)d, false); }
+template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
+static inline unsigned long long __ballot(int pred)
+{
+	emu::WaveState *w = emu::t_wave;
+	w->xbuf[emu::t_lane] = pred ? 1 : 0;
+	pthread_barrier_wait(&w->bar);
+	unsigned long long m = 0;
+	for (int i = 0; i < w->nthreads; ++i)
+		if (w->xbuf[i]) m |= (1ull << i);
+	pthread_barrier_wait(&w->bar);
+	return m;
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
+
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicMax(unsigned *p, unsigned v)
+{
+	unsigned o = __atomic_load_n(p, __ATOMIC_RELAXED);
+	while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+	return o;
+}
+static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
+static inline double __longlong_as_double(long long u) { double d; memcpy(&d, &u, 8); return d; }
+
+// ---- host runtime subset -----------------------------------------------------------------
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+typedef void *hipStream_t;
+struct emuEvent { std::chrono::steady_clock::time_point t; };
+typedef emuEvent *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+struct hipDeviceProp_t { int multiProcessorCount; size_t totalGlobalMem; char name[64]; char gcnArchName[64]; };
+
+static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emu error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
+{
+	memset(p, 0, sizeof(*p));
+	p->multiProcessorCount = 2; // keep emulated grids tiny
+	p->totalGlobalMem = (size_t)8 << 30;
+	strcpy(p->name, "SIMT emulator (tests only)");
+	strcpy(p->gcnArchName, "emu");
+	return hipSuccess;
+}
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)4 << 30; *t = (size_t)8 << 30; return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emuEvent; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
+{
+	*ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+	return hipSuccess;
+}
