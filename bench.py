@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — sequence-pairs/sec of the MPCFlat all-pairs posterior stage on MI355X.
+
+One "step" = one full pass of the hot path over the workload: fwd + bwd + posterior (+ sparsify +
+EA score) for ALL N(N-1)/2 pairs, then 2 consistency-relax iterations (BASELINE.json metric;
+timed region = MPCFlat::CalcPosteriors + MPCFlat::Consistency, mpcflat.cpp:313,328). Inputs
+(sequences, HMM tables) are resident on the device before the timed region. Synthetic protein
+family (muscle_amd/synth.py, seed 1), default N=1000 L~400 = BASELINE configs[2].
+
+  python bench.py [--gpus N --steps K --warmup W] [--n 1000 --len 400]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+       (pairs sharded over ranks, RCCL all-gather of sparse posteriors before relax; weak=no:
+        total work is fixed, so "scaling": "strong")
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA dense peak
+
+
+def load_hmm():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "hmm_amino.npz"))
+    return z["start"], z["trans"], z["match"], z["ins"], np.float32(z["min_sparse_score"])
+
+
+def stage_a_flops(lens):
+    """F_A = 164*(LX+1)(LY+1) + 5*LX*LY FP32 ops per pair."""
+    from muscle_amd.mpcflat import pair_lengths
+    lx, ly = pair_lengths(lens)
+    return float(np.sum(164.0 * (lx + 1) * (ly + 1) + 5.0 * lx * ly))
+
+
+def stage_b_bytes(lens, nnz):
+    """per (pair,Z) the operands read once = 8*(nnz_XZ+nnz_YZ) + 4*(LX+LY+2) bytes,
+    summed over all pairs and all Z != X,Y; plus 4*nnz written per pair."""
+    lens = np.asarray(lens, np.int64)
+    n = len(lens)
+    ii, jj = np.triu_indices(n, 1)
+    nnz = np.asarray(nnz, np.int64)
+    per_seq = np.zeros(n, np.int64)
+    np.add.at(per_seq, ii, nnz)
+    np.add.at(per_seq, jj, nnz)
+    ent = 8 * (per_seq[ii] + per_seq[jj] - 2 * nnz)
+    ptr = 4 * (n - 2) * (lens[ii] + lens[jj] + 2)
+    return float(np.sum(ent + ptr + 4 * nnz))
+
+
+def cpu_baseline(seqs, n_full, budget_s=20.0):
+    """Reference (oracle/_ref/libmuscle_ref.so = the reference's own MPCFlat::CalcPosteriors +
+    ConsIter, OpenMP over all host cores) on a bounded sample of the same family, extrapolated to
+    the full N: stage A scales per pair, relax per (pair,Z) triple. Falls back to the C oracle
+    ("port") if the compiled reference is not shipped."""
+    cores = os.cpu_count() or 1
+    n_s = 24
+    sample = seqs[:n_s]
+    np_s = n_s * (n_s - 1) // 2
+    try:
+        import _ref as R
+        if not R.available():
+            raise RuntimeError("no libmuscle_ref.so")
+        R.init_hmm(False, 0)
+        import ctypes as C
+        L = R.lib()
+        arr = (C.c_char_p * len(sample))(*[s.encode() for s in sample])
+        if L.ref_mpc_begin(len(sample), arr, cores) != 0:
+            raise RuntimeError("ref_mpc_begin failed")
+        t0 = time.perf_counter(); L.ref_mpc_calc_posteriors(); tA = time.perf_counter() - t0
+        t0 = time.perf_counter(); L.ref_mpc_cons_iter(0); L.ref_mpc_cons_iter(1); tB = time.perf_counter() - t0
+        kind = "reference"
+    except Exception as e:  # noqa: BLE001
+        import _oracle as O
+        s, t, m, i, thr = load_hmm()
+        h = O.make_hmm(s, t, m, i)
+        st = O.Store(sample)
+        t0 = time.perf_counter(); st.calc_posteriors(h, threads=cores); tA = time.perf_counter() - t0
+        t0 = time.perf_counter(); c1 = st.cons_iter(threads=cores); c1.cons_iter(threads=cores); tB = time.perf_counter() - t0
+        kind = "port"
+    per_pair_a = tA / np_s
+    per_triple = tB / (2.0 * np_s * (n_s - 2))
+    per_pair_full = per_pair_a + 2.0 * (n_full - 2) * per_triple
+    return {"value": 1.0 / per_pair_full, "unit": "pairs/s", "cores": cores, "kind": kind,
+            "sample": "first %d sequences of the same family (%d pairs): stage A %.2f s, 2 relax iterations %.2f s; "
+                      "extrapolated to N=%d as t_pair = tA/pairs + 2*(N-2)*t_triple" % (n_s, np_s, tA, tB, n_full)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1000)
+    ap.add_argument("--len", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from muscle_amd._lib import MpcGpu
+    from muscle_amd.mpcflat import TorchExchange, run_stage
+    from muscle_amd.synth import make_family
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (a.gpus, world))
+    torch.cuda.set_device(local)
+    device = "cuda:%d" % local
+    exchange = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(device))
+        exchange = TorchExchange(dist, device)
+
+    seqs = make_family(a.n, a.len, seed=a.seed)
+    lens = [len(s) for s in seqs]
+    npairs = a.n * (a.n - 1) // 2
+    g = MpcGpu(local)
+    g.set_hmm(*load_hmm())
+    g.set_seqs(seqs)  # inputs resident in HBM from here on
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        run_stage(g, lens, exchange, torch_mod=torch)
+    g.timers_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run_stage(g, lens, exchange, torch_mod=torch)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    timers = g.timers_get()
+
+    if rank == 0:
+        nnz = g.get_nnz()
+        ms_step = 1000.0 * el / a.steps
+        # dominant kernel family of THIS rank over the timed steps (hipEvents on the library's stream)
+        fam = max(("fb", "relax"), key=lambda k: timers[k][0])
+        ms, launches = timers[fam]
+        my_frac = 1.0 / world  # this rank's share of the pair-sharded work
+        if fam == "fb":
+            work = stage_a_flops(lens) * a.steps * my_frac
+            achieved = work / (ms * 1e-3) / 1e12
+            roof = {"kernel": "fb_kernel<H> (pair-HMM fwd+bwd+posterior, one wave per pair)", "bound": "valu",
+                    "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+                    "traffic": None,
+                    "note": "FP32 vector-ALU bound recurrence (no contraction, no MFMA: SURVEY.md §8d); peak = 157.3 TFLOP/s "
+                            "FP32 vector = FP32 dense MFMA peak; algorithmic flops = sum 164(LX+1)(LY+1)+5LXLY"}
+        else:
+            work = stage_b_bytes(lens, nnz) * a.steps * my_frac
+            achieved = work / (ms * 1e-3) / 1e9
+            roof = {"kernel": "relax_kernel (consistency SDDMM over the sparse store)", "bound": "hbm",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None,
+                    "note": "algorithmic bytes = operands of every (pair,Z) read once (SURVEY.md §8d stage B)"}
+        roof["launches"] = launches
+        roof["avg_launch_ms"] = ms / max(launches, 1)
+        out = {
+            "metric": "sequence-pairs/sec (fwd+bwd+posterior+relax)", "value": npairs * a.steps / el, "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MPCFlat posterior stage: %d synthetic protein seqs L~%d (seed %d), %d pairs, "
+                                   "fwd+bwd+posterior+sparsify+EA + 2 relax iterations" % (a.n, a.len, a.seed, npairs),
+                       "n_seqs": a.n, "mean_len": float(np.mean(lens)), "pairs": npairs,
+                       "stored_posteriors": int(nnz.sum()), "parallelism": "pair-shard x%d" % world},
+            "kernel_ms_per_step": {k: v[0] / a.steps for k, v in timers.items()},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seqs, a.n)
+        print(json.dumps(out))
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,8 @@ int mpcgpu_build_store(mpcgpu_ctx *ctx);
  * all-gather over xGMI on these device pointers — SURVEY.md §8e) --------------------------- */
 /* Size in bytes and device address of this context's packed shard (valid after calc_posteriors). */
 int mpcgpu_shard_info(mpcgpu_ctx *ctx, uint64_t *bytes, void **dev_ptr);
+/* Copy the packed shard (bytes from mpcgpu_shard_info) into caller-owned device memory. */
+int mpcgpu_shard_export(mpcgpu_ctx *ctx, void *dev_dst);
 /* Build the all-pairs store from nshards packed shards laid out back to back in device memory
  * (dev_all; shard s occupies bytes[s] bytes, covers pairs [k0[s],k1[s]), ascending, contiguous,
  * covering [0,pair_count)). dev_all must stay valid until the next set_seqs/destroy. */
@@ -84,6 +86,10 @@ int mpcgpu_store_import(mpcgpu_ctx *ctx, uint32_t nshards, const uint64_t *k0, c
  * slice that cons_iter(k0,k1) writes. The caller all-gathers the slices in place, then commits. */
 int mpcgpu_values_info(mpcgpu_ctx *ctx, void **dev_ptr, uint64_t *total_count);
 int mpcgpu_values_slice(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1, uint64_t *first, uint64_t *count);
+/* Copy count floats starting at canonical entry index `first` out of / into the values array
+ * (caller-owned device memory on the other side) — the staging form of the same exchange. */
+int mpcgpu_values_export(mpcgpu_ctx *ctx, uint64_t first, uint64_t count, void *dev_dst);
+int mpcgpu_values_import(mpcgpu_ctx *ctx, uint64_t first, uint64_t count, const void *dev_src);
 
 /* One consistency iteration for the pair range [k0,k1): replaces MPCFlat::ConsIter
  * (consflat.cpp:5-23) -> ConsPair (conspairflat.cpp:10-110) -> RelaxFlat_{XZ_ZY,ZX_ZY,XZ_YZ}

@@ -17,7 +17,7 @@ KERNEL_FAMILIES = ["fb", "post", "store_build", "relax", "commit"]
 SYMBOLS = [
     "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_version", "mpcgpu_set_hmm",
     "mpcgpu_set_seqs", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
-    "mpcgpu_shard_info", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice",
+    "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
     "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_timers_reset", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize",
@@ -53,6 +53,9 @@ def load(lib_path=None):
     L.mpcgpu_calc_posteriors.argtypes = [vp, u64, u64]
     L.mpcgpu_build_store.argtypes = [vp]
     L.mpcgpu_shard_info.argtypes = [vp, C.POINTER(u64), C.POINTER(vp)]
+    L.mpcgpu_shard_export.argtypes = [vp, vp]
+    L.mpcgpu_values_export.argtypes = [vp, u64, u64, vp]
+    L.mpcgpu_values_import.argtypes = [vp, u64, u64, vp]
     L.mpcgpu_store_import.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mpcgpu_values_info.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.mpcgpu_values_slice.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(u64)]
@@ -127,6 +130,15 @@ class MpcGpu:
         b, p = C.c_uint64(), C.c_void_p()
         self._ck(self.L.mpcgpu_shard_info(self.h, C.byref(b), C.byref(p)))
         return b.value, p.value
+
+    def shard_export(self, dev_ptr):
+        self._ck(self.L.mpcgpu_shard_export(self.h, dev_ptr))
+
+    def values_export(self, first, count, dev_ptr):
+        self._ck(self.L.mpcgpu_values_export(self.h, first, count, dev_ptr))
+
+    def values_import(self, first, count, dev_ptr):
+        self._ck(self.L.mpcgpu_values_import(self.h, first, count, dev_ptr))
 
     def store_import(self, k0s, k1s, nbytes, dev_ptr):
         a, b, c = (np.ascontiguousarray(x, np.uint64) for x in (k0s, k1s, nbytes))

@@ -179,6 +179,25 @@ template <int H> void launch_fb(const FbParams &p, u32 grid, u32 block, size_t s
 	MPC_LAUNCH(HIP_KERNEL_NAME(fb_kernel<H>), grid, block, smem, st, p);
 }
 
+template <int H> int occ_fb(u32 block, size_t smem)
+{
+	int nb = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_kernel<H>, (int)block, smem) != hipSuccess || nb < 1)
+		nb = 1;
+	return nb;
+}
+
+int occ_fb_h(int H, u32 block, size_t smem)
+{
+	switch (H) {
+#define MPC_CASE(h) case h: return occ_fb<h>(block, smem);
+	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
+	MPC_CASE(9) MPC_CASE(10) MPC_CASE(11) MPC_CASE(12) MPC_CASE(13) MPC_CASE(14) MPC_CASE(15) MPC_CASE(16)
+#undef MPC_CASE
+	default: return 1;
+	}
+}
+
 void launch_fb_h(int H, const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
 	switch (H) {
@@ -452,10 +471,9 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 		for (u32 H = 1; H <= MPC_HMAX; ++H) {
 			if (!hcount[H]) continue;
 			const u32 cnt = hcount[H];
-			// resident waves: enough slots to fill the chip (VGPR-limited: ~8 waves/SIMD for small H)
-			const u32 waves_per_cu = H <= 4 ? 32 : (H <= 8 ? 20 : 12);
-			u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block,
-				cus * std::max(1u, waves_per_cu / waves_per_block));
+			// persistent waves: exactly as many workgroups as the chip keeps resident (VGPR-limited)
+			const u32 occ = (u32)occ_fb_h((int)H, block, fb_smem);
+			u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ);
 			grid = std::max(grid, 1u);
 			const u64 fm_stride = (u64)(LYmax + 64) * H * 64;
 			HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
@@ -544,6 +562,16 @@ int mpcgpu_shard_info(mpcgpu_ctx *c, uint64_t *bytes, void **dev_ptr)
 	if (!c->have_shard) return fail(c, "mpcgpu_shard_info: no shard (call mpcgpu_calc_posteriors)");
 	if (bytes) *bytes = c->shard_bytes;
 	if (dev_ptr) *dev_ptr = c->d_shard.p;
+	return 0;
+}
+
+int mpcgpu_shard_export(mpcgpu_ctx *c, void *dev_dst)
+{
+	if (!c) return 1;
+	if (!c->have_shard) return fail(c, "mpcgpu_shard_export: no shard (call mpcgpu_calc_posteriors)");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemcpyAsync(dev_dst, c->d_shard.p, c->shard_bytes, hipMemcpyDeviceToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return 0;
 }
 
@@ -661,6 +689,30 @@ int mpcgpu_values_slice(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, uint64_t *first
 	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_values_slice: bad pair range");
 	if (first) *first = c->h_vbase[k0];
 	if (count) *count = c->h_vbase[k1] - c->h_vbase[k0];
+	return 0;
+}
+
+int mpcgpu_values_export(mpcgpu_ctx *c, uint64_t first, uint64_t count, void *dev_dst)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_values_export: no store");
+	if (first + count > c->total_entries) return fail(c, "mpcgpu_values_export: range out of bounds");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (count)
+		HIPCHK(c, hipMemcpyAsync(dev_dst, c->d_vnext.as<float>() + first, count * 4, hipMemcpyDeviceToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+int mpcgpu_values_import(mpcgpu_ctx *c, uint64_t first, uint64_t count, const void *dev_src)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_values_import: no store");
+	if (first + count > c->total_entries) return fail(c, "mpcgpu_values_import: range out of bounds");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (count)
+		HIPCHK(c, hipMemcpyAsync(c->d_vnext.as<float>() + first, dev_src, count * 4, hipMemcpyDeviceToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return 0;
 }
 

@@ -1,0 +1,121 @@
+"""N>1 host path on CPU: world_size-2 gloo run of muscle_amd.mpcflat.run_stage with a recording
+stand-in for the device engine (the real compute only exists on the GPU). Checks that the pair
+shards tile [0,pairs), that every rank imports the same concatenation of packed shards, and that
+the relaxed values of all ranks reach every rank in canonical order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from muscle_amd.mpcflat import TorchExchange, run_stage, shard_bounds, pair_lengths
+
+
+def test_shard_bounds_tile_and_balance():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(50, 500, size=97)
+    lx, ly = pair_lengths(lens)
+    w = (lx + 1) * (ly + 1)
+    for world in (1, 2, 3, 8):
+        cuts = shard_bounds(lens, world)
+        assert cuts[0] == 0 and cuts[-1] == len(lx) and len(cuts) == world + 1
+        assert all(a <= b for a, b in zip(cuts[:-1], cuts[1:]))
+        loads = [w[a:b].sum() for a, b in zip(cuts[:-1], cuts[1:])]
+        assert max(loads) <= 1.05 * (w.sum() / world) + w.max()
+    assert shard_bounds([10, 10], 8)[-1] == 1  # more ranks than pairs: empty shards allowed
+
+
+class FakeEngine:
+    """Stands in for muscle_amd._lib.MpcGpu on CPU: 'device pointers' are addresses of CPU tensors."""
+
+    def __init__(self, lens):
+        self.lens = lens
+        self.n = len(lens)
+        self.npairs = self.n * (self.n - 1) // 2
+        self.log = []
+        self.nnz = np.arange(self.npairs) % 5 + 1  # entries per pair
+        self.vbase = np.concatenate([[0], np.cumsum(self.nnz)])
+
+    def calc_posteriors(self, k0, k1):
+        self.k0, self.k1 = k0, k1
+        # shard blob: one byte per entry of each pair, value = pair index mod 251
+        self.blob = torch.tensor(np.repeat(np.arange(k0, k1) % 251, self.nnz[k0:k1]).astype(np.uint8))
+
+    def shard_info(self):
+        return int(self.blob.numel()), self.blob.data_ptr()
+
+    def shard_export(self, ptr):
+        import ctypes
+        ctypes.memmove(ptr, self.blob.data_ptr(), self.blob.numel())
+
+    def store_import(self, k0s, k1s, sizes, ptr):
+        import ctypes
+        total = int(sum(sizes))
+        buf = (ctypes.c_ubyte * total).from_address(ptr)
+        self.imported = np.frombuffer(buf, np.uint8).copy()
+        self.cuts = (list(k0s), list(k1s), list(sizes))
+        self.values = np.zeros(int(self.vbase[-1]), np.float32)
+
+    def values_slice(self, k0, k1):
+        return int(self.vbase[k0]), int(self.vbase[k1] - self.vbase[k0])
+
+    def cons_iter(self, k0, k1):
+        self.iter = getattr(self, "iter", 0) + 1
+        f, c = self.values_slice(k0, k1)
+        self.values[f:f + c] = np.arange(f, f + c) + 1000 * self.iter  # only MY slice is fresh
+
+    def values_export(self, first, count, ptr):
+        import ctypes
+        ctypes.memmove(ptr, self.values[first:first + count].ctypes.data, 4 * count)
+
+    def values_import(self, first, count, ptr):
+        import ctypes
+        buf = (ctypes.c_float * count).from_address(ptr)
+        self.values[first:first + count] = np.frombuffer(buf, np.float32)
+
+    def cons_commit(self):
+        self.log.append(self.values.copy())
+
+    def build_store(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = [30, 45, 60, 75, 90, 33, 48]
+    eng = FakeEngine(lens)
+    k0, k1 = run_stage(eng, lens, TorchExchange(dist, "cpu"), torch_mod=torch)
+    q.put((rank, k0, k1, eng.imported, eng.cuts, [v for v in eng.log]))
+    dist.destroy_process_group()
+
+
+def test_run_stage_world2_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, a0, b0, imp0, cuts0, log0), (r1, a1, b1, imp1, cuts1, log1) = res
+    npairs = 21
+    assert a0 == 0 and b0 == a1 and b1 == npairs
+    eng = FakeEngine([30, 45, 60, 75, 90, 33, 48])
+    want = np.repeat(np.arange(npairs) % 251, eng.nnz).astype(np.uint8)
+    assert np.array_equal(imp0, want) and np.array_equal(imp1, want)
+    assert cuts0 == cuts1
+    total = int(eng.vbase[-1])
+    assert len(log0) == 2 and len(log1) == 2
+    for it in (1, 2):
+        expect = np.arange(total, dtype=np.float32) + 1000 * it
+        assert np.array_equal(log0[it - 1], expect) and np.array_equal(log1[it - 1], expect)
