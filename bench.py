@@ -61,8 +61,9 @@ def cpu_baseline(seqs, n_full, budget_s=20.0):
     ConsIter, OpenMP over all host cores) on a bounded sample of the same family, extrapolated to
     the full N: stage A scales per pair, relax per (pair,Z) triple. Falls back to the C oracle
     ("port") if the compiled reference is not shipped."""
-    cores = os.cpu_count() or 1
-    n_s = 24
+    from muscle_amd.hostinfo import usable_cores
+    cores = usable_cores()
+    n_s = min(len(seqs), 128)  # ~170 core-seconds of stage A at L~400: 10-30 s on a 8-16 core quota
     sample = seqs[:n_s]
     np_s = n_s * (n_s - 1) // 2
     try:
@@ -105,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
+    from muscle_amd.hostinfo import pin_openmp_team
+    pin_openmp_team()
     import torch
     import torch.distributed as dist
     from muscle_amd._lib import MpcGpu
@@ -188,7 +191,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seqs, a.n)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     g.close()
     if world > 1:
         dist.destroy_process_group()

@@ -74,10 +74,14 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 	const int A = p.A;
 
 	for (;;) {
-		u32 qi = 0;
-		if (t == 0)
-			qi = atomicAdd(p.queue, 1u);
-		qi = __shfl(qi, 0);
+		// Work queue: lane 0 adds 1, the other lanes add 0 (branch-free; the compiler's atomic optimizer
+		// folds the wave into one atomic), and lane 0's return value — the grab index — is broadcast
+		// through readfirstlane so that it and everything derived from it (pair id, lengths, trip
+		// counts) is wave-uniform in SGPRs and the loop exit is a scalar branch. Do NOT rewrite this as
+		// `if (lane == 0) atomicAdd` + shuffle: a lane-dependent branch at the head of a loop that
+		// contains wave shuffles gets rotated into two back edges and the lanes lose reconvergence
+		// (observed on gfx950: lanes 1..63 spin forever).
+		const u32 qi = mpc_wave_first(atomicAdd(p.queue, t == 0 ? 1u : 0u));
 		if (qi >= p.count)
 			break;
 		const u32 pid = p.order[qi];

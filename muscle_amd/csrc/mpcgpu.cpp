@@ -124,9 +124,19 @@ int fail(mpcgpu_ctx *c, const char *fmt, ...)
 			return fail((c), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
 	} while (0)
 
+// MPCGPU_TRACE=1: every timed span is synchronised and reported on stderr as it completes
+// (diagnostics only: serialises the stream).
+bool trace_on()
+{
+	static int on = -1;
+	if (on < 0) { const char *s = getenv("MPCGPU_TRACE"); on = (s && *s && *s != '0') ? 1 : 0; }
+	return on == 1;
+}
+
 int span_begin(mpcgpu_ctx *c, int fam, TimedSpan *sp)
 {
 	sp->fam = fam;
+	if (trace_on()) { fprintf(stderr, "[mpcgpu] launch family %d ...\n", fam); fflush(stderr); }
 	HIPCHK(c, hipEventCreate(&sp->a));
 	HIPCHK(c, hipEventCreate(&sp->b));
 	HIPCHK(c, hipEventRecord(sp->a, c->stream));
@@ -137,6 +147,13 @@ int span_end(mpcgpu_ctx *c, TimedSpan *sp)
 	HIPCHK(c, hipEventRecord(sp->b, c->stream));
 	c->spans.push_back(*sp);
 	c->launches[sp->fam] += 1;
+	if (trace_on()) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		float t = 0;
+		HIPCHK(c, hipEventElapsedTime(&t, sp->a, sp->b));
+		fprintf(stderr, "[mpcgpu] family %d done: %.3f ms\n", sp->fam, t);
+		fflush(stderr);
+	}
 	return 0;
 }
 int spans_collect(mpcgpu_ctx *c)
@@ -477,6 +494,11 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 			grid = std::max(grid, 1u);
 			const u64 fm_stride = (u64)(LYmax + 64) * H * 64;
 			HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
+			if (trace_on()) {
+				fprintf(stderr, "[mpcgpu] fb H=%u pairs=%u grid=%u block=%d occ=%u capc=%u batch=%llu fm=%.1f MB\n", H, cnt, grid,
+					block, occ, capc, B, (double)grid * waves_per_block * fm_stride * 4 / 1048576.0);
+				fflush(stderr);
+			}
 			fp.order = c->d_order.as<u32>() + pos; fp.count = cnt;
 			fp.queue = c->d_queue.as<u32>() + H;
 			fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride;

@@ -1,19 +1,18 @@
 #!/bin/bash
-# One gpurun call: GPU parity tests, smoke, a short bench and a rocprofv3 kernel trace.
-# Usage (from the repo root, on the GPU box): bash scripts/gpu_check.sh [N] [LEN] [STEPS]
+# One gpurun call: gated first-light checks, smoke, benches, rocprofv3 kernel trace, GPU parity tests.
+# Every step has its own timeout and is logged unbuffered to gpurun_out/check.log.
 set -u
-N=${1:-1000}; LEN=${2:-400}; STEPS=${3:-2}
-OUT=gpurun_out; mkdir -p $OUT
-export TMPDIR=/tmp
-echo "== rocm-smi"; rocm-smi --showproductname 2>/dev/null | head -8; nproc; lscpu | grep "Model name"
-echo "== pytest -m gpu"
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest_gpu.log
-echo "== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.log
-echo "== bench small (256x300)"
-timeout 600 python bench.py --n 256 --len 300 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -2 | tee $OUT/bench_256x300.json
-echo "== bench ${N}x${LEN}"
-timeout 1500 python bench.py --n $N --len $LEN --steps $STEPS --warmup 1 2>&1 | tail -2 | tee $OUT/bench_${N}x${LEN}.json
-echo "== rocprofv3 kernel trace (256x300)"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_256 -o r1 -- python $GRAFT_REPO_ROOT/bench.py --n 256 --len 300 --steps 2 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_256.log 2>&1 )
-find $OUT/prof_256 -name "*stats*" | head; for f in $(find $OUT/prof_256 -name "*kernel_stats*csv" | head -1); do head -20 $f; done
+OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/check.log; : > $LOG
+R=${GRAFT_REPO_ROOT:-$PWD}
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+step() { echo "=== $* (t=$SECONDS)" | tee -a $LOG; "$@" 2>&1 | tee -a $LOG | tail -25; rc=${PIPESTATUS[0]}; echo "=== rc=$rc (t=$SECONDS)" | tee -a $LOG; return $rc; }
+MPCGPU_TRACE=1 step timeout 40 python -u diag/step.py 2 5 || exit 10
+MPCGPU_TRACE=1 DIAG_DUMP_AFTER=80 step timeout 90 python -u diag/step.py 12 180 oracle || exit 11
+step timeout 90 python -u -c "import __graft_entry__ as g; g.smoke()"
+step timeout 150 python -u bench.py --n 256 --len 300 --steps 2 --warmup 1 --no-cpu-baseline
+tail -1 $LOG > /dev/null
+step timeout 320 python -u bench.py --n 1000 --len 400 --steps 1 --warmup 1
+( cd /tmp && step timeout 260 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_1000 -o r1 -- python -u $R/bench.py --n 1000 --len 400 --steps 1 --warmup 1 --no-cpu-baseline ) 2>&1 | tail -5
+find $OUT/prof_1000 -name "*stats*" | head; for f in $(find $OUT/prof_1000 -name "*kernel_stats*csv" | head -1); do head -20 $f | tee -a $LOG; done
+find $OUT/prof_1000 -name "*kernel_trace.csv" -size +20M -delete
+step timeout 420 python -u -m pytest tests -m gpu -x -q
