@@ -1,0 +1,221 @@
+// kernels_relax.h — consistency relax, LDS-tiled ("relax_tile_kernel").
+//
+// Replaces MPCFlat::ConsPair (conspairflat.cpp:10-110) -> RelaxFlat_{XZ_ZY,ZX_ZY,XZ_YZ}
+// (relaxflat.cpp:4-94) -> MySparseMx::UpdateFromPost (mysparsemx.cpp:87-113) for a TILE of pairs
+// at a time. Same arithmetic as relax_kernel (kernels_store.h): per stored cell (x,y) of (X,Y)
+//     acc = 2*P_XY(x,y);  for Z = 0..N-1: acc += sum_z M(X,Z)(x,z) * M(Y,Z)(y,z)  (z ascending)
+//     P'  = acc / N
+// product rounded, then added (no FMA), Z ascending, z ascending: bit-identical to the reference.
+//
+// Why a tile. One cell-per-thread gather (relax_kernel) re-reads M(X,Z) for every Y and M(Y,Z)
+// for every X: 2 matrices (~16 KB at L=400, r=2) per (pair,Z), ~8 TB per iteration at N=1000, all
+// of it as short latency-bound gathers. Here a workgroup of 1024 threads owns the pairs
+// {X in [x0,x0+nx)} x {Y in [y0,y0+ny)}, X<Y (nx,ny <= 4, <= 16 register "slots" of 1024 cells)
+// and walks Z = 0..N-1 once: for every Z the nx+ny matrices M(S,Z) (row pointers + entries, both
+// contiguous in the slab layout) are streamed with wide coalesced loads into LDS and every pair of
+// the tile is served from LDS — (nx+ny)/(nx*ny) = 0.5 matrices per (pair,Z) instead of 2, and the
+// loads of step Z+1 are in flight (staged in registers) while step Z is computed. Accumulators
+// and cell coordinates stay in VGPRs for the whole walk. The host orders the tile list in 8x8
+// super-tiles and deals consecutive tiles to the same XCD (block b runs on XCD b % 8), so the
+// workgroups sharing an L2 read the same 64 sequences' slabs at about the same Z.
+#pragma once
+#include "kernels_store.h"
+
+#define MPC_RT_THREADS 1024
+#define MPC_RT_SLOTS 16
+
+struct RelaxTileParams {
+	StoreParams s;
+	const u32 *tiles; // 4 u32 per tile: x0, nx, y0, ny
+	u32 ntiles;
+	u32 lcap1;  // LDS dwords reserved per matrix for row pointers (>= Lmax+1, even)
+	u32 ecap;   // LDS entries reserved per matrix
+	u64 k0, k1; // only pairs in [k0,k1) are relaxed (multi-GPU shard)
+};
+
+// MAXSEQ: matrices resident per step; NRP: row-pointer dwords staged per thread per matrix
+// (lcap1 <= NRP*1024); NENT: entries staged per thread per matrix (ecap <= NENT*1024), also the
+// slots one pair may take (nnz <= NENT*1024).
+template <int MAXSEQ, int NRP, int NENT>
+__global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTileParams p)
+{
+	MPC_DYN_SMEM(smem_raw);
+	const StoreParams &s = p.s;
+	const u32 tid = threadIdx.x;
+	const u32 n = s.n;
+	const u32 mat_dwords = p.lcap1 + 2 * p.ecap;
+	u32 *lds = (u32 *)smem_raw;
+
+	// XCD-aware static schedule: the tile list is cut into 8 contiguous ranges, one per XCD
+	// (block b is placed on XCD b % 8 — affinity only, any placement is correct); the workgroups of
+	// one XCD walk their range round-robin, so at any time they sit on consecutive tiles.
+	const u32 G = gridDim.x < 8u ? gridDim.x : 8u;
+	const u32 xcd = blockIdx.x % G, lb = blockIdx.x / G, per_xcd = (gridDim.x - xcd + G - 1u) / G;
+	const u32 chunk = (p.ntiles + G - 1u) / G;
+	const u32 t_begin = xcd * chunk, t_end = (t_begin + chunk < p.ntiles) ? t_begin + chunk : p.ntiles;
+
+	for (u32 tl = t_begin + lb; tl < t_end; tl += per_xcd) {
+		const u32 x0 = p.tiles[4 * tl], nx = p.tiles[4 * tl + 1], y0 = p.tiles[4 * tl + 2], ny = p.tiles[4 * tl + 3];
+		// resident sequences: the X range, then the part of the Y range not already in it
+		u32 seq[MAXSEQ];
+		u32 nseq = 0;
+#pragma unroll
+		for (int i = 0; i < MAXSEQ; ++i) seq[i] = 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			if ((u32)i < nx && nseq < (u32)MAXSEQ) {
+#pragma unroll
+				for (int q = 0; q < MAXSEQ; ++q) if ((u32)q == nseq) seq[q] = x0 + i;
+				++nseq;
+			}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const u32 Y = y0 + i;
+			if ((u32)i < ny && !(Y >= x0 && Y < x0 + nx) && nseq < (u32)MAXSEQ) {
+#pragma unroll
+				for (int q = 0; q < MAXSEQ; ++q) if ((u32)q == nseq) seq[q] = Y;
+				++nseq;
+			}
+		}
+		// ---- slots: (pair, 1024-cell chunk) -> this thread's cell, accumulator, LDS matrix slots.
+		// The enumeration order is a pure function of the tile, so the epilogue repeats it instead of
+		// keeping 16 entry indices alive in registers through the Z walk.
+		float acc[MPC_RT_SLOTS];
+		u32 xy[MPC_RT_SLOTS];    // (x << 16) | y ; 0xffffffff = no cell
+		u32 sl_ab[MPC_RT_SLOTS]; // wave-uniform: (lds matrix of X) | (lds matrix of Y) << 8 ; 0xffff = unused slot
+#pragma unroll
+		for (int q = 0; q < MPC_RT_SLOTS; ++q) { acc[q] = 0.0f; xy[q] = 0xffffffffu; sl_ab[q] = 0xffffu; }
+		auto for_each_slot = [&](auto &&fn) {
+			u32 slot = 0;
+			for (u32 ix = 0; ix < nx; ++ix) {
+				for (u32 iy = 0; iy < ny; ++iy) {
+					const u32 X = x0 + ix, Y = y0 + iy;
+					if (X >= Y) continue;
+					const u64 k = mpc_pair_index(n, X, Y);
+					if (k < p.k0 || k >= p.k1) continue;
+					const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+					// LDS matrix slots of X and Y
+					u32 mb = 0;
+					if (Y >= x0 && Y < x0 + nx) mb = Y - x0;
+					else {
+						u32 before = 0; // Y's rank among the Y-range sequences that are not in the X range
+						for (u32 j = 0; j < iy; ++j) { const u32 Yj = y0 + j; if (!(Yj >= x0 && Yj < x0 + nx)) ++before; }
+						mb = nx + before;
+					}
+					for (u32 c0 = 0; c0 < nnz; c0 += MPC_RT_THREADS) {
+						fn(slot, k, X, Y, nnz, c0 + tid, ix | (mb << 8));
+						++slot;
+					}
+				}
+			}
+		};
+		for_each_slot([&](u32 slot, u64 k, u32 X, u32 Y, u32 nnz, u32 idx, u32 ab) {
+			const u32 *ent = s.packed + s.pbase[k] + s.seq_len[X] + s.seq_len[Y];
+			float a0 = 0.0f;
+			u32 c = 0xffffffffu;
+			if (idx < nnz) {
+				a0 = __uint_as_float(ent[2 * (u64)idx]) * 2.0f; // conspairflat.cpp:29-30
+				c = (ent[2 * (u64)nnz + idx] << 16) | ent[2 * (u64)idx + 1];
+			}
+#pragma unroll
+			for (int q = 0; q < MPC_RT_SLOTS; ++q)
+				if ((u32)q == slot) { acc[q] = a0; xy[q] = c; sl_ab[q] = ab; }
+		});
+
+		// ---- walk Z with register-staged prefetch
+		u32 st_rp[MAXSEQ][NRP];
+		u32 st_e0[MAXSEQ][NENT], st_e1[MAXSEQ][NENT];
+		u32 st_base[MAXSEQ]; // slab-relative entry offset of M(seq[i], Z) (wave-uniform)
+		auto stage_load = [&](u32 Z) {
+#pragma unroll
+			for (int i = 0; i < MAXSEQ; ++i) {
+				if ((u32)i < nseq) {
+					const u32 A = seq[i];
+					const u32 LA = s.seq_len[A];
+					const u32 *rp = s.rp + s.rp_base[A] + (u64)Z * (LA + 1);
+					const u32 e0 = s.mbase[(u64)A * (n + 1) + Z], e1 = s.mbase[(u64)A * (n + 1) + Z + 1];
+					const MpcEnt *ent = s.ent + s.ent_base[A] + e0;
+					st_base[i] = e0;
+#pragma unroll
+					for (int r = 0; r < NRP; ++r) {
+						const u32 q = tid + r * MPC_RT_THREADS;
+						st_rp[i][r] = (q <= LA) ? rp[q] : 0u;
+					}
+#pragma unroll
+					for (int r = 0; r < NENT; ++r) {
+						const u32 q = tid + r * MPC_RT_THREADS;
+						MpcEnt v; v.p = 0; v.c = 0;
+						if (q < e1 - e0) v = ent[q];
+						st_e0[i][r] = v.p; st_e1[i][r] = v.c;
+					}
+				}
+			}
+		};
+		auto stage_store = [&]() {
+#pragma unroll
+			for (int i = 0; i < MAXSEQ; ++i) {
+				if ((u32)i < nseq) {
+					u32 *m = lds + (u32)i * mat_dwords;
+#pragma unroll
+					for (int r = 0; r < NRP; ++r) {
+						const u32 q = tid + r * MPC_RT_THREADS;
+						if (q < p.lcap1) m[q] = st_rp[i][r] - st_base[i]; // LDS-relative entry index
+					}
+					MpcEnt *me = (MpcEnt *)(m + p.lcap1);
+#pragma unroll
+					for (int r = 0; r < NENT; ++r) {
+						const u32 q = tid + r * MPC_RT_THREADS;
+						if (q < p.ecap) { MpcEnt v; v.p = st_e0[i][r]; v.c = st_e1[i][r]; me[q] = v; }
+					}
+				}
+			}
+		};
+
+		stage_load(0);
+		for (u32 Z = 0; Z < n; ++Z) {
+			__syncthreads(); // every wave is done reading step Z-1 from LDS
+			stage_store();
+			__syncthreads();
+			if (Z + 1 < n) stage_load(Z + 1); // in flight while step Z is computed
+#pragma unroll
+			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
+				if (sl_ab[q] != 0xffffu) { // wave-uniform
+					const u32 *ma = lds + (sl_ab[q] & 0xffu) * mat_dwords;
+					const u32 *mb = lds + (sl_ab[q] >> 8) * mat_dwords;
+					if (xy[q] != 0xffffffffu) {
+						const u32 x = xy[q] >> 16, y = xy[q] & 0xffffu;
+						u32 a = ma[x], a1 = ma[x + 1];
+						u32 b = mb[y], b1 = mb[y + 1];
+						if (a != a1 && b != b1) {
+							// lcap1 is even and the LDS base 16-byte aligned: entries are 8-byte aligned (ds_read_b64)
+							const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(ma + p.lcap1, 8);
+							const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(mb + p.lcap1, 8);
+							// Branch-free merge of the two sorted rows: one LDS read per side per step, the
+							// product is added only on a column match (the sum is otherwise left untouched, so
+							// the rounding sequence is exactly the reference's: relaxflat.cpp:27, w == 1.0f).
+							float sum = acc[q];
+							do {
+								const MpcEnt va = ea[a], vb = eb[b];
+								const float prod = __uint_as_float(va.p) * __uint_as_float(vb.p);
+								const float added = sum + prod;
+								sum = (va.c == vb.c) ? added : sum;
+								a += (va.c <= vb.c) ? 1u : 0u;
+								b += (vb.c <= va.c) ? 1u : 0u;
+							} while (a < a1 && b < b1);
+							acc[q] = sum;
+						}
+					}
+				}
+			}
+		}
+		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern
+		for_each_slot([&](u32 slot, u64 k, u32, u32, u32 nnz, u32 idx, u32) {
+			float v = 0.0f;
+#pragma unroll
+			for (int q = 0; q < MPC_RT_SLOTS; ++q)
+				if ((u32)q == slot) v = acc[q];
+			if (idx < nnz) s.vnext[s.vbase[k] + idx] = v / (float)n; // uint -> float, IEEE divide (mysparsemx.cpp:108)
+		});
+		__syncthreads();
+	}
+}

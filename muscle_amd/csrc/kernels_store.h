@@ -19,7 +19,7 @@
 #pragma once
 #include "device_math.h"
 
-struct MpcEnt { u32 p; u32 c; }; // {float bits, column}: MySparseMx entry layout (mysparsemx.h:56-82)
+struct __attribute__((aligned(8))) MpcEnt { u32 p; u32 c; }; // {float bits, column}: MySparseMx entry layout (mysparsemx.h:56-82)
 
 struct StoreParams {
 	u32 n;
@@ -35,7 +35,7 @@ struct StoreParams {
 	const u64 *rp_base; // n+1
 	MpcEnt *ent;
 	const u64 *ent_base; // n+1
-	const u32 *mbase;    // n*n, entry offset of M(A,Z) inside slab A
+	const u32 *mbase;    // n*(n+1): entry offset of M(A,Z) inside slab A at [A*(n+1)+Z]; [..+n] = slab size
 	// values of the next iteration, canonical order
 	float *vnext;
 };
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(64) slab_build_kernel(StoreParams s)
 		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
 		const u32 LA = s.seq_len[A];
 		u32 *rp = s.rp + s.rp_base[A] + (u64)Z * (LA + 1);
-		const u32 mb = s.mbase[(u64)A * s.n + Z];
+		const u32 mb = s.mbase[(u64)A * (s.n + 1) + Z];
 		if (A == Z) {
 			for (u32 a = t; a <= LA; a += 64) rp[a] = mb;
 			continue;
@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(256) commit_kernel(StoreParams s)
 		const u32 pb = __float_as_uint(s.vnext[e]);
 		const u32 tq = ent[3 * (u64)nnz + idx];
 		ent[2 * (u64)idx] = pb;
-		s.ent[s.ent_base[X] + s.mbase[(u64)X * s.n + Y] + idx].p = pb;
-		s.ent[s.ent_base[Y] + s.mbase[(u64)Y * s.n + X] + tq].p = pb;
+		s.ent[s.ent_base[X] + s.mbase[(u64)X * (s.n + 1) + Y] + idx].p = pb;
+		s.ent[s.ent_base[Y] + s.mbase[(u64)Y * (s.n + 1) + X] + tq].p = pb;
 	}
 }
 

@@ -5,6 +5,7 @@
 #include "kernels_fb.h"
 #include "kernels_post.h"
 #include "kernels_store.h"
+#include "kernels_relax.h"
 
 #include <algorithm>
 #include <climits>
@@ -92,6 +93,8 @@ struct mpcgpu_ctx {
 	std::vector<float> all_ea;
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
+	u32 max_nnz = 0, max_len = 0;
+	DevBuf d_tiles;
 
 	// scratch
 	DevBuf d_queue, d_order, d_bx, d_by, d_fm, d_cand, d_cand_cnt, d_total, d_res, d_nnz, d_ea, d_flags,
@@ -248,6 +251,82 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.vnext = c->d_vnext.as<float>();
 }
 
+template <int MS, int R, int E> void launch_relax_tile(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
+{
+	auto kern = relax_tile_kernel<MS, R, E>;
+	MPC_LAUNCH(kern, grid, MPC_RT_THREADS, smem, st, rp);
+}
+
+// LDS-tiled relax (kernels_relax.h) when the matrices of a tile fit the CU's 160 KiB LDS; returns
+// 0 = launched, 1 = error, 2 = not applicable (caller uses the gather kernel).
+int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
+{
+	const u32 n = c->n;
+	if (c->max_len > 65535u) return 2; // cell coordinates are packed 16:16
+	int nrp, nent;
+	if (c->max_len + 1 <= 1024) nrp = 1; else if (c->max_len + 1 <= 2048) nrp = 2; else return 2;
+	if (c->max_nnz <= 1024) nent = 1; else if (c->max_nnz <= 2048) nent = 2; else if (c->max_nnz <= 4096) nent = 4; else return 2;
+	const u32 lcap1 = (c->max_len + 2) & ~1u; // >= Lmax+1, even (entries stay 8-byte aligned in LDS)
+	const u32 ecap = std::max<u32>(c->max_nnz, 1);
+	const u64 mat_bytes = ((u64)lcap1 + 2 * (u64)ecap) * 4;
+	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", 160) * 1024;
+	// tile shape: nx*ny*nent <= 16 slots, (nx+ny) matrices resident
+	static const u32 shapes[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+	u32 bx = 0, by = 0;
+	for (auto &sh : shapes)
+		if (sh[0] * sh[1] * (u32)nent <= MPC_RT_SLOTS && (sh[0] + sh[1]) * mat_bytes <= lds_cap) { bx = sh[0]; by = sh[1]; break; }
+	if (!bx) return 2;
+	const int maxseq = nent == 1 ? 8 : (nent == 2 ? 6 : 4);
+	if ((int)(bx + by) > maxseq) return 2;
+	// tile list: X blocks of bx, Y blocks of by, in 8x8 super-tiles; only tiles with a pair in [k0,k1)
+	std::vector<u32> tiles;
+	const u32 nbx = (n + bx - 1) / bx, nby = (n + by - 1) / by;
+	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
+	for (u32 sx = 0; sx < nbx; sx += 8)
+		for (u32 sy = 0; sy < nby; sy += 8)
+			for (u32 xb = sx; xb < std::min(sx + 8, nbx); ++xb)
+				for (u32 yb = sy; yb < std::min(sy + 8, nby); ++yb) {
+					const u32 x0 = xb * bx, nx = std::min(bx, n - x0), y0 = yb * by, ny = std::min(by, n - y0);
+					bool any = false;
+					for (u32 X = x0; X < x0 + nx && !any; ++X)
+						for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
+							const u64 k = pidx(X, Y);
+							if (k >= k0 && k < k1 && c->all_nnz[k] > 0) { any = true; break; }
+						}
+					if (any) { tiles.push_back(x0); tiles.push_back(nx); tiles.push_back(y0); tiles.push_back(ny); }
+				}
+	if (tiles.empty()) return 0;
+	if (upload(c, c->d_tiles, tiles)) return 1;
+	RelaxTileParams rp;
+	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
+	rp.lcap1 = lcap1; rp.ecap = ecap; rp.k0 = k0; rp.k1 = k1;
+	const size_t smem = (size_t)(bx + by) * mat_bytes;
+	const void *fn = nullptr;
+#define MPC_RT_CASE(ms, r, e) if (maxseq == ms && nrp == r && nent == e) fn = (const void *)relax_tile_kernel<ms, r, e>;
+	MPC_RT_CASE(8, 1, 1) MPC_RT_CASE(8, 2, 1) MPC_RT_CASE(6, 1, 2) MPC_RT_CASE(6, 2, 2) MPC_RT_CASE(4, 1, 4) MPC_RT_CASE(4, 2, 4)
+#undef MPC_RT_CASE
+	if (!fn) return 2;
+	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	int occ = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, MPC_RT_THREADS, smem) != hipSuccess || occ < 1) occ = 1;
+	u32 grid = std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ);
+	grid = std::max(grid, 1u);
+	if (trace_on()) {
+		fprintf(stderr, "[mpcgpu] relax tiled: tiles=%u shape=%ux%u nrp=%d nent=%d lds=%zu B occ=%d grid=%u\n", rp.ntiles, bx, by,
+			nrp, nent, smem, occ, grid);
+		fflush(stderr);
+	}
+	TimedSpan ts;
+	if (span_begin(c, 3, &ts)) return 1;
+#define MPC_RT_CASE(ms, r, e) \
+	if (maxseq == ms && nrp == r && nent == e) launch_relax_tile<ms, r, e>(rp, grid, smem, c->stream);
+	MPC_RT_CASE(8, 1, 1) MPC_RT_CASE(8, 2, 1) MPC_RT_CASE(6, 1, 2) MPC_RT_CASE(6, 2, 2) MPC_RT_CASE(4, 1, 4) MPC_RT_CASE(4, 2, 4)
+#undef MPC_RT_CASE
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts)) return 1;
+	return 0;
+}
+
 } // namespace
 
 extern "C" {
@@ -296,7 +375,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_shard, &c->d_pbase, &c->d_vbase, &c->d_rp, &c->d_rp_base, &c->d_ent, &c->d_ent_base, &c->d_mbase,
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
-		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase};
+		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles};
 	for (DevBuf *b : all) b->release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -641,9 +720,13 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	c->h_pbase[c->npairs] = byte_off / 4;
 	for (u64 k = 0; k < c->npairs; ++k) c->h_vbase[k + 1] = c->h_vbase[k] + c->all_nnz[k];
 	c->total_entries = c->h_vbase[c->npairs];
+	c->max_nnz = 0;
+	for (u64 k = 0; k < c->npairs; ++k) c->max_nnz = std::max(c->max_nnz, c->all_nnz[k]);
+	c->max_len = 0;
+	for (u32 i = 0; i < n; ++i) c->max_len = std::max(c->max_len, c->len[i]);
 	c->st_packed = (const u32 *)dev_all;
 	// ---- slab geometry: per ordered pair entry counts -> mbase (within slab), slab bases
-	std::vector<u32> mbase((size_t)n * n, 0);
+	std::vector<u32> mbase((size_t)n * (n + 1), 0);
 	std::vector<u64> ent_base(n + 1, 0), rp_base(n + 1, 0);
 	{
 		std::vector<u64> slab(n, 0);
@@ -652,13 +735,15 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 			u64 run = 0;
 			for (u32 Z = 0; Z < n; ++Z) {
 				if (run > 0xffffffffull) return fail(c, "mpcgpu_store_import: slab of sequence %u exceeds 2^32 entries", A);
-				mbase[(size_t)A * n + Z] = (u32)run;
+				mbase[(size_t)A * (n + 1) + Z] = (u32)run;
 				if (Z != A) {
 					const u64 k = A < Z ? (u64)A * n - ((u64)A * (A + 1)) / 2 + (Z - A - 1)
 					                    : (u64)Z * n - ((u64)Z * (Z + 1)) / 2 + (A - Z - 1);
 					run += c->all_nnz[k];
 				}
 			}
+			if (run > 0xffffffffull) return fail(c, "mpcgpu_store_import: slab of sequence %u exceeds 2^32 entries", A);
+			mbase[(size_t)A * (n + 1) + n] = (u32)run;
 			slab[A] = run;
 		}
 		for (u32 A = 0; A < n; ++A) {
@@ -749,6 +834,13 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	if (cnt == 0) return 0;
 	StoreParams sp;
 	fill_store_params(c, sp);
+	// MPCGPU_RELAX=gather forces the one-cell-per-thread gather kernel (also the path for sequences
+	// whose matrices do not fit the LDS tile); both are device kernels with identical results.
+	const char *mode = getenv("MPCGPU_RELAX");
+	if (!(mode && !strcmp(mode, "gather"))) {
+		const int rc = relax_tiled(c, sp, k0, k1);
+		if (rc != 2) return rc;
+	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
 	const u32 block = 256;

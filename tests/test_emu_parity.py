@@ -40,3 +40,41 @@ def test_emu_multirow_lanes(emu):
     # LX > 64 -> H = 2..3 rows per lane, several lanes idle at the tail
     seqs = make_family(3, 150, seed=4)
     P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "H>1")
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_emu_relax_many_tiles(emu):
+    # 11 sequences -> 3x3 blocks of 4: diagonal, off-diagonal and ragged edge tiles of the LDS-tiled relax
+    seqs = make_family(11, 26, seed=5)
+    want = P.run_oracle(seqs)
+    P.assert_same(P.run_lib(seqs, lib_path=emu), want, "tiled 4x4")
+    P.assert_same(_with_env({"MPCGPU_RELAX": "gather"}, lambda: P.run_lib(seqs, lib_path=emu)), want, "gather")
+
+
+@pytest.mark.parametrize("lds_kb", [3, 2, 1])
+def test_emu_relax_small_lds_shapes(emu, lds_kb):
+    # a tiny LDS budget forces the 4x2 / 2x2 / 2x1 / 1x1 tile shapes (or the gather fallback)
+    seqs = make_family(7, 24, seed=6)
+    got = _with_env({"MPCGPU_RELAX_LDS_KB": str(lds_kb)}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "lds %d KB" % lds_kb)
+
+
+def test_emu_relax_two_slots_per_pair(emu):
+    # nnz > 1024 -> NENT = 2: one pair spans two register slots, matrices are staged in two passes
+    # (low-complexity repeats spread the posterior over many diagonals: ~3.5 stored cells per row)
+    seqs = ["AC" * 165, "AC" * 162 + "A", "CA" * 164]
+    stages, ea = P.run_lib(seqs, lib_path=emu)
+    assert max(len(v) // 2 for _, v in stages[0]) > 1024
+    P.assert_same((stages, ea), P.run_oracle(seqs), "nent=2")
