@@ -1,0 +1,36 @@
+#!/bin/bash
+# Builds hostcxx/_build/muscle_gpu: the reference's own `muscle` with the MI355X posterior stage
+# linked in as a drop-in. Needs the reference objects that oracle/build_ref.sh
+# compiles from the sources where they lie ($MUSCLE_REF_SRC, default /root/reference/src) — nothing
+# of the reference is copied into the repo, and the combined (GPL-3.0) binary is git-ignored; it
+# travels to the GPU box as a built artefact.
+#
+#   reference objects  - consflat.o                      (MPCFlat::ConsIter is ours)
+#                      - calcposteriorflat.o's CalcPosterior symbol, weakened with objcopy so that
+#                        hostcxx/mpcflat_gpu.cpp's strong definition wins while CalcPostFlat and the
+#                        two vestigial virtuals in the same object stay available
+#   + hostcxx/mpcflat_gpu.cpp (g++, against the reference headers) + -lmpcgpu
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(dirname "$HERE")"
+SRC="${MUSCLE_REF_SRC:-/root/reference/src}"
+REFOBJ="$ROOT/oracle/_ref/obj"
+OUT="$HERE/_build"
+if [ ! -d "$SRC" ] || [ ! -d "$REFOBJ" ]; then
+  echo "build_muscle_gpu.sh: reference sources/objects not available (run oracle/build_ref.sh where /root/reference exists) - skipping" >&2
+  exit 0
+fi
+mkdir -p "$OUT"
+CXXFLAGS="-std=c++17 -O3 -fopenmp -DNDEBUG -pthread -fPIC -w -I$ROOT/oracle/_ref/inc -I$SRC -I$ROOT/include"
+g++ $CXXFLAGS -c "$HERE/mpcflat_gpu.cpp" -o "$OUT/mpcflat_gpu.o"
+objcopy --weaken-symbol=_ZN7MPCFlat13CalcPosteriorEj "$REFOBJ/calcposteriorflat.o" "$OUT/calcposteriorflat_weak.o"
+OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/consflat\.o$' -e '/calcposteriorflat\.o$')
+# The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
+# MPCGPU_LIBDIR/MPCGPU_LIBNAME pointing at the SIMT-emulator build of the same library sources
+# (tests/emu, test infrastructure) to check the host-side plumbing of this file without a GPU.
+LIBDIR="${MPCGPU_LIBDIR:-$ROOT/muscle_amd/csrc}"
+LIBNAME="${MPCGPU_LIBNAME:-mpcgpu}"
+BIN="${MPCGPU_BIN:-muscle_gpu}"
+g++ -O3 -fopenmp -pthread $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/mpcflat_gpu.o" \
+  -L"$LIBDIR" -l"$LIBNAME" -Wl,-rpath,"$LIBDIR" -Wl,-rpath,'$ORIGIN/../../muscle_amd/csrc' -Wl,-rpath,/opt/rocm/lib -o "$OUT/$BIN"
+echo "built: $OUT/$BIN"

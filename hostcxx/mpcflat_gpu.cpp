@@ -1,0 +1,183 @@
+// hostcxx/mpcflat_gpu.cpp — link-time drop-in that makes an UNMODIFIED mpcflat.{h,cpp} consume
+// the MI355X path (include/mpcgpu.h, libmpcgpu.so).
+//
+// The reference (rcedgar/muscle 5.3) has no plugin API; its seam is one numeric function per
+// translation unit. This file is compiled against the reference's own headers
+// (-I<muscle>/src, nothing copied) and defines the two MPCFlat members that own the hot loops:
+//
+//   MPCFlat::CalcPosterior(uint)   replaces calcposteriorflat.cpp:45-92  (called from the OpenMP loop
+//                                  of MPCFlat::CalcPosteriors, mpcflat.cpp:239-251)
+//   MPCFlat::ConsIter(uint)        replaces consflat.cpp:5-23            (called per iteration from
+//                                  MPCFlat::Consistency, mpcflat.cpp:173-181)
+//
+// Build: every reference object except consflat.o, calcposteriorflat.o with its CalcPosterior
+// symbol weakened (the same object also defines CalcPostFlat and the two vestigial virtuals that
+// other translation units / the vtable need), plus this file, plus -lmpcgpu
+// (hostcxx/build_muscle_gpu.sh; INTEGRATION.md shows the two-line change a maintainer would make
+// in the source tree instead of the objcopy step).
+//
+// There is no CPU path in here: if libmpcgpu cannot create a device context the run Die()s, like
+// every other fatal condition in the reference (myutils.cpp:883-927).
+#include "muscle.h"
+#include "mpcflat.h"
+#include "pairhmm.h"
+#include "mpcgpu.h"
+
+#include <map>
+#include <mutex>
+
+namespace
+{
+struct Batch
+	{
+	const MultiSequence *m_Seqs = 0;
+	uint m_PairCount = 0;
+	uint m_Served = 0;	// CalcPosterior calls answered from this batch
+	bool m_Materialise = false; // host copies of the stage-A matrices are needed (no relax follows)
+	vector<float> m_EA;	// what calcposteriorflat.cpp:89 stores in m_DistMx
+	};
+
+std::mutex g_Mu;
+mpcgpu_ctx *g_Ctx = 0;
+std::map<const MPCFlat *, Batch> g_Batches;
+
+mpcgpu_ctx *GetCtx()
+	{
+	if (g_Ctx != 0)
+		return g_Ctx;
+	int Device = 0;
+	const char *s = getenv("MUSCLE_GPU_DEVICE");
+	if (s != 0 && *s != 0)
+		Device = atoi(s);
+	if (mpcgpu_create(&g_Ctx, Device) != 0)
+		Die("GPU posterior stage: %s", mpcgpu_last_error(0));
+	return g_Ctx;
+	}
+
+#define GPUCHK(call)	do { if ((call) != 0) Die("GPU posterior stage: %s", mpcgpu_last_error(Ctx)); } while (0)
+
+// Copies pairs [k0,k1) of the device store into MySparseMx objects (layout of
+// mysparsemx.h:6-98; buffers through AllocLX/AllocVec so ownership stays with myalloc/myfree).
+template<class GETMX> void Download(mpcgpu_ctx *Ctx, MPCFlat &M, uint PairCount, GETMX GetMx)
+	{
+	vector<uint32_t> NNZ(PairCount);
+	GPUCHK(mpcgpu_get_nnz(Ctx, 0, PairCount, NNZ.data()));
+	const uint64_t MaxEntriesPerChunk = uint64_t(32)*1024*1024; // 256 MB of values per transfer
+	unsigned ThreadCount = GetRequestedThreadCount();
+	uint k0 = 0;
+	vector<uint32_t> Offs;
+	vector<uint64_t> Vals;
+	vector<uint64_t> OffBase, ValBase;
+	while (k0 < PairCount)
+		{
+		uint k1 = k0;
+		uint64_t Entries = 0, OffCount = 0;
+		OffBase.clear();
+		ValBase.clear();
+		while (k1 < PairCount && (k1 == k0 || Entries + NNZ[k1] <= MaxEntriesPerChunk))
+			{
+			OffBase.push_back(OffCount);
+			ValBase.push_back(Entries);
+			OffCount += M.GetSeqLength(M.GetPair(k1).first) + 1;
+			Entries += NNZ[k1];
+			++k1;
+			}
+		Offs.resize(OffCount);
+		Vals.resize(Entries + 1);
+		GPUCHK(mpcgpu_get_sparse_range(Ctx, k0, k1, Offs.data(), Vals.data()));
+#pragma omp parallel for num_threads(ThreadCount) schedule(dynamic, 64)
+		for (int k = (int) k0; k < (int) k1; ++k)
+			{
+			const pair<uint, uint> &Pair = M.GetPair((uint) k);
+			const uint LX = M.GetSeqLength(Pair.first);
+			const uint LY = M.GetSeqLength(Pair.second);
+			MySparseMx &Mx = GetMx((uint) k);
+			Mx.AllocLX(LX);
+			Mx.AllocVec(NNZ[k]);
+			Mx.m_LX = LX;
+			Mx.m_LY = LY;
+			Mx.m_VecSize = NNZ[k];
+			memcpy(Mx.m_Offsets, Offs.data() + OffBase[k - k0], sizeof(uint)*(LX + 1));
+			memcpy(Mx.m_ValueVec, Vals.data() + ValBase[k - k0], 8*size_t(NNZ[k]));
+			Mx.m_X = M.GetBytePtr(Pair.first);
+			Mx.m_Y = M.GetBytePtr(Pair.second);
+			}
+		k0 = k1;
+		}
+	}
+
+// First CalcPosterior call of a run: the whole all-pairs stage A on the device.
+void StartBatch(MPCFlat &M, Batch &B)
+	{
+	mpcgpu_ctx *Ctx = GetCtx();
+	const uint SeqCount = M.GetSeqCount();
+	const uint PairCount = SIZE(M.m_Pairs);
+	asserta(PairCount == (SeqCount*(SeqCount - 1))/2);
+
+// The PairHMM tables are process globals that can change between replicates (align.cpp:35-40)
+	GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
+	  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
+
+	vector<const uint8_t *> Ptrs(SeqCount);
+	vector<uint32_t> Lens(SeqCount);
+	for (uint i = 0; i < SeqCount; ++i)
+		{
+		Ptrs[i] = M.GetBytePtr(i);
+		Lens[i] = M.GetSeqLength(i);
+		}
+// (the "HMM overflow" length check of calcposteriorflat.cpp:54-61 is made by the library)
+	GPUCHK(mpcgpu_set_seqs(Ctx, SeqCount, Ptrs.data(), Lens.data()));
+	GPUCHK(mpcgpu_calc_posteriors(Ctx, 0, PairCount));
+	GPUCHK(mpcgpu_build_store(Ctx));
+
+	B.m_Seqs = M.m_MyInputSeqs;
+	B.m_PairCount = PairCount;
+	B.m_Served = 0;
+	B.m_EA.resize(PairCount);
+	GPUCHK(mpcgpu_get_ea(Ctx, 0, PairCount, B.m_EA.data()));
+// MPCFlat::Consistency (mpcflat.cpp:173-181) is skipped for < 3 sequences or 0 iterations: then the
+// progressive stage reads the stage-A matrices, so they must exist on the host.
+	B.m_Materialise = (SeqCount < 3 || M.m_ConsistencyIterCount == 0);
+	}
+} // namespace
+
+void MPCFlat::CalcPosterior(uint PairIndex)
+	{
+	const pair<uint, uint> &Pair = GetPair(PairIndex);
+	const uint SeqIndexX = Pair.first;
+	const uint SeqIndexY = Pair.second;
+	float EA;
+		{
+		std::lock_guard<std::mutex> Guard(g_Mu);
+		Batch &B = g_Batches[this];
+		if (B.m_Seqs != m_MyInputSeqs || B.m_PairCount != SIZE(m_Pairs) || B.m_Served >= B.m_PairCount)
+			{
+			StartBatch(*this, B);
+			if (B.m_Materialise)
+				Download(g_Ctx, *this, B.m_PairCount, [this](uint k) -> MySparseMx & { return GetSparsePost(k); });
+			}
+		asserta(PairIndex < B.m_PairCount);
+		EA = B.m_EA[PairIndex];
+		++B.m_Served;
+		}
+	m_DistMx[SeqIndexX][SeqIndexY] = EA; // calcposteriorflat.cpp:89-91
+	m_DistMx[SeqIndexY][SeqIndexX] = EA;
+	}
+
+void MPCFlat::ConsIter(uint Iter)
+	{
+	uint PairCount = SIZE(m_Pairs);
+	asserta(PairCount > 0);
+	ProgressStep(0, 1, "Consistency (%u/%u)", Iter+1, m_ConsistencyIterCount);
+		{
+		std::lock_guard<std::mutex> Guard(g_Mu);
+		mpcgpu_ctx *Ctx = GetCtx();
+		GPUCHK(mpcgpu_cons_iter(Ctx, 0, PairCount));
+		GPUCHK(mpcgpu_cons_commit(Ctx));
+// Only the matrices of the last iteration are read by the host (ProgressiveAlign/Refine ->
+// BuildPost, buildpostflat.cpp:18); intermediate iterations stay on the device.
+		if (Iter + 1 == m_ConsistencyIterCount)
+			Download(Ctx, *this, PairCount, [this](uint k) -> MySparseMx & { return GetUpdatedSparsePost(k); });
+		}
+	swap(m_ptrSparsePosts, m_ptrUpdatedSparsePosts); // consflat.cpp:22
+	}

@@ -1,0 +1,50 @@
+"""Final-MSA parity helpers: run a `muscle` binary (the compiled reference, or the same reference
+with the GPU drop-in linked in) on one of the named input sets and hash the output alignment.
+TEST INFRASTRUCTURE."""
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+import _golden as G
+from muscle_amd.synth import make_family, write_fasta
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_MUSCLE = os.path.join(ROOT, "oracle", "_ref", "muscle")
+GPU_MUSCLE = os.path.join(ROOT, "hostcxx", "_build", "muscle_gpu")
+EMU_MUSCLE = os.path.join(ROOT, "hostcxx", "_build", "muscle_gpu_emu")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "msa_md5.json")
+
+
+def input_set(name):
+    """-> (seqs, labels, extra command-line args)"""
+    if name.startswith("synth"):  # synth_<n>x<L>_s<seed>
+        n, rest = name[6:].split("x")
+        L, seed = rest.split("_s")
+        return make_family(int(n), int(L), seed=int(seed)), None, []
+    if name == "dupes":  # exact duplicates exercise Derep + InsertDupes around the stage (mpcflat.cpp:290-336)
+        s = make_family(5, 50, seed=9)
+        return [s[0], s[1], s[0], s[2], s[1], s[3], s[4]], None, []
+    if name == "consiters0":
+        return make_family(6, 45, seed=4), None, ["-consiters", "0"]
+    if name == "perturb":
+        return make_family(7, 60, seed=5), None, ["-perturb", "3", "-perm", "acb"]
+    return G.mpc(name)["seqs"], None, []
+
+
+def run_muscle(binary, name, threads=4, timeout=900):
+    seqs, labels, extra = input_set(name)
+    with tempfile.TemporaryDirectory() as d:
+        fa, out = os.path.join(d, "in.fa"), os.path.join(d, "out.afa")
+        write_fasta(fa, seqs, labels)
+        subprocess.run([binary, "-align", fa, "-output", out, "-threads", str(threads), "-quiet"] + extra,
+                       check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        with open(out, "rb") as f:
+            data = f.read()
+    return hashlib.md5(data).hexdigest(), data
+
+
+def golden_md5():
+    with open(GOLDEN) as f:
+        return json.load(f)

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/msa_md5.json: MD5 of the final MSA the compiled reference
+(oracle/_ref/muscle, built by oracle/build_ref.sh from /root/reference/src) writes for each named
+input set of tests/_msa.py. Run in the container that has /root/reference; the JSON is committed."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import _msa  # noqa: E402
+
+SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "bb11001", "bb11005", "n32_L150", "dupes", "consiters0", "perturb",
+        "synth_6x40_s2", "synth_64x200_s1", "synth_128x300_s1"]
+out = {}
+for s in SETS:
+    out[s] = _msa.run_muscle(_msa.REF_MUSCLE, s, threads=os.cpu_count() or 4)[0]
+    print(s, out[s])
+with open(_msa.GOLDEN, "w") as f:
+    json.dump(out, f, indent=1, sort_keys=True)

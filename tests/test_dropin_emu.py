@@ -1,0 +1,35 @@
+"""Host-side plumbing of the C++ drop-in (hostcxx/mpcflat_gpu.cpp) WITHOUT a GPU: the reference's
+own `muscle` is linked with the drop-in and the SIMT-emulator build of libmpcgpu (test
+infrastructure) and must write byte-identical final MSAs to the committed golden MD5s of the
+unmodified reference (tests/golden/msa_md5.json). Checks lazy batching from the OpenMP loop, the
+HMM-table hand-over, Derep/InsertDupes around the stage, the <3-sequence / -consiters 0 paths and
+the final download + buffer swap. Needs the reference objects (oracle/_ref/obj): skipped where
+/root/reference was never available."""
+import os
+import subprocess
+
+import pytest
+
+import _msa
+
+ROOT = _msa.ROOT
+pytestmark = pytest.mark.ref
+
+
+@pytest.fixture(scope="module")
+def emu_muscle():
+    if not os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "obj")) or not os.path.isdir("/root/reference/src"):
+        if os.path.exists(_msa.EMU_MUSCLE):
+            return _msa.EMU_MUSCLE
+        pytest.skip("reference objects not available")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, MPCGPU_LIBDIR=os.path.join(ROOT, "tests", "emu"), MPCGPU_LIBNAME="mpcgpu_emu",
+               MPCGPU_BIN="muscle_gpu_emu")
+    subprocess.check_call(["bash", os.path.join(ROOT, "hostcxx", "build_muscle_gpu.sh")], env=env, stdout=subprocess.DEVNULL)
+    return _msa.EMU_MUSCLE
+
+
+@pytest.mark.parametrize("name", ["n2_L40", "n3_L30", "synth_6x40_s2", "dupes", "consiters0", "perturb"])
+def test_final_msa_identical(emu_muscle, name):
+    md5, _ = _msa.run_muscle(emu_muscle, name, threads=3)
+    assert md5 == _msa.golden_md5()[name]
