@@ -23,6 +23,7 @@
 
 #define MPC_RT_THREADS 1024
 #define MPC_RT_SLOTS 16
+#define MPC_RT_ROW 4 // entries per row the register-matched fast path handles
 
 struct RelaxTileParams {
 	StoreParams s;
@@ -34,9 +35,11 @@ struct RelaxTileParams {
 };
 
 // MAXSEQ: matrices resident per step; NRP: row-pointer dwords staged per thread per matrix
-// (lcap1 <= NRP*1024); NENT: entries staged per thread per matrix (ecap <= NENT*1024), also the
-// slots one pair may take (nnz <= NENT*1024).
-template <int MAXSEQ, int NRP, int NENT>
+// (lcap1 <= NRP*1024). One entry per thread per matrix is staged in registers (1024 entries); the
+// rare matrix with more entries gets its tail copied global -> LDS at store time (slow path), and a
+// pair with more than 1024 cells takes several slots — the host splits any tile that would need
+// more than MPC_RT_SLOTS slots.
+template <int MAXSEQ, int NRP>
 __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTileParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
@@ -124,7 +127,8 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 
 		// ---- walk Z with register-staged prefetch
 		u32 st_rp[MAXSEQ][NRP];
-		u32 st_e0[MAXSEQ][NENT], st_e1[MAXSEQ][NENT];
+		u32 st_e0[MAXSEQ], st_e1[MAXSEQ];
+		u32 st_cnt[MAXSEQ]; // entries of M(seq[i], Z) (wave-uniform)
 		u32 st_base[MAXSEQ]; // slab-relative entry offset of M(seq[i], Z) (wave-uniform)
 		auto stage_load = [&](u32 Z) {
 #pragma unroll
@@ -141,13 +145,10 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 						const u32 q = tid + r * MPC_RT_THREADS;
 						st_rp[i][r] = (q <= LA) ? rp[q] : 0u;
 					}
-#pragma unroll
-					for (int r = 0; r < NENT; ++r) {
-						const u32 q = tid + r * MPC_RT_THREADS;
-						MpcEnt v; v.p = 0; v.c = 0;
-						if (q < e1 - e0) v = ent[q];
-						st_e0[i][r] = v.p; st_e1[i][r] = v.c;
-					}
+					MpcEnt v; v.p = 0; v.c = 0;
+					if (tid < e1 - e0) v = ent[tid];
+					st_e0[i] = v.p; st_e1[i] = v.c;
+					st_cnt[i] = e1 - e0;
 				}
 			}
 		};
@@ -162,10 +163,10 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 						if (q < p.lcap1) m[q] = st_rp[i][r] - st_base[i]; // LDS-relative entry index
 					}
 					MpcEnt *me = (MpcEnt *)(m + p.lcap1);
-#pragma unroll
-					for (int r = 0; r < NENT; ++r) {
-						const u32 q = tid + r * MPC_RT_THREADS;
-						if (q < p.ecap) { MpcEnt v; v.p = st_e0[i][r]; v.c = st_e1[i][r]; me[q] = v; }
+					if (tid < p.ecap) { MpcEnt v; v.p = st_e0[i]; v.c = st_e1[i]; me[tid] = v; }
+					if (st_cnt[i] > MPC_RT_THREADS) { // rare: tail of a matrix with more than 1024 entries
+						const MpcEnt *ent = s.ent + s.ent_base[seq[i]] + st_base[i];
+						for (u32 q = tid + MPC_RT_THREADS; q < st_cnt[i]; q += MPC_RT_THREADS) me[q] = ent[q];
 					}
 				}
 			}
@@ -182,29 +183,55 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 				if (sl_ab[q] != 0xffffu) { // wave-uniform
 					const u32 *ma = lds + (sl_ab[q] & 0xffu) * mat_dwords;
 					const u32 *mb = lds + (sl_ab[q] >> 8) * mat_dwords;
-					if (xy[q] != 0xffffffffu) {
-						const u32 x = xy[q] >> 16, y = xy[q] & 0xffffu;
-						u32 a = ma[x], a1 = ma[x + 1];
-						u32 b = mb[y], b1 = mb[y + 1];
-						if (a != a1 && b != b1) {
-							// lcap1 is even and the LDS base 16-byte aligned: entries are 8-byte aligned (ds_read_b64)
-							const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(ma + p.lcap1, 8);
-							const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(mb + p.lcap1, 8);
-							// Branch-free merge of the two sorted rows: one LDS read per side per step, the
-							// product is added only on a column match (the sum is otherwise left untouched, so
-							// the rounding sequence is exactly the reference's: relaxflat.cpp:27, w == 1.0f).
-							float sum = acc[q];
-							do {
-								const MpcEnt va = ea[a], vb = eb[b];
-								const float prod = __uint_as_float(va.p) * __uint_as_float(vb.p);
-								const float added = sum + prod;
-								sum = (va.c == vb.c) ? added : sum;
-								a += (va.c <= vb.c) ? 1u : 0u;
-								b += (vb.c <= va.c) ? 1u : 0u;
-							} while (a < a1 && b < b1);
-							acc[q] = sum;
+					u32 c = xy[q];
+					MPC_OPAQUE(c); // keep one register per slot: recompute the two LDS addresses per step
+					const bool have = c != 0xffffffffu;
+					if (__ballot(have) == 0) continue; // this wave holds no cell of the slot
+					const u32 x = have ? (c >> 16) : 0u, y = have ? (c & 0xffffu) : 0u;
+					u32 a = ma[x], b = mb[y];
+					u32 na = ma[x + 1] - a, nb = mb[y + 1] - b;
+					if (!have) { na = 0; nb = 0; }
+					// lcap1 is even and the LDS base 16-byte aligned: entries are 8-byte aligned (ds_read_b64)
+					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(ma + p.lcap1, 8);
+					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(mb + p.lcap1, 8);
+					float sum = acc[q];
+					if (__ballot(na > MPC_RT_ROW || nb > MPC_RT_ROW) == 0) {
+						// Fast path (every lane's two rows hold <= MPC_RT_ROW entries): both rows are fetched
+						// whole — all LDS reads of the slot are in flight together, two dependent round trips
+						// instead of one per merge step — and matched in registers. Row a is walked in
+						// ascending z; its partner in row b (columns are distinct within a row, so at most
+						// one) is picked by compares. An unmatched or absent entry contributes pa * 0.0f =
+						// +0.0f, which leaves the (strictly positive) sum bit-for-bit unchanged, so the
+						// rounding sequence is the reference's (relaxflat.cpp:16-29 / :41-58 / :78-92; the
+						// XZ_YZ form adds such explicit zeros itself).
+						MpcEnt va[MPC_RT_ROW], vb[MPC_RT_ROW];
+#pragma unroll
+						for (int r = 0; r < MPC_RT_ROW; ++r) { va[r] = ea[a + r]; vb[r] = eb[b + r]; } // reads past a row end are masked below
+						u32 cb[MPC_RT_ROW];
+#pragma unroll
+						for (int r = 0; r < MPC_RT_ROW; ++r) cb[r] = ((u32)r < nb) ? vb[r].c : 0xfffffffeu;
+#pragma unroll
+						for (int r = 0; r < MPC_RT_ROW; ++r) {
+							const u32 ca = va[r].c;
+							float pb = 0.0f;
+#pragma unroll
+							for (int t2 = MPC_RT_ROW - 1; t2 >= 0; --t2) pb = (ca == cb[t2]) ? __uint_as_float(vb[t2].p) : pb;
+							const float pa = ((u32)r < na) ? __uint_as_float(va[r].p) : 0.0f;
+							sum += pa * pb; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
 						}
+					} else if (na != 0 && nb != 0) {
+						// General path: branch-free merge of the two sorted rows, one LDS read per side per step.
+						const u32 a1 = a + na, b1 = b + nb;
+						do {
+							const MpcEnt wa = ea[a], wb = eb[b];
+							const float prod = __uint_as_float(wa.p) * __uint_as_float(wb.p);
+							const float added = sum + prod;
+							sum = (wa.c == wb.c) ? added : sum;
+							a += (wa.c <= wb.c) ? 1u : 0u;
+							b += (wb.c <= wa.c) ? 1u : 0u;
+						} while (a < a1 && b < b1);
 					}
+					acc[q] = sum;
 				}
 			}
 		}

@@ -9,6 +9,8 @@
 #define MPC_LAUNCH(kern, grid, block, smem, stream, ...) \
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (smem), (stream), __VA_ARGS__)
 #define MPC_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+// optimisation barrier on one VGPR value (no code): stops hoisting of what is derived from it
+#define MPC_OPAQUE(v) asm volatile("" : "+v"(v))
 // value held by the first active lane, as a wave-uniform scalar (v_readfirstlane_b32 -> SGPR)
 __device__ __forceinline__ unsigned mpc_wave_first(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 #endif

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,10 @@ struct mpcgpu_ctx {
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
 	DevBuf d_tiles;
+	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
+	std::vector<u32> h_tiles;
+	u64 tiles_k0 = ~0ull, tiles_k1 = ~0ull;
+	u32 tiles_bx = 0, tiles_by = 0;
 
 	// scratch
 	DevBuf d_queue, d_order, d_bx, d_by, d_fm, d_cand, d_cand_cnt, d_total, d_res, d_nnz, d_ea, d_flags,
@@ -251,9 +256,9 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.vnext = c->d_vnext.as<float>();
 }
 
-template <int MS, int R, int E> void launch_relax_tile(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
+template <int MS, int R> void launch_relax_tile(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
 {
-	auto kern = relax_tile_kernel<MS, R, E>;
+	auto kern = relax_tile_kernel<MS, R>;
 	MPC_LAUNCH(kern, grid, MPC_RT_THREADS, smem, st, rp);
 }
 
@@ -263,65 +268,82 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 {
 	const u32 n = c->n;
 	if (c->max_len > 65535u) return 2; // cell coordinates are packed 16:16
-	int nrp, nent;
+	int nrp;
 	if (c->max_len + 1 <= 1024) nrp = 1; else if (c->max_len + 1 <= 2048) nrp = 2; else return 2;
-	if (c->max_nnz <= 1024) nent = 1; else if (c->max_nnz <= 2048) nent = 2; else if (c->max_nnz <= 4096) nent = 4; else return 2;
 	const u32 lcap1 = (c->max_len + 2) & ~1u; // >= Lmax+1, even (entries stay 8-byte aligned in LDS)
 	const u32 ecap = std::max<u32>(c->max_nnz, 1);
 	const u64 mat_bytes = ((u64)lcap1 + 2 * (u64)ecap) * 4;
 	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", 160) * 1024;
-	// tile shape: nx*ny*nent <= 16 slots, (nx+ny) matrices resident
+	// block shape by LDS capacity: (bx+by) matrices resident
 	static const u32 shapes[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
 	u32 bx = 0, by = 0;
 	for (auto &sh : shapes)
-		if (sh[0] * sh[1] * (u32)nent <= MPC_RT_SLOTS && (sh[0] + sh[1]) * mat_bytes <= lds_cap) { bx = sh[0]; by = sh[1]; break; }
+		if ((sh[0] + sh[1]) * mat_bytes + 8 * MPC_RT_ROW <= lds_cap) { bx = sh[0]; by = sh[1]; break; }
 	if (!bx) return 2;
-	const int maxseq = nent == 1 ? 8 : (nent == 2 ? 6 : 4);
-	if ((int)(bx + by) > maxseq) return 2;
-	// tile list: X blocks of bx, Y blocks of by, in 8x8 super-tiles; only tiles with a pair in [k0,k1)
-	std::vector<u32> tiles;
-	const u32 nbx = (n + bx - 1) / bx, nby = (n + by - 1) / by;
 	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
-	for (u32 sx = 0; sx < nbx; sx += 8)
-		for (u32 sy = 0; sy < nby; sy += 8)
-			for (u32 xb = sx; xb < std::min(sx + 8, nbx); ++xb)
-				for (u32 yb = sy; yb < std::min(sy + 8, nby); ++yb) {
-					const u32 x0 = xb * bx, nx = std::min(bx, n - x0), y0 = yb * by, ny = std::min(by, n - y0);
-					bool any = false;
-					for (u32 X = x0; X < x0 + nx && !any; ++X)
-						for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
-							const u64 k = pidx(X, Y);
-							if (k >= k0 && k < k1 && c->all_nnz[k] > 0) { any = true; break; }
-						}
-					if (any) { tiles.push_back(x0); tiles.push_back(nx); tiles.push_back(y0); tiles.push_back(ny); }
-				}
+	// slots a tile needs: one per started 1024 cells of every pair in [k0,k1)
+	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
+		u32 slots = 0;
+		for (u32 X = x0; X < x0 + nx; ++X)
+			for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
+				const u64 k = pidx(X, Y);
+				if (k >= k0 && k < k1) slots += (c->all_nnz[k] + MPC_RT_THREADS - 1) / MPC_RT_THREADS;
+			}
+		return slots;
+	};
+	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != bx || c->tiles_by != by) {
+		std::vector<u32> &tiles = c->h_tiles;
+		tiles.clear();
+		bool too_big = false;
+		const u32 slot_budget = (u32)std::min(std::max(env_int("MPCGPU_RELAX_SLOTS", MPC_RT_SLOTS), 1), MPC_RT_SLOTS);
+		// a tile over the slot budget is split (Y range first, then X range) until it fits
+		std::function<void(u32, u32, u32, u32)> emit = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
+			const u32 slots = tile_slots(x0, nx, y0, ny);
+			if (slots == 0) return;
+			if (slots <= slot_budget) { tiles.push_back(x0); tiles.push_back(nx); tiles.push_back(y0); tiles.push_back(ny); return; }
+			if (ny > 1) { emit(x0, nx, y0, ny / 2); emit(x0, nx, y0 + ny / 2, ny - ny / 2); }
+			else if (nx > 1) { emit(x0, nx / 2, y0, ny); emit(x0 + nx / 2, nx - nx / 2, y0, ny); }
+			else too_big = true; // a single pair with more than 16*1024 cells
+		};
+		// X blocks of bx, Y blocks of by, walked in 8x8 super-tiles (L2 sharing between the workgroups of an XCD)
+		const u32 nbx = (n + bx - 1) / bx, nby = (n + by - 1) / by;
+		for (u32 sx = 0; sx < nbx; sx += 8)
+			for (u32 sy = 0; sy < nby; sy += 8)
+				for (u32 xb = sx; xb < std::min(sx + 8, nbx); ++xb)
+					for (u32 yb = sy; yb < std::min(sy + 8, nby); ++yb) {
+						const u32 x0 = xb * bx, nx = std::min(bx, n - x0), y0 = yb * by, ny = std::min(by, n - y0);
+						if (y0 + ny <= x0 + 1) continue; // no pair X < Y in this block
+						emit(x0, nx, y0, ny);
+					}
+		c->tiles_k0 = c->tiles_k1 = ~0ull;
+		if (too_big) { tiles.clear(); return 2; }
+		// the source of an async H2D copy must outlive it: the list lives in the context AND the
+		// stream is drained before it can be rebuilt
+		if (upload(c, c->d_tiles, tiles)) return 1;
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		c->tiles_k0 = k0; c->tiles_k1 = k1; c->tiles_bx = bx; c->tiles_by = by;
+	}
+	const std::vector<u32> &tiles = c->h_tiles;
 	if (tiles.empty()) return 0;
-	if (upload(c, c->d_tiles, tiles)) return 1;
 	RelaxTileParams rp;
 	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
 	rp.lcap1 = lcap1; rp.ecap = ecap; rp.k0 = k0; rp.k1 = k1;
-	const size_t smem = (size_t)(bx + by) * mat_bytes;
-	const void *fn = nullptr;
-#define MPC_RT_CASE(ms, r, e) if (maxseq == ms && nrp == r && nent == e) fn = (const void *)relax_tile_kernel<ms, r, e>;
-	MPC_RT_CASE(8, 1, 1) MPC_RT_CASE(8, 2, 1) MPC_RT_CASE(6, 1, 2) MPC_RT_CASE(6, 2, 2) MPC_RT_CASE(4, 1, 4) MPC_RT_CASE(4, 2, 4)
-#undef MPC_RT_CASE
-	if (!fn) return 2;
+	const size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-row reads may run past the last matrix
+	const void *fn = nrp == 1 ? (const void *)relax_tile_kernel<8, 1> : (const void *)relax_tile_kernel<8, 2>;
 	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 	int occ = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, MPC_RT_THREADS, smem) != hipSuccess || occ < 1) occ = 1;
 	u32 grid = std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ);
 	grid = std::max(grid, 1u);
 	if (trace_on()) {
-		fprintf(stderr, "[mpcgpu] relax tiled: tiles=%u shape=%ux%u nrp=%d nent=%d lds=%zu B occ=%d grid=%u\n", rp.ntiles, bx, by,
-			nrp, nent, smem, occ, grid);
+		fprintf(stderr, "[mpcgpu] relax tiled: tiles=%u block=%ux%u nrp=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n", rp.ntiles, bx, by,
+			nrp, c->max_nnz, smem, occ, grid);
 		fflush(stderr);
 	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
-#define MPC_RT_CASE(ms, r, e) \
-	if (maxseq == ms && nrp == r && nent == e) launch_relax_tile<ms, r, e>(rp, grid, smem, c->stream);
-	MPC_RT_CASE(8, 1, 1) MPC_RT_CASE(8, 2, 1) MPC_RT_CASE(6, 1, 2) MPC_RT_CASE(6, 2, 2) MPC_RT_CASE(4, 1, 4) MPC_RT_CASE(4, 2, 4)
-#undef MPC_RT_CASE
+	if (nrp == 1) launch_relax_tile<8, 1>(rp, grid, smem, c->stream);
+	else launch_relax_tile<8, 2>(rp, grid, smem, c->stream);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
 	return 0;
@@ -683,6 +705,7 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	if (c->n == 0) return fail(c, "mpcgpu_store_import: call mpcgpu_set_seqs first");
 	HIPCHK(c, hipSetDevice(c->device));
 	c->have_store = false;
+	c->tiles_k0 = c->tiles_k1 = ~0ull;
 	const u32 n = c->n;
 	// ---- read shard headers, check coverage
 	c->all_nnz.assign(c->npairs, 0);

@@ -81,6 +81,7 @@ template <class T> static inline T emu_xchg(T v, int src_lane_delta, bool absolu
 template <class T> static inline T __shfl_up(T v, unsigned d) { return emu_xchg(v, -(int)d, false); }
 template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xchg(v, (int)d, false); }
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
+#define MPC_OPAQUE(v) ((void)0)
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
 static inline unsigned long long __ballot(int pred)
 {

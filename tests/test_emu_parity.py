@@ -71,6 +71,13 @@ def test_emu_relax_small_lds_shapes(emu, lds_kb):
     P.assert_same(got, P.run_oracle(seqs), "lds %d KB" % lds_kb)
 
 
+def test_emu_relax_tile_splitting(emu):
+    # a slot budget of 3 makes the host split every 4x4 block recursively (Y range, then X range)
+    seqs = make_family(9, 22, seed=8)
+    got = _with_env({"MPCGPU_RELAX_SLOTS": "3"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "split tiles")
+
+
 def test_emu_relax_two_slots_per_pair(emu):
     # nnz > 1024 -> NENT = 2: one pair spans two register slots, matrices are staged in two passes
     # (low-complexity repeats spread the posterior over many diagonals: ~3.5 stored cells per row)

@@ -24,15 +24,18 @@ def gpu_muscle():
 
 @pytest.mark.parametrize("name", SETS)
 def test_final_msa_identical_to_reference(gpu_muscle, name):
+    """Primary check: muscle_gpu vs the unmodified reference binary run on THIS box, same input,
+    same thread count. Secondary: both equal the MD5 committed from the build container (a host
+    whose libm/ifunc selection differs could legitimately move both together; report, don't hide)."""
     from muscle_amd.hostinfo import usable_cores
-    md5, data = _msa.run_muscle(gpu_muscle, name, threads=usable_cores())
-    assert md5 == _msa.golden_md5()[name], "final MSA differs from the reference's for %s" % name
-
-
-def test_live_reference_agrees(gpu_muscle):
-    if not os.path.exists(_msa.REF_MUSCLE):
-        pytest.skip("compiled reference not shipped")
-    from muscle_amd.hostinfo import usable_cores
-    a = _msa.run_muscle(gpu_muscle, "synth_40x120_s7", threads=usable_cores())
-    b = _msa.run_muscle(_msa.REF_MUSCLE, "synth_40x120_s7", threads=usable_cores())
-    assert a[1] == b[1]
+    th = usable_cores()
+    md5_gpu, data_gpu = _msa.run_muscle(gpu_muscle, name, threads=th)
+    golden = _msa.golden_md5()[name]
+    if os.path.exists(_msa.REF_MUSCLE):
+        md5_ref, data_ref = _msa.run_muscle(_msa.REF_MUSCLE, name, threads=th)
+        print("%s gpu=%s ref(live)=%s golden=%s" % (name, md5_gpu, md5_ref, golden))
+        assert data_gpu == data_ref, "final MSA differs from the live reference's for %s" % name
+        if md5_ref != golden:
+            pytest.xfail("the unmodified reference itself writes a different MSA on this host than in the build "
+                         "container (%s vs %s); muscle_gpu follows the live reference" % (md5_ref, golden))
+    assert md5_gpu == golden, "final MSA differs from the reference's committed MD5 for %s" % name

@@ -117,6 +117,43 @@ def test_sharded_equals_whole():
         c.close()
 
 
+def test_back_to_back_iterations_without_sync():
+    """The drop-in (hostcxx/mpcflat_gpu.cpp) and bench.py queue both relax iterations without reading
+    anything back in between; the result must not depend on host-side synchronisation (regression:
+    the tile list of the second iteration was uploaded from a temporary that had gone out of scope)."""
+    for n, L, seed in ((8, 60, 31), (14, 90, 32), (23, 40, 33)):
+        seqs = make_family(n, L, seed=seed)
+        s, t, m, i, thr = G.hmm_tables()
+        g = MpcGpu(0)
+        g.set_hmm(s, t, m, i, thr)
+        g.set_seqs(seqs)
+        g.calc_posteriors()
+        g.build_store()
+        for _ in range(2):
+            g.cons_iter()
+            g.cons_commit()
+        got = g.get_sparse_range()
+        g.close()
+        want = P.run_oracle(seqs)[0][2]
+        for k, ((o1, v1), (o2, v2)) in enumerate(zip(got, want)):
+            assert np.array_equal(o1, o2) and np.array_equal(v1, v2), "n=%d pair %d" % (n, k)
+
+
+def test_relax_gather_equals_tiled():
+    """Both relax kernels (LDS-tiled default, one-cell-per-thread gather fallback) are device code
+    with the reference's accumulation order: identical bits."""
+    import os
+    seqs = make_family(21, 120, seed=41)
+    a = P.run_lib(seqs)
+    os.environ["MPCGPU_RELAX"] = "gather"
+    try:
+        b = P.run_lib(seqs)
+    finally:
+        del os.environ["MPCGPU_RELAX"]
+    P.assert_same(a, b, "gather vs tiled")
+    P.assert_same(a, P.run_oracle(seqs), "tiled vs oracle")
+
+
 def test_errors_are_loud():
     s, t, m, i, thr = G.hmm_tables()
     g = MpcGpu(0)
