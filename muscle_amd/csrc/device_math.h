@@ -35,6 +35,44 @@ __device__ __forceinline__ float mpc_la2(float x, float y)
 	return d >= MPC_LOG_UNDERFLOW ? hi : p;
 }
 
+// ---- hot-path form of LOG_ADD (kernels_fb.h): same values, fewer instructions ------------------
+// The four coefficient sets of LOGEXP1 are picked with 12 selects above. The interval bounds
+// (1, 2.5, 4.5, 7.5) are all multiples of 0.5, so ceil(2d) identifies the interval exactly
+// (2d and the ceiling are exact in float; "d <= bound" <=> ceil(2d) <= 2*bound): one 16-entry LDS
+// table indexed by ceil(2d), fetched with a single 16-byte read, replaces the selects. lo/hi use
+// min/max (no NaNs on this path; equal operands give d = 0 either way). The Horner chain and every
+// rounding step are unchanged, so results are bit-identical to mpc_la2.
+struct __attribute__((aligned(16))) MpcCoef { float c3, c2, c1, c0; };
+#define MPC_COEF_ENTRIES 16
+
+// entry k of the table = coefficient set of the interval that holds d with ceil(2d) == k
+__device__ __forceinline__ void mpc_coef_table_init(MpcCoef *tab, int k)
+{
+	MpcCoef c;
+	if (k <= 2) { c.c3 = -0.009350833524763f; c.c2 = 0.130659527668286f; c.c1 = 0.498799810682272f; c.c0 = 0.693203116424741f; }
+	else if (k <= 5) { c.c3 = -0.014532321752540f; c.c2 = 0.139942324101744f; c.c1 = 0.495635523139337f; c.c0 = 0.692140569840976f; }
+	else if (k <= 9) { c.c3 = -0.004605031767994f; c.c2 = 0.063427417320019f; c.c1 = 0.695956496475118f; c.c0 = 0.514272634594009f; }
+	else { c.c3 = -0.000458661602210f; c.c2 = 0.009695946122598f; c.c1 = 0.930734667215156f; c.c0 = 0.168037164329057f; }
+	tab[k] = c;
+}
+
+__device__ __forceinline__ float mpc_la2t(float x, float y, const MpcCoef *tab)
+{
+	const float lo = fminf(x, y);
+	const float hi = fmaxf(x, y);
+	const float d = hi - lo;
+	// ceil(2d), clamped in float first (d can be as large as 4e20 when an operand is LOG_ZERO)
+	const int k = (int)fminf(-floorf(-(d + d)), (float)(MPC_COEF_ENTRIES - 1));
+	const MpcCoef c = tab[k];
+	const float p = ((c.c3 * d + c.c2) * d + c.c1) * d + c.c0 + lo;
+	return d >= MPC_LOG_UNDERFLOW ? hi : p;
+}
+
+__device__ __forceinline__ float mpc_la5t(float a, float b, float c, float d, float e, const MpcCoef *tab)
+{
+	return mpc_la2t(a, mpc_la2t(b, mpc_la2t(c, mpc_la2t(d, e, tab), tab), tab), tab);
+}
+
 // 5-ary LOG_ADD nests to the right, scoretype.h:136-139
 __device__ __forceinline__ float mpc_la5(float a, float b, float c, float d, float e)
 {

@@ -26,6 +26,7 @@
 #include "device_math.h"
 
 #define MPC_HMAX 16
+#define MPC_FB_COEF_BYTES (MPC_COEF_ENTRIES * 16)
 
 struct FbParams {
 	// sequences (compact alphabet codes 0..A-1)
@@ -56,8 +57,11 @@ template <int H>
 __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
-	float *s_match = (float *)smem_raw; // A*A
-	float *s_ins = s_match + p.A * p.A; // A
+	MpcCoef *s_coef = (MpcCoef *)smem_raw;                        // LOGEXP1 coefficient table, LDS offset 0
+	float *s_match = (float *)(smem_raw + MPC_FB_COEF_BYTES);    // A*A
+	float *s_ins = s_match + p.A * p.A;                          // A
+	if (threadIdx.x < MPC_COEF_ENTRIES)
+		mpc_coef_table_init(s_coef, (int)threadIdx.x);
 	for (int q = threadIdx.x; q < p.A * p.A; q += blockDim.x)
 		s_match[q] = p.match[q];
 	for (int q = threadIdx.x; q < p.A; q += blockDim.x)
@@ -134,21 +138,25 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			float *fmrow = fm + ((u64)s * H) * 64 + t;
 #pragma unroll
 			for (int r = 0; r < H; ++r) {
-				const int i = t * H + r + 1;
 				const float oM = cM[r], oIX = cIX[r], oJX = cJX[r], oIY = cIY[r], oJY = cJY[r]; // (i, j-1)
 				const float m = s_match[mrow[r] + yc];
-				// fwdflat3.cpp:116-145
-				float vM = mpc_la5(dM + tMM, dIX + tIM, dJX + tJM, dIY + tIM, dJY + tJM) + m;
-				float vIX = mpc_la2(upIX + tII, upM + tMI) + insx[r];
-				float vJX = mpc_la2(upJX + tJJ, upM + tMJ) + insx[r];
-				float vIY = mpc_la2(oIY + tII, oM + tMI) + insy;
-				float vJY = mpc_la2(oJY + tJJ, oM + tMJ) + insy;
-				if (j <= 0) { // column 0 (fwdflat3.cpp:42-43, :48-55, :67-79); j<0: lane not started yet
-					vM = LZ; vIY = LZ; vJY = LZ;
-					if (i == 1) { vIX = tSI + insx[r]; vJX = tSJ + insx[r]; }
+				// fwdflat3.cpp:116-145. No per-cell border tests: for j <= 0 (column 0 and the columns a
+				// lane "computes" before it has started) every input that should be LOG_ZERO is exactly
+				// LOG_ZERO, LOG_ZERO + score == LOG_ZERO and LOG_ADD(LOG_ZERO, v) == v, so the same
+				// expressions give M = IY = JY = LOG_ZERO and the column-0 chains
+				// IX(i,0) = IX(i-1,0) + tII + Ins(x_i), JX likewise (fwdflat3.cpp:48-55, :67-79). The only
+				// genuinely special cells are in row 1 (lane 0, r == 0), below. Rows past LX and columns
+				// past LY compute garbage that nothing reads.
+				float vM = mpc_la5t(dM + tMM, dIX + tIM, dJX + tJM, dIY + tIM, dJY + tJM, s_coef) + m;
+				float vIX = mpc_la2t(upIX + tII, upM + tMI, s_coef) + insx[r];
+				float vJX = mpc_la2t(upJX + tJJ, upM + tMJ, s_coef) + insx[r];
+				float vIY = mpc_la2t(oIY + tII, oM + tMI, s_coef) + insy;
+				float vJY = mpc_la2t(oJY + tJJ, oM + tMJ, s_coef) + insy;
+				if (r == 0) {
+					const bool row1 = (t == 0);
+					if (row1 && j == 0) { vIX = tSI + insx[0]; vJX = tSJ + insx[0]; } // fwdflat3.cpp:42-43
+					if (row1 && j == 1) vM = tSM + m;                                 // fwdflat3.cpp:111-112
 				}
-				if (j == 1 && i == 1) // fwdflat3.cpp:111-112
-					vM = tSM + m;
 				cM[r] = vM; cIX[r] = vIX; cJX[r] = vJX; cIY[r] = vIY; cJY[r] = vJY;
 				fmrow[r * 64] = vM;
 				dM = oM; dIX = oIX; dJX = oJX; dIY = oIY; dJY = oJY;
@@ -170,11 +178,11 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 		// totalprobflat.cpp:3-16 with B(LX,LY,*) = start scores (bwdflat3.cpp:53-61); state order
 		// M, IX, IY, JX, JY (pairhmm.h:11-19), left fold from LOG_ZERO.
 		float total = LZ;
-		total = mpc_la2(total, eM + tSM);
-		total = mpc_la2(total, eIX + tSI);
-		total = mpc_la2(total, eIY + tSI);
-		total = mpc_la2(total, eJX + tSJ);
-		total = mpc_la2(total, eJY + tSJ);
+		total = mpc_la2t(total, eM + tSM, s_coef);
+		total = mpc_la2t(total, eIX + tSI, s_coef);
+		total = mpc_la2t(total, eIY + tSI, s_coef);
+		total = mpc_la2t(total, eJX + tSJ, s_coef);
+		total = mpc_la2t(total, eJY + tSJ, s_coef);
 		if (t == 0)
 			p.total[pid] = total;
 
@@ -225,21 +233,23 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 				const float xJY = oJY + insy;
 				// bwdflat3.cpp:81-118 (interior); the right column (:132-153) and bottom row (:155-176)
 				// formulas fall out of the same expressions over LOG_ZERO virtual neighbours.
-				float vM = mpc_la5(tMM + xM, tMI + xIX, tMJ + xJX, tMI + xIY, tMJ + xJY);
-				float vIX = mpc_la2(tII + xIX, tIM + xM);
-				float vJX = mpc_la2(tJJ + xJX, tJM + xM);
-				float vIY = mpc_la2(tII + xIY, tIM + xM);
-				float vJY = mpc_la2(tJJ + xJY, tJM + xM);
+				float vM = mpc_la5t(tMM + xM, tMI + xIX, tMJ + xJX, tMI + xIY, tMJ + xJY, s_coef);
+				float vIX = mpc_la2t(tII + xIX, tIM + xM, s_coef);
+				float vJX = mpc_la2t(tJJ + xJX, tJM + xM, s_coef);
+				float vIY = mpc_la2t(tII + xIY, tIM + xM, s_coef);
+				float vJY = mpc_la2t(tJJ + xJY, tJM + xM, s_coef);
 				if (i == LX && j == LY) { // bwdflat3.cpp:53-61
 					vM = tSM; vIX = tSI; vIY = tSI; vJX = tSJ; vJY = tSJ;
 				}
-				const bool live = (i <= LX) && (j >= 1) && (j <= LY);
-				if (!live) { vM = LZ; vIX = LZ; vJX = LZ; vIY = LZ; vJY = LZ; }
+				// No "outside the matrix" masking: rows below LX and columns right of LY start as
+				// LOG_ZERO and only ever combine LOG_ZERO inputs, so they stay exactly LOG_ZERO (the
+				// virtual neighbours the border formulas bwdflat3.cpp:132-176 need); column 0 and beyond
+				// is never read back (posteriors use i,j >= 1).
 				// calcposteriorflat.cpp:14: Score = F_M + B_M - Total
 				const float f = fmrow[r * 64];
 				const float score = (f + vM) - total;
 				sc[r] = score;
-				anyhit = anyhit || (live && score >= p.thr);
+				anyhit = anyhit || ((i <= LX) && (j >= 1) && (j <= LY) && score >= p.thr);
 				dgM = oM; // becomes M(i, j+1) = diagonal of row i-1
 				cM[r] = vM; cIX[r] = vIX; cJX[r] = vJX; cIY[r] = vIY; cJY[r] = vJY;
 				dnIX = vIX; dnJX = vJX;

@@ -194,42 +194,46 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 					// lcap1 is even and the LDS base 16-byte aligned: entries are 8-byte aligned (ds_read_b64)
 					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(ma + p.lcap1, 8);
 					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(mb + p.lcap1, 8);
+					// Block merge of the two sorted rows, MPC_RT_ROW entries of each per step: all LDS reads
+					// of a step are in flight together and the match is done in registers, so a cell costs
+					// ceil(na/4)+ceil(nb/4)-1 dependent LDS round trips (1 for ~97 % of the rows) instead of
+					// one per merged entry — and a wave only waits for its longest row pair at that rate.
+					// Row a is walked in ascending z; the partner of an entry in row b (columns are distinct
+					// within a row: at most one) is picked by compares. Columns ascend in both rows, so
+					// matches are monotone and the block order preserves the reference's order of additions
+					// (relaxflat.cpp:16-29 / :41-58 / :78-92: z ascending). An unmatched or absent entry
+					// contributes pa * 0.0f = +0.0f, which leaves the strictly positive sum bit-for-bit
+					// unchanged (the XZ_YZ form of the reference adds such explicit zeros itself).
 					float sum = acc[q];
-					if (__ballot(na > MPC_RT_ROW || nb > MPC_RT_ROW) == 0) {
-						// Fast path (every lane's two rows hold <= MPC_RT_ROW entries): both rows are fetched
-						// whole — all LDS reads of the slot are in flight together, two dependent round trips
-						// instead of one per merge step — and matched in registers. Row a is walked in
-						// ascending z; its partner in row b (columns are distinct within a row, so at most
-						// one) is picked by compares. An unmatched or absent entry contributes pa * 0.0f =
-						// +0.0f, which leaves the (strictly positive) sum bit-for-bit unchanged, so the
-						// rounding sequence is the reference's (relaxflat.cpp:16-29 / :41-58 / :78-92; the
-						// XZ_YZ form adds such explicit zeros itself).
+					u32 ia = 0, ib = 0;
+					while (ia < na && ib < nb) {
+						const u32 ra = na - ia, rb = nb - ib; // entries left in each row (>= 1)
 						MpcEnt va[MPC_RT_ROW], vb[MPC_RT_ROW];
 #pragma unroll
-						for (int r = 0; r < MPC_RT_ROW; ++r) { va[r] = ea[a + r]; vb[r] = eb[b + r]; } // reads past a row end are masked below
-						u32 cb[MPC_RT_ROW];
-#pragma unroll
-						for (int r = 0; r < MPC_RT_ROW; ++r) cb[r] = ((u32)r < nb) ? vb[r].c : 0xfffffffeu;
+						for (int r = 0; r < MPC_RT_ROW; ++r) { va[r] = ea[a + ia + r]; vb[r] = eb[b + ib + r]; } // reads past a row end are masked
+						u32 ca[MPC_RT_ROW], cb[MPC_RT_ROW];
 #pragma unroll
 						for (int r = 0; r < MPC_RT_ROW; ++r) {
-							const u32 ca = va[r].c;
+							ca[r] = ((u32)r < ra) ? va[r].c : 0xffffffffu;
+							cb[r] = ((u32)r < rb) ? vb[r].c : 0xfffffffeu;
+						}
+#pragma unroll
+						for (int r = 0; r < MPC_RT_ROW; ++r) {
 							float pb = 0.0f;
 #pragma unroll
-							for (int t2 = MPC_RT_ROW - 1; t2 >= 0; --t2) pb = (ca == cb[t2]) ? __uint_as_float(vb[t2].p) : pb;
-							const float pa = ((u32)r < na) ? __uint_as_float(va[r].p) : 0.0f;
+							for (int t2 = MPC_RT_ROW - 1; t2 >= 0; --t2) pb = (ca[r] == cb[t2]) ? __uint_as_float(vb[t2].p) : pb;
+							const float pa = ((u32)r < ra) ? __uint_as_float(va[r].p) : 0.0f;
 							sum += pa * pb; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
 						}
-					} else if (na != 0 && nb != 0) {
-						// General path: branch-free merge of the two sorted rows, one LDS read per side per step.
-						const u32 a1 = a + na, b1 = b + nb;
-						do {
-							const MpcEnt wa = ea[a], wb = eb[b];
-							const float prod = __uint_as_float(wa.p) * __uint_as_float(wb.p);
-							const float added = sum + prod;
-							sum = (wa.c == wb.c) ? added : sum;
-							a += (wa.c <= wb.c) ? 1u : 0u;
-							b += (wb.c <= wa.c) ? 1u : 0u;
-						} while (a < a1 && b < b1);
+						// largest column present in each block decides which row moves on
+						u32 amax = ca[0], bmax = cb[0];
+#pragma unroll
+						for (int r = 1; r < MPC_RT_ROW; ++r) {
+							amax = ((u32)r < ra) ? ca[r] : amax;
+							bmax = ((u32)r < rb) ? cb[r] : bmax;
+						}
+						ia += (amax <= bmax) ? (u32)MPC_RT_ROW : 0u;
+						ib += (bmax <= amax) ? (u32)MPC_RT_ROW : 0u;
 					}
 					acc[q] = sum;
 				}

@@ -530,7 +530,7 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	capc = std::max(capc, 1024u);
 	const int waves_per_block = 4, block = 64 * waves_per_block;
 	const u32 cus = (u32)c->prop.multiProcessorCount;
-	const size_t fb_smem = ((size_t)c->A * c->A + c->A) * sizeof(float);
+	const size_t fb_smem = MPC_FB_COEF_BYTES + ((size_t)c->A * c->A + c->A) * sizeof(float);
 
 	u64 words_done = 0; // record words packed so far
 	u64 done = 0;

@@ -39,7 +39,7 @@ def run_muscle(binary, name, threads=4, timeout=900):
         fa, out = os.path.join(d, "in.fa"), os.path.join(d, "out.afa")
         write_fasta(fa, seqs, labels)
         subprocess.run([binary, "-align", fa, "-output", out, "-threads", str(threads), "-quiet"] + extra,
-                       check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                       check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         with open(out, "rb") as f:
             data = f.read()
     return hashlib.md5(data).hexdigest(), data
