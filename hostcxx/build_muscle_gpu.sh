@@ -9,7 +9,8 @@
 #                      - calcposteriorflat.o's CalcPosterior symbol, weakened with objcopy so that
 #                        hostcxx/mpcflat_gpu.cpp's strong definition wins while CalcPostFlat and the
 #                        two vestigial virtuals in the same object stay available
-#   + hostcxx/mpcflat_gpu.cpp (g++, against the reference headers) + -lmpcgpu
+#   + hostcxx/mpcflat_gpu.cpp (g++, against the reference headers) + hostcxx/rand_isolate.cpp
+#     (-Wl,--wrap=rand) + -lmpcgpu
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(dirname "$HERE")"
@@ -23,6 +24,7 @@ fi
 mkdir -p "$OUT"
 CXXFLAGS="-std=c++17 -O3 -fopenmp -DNDEBUG -pthread -fPIC -w -I$ROOT/oracle/_ref/inc -I$SRC -I$ROOT/include"
 g++ $CXXFLAGS -c "$HERE/mpcflat_gpu.cpp" -o "$OUT/mpcflat_gpu.o"
+g++ $CXXFLAGS -c "$HERE/rand_isolate.cpp" -o "$OUT/rand_isolate.o"
 objcopy --weaken-symbol=_ZN7MPCFlat13CalcPosteriorEj "$REFOBJ/calcposteriorflat.o" "$OUT/calcposteriorflat_weak.o"
 OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/consflat\.o$' -e '/calcposteriorflat\.o$')
 # The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
@@ -31,6 +33,8 @@ OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/consflat\.o$' -e '/calcposteriorflat\.o$'
 LIBDIR="${MPCGPU_LIBDIR:-$ROOT/muscle_amd/csrc}"
 LIBNAME="${MPCGPU_LIBNAME:-mpcgpu}"
 BIN="${MPCGPU_BIN:-muscle_gpu}"
-g++ -O3 -fopenmp -pthread $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/mpcflat_gpu.o" \
+# --wrap=rand: the reference's rand() (refineflat.cpp:14) gets a private copy of glibc's default
+# stream; the HIP runtime in the same process otherwise consumes it (hostcxx/rand_isolate.cpp)
+g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
   -L"$LIBDIR" -l"$LIBNAME" -Wl,-rpath,"$LIBDIR" -Wl,-rpath,'$ORIGIN/../../muscle_amd/csrc' -Wl,-rpath,/opt/rocm/lib -o "$OUT/$BIN"
 echo "built: $OUT/$BIN"

@@ -54,6 +54,29 @@ mpcgpu_ctx *GetCtx()
 	return g_Ctx;
 	}
 
+// MUSCLE_GPU_DEBUG=1: FNV-1a digests of what crosses the boundary, on stderr (diagnostics)
+bool DebugOn()
+	{
+	static int On = -1;
+	if (On < 0)
+		{
+		const char *s = getenv("MUSCLE_GPU_DEBUG");
+		On = (s != 0 && *s != 0 && *s != '0') ? 1 : 0;
+		}
+	return On == 1;
+	}
+
+uint64_t Fnv(uint64_t h, const void *p, size_t n)
+	{
+	const unsigned char *b = (const unsigned char *) p;
+	for (size_t i = 0; i < n; ++i)
+		{
+		h ^= b[i];
+		h *= 1099511628211ull;
+		}
+	return h;
+	}
+
 #define GPUCHK(call)	do { if ((call) != 0) Die("GPU posterior stage: %s", mpcgpu_last_error(Ctx)); } while (0)
 
 // Copies pairs [k0,k1) of the device store into MySparseMx objects (layout of
@@ -104,6 +127,20 @@ template<class GETMX> void Download(mpcgpu_ctx *Ctx, MPCFlat &M, uint PairCount,
 			}
 		k0 = k1;
 		}
+	if (DebugOn())
+		{
+		uint64_t h = 14695981039346656037ull;
+		uint64_t Total = 0;
+		for (uint k = 0; k < PairCount; ++k)
+			{
+			MySparseMx &Mx = GetMx(k);
+			h = Fnv(h, Mx.m_Offsets, sizeof(uint)*(Mx.m_LX + 1));
+			h = Fnv(h, Mx.m_ValueVec, 8*size_t(NNZ[k]));
+			Total += NNZ[k];
+			}
+		fprintf(stderr, "[muscle_gpu] download: %u pairs, %llu entries, fnv %016llx\n", PairCount,
+		  (unsigned long long) Total, (unsigned long long) h);
+		}
 	}
 
 // First CalcPosterior call of a run: the whole all-pairs stage A on the device.
@@ -138,6 +175,19 @@ void StartBatch(MPCFlat &M, Batch &B)
 // MPCFlat::Consistency (mpcflat.cpp:173-181) is skipped for < 3 sequences or 0 iterations: then the
 // progressive stage reads the stage-A matrices, so they must exist on the host.
 	B.m_Materialise = (SeqCount < 3 || M.m_ConsistencyIterCount == 0);
+	if (DebugOn())
+		{
+		uint64_t h = Fnv(14695981039346656037ull, B.m_EA.data(), 4*size_t(PairCount));
+		uint64_t hs = 14695981039346656037ull;
+		for (uint i = 0; i < SeqCount; ++i)
+			hs = Fnv(hs, Ptrs[i], Lens[i]);
+		uint64_t hh = Fnv(14695981039346656037ull, PairHMM::m_StartScore, sizeof(PairHMM::m_StartScore));
+		hh = Fnv(hh, PairHMM::m_TransScore, sizeof(PairHMM::m_TransScore));
+		hh = Fnv(hh, PairHMM::m_MatchScore, sizeof(PairHMM::m_MatchScore));
+		hh = Fnv(hh, PairHMM::m_InsScore, sizeof(PairHMM::m_InsScore));
+		fprintf(stderr, "[muscle_gpu] stage A: %u seqs fnv(seqs) %016llx fnv(hmm) %016llx fnv(EA) %016llx\n", SeqCount,
+		  (unsigned long long) hs, (unsigned long long) hh, (unsigned long long) h);
+		}
 	}
 } // namespace
 

@@ -1,0 +1,11 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/quick2.log; : > $LOG
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+step() { echo "=== $* (t=$SECONDS)" | tee -a $LOG; "$@" 2>&1 | tee -a $LOG | tail -${TAILN:-30}; rc=${PIPESTATUS[0]}; echo "=== rc=$rc (t=$SECONDS)" | tee -a $LOG; return $rc; }
+step ./diag/rand_probe
+step ./diag/rand_probe hip
+step ./diag/rand_probe hip
+TAILN=60 step timeout 200 python -u diag/dropin_diag.py n8_L60 perturb bb11005
+TAILN=15 step timeout 300 python -u -m pytest tests -m gpu -q
+step timeout 150 python -u bench.py --n 1000 --len 400 --steps 1 --warmup 1 --no-cpu-baseline
