@@ -12,8 +12,8 @@
 // of it as short latency-bound gathers. Here a workgroup of 1024 threads owns the pairs
 // {X in [x0,x0+nx)} x {Y in [y0,y0+ny)}, X<Y (nx,ny <= 4, <= 16 register "slots" of 1024 cells)
 // and walks Z = 0..N-1 once: for every Z the nx+ny matrices M(S,Z) (row pointers + entries, both
-// contiguous in the slab layout) are streamed with wide coalesced loads into LDS and every pair of
-// the tile is served from LDS — (nx+ny)/(nx*ny) = 0.5 matrices per (pair,Z) instead of 2, and the
+// one fixed-size 16-byte-aligned record in the padded layout, kernels_store.h) are streamed with
+// one global_load_dwordx4 per thread per matrix into LDS and every pair of the tile is served from LDS — (nx+ny)/(nx*ny) = 0.5 matrices per (pair,Z) instead of 2, and the
 // loads of step Z+1 are in flight (staged in registers) while step Z is computed. Accumulators
 // and cell coordinates stay in VGPRs for the whole walk. The host orders the tile list in 8x8
 // super-tiles and deals consecutive tiles to the same XCD (block b runs on XCD b % 8), so the
@@ -26,27 +26,26 @@
 #define MPC_RT_ROW 4 // entries per row the register-matched fast path handles
 
 struct RelaxTileParams {
-	StoreParams s;
+	StoreParams s;    // s.pad / s.pad_stride / s.lcap1 / s.ecap describe the padded records
 	const u32 *tiles; // 4 u32 per tile: x0, nx, y0, ny
 	u32 ntiles;
-	u32 lcap1;  // LDS dwords reserved per matrix for row pointers (>= Lmax+1, even)
-	u32 ecap;   // LDS entries reserved per matrix
 	u64 k0, k1; // only pairs in [k0,k1) are relaxed (multi-GPU shard)
 };
 
-// MAXSEQ: matrices resident per step; NRP: row-pointer dwords staged per thread per matrix
-// (lcap1 <= NRP*1024). One entry per thread per matrix is staged in registers (1024 entries); the
-// rare matrix with more entries gets its tail copied global -> LDS at store time (slow path), and a
-// pair with more than 1024 cells takes several slots — the host splits any tile that would need
-// more than MPC_RT_SLOTS slots.
-template <int MAXSEQ, int NRP>
+struct __attribute__((aligned(16))) MpcU4 { u32 x, y, z, w; };
+
+// MAXSEQ: matrices resident per step; NLD: 16-byte loads per thread per matrix (record bytes <=
+// NLD * 16 KiB). A pair with more than 1024 cells takes several slots — the host splits any tile
+// that would need more than MPC_RT_SLOTS slots.
+template <int MAXSEQ, int NLD>
 __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTileParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
 	const StoreParams &s = p.s;
 	const u32 tid = threadIdx.x;
 	const u32 n = s.n;
-	const u32 mat_dwords = p.lcap1 + 2 * p.ecap;
+	const u32 mat_dwords = s.pad_stride;
+	const u32 lcap1 = s.lcap1;
 	u32 *lds = (u32 *)smem_raw;
 
 	// XCD-aware static schedule: the tile list is cut into 8 contiguous ranges, one per XCD
@@ -125,30 +124,23 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 				if ((u32)q == slot) { acc[q] = a0; xy[q] = c; sl_ab[q] = ab; }
 		});
 
-		// ---- walk Z with register-staged prefetch
-		u32 st_rp[MAXSEQ][NRP];
-		u32 st_e0[MAXSEQ], st_e1[MAXSEQ];
-		u32 st_cnt[MAXSEQ]; // entries of M(seq[i], Z) (wave-uniform)
-		u32 st_base[MAXSEQ]; // slab-relative entry offset of M(seq[i], Z) (wave-uniform)
+		// ---- walk Z with register-staged prefetch: record (A,Z) of the padded layout is copied
+		// verbatim, 16 bytes per thread per load, from pad + (A*n+Z)*stride (wave-uniform base in
+		// SGPRs, advanced by one record per step) to LDS matrix slot i.
+		MpcU4 st[MAXSEQ][NLD];
+		const u32 rec_bytes = mat_dwords * 4u;
 		auto stage_load = [&](u32 Z) {
 #pragma unroll
 			for (int i = 0; i < MAXSEQ; ++i) {
 				if ((u32)i < nseq) {
-					const u32 A = seq[i];
-					const u32 LA = s.seq_len[A];
-					const u32 *rp = s.rp + s.rp_base[A] + (u64)Z * (LA + 1);
-					const u32 e0 = s.mbase[(u64)A * (n + 1) + Z], e1 = s.mbase[(u64)A * (n + 1) + Z + 1];
-					const MpcEnt *ent = s.ent + s.ent_base[A] + e0;
-					st_base[i] = e0;
+					const unsigned char *src = (const unsigned char *)(s.pad + ((u64)seq[i] * n + Z) * (u64)mat_dwords);
 #pragma unroll
-					for (int r = 0; r < NRP; ++r) {
-						const u32 q = tid + r * MPC_RT_THREADS;
-						st_rp[i][r] = (q <= LA) ? rp[q] : 0u;
+					for (int r = 0; r < NLD; ++r) {
+						const u32 off = (tid + (u32)r * MPC_RT_THREADS) * 16u;
+						MpcU4 v; v.x = 0; v.y = 0; v.z = 0; v.w = 0;
+						if (off < rec_bytes) v = *(const MpcU4 *)(src + off);
+						st[i][r] = v;
 					}
-					MpcEnt v; v.p = 0; v.c = 0;
-					if (tid < e1 - e0) v = ent[tid];
-					st_e0[i] = v.p; st_e1[i] = v.c;
-					st_cnt[i] = e1 - e0;
 				}
 			}
 		};
@@ -156,17 +148,11 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 #pragma unroll
 			for (int i = 0; i < MAXSEQ; ++i) {
 				if ((u32)i < nseq) {
-					u32 *m = lds + (u32)i * mat_dwords;
+					unsigned char *m = (unsigned char *)(lds + (u32)i * mat_dwords);
 #pragma unroll
-					for (int r = 0; r < NRP; ++r) {
-						const u32 q = tid + r * MPC_RT_THREADS;
-						if (q < p.lcap1) m[q] = st_rp[i][r] - st_base[i]; // LDS-relative entry index
-					}
-					MpcEnt *me = (MpcEnt *)(m + p.lcap1);
-					if (tid < p.ecap) { MpcEnt v; v.p = st_e0[i]; v.c = st_e1[i]; me[tid] = v; }
-					if (st_cnt[i] > MPC_RT_THREADS) { // rare: tail of a matrix with more than 1024 entries
-						const MpcEnt *ent = s.ent + s.ent_base[seq[i]] + st_base[i];
-						for (u32 q = tid + MPC_RT_THREADS; q < st_cnt[i]; q += MPC_RT_THREADS) me[q] = ent[q];
+					for (int r = 0; r < NLD; ++r) {
+						const u32 off = (tid + (u32)r * MPC_RT_THREADS) * 16u;
+						if (off < rec_bytes) *(MpcU4 *)(m + off) = st[i][r];
 					}
 				}
 			}
@@ -192,8 +178,8 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 					u32 na = ma[x + 1] - a, nb = mb[y + 1] - b;
 					if (!have) { na = 0; nb = 0; }
 					// lcap1 is even and the LDS base 16-byte aligned: entries are 8-byte aligned (ds_read_b64)
-					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(ma + p.lcap1, 8);
-					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(mb + p.lcap1, 8);
+					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(ma + lcap1, 8);
+					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(mb + lcap1, 8);
 					// Block merge of the two sorted rows, MPC_RT_ROW entries of each per step: all LDS reads
 					// of a step are in flight together and the match is done in registers, so a cell costs
 					// ceil(na/4)+ceil(nb/4)-1 dependent LDS round trips (1 for ~97 % of the rows) instead of

@@ -38,6 +38,14 @@ struct StoreParams {
 	const u32 *mbase;    // n*(n+1): entry offset of M(A,Z) inside slab A at [A*(n+1)+Z]; [..+n] = slab size
 	// values of the next iteration, canonical order
 	float *vnext;
+	// padded layout for the LDS-tiled relax (kernels_relax.h), used INSTEAD of the slabs when it fits:
+	// one fixed-size record per ordered pair (A,Z) at pad + (A*n+Z)*pad_stride dwords =
+	//   [row pointers: lcap1 dwords, relative to the record's own entries][entries: ecap x {P bits, col}]
+	// A record is a straight 16-byte-aligned copy of what the kernel wants in LDS: no per-matrix
+	// metadata, no dependent address loads, one global_load_dwordx4 per thread per matrix.
+	u32 *pad;
+	u32 pad_stride; // dwords per record = lcap1 + 2*ecap (multiple of 4)
+	u32 lcap1, ecap;
 };
 
 __device__ __forceinline__ u64 mpc_pair_index(u32 n, u32 i, u32 j) // i<j, mpcflat.cpp:145-155 order
@@ -89,6 +97,52 @@ __global__ void __launch_bounds__(64) slab_build_kernel(StoreParams s)
 			if (fwd) { v.c = e[2 * (u64)q + 1]; dst[q] = v; }
 			else { v.c = rowv[q]; dst[tperm[q]] = v; }
 		}
+	}
+}
+
+// Padded layout: one 64-thread workgroup per ordered pair (A,Z), same sources as slab_build_kernel.
+__global__ void __launch_bounds__(64) pad_build_kernel(StoreParams s)
+{
+	const int t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		const u32 LA = s.seq_len[A];
+		u32 *rec_out = s.pad + b * (u64)s.pad_stride;
+		MpcEnt *dst = (MpcEnt *)(rec_out + s.lcap1);
+		if (A == Z) { // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
+			for (u32 q = t; q < s.pad_stride; q += 64) rec_out[q] = 0;
+			continue;
+		}
+		const bool fwd = A < Z;
+		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 LX = fwd ? LA : s.seq_len[Z]; // rows of the stored (unordered) pair
+		const u32 LY = fwd ? s.seq_len[Z] : LA;
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		const u32 *cnt = fwd ? rec : rec + LX; // rowcnt or colcnt, LA entries
+		u32 carry = 0;
+		for (u32 a0 = 0; a0 < s.lcap1; a0 += 64) {
+			const u32 a = a0 + t;
+			const u32 v = (a < LA) ? cnt[a] : 0;
+			u32 incl = v;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d);
+				if (t >= d) incl += o;
+			}
+			if (a < s.lcap1) rec_out[a] = carry + incl - v; // rows past LA repeat the total
+			carry += __shfl(incl, 63);
+		}
+		const u32 *e = rec + LX + LY;
+		const u32 *rowv = e + 2 * (u64)nnz;
+		const u32 *tperm = rowv + nnz;
+		for (u32 q = t; q < nnz; q += 64) {
+			MpcEnt v;
+			v.p = e[2 * (u64)q];
+			if (fwd) { v.c = e[2 * (u64)q + 1]; dst[q] = v; }
+			else { v.c = rowv[q]; dst[tperm[q]] = v; }
+		}
+		for (u32 q = nnz + t; q < s.ecap; q += 64) { MpcEnt v; v.p = 0; v.c = 0; dst[q] = v; }
 	}
 }
 
@@ -166,6 +220,26 @@ __global__ void __launch_bounds__(256) commit_kernel(StoreParams s)
 		ent[2 * (u64)idx] = pb;
 		s.ent[s.ent_base[X] + s.mbase[(u64)X * (s.n + 1) + Y] + idx].p = pb;
 		s.ent[s.ent_base[Y] + s.mbase[(u64)Y * (s.n + 1) + X] + tq].p = pb;
+	}
+}
+
+// commit for the padded layout
+__global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
+{
+	const u64 last = s.vbase[s.npairs];
+	for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < last; e += (u64)gridDim.x * blockDim.x) {
+		const u64 k = mpc_find_pair(s.vbase, 0, s.npairs, e);
+		const u32 X = s.pair_x[k], Y = s.pair_y[k];
+		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];
+		u32 *rec = s.packed + s.pbase[k];
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		const u32 idx = (u32)(e - s.vbase[k]);
+		u32 *ent = rec + LX + LY;
+		const u32 pb = __float_as_uint(s.vnext[e]);
+		const u32 tq = ent[3 * (u64)nnz + idx];
+		ent[2 * (u64)idx] = pb;
+		s.pad[((u64)X * s.n + Y) * s.pad_stride + s.lcap1 + 2 * (u64)idx] = pb;
+		s.pad[((u64)Y * s.n + X) * s.pad_stride + s.lcap1 + 2 * (u64)tq] = pb;
 	}
 }
 

@@ -95,7 +95,9 @@ struct mpcgpu_ctx {
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
-	DevBuf d_tiles;
+	DevBuf d_tiles, d_pad;
+	bool have_pad = false;       // padded layout + LDS-tiled relax (else: slabs + gather relax)
+	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0;
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
 	std::vector<u32> h_tiles;
 	u64 tiles_k0 = ~0ull, tiles_k1 = ~0ull;
@@ -254,32 +256,41 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.ent_base = c->d_ent_base.as<u64>();
 	s.mbase = c->d_mbase.as<u32>();
 	s.vnext = c->d_vnext.as<float>();
+	s.pad = c->d_pad.as<u32>();
+	s.lcap1 = c->pad_lcap1;
+	s.ecap = c->pad_ecap;
+	s.pad_stride = c->pad_lcap1 + 2 * c->pad_ecap;
 }
 
-template <int MS, int R> void launch_relax_tile(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
+// Padded-layout geometry for the LDS-tiled relax; false when a tile cannot fit the CU's LDS (or the
+// cell coordinates do not pack into 16:16): the caller then builds the slabs for the gather kernel.
+bool pad_geometry(const mpcgpu_ctx *c, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by)
 {
-	auto kern = relax_tile_kernel<MS, R>;
+	if (c->max_len > 65535u) return false;
+	*lcap1 = (c->max_len + 1 + 3) & ~3u;                 // >= Lmax+1, multiple of 4 dwords
+	*ecap = (std::max<u32>(c->max_nnz, 1) + 1) & ~1u;    // even: the record is a multiple of 16 bytes
+	const u64 rec_bytes = ((u64)*lcap1 + 2 * (u64)*ecap) * 4;
+	if (rec_bytes > 2 * 16384u) return false;            // at most two 16-byte loads per thread per matrix
+	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", 160) * 1024;
+	static const u32 shapes[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+	for (auto &sh : shapes)
+		if ((sh[0] + sh[1]) * rec_bytes + 8 * MPC_RT_ROW <= lds_cap) { *bx = sh[0]; *by = sh[1]; return true; }
+	return false;
+}
+
+template <int MS, int NLD> void launch_relax_tile(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
+{
+	auto kern = relax_tile_kernel<MS, NLD>;
 	MPC_LAUNCH(kern, grid, MPC_RT_THREADS, smem, st, rp);
 }
 
-// LDS-tiled relax (kernels_relax.h) when the matrices of a tile fit the CU's 160 KiB LDS; returns
-// 0 = launched, 1 = error, 2 = not applicable (caller uses the gather kernel).
+// LDS-tiled relax (kernels_relax.h) over the padded layout; 0 = launched, 1 = error.
 int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 {
 	const u32 n = c->n;
-	if (c->max_len > 65535u) return 2; // cell coordinates are packed 16:16
-	int nrp;
-	if (c->max_len + 1 <= 1024) nrp = 1; else if (c->max_len + 1 <= 2048) nrp = 2; else return 2;
-	const u32 lcap1 = (c->max_len + 2) & ~1u; // >= Lmax+1, even (entries stay 8-byte aligned in LDS)
-	const u32 ecap = std::max<u32>(c->max_nnz, 1);
-	const u64 mat_bytes = ((u64)lcap1 + 2 * (u64)ecap) * 4;
-	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", 160) * 1024;
-	// block shape by LDS capacity: (bx+by) matrices resident
-	static const u32 shapes[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
-	u32 bx = 0, by = 0;
-	for (auto &sh : shapes)
-		if ((sh[0] + sh[1]) * mat_bytes + 8 * MPC_RT_ROW <= lds_cap) { bx = sh[0]; by = sh[1]; break; }
-	if (!bx) return 2;
+	const u32 bx = c->pad_bx, by = c->pad_by;
+	const u64 mat_bytes = ((u64)c->pad_lcap1 + 2 * (u64)c->pad_ecap) * 4;
+	const int nld = mat_bytes <= 16384u ? 1 : 2;
 	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
 	// slots a tile needs: one per started 1024 cells of every pair in [k0,k1)
 	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
@@ -316,7 +327,7 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 						emit(x0, nx, y0, ny);
 					}
 		c->tiles_k0 = c->tiles_k1 = ~0ull;
-		if (too_big) { tiles.clear(); return 2; }
+		if (too_big) { tiles.clear(); return fail(c, "mpcgpu_cons_iter: a pair has more than %u stored cells (tile slot budget)", MPC_RT_SLOTS * MPC_RT_THREADS); }
 		// the source of an async H2D copy must outlive it: the list lives in the context AND the
 		// stream is drained before it can be rebuilt
 		if (upload(c, c->d_tiles, tiles)) return 1;
@@ -327,22 +338,22 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	if (tiles.empty()) return 0;
 	RelaxTileParams rp;
 	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
-	rp.lcap1 = lcap1; rp.ecap = ecap; rp.k0 = k0; rp.k1 = k1;
-	const size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-row reads may run past the last matrix
-	const void *fn = nrp == 1 ? (const void *)relax_tile_kernel<8, 1> : (const void *)relax_tile_kernel<8, 2>;
+	rp.k0 = k0; rp.k1 = k1;
+	const size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-block reads may run past the last matrix
+	const void *fn = nld == 1 ? (const void *)relax_tile_kernel<8, 1> : (const void *)relax_tile_kernel<8, 2>;
 	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 	int occ = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, MPC_RT_THREADS, smem) != hipSuccess || occ < 1) occ = 1;
 	u32 grid = std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ);
 	grid = std::max(grid, 1u);
 	if (trace_on()) {
-		fprintf(stderr, "[mpcgpu] relax tiled: tiles=%u block=%ux%u nrp=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n", rp.ntiles, bx, by,
-			nrp, c->max_nnz, smem, occ, grid);
+		fprintf(stderr, "[mpcgpu] relax tiled: tiles=%u block=%ux%u nld=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n", rp.ntiles, bx, by,
+			nld, c->max_nnz, smem, occ, grid);
 		fflush(stderr);
 	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
-	if (nrp == 1) launch_relax_tile<8, 1>(rp, grid, smem, c->stream);
+	if (nld == 1) launch_relax_tile<8, 1>(rp, grid, smem, c->stream);
 	else launch_relax_tile<8, 2>(rp, grid, smem, c->stream);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
@@ -397,7 +408,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_shard, &c->d_pbase, &c->d_vbase, &c->d_rp, &c->d_rp_base, &c->d_ent, &c->d_ent_base, &c->d_mbase,
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
-		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles};
+		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad};
 	for (DevBuf *b : all) b->release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -748,6 +759,46 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	c->max_len = 0;
 	for (u32 i = 0; i < n; ++i) c->max_len = std::max(c->max_len, c->len[i]);
 	c->st_packed = (const u32 *)dev_all;
+	HIPCHK(c, c->d_vnext.ensure(std::max<u64>(c->total_entries, 1) * 4));
+	if (upload(c, c->d_pbase, c->h_pbase) || upload(c, c->d_vbase, c->h_vbase)) return 1;
+	// ---- layout for relax: padded records + LDS-tiled kernel when a tile fits the LDS and the
+	// records fit HBM; otherwise compact slabs + the gather kernel (MPCGPU_RELAX=gather forces it).
+	// Both are device paths with identical results.
+	c->have_pad = false;
+	{
+		const char *mode = getenv("MPCGPU_RELAX");
+		u32 lcap1 = 0, ecap = 0, bx = 0, by = 0;
+		if (!(mode && !strcmp(mode, "gather")) && pad_geometry(c, &lcap1, &ecap, &bx, &by)) {
+			const u64 pad_bytes = (u64)n * n * ((u64)lcap1 + 2 * (u64)ecap) * 4;
+			size_t freeb = 0, totb = 0;
+			HIPCHK(c, hipMemGetInfo(&freeb, &totb));
+			if (pad_bytes <= c->d_pad.cap || pad_bytes + ((u64)2 << 30) <= (u64)freeb) {
+				c->have_pad = true;
+				c->pad_lcap1 = lcap1; c->pad_ecap = ecap; c->pad_bx = bx; c->pad_by = by;
+				c->d_rp.release(); c->d_ent.release(); c->d_mbase.release(); // slabs of an earlier run are not needed
+				HIPCHK(c, c->d_pad.ensure(pad_bytes));
+			}
+		}
+	}
+	TimedSpan ts;
+	if (c->have_pad) {
+		StoreParams sp;
+		fill_store_params(c, sp);
+		if (trace_on()) {
+			fprintf(stderr, "[mpcgpu] store: padded layout, %u x %u records of %u B (%.2f GB), tile block %ux%u\n", n, n,
+				sp.pad_stride * 4, (double)n * n * sp.pad_stride * 4 / 1e9, c->pad_bx, c->pad_by);
+			fflush(stderr);
+		}
+		if (span_begin(c, 2, &ts)) return 1;
+		const u64 blocks = (u64)n * n;
+		MPC_LAUNCH(pad_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp);
+		HIPCHK(c, hipGetLastError());
+		if (span_end(c, &ts)) return 1;
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		c->have_store = true;
+		return 0;
+	}
+	c->d_pad.release();
 	// ---- slab geometry: per ordered pair entry counts -> mbase (within slab), slab bases
 	std::vector<u32> mbase((size_t)n * (n + 1), 0);
 	std::vector<u64> ent_base(n + 1, 0), rp_base(n + 1, 0);
@@ -776,13 +827,9 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	}
 	HIPCHK(c, c->d_rp.ensure(rp_base[n] * 4));
 	HIPCHK(c, c->d_ent.ensure(std::max<u64>(ent_base[n], 1) * 8));
-	HIPCHK(c, c->d_vnext.ensure(std::max<u64>(c->total_entries, 1) * 4));
-	if (upload(c, c->d_pbase, c->h_pbase) || upload(c, c->d_vbase, c->h_vbase) || upload(c, c->d_mbase, mbase) ||
-		upload(c, c->d_ent_base, ent_base) || upload(c, c->d_rp_base, rp_base))
-		return 1;
+	if (upload(c, c->d_mbase, mbase) || upload(c, c->d_ent_base, ent_base) || upload(c, c->d_rp_base, rp_base)) return 1;
 	StoreParams sp;
 	fill_store_params(c, sp);
-	TimedSpan ts;
 	if (span_begin(c, 2, &ts)) return 1;
 	const u64 blocks = (u64)n * n;
 	MPC_LAUNCH(slab_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp);
@@ -857,13 +904,7 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	if (cnt == 0) return 0;
 	StoreParams sp;
 	fill_store_params(c, sp);
-	// MPCGPU_RELAX=gather forces the one-cell-per-thread gather kernel (also the path for sequences
-	// whose matrices do not fit the LDS tile); both are device kernels with identical results.
-	const char *mode = getenv("MPCGPU_RELAX");
-	if (!(mode && !strcmp(mode, "gather"))) {
-		const int rc = relax_tiled(c, sp, k0, k1);
-		if (rc != 2) return rc;
-	}
+	if (c->have_pad) return relax_tiled(c, sp, k0, k1);
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
 	const u32 block = 256;
@@ -887,7 +928,8 @@ int mpcgpu_cons_commit(mpcgpu_ctx *c)
 	if (span_begin(c, 4, &ts)) return 1;
 	const u32 block = 256;
 	const u64 blocks = (c->total_entries + block - 1) / block;
-	MPC_LAUNCH(commit_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64), block, 0, c->stream, sp);
+	if (c->have_pad) MPC_LAUNCH(commit_pad_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64), block, 0, c->stream, sp);
+	else MPC_LAUNCH(commit_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64), block, 0, c->stream, sp);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
 	return 0;
