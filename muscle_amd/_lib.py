@@ -199,6 +199,15 @@ class MpcGpu:
             pv += 2 * nnz[q]
         return out
 
+    def calc_aln(self, post):
+        """post: (LX, LY) float32 dense matrix in host memory -> (path str of B/X/Y, score)"""
+        post = np.ascontiguousarray(post, np.float32)
+        LX, LY = post.shape
+        path = np.empty(LX + LY, np.uint8)
+        n, sc = C.c_uint32(), C.c_float()
+        self._ck(self.L.mpcgpu_calc_aln(self.h, post.ctypes.data, LX, LY, path.ctypes.data, C.byref(n), C.byref(sc)))
+        return path[:n.value].tobytes().decode(), float(np.float32(sc.value))
+
     def timers_reset(self):
         self._ck(self.L.mpcgpu_timers_reset(self.h))
 

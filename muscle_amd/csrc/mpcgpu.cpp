@@ -6,6 +6,7 @@
 #include "kernels_post.h"
 #include "kernels_store.h"
 #include "kernels_relax.h"
+#include "kernels_aln.h"
 
 #include <algorithm>
 #include <climits>
@@ -95,7 +96,7 @@ struct mpcgpu_ctx {
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
-	DevBuf d_tiles, d_pad;
+	DevBuf d_tiles, d_pad, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // padded layout + LDS-tiled relax (else: slabs + gather relax)
 	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0;
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
@@ -408,7 +409,8 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_shard, &c->d_pbase, &c->d_vbase, &c->d_rp, &c->d_rp_base, &c->d_ent, &c->d_ent_base, &c->d_mbase,
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
-		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad};
+		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
+		&c->d_aln_out};
 	for (DevBuf *b : all) b->release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
@@ -983,9 +985,38 @@ int mpcgpu_get_sparse(mpcgpu_ctx *c, uint64_t k, uint32_t *offsets, void *values
 	return mpcgpu_get_sparse_range(c, k, k + 1, offsets, values);
 }
 
-int mpcgpu_calc_aln(mpcgpu_ctx *c, const float *, uint32_t, uint32_t, char *, uint32_t *, float *)
+int mpcgpu_calc_aln(mpcgpu_ctx *c, const float *post, uint32_t LX, uint32_t LY, char *path, uint32_t *pathlen, float *score)
 {
-	return fail(c, "mpcgpu_calc_aln: not implemented in this build");
+	if (!c) return 1;
+	if (!post || !path || !pathlen) return fail(c, "mpcgpu_calc_aln: NULL argument");
+	if (LX == 0 || LY == 0) return fail(c, "mpcgpu_calc_aln: empty matrix (%u x %u)", LX, LY);
+	const u64 W = (u64)LY + 1;
+	const size_t smem = (size_t)(2 * W + MPC_ALN_THREADS / 64 + 4) * 4;
+	if (smem > 160u * 1024u)
+		return fail(c, "mpcgpu_calc_aln: %u columns exceed the LDS-resident DP rows of this build", LY);
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, c->d_aln_post.ensure((u64)LX * LY * 4));
+	HIPCHK(c, c->d_aln_tb.ensure(((u64)LX + 1) * W));
+	HIPCHK(c, c->d_aln_rev.ensure((u64)LX + LY));
+	HIPCHK(c, c->d_aln_path.ensure((u64)LX + LY));
+	HIPCHK(c, c->d_aln_out.ensure(8));
+	HIPCHK(c, hipMemcpyAsync(c->d_aln_post.p, post, (u64)LX * LY * 4, hipMemcpyHostToDevice, c->stream));
+	AlnParams ap;
+	ap.post = c->d_aln_post.as<float>(); ap.LX = LX; ap.LY = LY;
+	ap.tb = c->d_aln_tb.as<char>(); ap.rev = c->d_aln_rev.as<char>(); ap.path = c->d_aln_path.as<char>();
+	ap.pathlen = c->d_aln_out.as<u32>(); ap.score = c->d_aln_out.as<float>() + 1;
+	(void)hipFuncSetAttribute((const void *)calc_aln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	MPC_LAUNCH(calc_aln_kernel, 1, MPC_ALN_THREADS, smem, c->stream, ap);
+	HIPCHK(c, hipGetLastError());
+	u32 out[2] = {0, 0};
+	HIPCHK(c, hipMemcpyAsync(out, c->d_aln_out.p, 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream)); // also: the H2D source (caller's buffer) is done with
+	if (out[0] > LX + LY) return fail(c, "mpcgpu_calc_aln: path length %u out of range (internal error)", out[0]);
+	*pathlen = out[0];
+	if (score) memcpy(score, &out[1], 4);
+	if (out[0]) HIPCHK(c, hipMemcpyAsync(path, c->d_aln_path.p, out[0], hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
 }
 
 int mpcgpu_timers_reset(mpcgpu_ctx *c)

@@ -85,3 +85,25 @@ def test_emu_relax_two_slots_per_pair(emu):
     stages, ea = P.run_lib(seqs, lib_path=emu)
     assert max(len(v) // 2 for _, v in stages[0]) > 1024
     P.assert_same((stages, ea), P.run_oracle(seqs), "nent=2")
+
+
+def test_emu_calc_aln(emu):
+    """CalcAlnFlat + TraceBackFlat on the device (kernels_aln.h) vs the oracle: same path string,
+    same score bits, including tie cases (equal B/X/Y candidates) and general non-posterior input."""
+    import _oracle as O
+    from muscle_amd._lib import MpcGpu
+    rng = np.random.default_rng(5)
+    g = MpcGpu(0, emu)
+    mats = []
+    for LX, LY in ((1, 1), (1, 7), (9, 1), (13, 17), (40, 33)):
+        P0 = (rng.random((LX, LY)) < 0.15) * rng.random((LX, LY))
+        mats.append(P0.astype(np.float32))
+        mats.append(np.round(P0 * 4).astype(np.float32) / 4)  # many exact ties
+    mats.append(np.zeros((5, 6), np.float32))                 # all ties: every cell equal
+    mats.append((rng.random((30, 1100)) * 3).astype(np.float32))  # more columns than threads
+    for M in mats:
+        path, sc = g.calc_aln(M)
+        sc0, path0 = O.calc_aln(M)
+        assert path == path0, M.shape
+        assert P.bits(sc) == P.bits(sc0)
+    g.close()

@@ -95,15 +95,28 @@ def test_sharded_equals_whole():
         g.calc_posteriors(a, b)
         ctxs.append(g)
         blobs.append(g.shard_info())
-    import torch
+    # caller-owned device memory for the "gathered" shards: straight from the HIP runtime (no torch:
+    # importing torch AFTER libmpcgpu has loaded the system HIP runtime breaks torch's device init)
+    import ctypes as C
+    hip = None
+    for name in ("libamdhip64.so.7", "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            hip = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    assert hip is not None
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
     total = sum(b for b, _ in blobs)
-    buf = torch.empty(total, dtype=torch.uint8, device="cuda:0")
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(total)) == 0
     off = 0
     for c, (nbytes, _) in zip(ctxs, blobs):
-        c.shard_export(buf.data_ptr() + off)
+        c.shard_export(dptr.value + off)
         off += nbytes
     g = ctxs[0]
-    g.store_import(cuts[:-1], cuts[1:], [b for b, _ in blobs], buf.data_ptr())
+    g.store_import(cuts[:-1], cuts[1:], [b for b, _ in blobs], dptr.value)
     stages = [g.get_sparse_range()]
     ea = g.get_ea()
     for _ in range(2):
@@ -115,6 +128,7 @@ def test_sharded_equals_whole():
     P.assert_same((stages, ea), whole, "sharded")
     for c in ctxs:
         c.close()
+    hip.hipFree(dptr)
 
 
 def test_back_to_back_iterations_without_sync():
@@ -152,6 +166,27 @@ def test_relax_gather_equals_tiled():
         del os.environ["MPCGPU_RELAX"]
     P.assert_same(a, b, "gather vs tiled")
     P.assert_same(a, P.run_oracle(seqs), "tiled vs oracle")
+
+
+def test_calc_aln_paths():
+    """CalcAlnFlat + TraceBackFlat on the device: integer traceback bit-for-bit (path string) and
+    score bits, vs the golden paths of the compiled reference (pairs_small) and vs the oracle on
+    dense MSA-sized matrices with many exact ties."""
+    import _oracle as O
+    g = MpcGpu(0)
+    z = G.load("pairs_small")
+    for k in range(int(z["n"])):
+        path, sc = g.calc_aln(z["post%d" % k])
+        assert path == str(z["path%d" % k])
+        assert P.bits(sc) == P.bits(z["calcaln_score%d" % k])
+    rng = np.random.default_rng(11)
+    for LX, LY in ((1, 1), (1, 9), (7, 1), (150, 170), (620, 580), (300, 2500)):
+        M = ((rng.random((LX, LY)) < 0.02) * rng.random((LX, LY)) * 3).astype(np.float32)
+        for Q in (M, np.round(M * 2) / 2):
+            path, sc = g.calc_aln(Q.astype(np.float32))
+            sc0, path0 = O.calc_aln(Q.astype(np.float32))
+            assert path == path0 and P.bits(sc) == P.bits(sc0), (LX, LY)
+    g.close()
 
 
 def test_errors_are_loud():
