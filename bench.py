@@ -56,6 +56,20 @@ def stage_b_bytes(lens, nnz):
     return float(np.sum(ent + ptr + 4 * nnz))
 
 
+def pmc_traffic(kernel, n, length):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json,
+    written by scripts/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    runs of this same command); None when no pass exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        e = d.get("%s@%dx%d" % (kernel, n, length))
+        return None if e is None else float(e["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(seqs, n_full, budget_s=20.0):
     """Reference (oracle/_ref/libmuscle_ref.so = the reference's own MPCFlat::CalcPosteriors +
     ConsIter, OpenMP over all host cores) on a bounded sample of the same family, extrapolated to
@@ -166,7 +180,7 @@ def main():
             achieved = work / (ms * 1e-3) / 1e12
             roof = {"kernel": "fb_kernel<H> (pair-HMM fwd+bwd+posterior, one wave per pair)", "bound": "valu",
                     "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                    "traffic": None,
+                    "traffic": pmc_traffic("fb_kernel", a.n, a.len),
                     "note": "FP32 vector-ALU bound recurrence (no contraction, no MFMA: SURVEY.md §8d); peak = 157.3 TFLOP/s "
                             "FP32 vector = FP32 dense MFMA peak; algorithmic flops = sum 164(LX+1)(LY+1)+5LXLY"}
         else:

@@ -10,20 +10,24 @@
 // Why a tile. One cell-per-thread gather (relax_kernel) re-reads M(X,Z) for every Y and M(Y,Z)
 // for every X: 2 matrices (~16 KB at L=400, r=2) per (pair,Z), ~8 TB per iteration at N=1000, all
 // of it as short latency-bound gathers. Here a workgroup of 1024 threads owns the pairs
-// {X in [x0,x0+nx)} x {Y in [y0,y0+ny)}, X<Y (nx,ny <= 4, <= 16 register "slots" of 1024 cells)
-// and walks Z = 0..N-1 once: for every Z the nx+ny matrices M(S,Z) (row pointers + entries, both
-// one fixed-size 16-byte-aligned record in the padded layout, kernels_store.h) are streamed with
-// one global_load_dwordx4 per thread per matrix into LDS and every pair of the tile is served from LDS — (nx+ny)/(nx*ny) = 0.5 matrices per (pair,Z) instead of 2, and the
-// loads of step Z+1 are in flight (staged in registers) while step Z is computed. Accumulators
-// and cell coordinates stay in VGPRs for the whole walk. The host orders the tile list in 8x8
-// super-tiles and deals consecutive tiles to the same XCD (block b runs on XCD b % 8), so the
-// workgroups sharing an L2 read the same 64 sequences' slabs at about the same Z.
+// {X in [x0,x0+nx)} x {Y in [y0,y0+ny)}, X<Y (nx,ny <= 4). The cells of all those pairs are laid
+// end to end and dealt to (slot, lane): cell g lives in slot g/1024, lane g%1024 — every lane of
+// every used slot but the last holds a cell (~12 slots for 16 pairs at L=400, r=2). Accumulator and
+// packed cell descriptor stay in VGPRs for the whole walk over Z = 0..N-1: for every Z the nx+ny
+// matrices M(S,Z) (each one fixed-size 16-byte-aligned record in the padded layout,
+// kernels_store.h) are streamed with one global_load_dwordx4 per thread per matrix into LDS and
+// every cell of the tile is served from LDS — (nx+ny)/(nx*ny) = 0.5 matrices per (pair,Z) instead
+// of 2, with the loads of step Z+1 in flight (staged in registers) while step Z is computed. The
+// host orders the tile list in 8x8 super-tiles and deals consecutive tiles to the same XCD (block b
+// runs on XCD b % 8), so the workgroups sharing an L2 read the same 64 sequences' records at about
+// the same Z.
 #pragma once
 #include "kernels_store.h"
 
 #define MPC_RT_THREADS 1024
 #define MPC_RT_SLOTS 16
-#define MPC_RT_ROW 4 // entries per row the register-matched fast path handles
+#define MPC_RT_ROW 4          // entries of each row handled per merge step
+#define MPC_RT_MAXLEN 8191u   // cell descriptor packs x:13 | y:13 | matrix of X:3 | matrix of Y:3
 
 struct RelaxTileParams {
 	StoreParams s;    // s.pad / s.pad_stride / s.lcap1 / s.ecap describe the padded records
@@ -35,8 +39,7 @@ struct RelaxTileParams {
 struct __attribute__((aligned(16))) MpcU4 { u32 x, y, z, w; };
 
 // MAXSEQ: matrices resident per step; NLD: 16-byte loads per thread per matrix (record bytes <=
-// NLD * 16 KiB). A pair with more than 1024 cells takes several slots — the host splits any tile
-// that would need more than MPC_RT_SLOTS slots.
+// NLD * 16 KiB). The host splits any tile whose cells would need more than MPC_RT_SLOTS slots.
 template <int MAXSEQ, int NLD>
 __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTileParams p)
 {
@@ -79,16 +82,17 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 				++nseq;
 			}
 		}
-		// ---- slots: (pair, 1024-cell chunk) -> this thread's cell, accumulator, LDS matrix slots.
-		// The enumeration order is a pure function of the tile, so the epilogue repeats it instead of
-		// keeping 16 entry indices alive in registers through the Z walk.
+		// ---- cells: the pairs of the tile in (ix, iy) order, their cells end to end; cell g ->
+		// slot g / 1024, lane g % 1024. The enumeration is a pure function of the tile, so the
+		// epilogue repeats it instead of keeping 16 entry indices alive through the Z walk. Lanes
+		// past the last cell get a dummy descriptor (cell (0,0) of matrix 0: valid LDS reads, result
+		// never stored), so the walk needs no per-lane validity tests.
 		float acc[MPC_RT_SLOTS];
-		u32 xy[MPC_RT_SLOTS];    // (x << 16) | y ; 0xffffffff = no cell
-		u32 sl_ab[MPC_RT_SLOTS]; // wave-uniform: (lds matrix of X) | (lds matrix of Y) << 8 ; 0xffff = unused slot
+		u32 xy[MPC_RT_SLOTS]; // x | y << 13 | (lds matrix of X) << 26 | (lds matrix of Y) << 29
 #pragma unroll
-		for (int q = 0; q < MPC_RT_SLOTS; ++q) { acc[q] = 0.0f; xy[q] = 0xffffffffu; sl_ab[q] = 0xffffu; }
-		auto for_each_slot = [&](auto &&fn) {
-			u32 slot = 0;
+		for (int q = 0; q < MPC_RT_SLOTS; ++q) { acc[q] = 1.0f; xy[q] = 0u; }
+		auto for_each_pair = [&](auto &&fn) {
+			u32 base = 0;
 			for (u32 ix = 0; ix < nx; ++ix) {
 				for (u32 iy = 0; iy < ny; ++iy) {
 					const u32 X = x0 + ix, Y = y0 + iy;
@@ -96,32 +100,31 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 					const u64 k = mpc_pair_index(n, X, Y);
 					if (k < p.k0 || k >= p.k1) continue;
 					const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
-					// LDS matrix slots of X and Y
-					u32 mb = 0;
+					u32 mb = 0; // LDS matrix slot of Y
 					if (Y >= x0 && Y < x0 + nx) mb = Y - x0;
 					else {
 						u32 before = 0; // Y's rank among the Y-range sequences that are not in the X range
 						for (u32 j = 0; j < iy; ++j) { const u32 Yj = y0 + j; if (!(Yj >= x0 && Yj < x0 + nx)) ++before; }
 						mb = nx + before;
 					}
-					for (u32 c0 = 0; c0 < nnz; c0 += MPC_RT_THREADS) {
-						fn(slot, k, X, Y, nnz, c0 + tid, ix | (mb << 8));
-						++slot;
-					}
+					fn(k, X, Y, nnz, base, (ix << 26) | (mb << 29));
+					base += nnz;
 				}
 			}
+			return base;
 		};
-		for_each_slot([&](u32 slot, u64 k, u32 X, u32 Y, u32 nnz, u32 idx, u32 ab) {
+		// cells of the tile (wave-uniform)
+		const u32 total = for_each_pair([&](u64 k, u32 X, u32 Y, u32 nnz, u32 base, u32 ab) {
 			const u32 *ent = s.packed + s.pbase[k] + s.seq_len[X] + s.seq_len[Y];
-			float a0 = 0.0f;
-			u32 c = 0xffffffffu;
-			if (idx < nnz) {
-				a0 = __uint_as_float(ent[2 * (u64)idx]) * 2.0f; // conspairflat.cpp:29-30
-				c = (ent[2 * (u64)nnz + idx] << 16) | ent[2 * (u64)idx + 1];
-			}
 #pragma unroll
-			for (int q = 0; q < MPC_RT_SLOTS; ++q)
-				if ((u32)q == slot) { acc[q] = a0; xy[q] = c; sl_ab[q] = ab; }
+			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
+				const u32 g = (u32)q * MPC_RT_THREADS + tid;
+				if (g >= base && g - base < nnz) {
+					const u32 idx = g - base;
+					acc[q] = __uint_as_float(ent[2 * (u64)idx]) * 2.0f; // conspairflat.cpp:29-30
+					xy[q] = ent[2 * (u64)nnz + idx] | (ent[2 * (u64)idx + 1] << 13) | ab;
+				}
+			}
 		});
 
 		// ---- walk Z with register-staged prefetch: record (A,Z) of the padded layout is copied
@@ -158,6 +161,7 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 			}
 		};
 
+		const u32 wave_first = tid & ~63u; // first lane of my wave
 		stage_load(0);
 		for (u32 Z = 0; Z < n; ++Z) {
 			__syncthreads(); // every wave is done reading step Z-1 from LDS
@@ -166,57 +170,53 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 			if (Z + 1 < n) stage_load(Z + 1); // in flight while step Z is computed
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
-				if (sl_ab[q] != 0xffffu) { // wave-uniform
-					const u32 *ma = lds + (sl_ab[q] & 0xffu) * mat_dwords;
-					const u32 *mb = lds + (sl_ab[q] >> 8) * mat_dwords;
+				if ((u32)q * MPC_RT_THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
 					u32 c = xy[q];
-					MPC_OPAQUE(c); // keep one register per slot: recompute the two LDS addresses per step
-					const bool have = c != 0xffffffffu;
-					if (__ballot(have) == 0) continue; // this wave holds no cell of the slot
-					const u32 x = have ? (c >> 16) : 0u, y = have ? (c & 0xffffu) : 0u;
-					u32 a = ma[x], b = mb[y];
-					u32 na = ma[x + 1] - a, nb = mb[y + 1] - b;
-					if (!have) { na = 0; nb = 0; }
-					// lcap1 is even and the LDS base 16-byte aligned: entries are 8-byte aligned (ds_read_b64)
+					MPC_OPAQUE(c); // keep one register per slot: recompute the LDS addresses per step
+					const u32 x = c & 0x1fffu, y = (c >> 13) & 0x1fffu;
+					const u32 *ma = lds + ((c >> 26) & 7u) * mat_dwords;
+					const u32 *mb = lds + (c >> 29) * mat_dwords;
+					const u32 a = ma[x], b = mb[y];
+					const u32 na = ma[x + 1] - a, nb = mb[y + 1] - b;
+					// lcap1 is a multiple of 4 and the LDS base 16-byte aligned: entries are 8-byte aligned
 					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(ma + lcap1, 8);
 					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(mb + lcap1, 8);
 					// Block merge of the two sorted rows, MPC_RT_ROW entries of each per step: all LDS reads
 					// of a step are in flight together and the match is done in registers, so a cell costs
 					// ceil(na/4)+ceil(nb/4)-1 dependent LDS round trips (1 for ~97 % of the rows) instead of
-					// one per merged entry — and a wave only waits for its longest row pair at that rate.
-					// Row a is walked in ascending z; the partner of an entry in row b (columns are distinct
-					// within a row: at most one) is picked by compares. Columns ascend in both rows, so
-					// matches are monotone and the block order preserves the reference's order of additions
-					// (relaxflat.cpp:16-29 / :41-58 / :78-92: z ascending). An unmatched or absent entry
-					// contributes pa * 0.0f = +0.0f, which leaves the strictly positive sum bit-for-bit
-					// unchanged (the XZ_YZ form of the reference adds such explicit zeros itself).
+					// one per merged entry. Row a is walked in ascending z; the partner of an entry in row b
+					// (columns are distinct within a row: at most one) is picked by compares. Entries read
+					// past a row end are neutralised through their probability (0.0f), not their column:
+					// a valid entry of row a can only pick up a real partner or a zeroed one, and if both
+					// exist the real one has the lower index and is assigned last. Columns ascend in both
+					// rows, so matches are monotone and the block order preserves the reference's order of
+					// additions (relaxflat.cpp:16-29 / :41-58 / :78-92: z ascending). An unmatched or
+					// absent entry contributes pa * 0.0f = +0.0f, which leaves the strictly positive sum
+					// bit-for-bit unchanged (the XZ_YZ form of the reference adds such zeros itself).
 					float sum = acc[q];
 					u32 ia = 0, ib = 0;
 					while (ia < na && ib < nb) {
 						const u32 ra = na - ia, rb = nb - ib; // entries left in each row (>= 1)
 						MpcEnt va[MPC_RT_ROW], vb[MPC_RT_ROW];
 #pragma unroll
-						for (int r = 0; r < MPC_RT_ROW; ++r) { va[r] = ea[a + ia + r]; vb[r] = eb[b + ib + r]; } // reads past a row end are masked
-						u32 ca[MPC_RT_ROW], cb[MPC_RT_ROW];
+						for (int r = 0; r < MPC_RT_ROW; ++r) { va[r] = ea[a + ia + r]; vb[r] = eb[b + ib + r]; }
+						float pbm[MPC_RT_ROW];
 #pragma unroll
-						for (int r = 0; r < MPC_RT_ROW; ++r) {
-							ca[r] = ((u32)r < ra) ? va[r].c : 0xffffffffu;
-							cb[r] = ((u32)r < rb) ? vb[r].c : 0xfffffffeu;
-						}
+						for (int r = 0; r < MPC_RT_ROW; ++r) pbm[r] = ((u32)r < rb) ? __uint_as_float(vb[r].p) : 0.0f;
 #pragma unroll
 						for (int r = 0; r < MPC_RT_ROW; ++r) {
 							float pb = 0.0f;
 #pragma unroll
-							for (int t2 = MPC_RT_ROW - 1; t2 >= 0; --t2) pb = (ca[r] == cb[t2]) ? __uint_as_float(vb[t2].p) : pb;
+							for (int t2 = MPC_RT_ROW - 1; t2 >= 0; --t2) pb = (va[r].c == vb[t2].c) ? pbm[t2] : pb;
 							const float pa = ((u32)r < ra) ? __uint_as_float(va[r].p) : 0.0f;
 							sum += pa * pb; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
 						}
-						// largest column present in each block decides which row moves on
-						u32 amax = ca[0], bmax = cb[0];
+						// the largest column present in each block decides which row moves on
+						u32 amax = va[0].c, bmax = vb[0].c;
 #pragma unroll
 						for (int r = 1; r < MPC_RT_ROW; ++r) {
-							amax = ((u32)r < ra) ? ca[r] : amax;
-							bmax = ((u32)r < rb) ? cb[r] : bmax;
+							amax = ((u32)r < ra) ? va[r].c : amax;
+							bmax = ((u32)r < rb) ? vb[r].c : bmax;
 						}
 						ia += (amax <= bmax) ? (u32)MPC_RT_ROW : 0u;
 						ib += (bmax <= amax) ? (u32)MPC_RT_ROW : 0u;
@@ -226,12 +226,13 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 			}
 		}
 		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern
-		for_each_slot([&](u32 slot, u64 k, u32, u32, u32 nnz, u32 idx, u32) {
-			float v = 0.0f;
+		for_each_pair([&](u64 k, u32, u32, u32 nnz, u32 base, u32) {
 #pragma unroll
-			for (int q = 0; q < MPC_RT_SLOTS; ++q)
-				if ((u32)q == slot) v = acc[q];
-			if (idx < nnz) s.vnext[s.vbase[k] + idx] = v / (float)n; // uint -> float, IEEE divide (mysparsemx.cpp:108)
+			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
+				const u32 g = (u32)q * MPC_RT_THREADS + tid;
+				if (g >= base && g - base < nnz)
+					s.vnext[s.vbase[k] + (g - base)] = acc[q] / (float)n; // uint -> float, IEEE divide (mysparsemx.cpp:108)
+			}
 		});
 		__syncthreads();
 	}

@@ -267,7 +267,7 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 // cell coordinates do not pack into 16:16): the caller then builds the slabs for the gather kernel.
 bool pad_geometry(const mpcgpu_ctx *c, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by)
 {
-	if (c->max_len > 65535u) return false;
+	if (c->max_len > MPC_RT_MAXLEN) return false; // cell descriptors pack x and y into 13 bits each
 	*lcap1 = (c->max_len + 1 + 3) & ~3u;                 // >= Lmax+1, multiple of 4 dwords
 	*ecap = (std::max<u32>(c->max_nnz, 1) + 1) & ~1u;    // even: the record is a multiple of 16 bytes
 	const u64 rec_bytes = ((u64)*lcap1 + 2 * (u64)*ecap) * 4;
@@ -293,15 +293,15 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	const u64 mat_bytes = ((u64)c->pad_lcap1 + 2 * (u64)c->pad_ecap) * 4;
 	const int nld = mat_bytes <= 16384u ? 1 : 2;
 	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
-	// slots a tile needs: one per started 1024 cells of every pair in [k0,k1)
+	// slots a tile needs: its cells (all pairs in [k0,k1), laid end to end) in chunks of 1024
 	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
-		u32 slots = 0;
+		u64 cells = 0;
 		for (u32 X = x0; X < x0 + nx; ++X)
 			for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
 				const u64 k = pidx(X, Y);
-				if (k >= k0 && k < k1) slots += (c->all_nnz[k] + MPC_RT_THREADS - 1) / MPC_RT_THREADS;
+				if (k >= k0 && k < k1) cells += c->all_nnz[k];
 			}
-		return slots;
+		return (u32)((cells + MPC_RT_THREADS - 1) / MPC_RT_THREADS);
 	};
 	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != bx || c->tiles_by != by) {
 		std::vector<u32> &tiles = c->h_tiles;

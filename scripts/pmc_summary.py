@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes into profiles/pmc_traffic.json.
+usage: scripts/pmc_summary.py N LEN fetch_dir write_dir [out.json]
+Each dir holds the csv output of `rocprofv3 --pmc FETCH_SIZE` (resp. WRITE_SIZE) `--output-format csv`.
+HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md §HBM (FETCH_SIZE on gfx950
+reports half the bytes of wide coalesced reads; both counters are in KiB); per launch = mean over
+the dispatches of the kernel."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def read(dirname, counter):
+    out = defaultdict(list)
+    for fn in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        with open(fn) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") == counter:
+                    out[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return out
+
+
+def main():
+    n, length, fdir, wdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                               "profiles", "pmc_traffic.json")
+    fetch, write = read(fdir, "FETCH_SIZE"), read(wdir, "WRITE_SIZE")
+    try:
+        with open(out) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        d = {}
+    for kname in sorted(set(fetch) | set(write)):
+        short = kname.split("(")[0].replace("void ", "").split("<")[0]
+        fv, wv = fetch.get(kname, []), write.get(kname, [])
+        if not fv and not wv:
+            continue
+        fm = sum(fv) / len(fv) if fv else 0.0
+        wm = sum(wv) / len(wv) if wv else 0.0
+        d["%s@%dx%d" % (short, n, length)] = {
+            "kernel": kname, "launches_sampled": max(len(fv), len(wv)), "FETCH_SIZE_KiB_mean": fm, "WRITE_SIZE_KiB_mean": wm,
+            "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0,
+            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}
+        print(short, d["%s@%dx%d" % (short, n, length)])
+    with open(out, "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
