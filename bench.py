@@ -175,21 +175,32 @@ def main():
         fam = max(("fb", "relax"), key=lambda k: timers[k][0])
         ms, launches = timers[fam]
         my_frac = 1.0 / world  # this rank's share of the pair-sharded work
+        avg_s = ms * 1e-3 / max(launches, 1)  # average launch duration of the dominant kernel
         if fam == "fb":
-            work = stage_a_flops(lens) * a.steps * my_frac
-            achieved = work / (ms * 1e-3) / 1e12
+            # all pairs of this rank per step, spread over `launches / steps` batch launches
+            per_launch = stage_a_flops(lens) * my_frac * a.steps / max(launches, 1)
+            achieved = per_launch / avg_s / 1e12
             roof = {"kernel": "fb_kernel<H> (pair-HMM fwd+bwd+posterior, one wave per pair)", "bound": "valu",
                     "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                     "traffic": pmc_traffic("fb_kernel", a.n, a.len),
-                    "note": "FP32 vector-ALU bound recurrence (no contraction, no MFMA: SURVEY.md §8d); peak = 157.3 TFLOP/s "
-                            "FP32 vector = FP32 dense MFMA peak; algorithmic flops = sum 164(LX+1)(LY+1)+5LXLY"}
+                    "note": "FP32 vector-ALU bound recurrence (no contraction, no MFMA: SURVEY.md 8d); peak = 157.3 TFLOP/s "
+                            "FP32 vector = FP32 dense MFMA peak; algorithmic flops per launch = sum over the launch's pairs of "
+                            "164(LX+1)(LY+1)+5LXLY"}
         else:
-            work = stage_b_bytes(lens, nnz) * a.steps * my_frac
-            achieved = work / (ms * 1e-3) / 1e9
-            roof = {"kernel": "relax_kernel (consistency SDDMM over the sparse store)", "bound": "hbm",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None,
-                    "note": "algorithmic bytes = operands of every (pair,Z) read once (SURVEY.md §8d stage B)"}
+            # one launch = one relax iteration over this rank's pairs
+            per_launch = stage_b_bytes(lens, nnz) * my_frac
+            achieved = per_launch / avg_s / 1e9
+            roof = {"kernel": "relax_tile_kernel (consistency relax: sampled sparse product over the all-pairs store, LDS-tiled)",
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic("relax_tile_kernel", a.n, a.len),
+                    "algorithmic_bytes_per_launch": per_launch,
+                    "note": "algorithmic bytes per launch (= one relax iteration) = operands of every (pair,Z) read once: sum "
+                            "over pairs and Z of 8*(nnz_XZ+nnz_YZ)+4*(LX+LY+2), + 4*nnz written (SURVEY.md 8d stage B), divided "
+                            "by the average launch time from hipEvents on the library stream; traffic = HBM bytes per launch "
+                            "from separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE, KiB, per "
+                            "MI355X_MICROARCH.md HBM section), null when none is committed for this workload. The LDS tiling "
+                            "serves 16 pairs from 8 records, so real traffic is below the algorithmic figure; the kernel is "
+                            "instruction-bound (DESIGN.md 4.3)"}
         roof["launches"] = launches
         roof["avg_launch_ms"] = ms / max(launches, 1)
         out = {
