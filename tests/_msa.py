@@ -28,6 +28,8 @@ def input_set(name):
         return [s[0], s[1], s[0], s[2], s[1], s[3], s[4]], None, []
     if name == "consiters0":
         return make_family(6, 45, seed=4), None, ["-consiters", "0"]
+    if name == "perturb_small":
+        return make_family(5, 36, seed=6), None, ["-perturb", "5", "-perm", "bca"]
     if name == "perturb":
         return make_family(7, 60, seed=5), None, ["-perturb", "3", "-perm", "acb"]
     return G.mpc(name)["seqs"], None, []
