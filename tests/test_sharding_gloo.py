@@ -119,3 +119,54 @@ def test_run_stage_world2_gloo():
     for it in (1, 2):
         expect = np.arange(total, dtype=np.float32) + 1000 * it
         assert np.array_equal(log0[it - 1], expect) and np.array_equal(log1[it - 1], expect)
+
+
+# ---------------------------------------------------------------------------------------------
+# Same world_size-2 gloo run with REAL kernel code on both ranks: the product kernel sources compiled
+# against the SIMT emulator (tests/emu, test infrastructure; "device pointers" are host addresses,
+# so the CPU tensors of the gloo exchange are valid shard / value buffers). Every rank must end with
+# the store the oracle computes for the whole problem, bit for bit: pair-sharded stage A, all-gather
+# of the packed shards, store import, sharded relax, all-gather of the values, commit — twice.
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libmpcgpu_emu.so")
+
+
+def _worker_emu(rank, world, port, q, seqs):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _golden as G
+    from muscle_amd._lib import MpcGpu
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, EMU_LIB)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    lens = [len(x) for x in seqs]
+    k0, k1 = run_stage(g, lens, TorchExchange(dist, "cpu"), torch_mod=torch)
+    final = g.get_sparse_range()
+    q.put((rank, k0, k1, [(o.copy(), v.copy()) for o, v in final], g.get_ea().copy()))
+    g.close()
+    dist.destroy_process_group()
+
+
+def test_run_stage_world2_gloo_real_kernels():
+    import subprocess
+    import _parity as P
+    from muscle_amd.synth import make_family
+    subprocess.check_call(["make", "-C", EMU_DIR], stdout=subprocess.DEVNULL)
+    seqs = make_family(7, 24, seed=17)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_emu, args=(r, 2, port, q, seqs)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in ps], key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want_stages, want_ea = P.run_oracle(seqs)
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == 21 and 0 < res[0][2] < 21
+    for rank, k0, k1, final, ea in res:
+        assert np.array_equal(P.bits(ea), P.bits(want_ea)), "rank %d EA" % rank
+        for k, ((o1, v1), (o2, v2)) in enumerate(zip(final, want_stages[2])):
+            assert np.array_equal(o1, o2) and np.array_equal(v1, v2), "rank %d pair %d" % (rank, k)
