@@ -168,19 +168,29 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 			stage_store();
 			__syncthreads();
 			if (Z + 1 < n) stage_load(Z + 1); // in flight while step Z is computed
+			// Software pipeline over the slots: the row pointers of slot q+1 are requested from LDS
+			// before the entries of slot q, so that round trip overlaps slot q's work (LDS returns in
+			// order; waiting for the younger entry reads of slot q also retires these).
+			u32 nx_oa = 0, nx_ob = 0, nx_a = 0, nx_b = 0, nx_na = 0, nx_nb = 0;
+			auto fetch_rows = [&](int q) {
+				u32 c = xy[q];
+				MPC_OPAQUE(c); // keep one register per slot: recompute the LDS addresses per step
+				const u32 x = c & 0x1fffu, y = (c >> 13) & 0x1fffu;
+				nx_oa = __umul24((c >> 26) & 7u, mat_dwords);
+				nx_ob = __umul24(c >> 29, mat_dwords);
+				const u32 *ma = lds + nx_oa, *mb = lds + nx_ob;
+				nx_a = ma[x]; nx_b = mb[y];
+				nx_na = ma[x + 1] - nx_a; nx_nb = mb[y + 1] - nx_b;
+			};
+			if (wave_first < total) fetch_rows(0);
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
 				if ((u32)q * MPC_RT_THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
-					u32 c = xy[q];
-					MPC_OPAQUE(c); // keep one register per slot: recompute the LDS addresses per step
-					const u32 x = c & 0x1fffu, y = (c >> 13) & 0x1fffu;
-					const u32 *ma = lds + ((c >> 26) & 7u) * mat_dwords;
-					const u32 *mb = lds + (c >> 29) * mat_dwords;
-					const u32 a = ma[x], b = mb[y];
-					const u32 na = ma[x + 1] - a, nb = mb[y + 1] - b;
+					const u32 a = nx_a, b = nx_b, na = nx_na, nb = nx_nb;
 					// lcap1 is a multiple of 4 and the LDS base 16-byte aligned: entries are 8-byte aligned
-					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(ma + lcap1, 8);
-					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(mb + lcap1, 8);
+					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(lds + nx_oa + lcap1, 8);
+					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(lds + nx_ob + lcap1, 8);
+					if (q + 1 < MPC_RT_SLOTS && (u32)(q + 1) * MPC_RT_THREADS + wave_first < total) fetch_rows(q + 1);
 					// Block merge of the two sorted rows, MPC_RT_ROW entries of each per step: all LDS reads
 					// of a step are in flight together and the match is done in registers, so a cell costs
 					// ceil(na/4)+ceil(nb/4)-1 dependent LDS round trips (1 for ~97 % of the rows) instead of

@@ -94,6 +94,7 @@ static inline unsigned long long __ballot(int pred)
 	pthread_barrier_wait(&w->bar);
 	return m;
 }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
