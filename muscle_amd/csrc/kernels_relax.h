@@ -24,7 +24,7 @@
 #pragma once
 #include "kernels_store.h"
 
-#define MPC_RT_THREADS 1024
+#define MPC_RT_THREADS 1024 // default workgroup size (MPCGPU_RELAX_WG=512: two 512-thread workgroups per CU on 4x2 blocks)
 #define MPC_RT_SLOTS 16
 #define MPC_RT_ROW 4          // entries of each row handled per merge step
 #define MPC_RT_MAXLEN 8191u   // cell descriptor packs x:13 | y:13 | matrix of X:3 | matrix of Y:3
@@ -38,10 +38,10 @@ struct RelaxTileParams {
 
 struct __attribute__((aligned(16))) MpcU4 { u32 x, y, z, w; };
 
-// MAXSEQ: matrices resident per step; NLD: 16-byte loads per thread per matrix (record bytes <=
-// NLD * 16 KiB). The host splits any tile whose cells would need more than MPC_RT_SLOTS slots.
-template <int MAXSEQ, int NLD>
-__global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTileParams p)
+// MAXSEQ: matrices resident per step; THREADS: workgroup size = cells per slot; NLD: 16-byte loads
+// per thread per matrix (record bytes <= NLD * THREADS * 16). The host splits any tile whose cells would need more than MPC_RT_SLOTS slots.
+template <int MAXSEQ, int NLD, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_kernel(RelaxTileParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
 	const StoreParams &s = p.s;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 			const u32 *ent = s.packed + s.pbase[k] + s.seq_len[X] + s.seq_len[Y];
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
-				const u32 g = (u32)q * MPC_RT_THREADS + tid;
+				const u32 g = (u32)q * THREADS + tid;
 				if (g >= base && g - base < nnz) {
 					const u32 idx = g - base;
 					acc[q] = __uint_as_float(ent[2 * (u64)idx]) * 2.0f; // conspairflat.cpp:29-30
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 					const unsigned char *src = (const unsigned char *)(s.pad + ((u64)seq[i] * n + Z) * (u64)mat_dwords);
 #pragma unroll
 					for (int r = 0; r < NLD; ++r) {
-						const u32 off = (tid + (u32)r * MPC_RT_THREADS) * 16u;
+						const u32 off = (tid + (u32)r * THREADS) * 16u;
 						MpcU4 v; v.x = 0; v.y = 0; v.z = 0; v.w = 0;
 						if (off < rec_bytes) v = *(const MpcU4 *)(src + off);
 						st[i][r] = v;
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 					unsigned char *m = (unsigned char *)(lds + (u32)i * mat_dwords);
 #pragma unroll
 					for (int r = 0; r < NLD; ++r) {
-						const u32 off = (tid + (u32)r * MPC_RT_THREADS) * 16u;
+						const u32 off = (tid + (u32)r * THREADS) * 16u;
 						if (off < rec_bytes) *(MpcU4 *)(m + off) = st[i][r];
 					}
 				}
@@ -185,12 +185,12 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 			if (wave_first < total) fetch_rows(0);
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
-				if ((u32)q * MPC_RT_THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
+				if ((u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
 					const u32 a = nx_a, b = nx_b, na = nx_na, nb = nx_nb;
 					// lcap1 is a multiple of 4 and the LDS base 16-byte aligned: entries are 8-byte aligned
 					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(lds + nx_oa + lcap1, 8);
 					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(lds + nx_ob + lcap1, 8);
-					if (q + 1 < MPC_RT_SLOTS && (u32)(q + 1) * MPC_RT_THREADS + wave_first < total) fetch_rows(q + 1);
+					if (q + 1 < MPC_RT_SLOTS && (u32)(q + 1) * THREADS + wave_first < total) fetch_rows(q + 1);
 					// Block merge of the two sorted rows, MPC_RT_ROW entries of each per step: all LDS reads
 					// of a step are in flight together and the match is done in registers, so a cell costs
 					// ceil(na/4)+ceil(nb/4)-1 dependent LDS round trips (1 for ~97 % of the rows) instead of
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(MPC_RT_THREADS) relax_tile_kernel(RelaxTilePar
 		for_each_pair([&](u64 k, u32, u32, u32 nnz, u32 base, u32) {
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
-				const u32 g = (u32)q * MPC_RT_THREADS + tid;
+				const u32 g = (u32)q * THREADS + tid;
 				if (g >= base && g - base < nnz)
 					s.vnext[s.vbase[k] + (g - base)] = acc[q] / (float)n; // uint -> float, IEEE divide (mysparsemx.cpp:108)
 			}

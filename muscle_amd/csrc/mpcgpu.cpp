@@ -98,7 +98,7 @@ struct mpcgpu_ctx {
 	u32 max_nnz = 0, max_len = 0;
 	DevBuf d_tiles, d_pad, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // padded layout + LDS-tiled relax (else: slabs + gather relax)
-	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0;
+	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0, pad_threads = MPC_RT_THREADS;
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
 	std::vector<u32> h_tiles;
 	u64 tiles_k0 = ~0ull, tiles_k1 = ~0ull;
@@ -265,24 +265,28 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 
 // Padded-layout geometry for the LDS-tiled relax; false when a tile cannot fit the CU's LDS (or the
 // cell coordinates do not pack into 16:16): the caller then builds the slabs for the gather kernel.
-bool pad_geometry(const mpcgpu_ctx *c, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by)
+bool pad_geometry(const mpcgpu_ctx *c, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by, u32 *threads)
 {
+	*threads = env_int("MPCGPU_RELAX_WG", MPC_RT_THREADS) == 512 ? 512u : 1024u;
 	if (c->max_len > MPC_RT_MAXLEN) return false; // cell descriptors pack x and y into 13 bits each
 	*lcap1 = (c->max_len + 1 + 3) & ~3u;                 // >= Lmax+1, multiple of 4 dwords
 	*ecap = (std::max<u32>(c->max_nnz, 1) + 1) & ~1u;    // even: the record is a multiple of 16 bytes
 	const u64 rec_bytes = ((u64)*lcap1 + 2 * (u64)*ecap) * 4;
-	if (rec_bytes > 2 * 16384u) return false;            // at most two 16-byte loads per thread per matrix
-	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", 160) * 1024;
+	if (rec_bytes > 2 * 16 * (u64)*threads) return false; // at most two 16-byte loads per thread per matrix
+	// 1024-thread workgroups own the whole LDS of a CU; 512-thread ones share it two per CU
+	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", *threads == 1024 ? 160 : 80) * 1024;
 	static const u32 shapes[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
-	for (auto &sh : shapes)
+	for (auto &sh : shapes) {
+		if (*threads == 512 && sh[0] + sh[1] > 6) continue; // the 512-thread kernel keeps at most 6 matrices resident
 		if ((sh[0] + sh[1]) * rec_bytes + 8 * MPC_RT_ROW <= lds_cap) { *bx = sh[0]; *by = sh[1]; return true; }
+	}
 	return false;
 }
 
-template <int MS, int NLD> void launch_relax_tile(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
+template <int MS, int NLD, int TH> void launch_relax_tile(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
 {
-	auto kern = relax_tile_kernel<MS, NLD>;
-	MPC_LAUNCH(kern, grid, MPC_RT_THREADS, smem, st, rp);
+	auto kern = relax_tile_kernel<MS, NLD, TH>;
+	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
 }
 
 // LDS-tiled relax (kernels_relax.h) over the padded layout; 0 = launched, 1 = error.
@@ -291,7 +295,8 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	const u32 n = c->n;
 	const u32 bx = c->pad_bx, by = c->pad_by;
 	const u64 mat_bytes = ((u64)c->pad_lcap1 + 2 * (u64)c->pad_ecap) * 4;
-	const int nld = mat_bytes <= 16384u ? 1 : 2;
+	const u32 threads = c->pad_threads;
+	const int nld = mat_bytes <= (u64)threads * 16 ? 1 : 2;
 	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
 	// slots a tile needs: its cells (all pairs in [k0,k1), laid end to end) in chunks of 1024
 	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
@@ -301,7 +306,7 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 				const u64 k = pidx(X, Y);
 				if (k >= k0 && k < k1) cells += c->all_nnz[k];
 			}
-		return (u32)((cells + MPC_RT_THREADS - 1) / MPC_RT_THREADS);
+		return (u32)((cells + threads - 1) / threads);
 	};
 	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != bx || c->tiles_by != by) {
 		std::vector<u32> &tiles = c->h_tiles;
@@ -328,7 +333,7 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 						emit(x0, nx, y0, ny);
 					}
 		c->tiles_k0 = c->tiles_k1 = ~0ull;
-		if (too_big) { tiles.clear(); return fail(c, "mpcgpu_cons_iter: a pair has more than %u stored cells (tile slot budget)", MPC_RT_SLOTS * MPC_RT_THREADS); }
+		if (too_big) { tiles.clear(); return fail(c, "mpcgpu_cons_iter: a pair has more than %u stored cells (tile slot budget)", MPC_RT_SLOTS * threads); }
 		// the source of an async H2D copy must outlive it: the list lives in the context AND the
 		// stream is drained before it can be rebuilt
 		if (upload(c, c->d_tiles, tiles)) return 1;
@@ -341,21 +346,28 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
 	rp.k0 = k0; rp.k1 = k1;
 	const size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-block reads may run past the last matrix
-	const void *fn = nld == 1 ? (const void *)relax_tile_kernel<8, 1> : (const void *)relax_tile_kernel<8, 2>;
+	const void *fn = nullptr;
+	if (threads == 1024) fn = nld == 1 ? (const void *)relax_tile_kernel<8, 1, 1024> : (const void *)relax_tile_kernel<8, 2, 1024>;
+	else fn = nld == 1 ? (const void *)relax_tile_kernel<6, 1, 512> : (const void *)relax_tile_kernel<6, 2, 512>;
 	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 	int occ = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, MPC_RT_THREADS, smem) != hipSuccess || occ < 1) occ = 1;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)threads, smem) != hipSuccess || occ < 1) occ = 1;
 	u32 grid = std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ);
 	grid = std::max(grid, 1u);
 	if (trace_on()) {
-		fprintf(stderr, "[mpcgpu] relax tiled: tiles=%u block=%ux%u nld=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n", rp.ntiles, bx, by,
-			nld, c->max_nnz, smem, occ, grid);
+		fprintf(stderr, "[mpcgpu] relax tiled: tiles=%u block=%ux%u wg=%u nld=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n", rp.ntiles, bx, by,
+			threads, nld, c->max_nnz, smem, occ, grid);
 		fflush(stderr);
 	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
-	if (nld == 1) launch_relax_tile<8, 1>(rp, grid, smem, c->stream);
-	else launch_relax_tile<8, 2>(rp, grid, smem, c->stream);
+	if (threads == 1024) {
+		if (nld == 1) launch_relax_tile<8, 1, 1024>(rp, grid, smem, c->stream);
+		else launch_relax_tile<8, 2, 1024>(rp, grid, smem, c->stream);
+	} else {
+		if (nld == 1) launch_relax_tile<6, 1, 512>(rp, grid, smem, c->stream);
+		else launch_relax_tile<6, 2, 512>(rp, grid, smem, c->stream);
+	}
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
 	return 0;
@@ -769,14 +781,14 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	c->have_pad = false;
 	{
 		const char *mode = getenv("MPCGPU_RELAX");
-		u32 lcap1 = 0, ecap = 0, bx = 0, by = 0;
-		if (!(mode && !strcmp(mode, "gather")) && pad_geometry(c, &lcap1, &ecap, &bx, &by)) {
+		u32 lcap1 = 0, ecap = 0, bx = 0, by = 0, threads = 0;
+		if (!(mode && !strcmp(mode, "gather")) && pad_geometry(c, &lcap1, &ecap, &bx, &by, &threads)) {
 			const u64 pad_bytes = (u64)n * n * ((u64)lcap1 + 2 * (u64)ecap) * 4;
 			size_t freeb = 0, totb = 0;
 			HIPCHK(c, hipMemGetInfo(&freeb, &totb));
 			if (pad_bytes <= c->d_pad.cap || pad_bytes + ((u64)2 << 30) <= (u64)freeb) {
 				c->have_pad = true;
-				c->pad_lcap1 = lcap1; c->pad_ecap = ecap; c->pad_bx = bx; c->pad_by = by;
+				c->pad_lcap1 = lcap1; c->pad_ecap = ecap; c->pad_bx = bx; c->pad_by = by; c->pad_threads = threads;
 				c->d_rp.release(); c->d_ent.release(); c->d_mbase.release(); // slabs of an earlier run are not needed
 				HIPCHK(c, c->d_pad.ensure(pad_bytes));
 			}
