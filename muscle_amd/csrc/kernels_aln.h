@@ -54,12 +54,8 @@ __global__ void __launch_bounds__(MPC_ALN_THREADS) calc_aln_kernel(AlnParams p)
 			run = T >= run ? T : run;
 		}
 		// workgroup-wide exclusive prefix maximum of the per-thread maxima
-		float incl = run;
-		for (int d = 1; d < 64; d <<= 1) {
-			const float o = __shfl_up(incl, d);
-			if ((int)lane >= d) incl = o >= incl ? o : incl;
-		}
-		float excl = __shfl_up(incl, 1);
+		const float incl = mpc_wave_scan_max_nonneg(run);
+		float excl = mpc_lane_up1(incl);
 		if (lane == 0) excl = 0.0f;
 		if (lane == 63) wmax[wave] = incl;
 		__syncthreads();

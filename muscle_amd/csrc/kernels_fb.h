@@ -8,7 +8,7 @@
 // H = ceil(LX/64) <= MPC_HMAX) and sweeps the columns of Y as a systolic array: at step s lane t
 // computes column j = s - t, so the three DP neighbours (i-1,j-1), (i-1,j), (i,j-1) are either in
 // the lane's own registers or in lane t-1's registers from the previous step (one wave shift of
-// 5 floats + the Y letter per step). All 5H state values live in VGPRs; LDS only holds the
+// 5 floats + the Y letter per step, as DPP wave_shr/wave_shl moves). All 5H state values live in VGPRs; LDS only holds the
 // compacted emission tables (A*A match + A insert scores). Only the forward M plane ever touches
 // HBM: it is written step-major [(step*H + r)*64 + lane] so both the forward store and the
 // backward load (which visits the same (lane,row,column) at forward-step index j+t, uniform over
@@ -114,12 +114,12 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 		for (int s = 0; s < nsteps; ++s) {
 			const int j = s - t;
 			// row t*H at column j comes from lane t-1's last row of the previous step
-			float nM = __shfl_up(cM[H - 1], 1);
-			float nIX = __shfl_up(cIX[H - 1], 1);
-			float nJX = __shfl_up(cJX[H - 1], 1);
-			float nIY = __shfl_up(cIY[H - 1], 1);
-			float nJY = __shfl_up(cJY[H - 1], 1);
-			int yc = __shfl_up(yprev, 1);
+			float nM = mpc_lane_up1(cM[H - 1]);
+			float nIX = mpc_lane_up1(cIX[H - 1]);
+			float nJX = mpc_lane_up1(cJX[H - 1]);
+			float nIY = mpc_lane_up1(cIY[H - 1]);
+			float nJY = mpc_lane_up1(cJY[H - 1]);
+			int yc = mpc_lane_up1(yprev);
 			const int yload = (s >= 1 && s <= LY) ? (int)Y[s - 1] : 0; // lane 0: letter of column j = s
 			if (t == 0)
 				yc = yload;
@@ -204,11 +204,11 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 		for (int s = 0; s < bsteps; ++s) {
 			const int j = LY - s + (T - 1 - t);
 			// row (t+1)*H+1 at column j: lane t+1's first row from the previous step
-			float nM = __shfl_down(cM[0], 1);
-			float nIX = __shfl_down(cIX[0], 1);
-			float nJX = __shfl_down(cJX[0], 1);
+			float nM = mpc_lane_down1(cM[0]);
+			float nIX = mpc_lane_down1(cIX[0]);
+			float nJX = mpc_lane_down1(cJX[0]);
 			if (t == 63) { nM = LZ; nIX = LZ; nJX = LZ; } // nothing below the wave: virtual row
-			int yc = __shfl_down(ynext_prev, 1);
+			int yc = mpc_lane_down1(ynext_prev);
 			const int jl = LY - s; // column of the leading lane T-1
 			const int yload = (jl >= 0 && jl < LY) ? (int)Y[jl] : 0;
 			if (t >= T - 1)

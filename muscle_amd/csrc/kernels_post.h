@@ -131,12 +131,9 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 					run = (q == 0) ? v : fmaxf(run, v);
 					Sn[j] = run; // prefix max inside my columns
 				}
-				float incl = run; // lanes without columns contribute 0 <= every S
-				for (int d = 1; d < 64; d <<= 1) {
-					const float o = __shfl_up(incl, d);
-					if (t >= d) incl = fmaxf(incl, o);
-				}
-				float excl = __shfl_up(incl, 1);
+				// lanes without columns contribute 0 <= every S
+				const float incl = mpc_wave_scan_max_nonneg(run);
+				float excl = mpc_lane_up1(incl);
 				if (t == 0) excl = 0.0f;
 				for (u32 q = 0; q < C; ++q) {
 					const u32 j = c0 + q;

@@ -9,6 +9,29 @@
 #define MPC_LAUNCH(kern, grid, block, smem, stream, ...) \
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (smem), (stream), __VA_ARGS__)
 #define MPC_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+// Lane shifts by one across the whole 64-lane wave as DPP moves (v_mov_b32_dpp wave_shr:1 /
+// wave_shl:1, gfx9 family) instead of ds_bpermute: no LDS round trip, a few cycles of latency.
+// Lane 0 (resp. 63) has no source and keeps its own value, like __shfl_up/__shfl_down.
+__device__ __forceinline__ int mpc_lane_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int mpc_lane_down1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float mpc_lane_up1(float v) { return __builtin_bit_cast(float, mpc_lane_up1(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float mpc_lane_down1(float v) { return __builtin_bit_cast(float, mpc_lane_down1(__builtin_bit_cast(int, v))); }
+// Inclusive prefix maximum over the wave for values >= 0 (identity 0.0f): DPP row shifts inside the
+// rows of 16 lanes, then row_bcast:15 / row_bcast:31 across rows. max is exact and associative, so
+// the order of combination does not matter.
+__device__ __forceinline__ float mpc_wave_scan_max_nonneg(float v)
+{
+#define MPC_DPP_MAX(ctrl, rmask)                                                                              \
+	v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false)))
+	MPC_DPP_MAX(0x111, 0xf); // row_shr:1
+	MPC_DPP_MAX(0x112, 0xf); // row_shr:2
+	MPC_DPP_MAX(0x114, 0xf); // row_shr:4
+	MPC_DPP_MAX(0x118, 0xf); // row_shr:8
+	MPC_DPP_MAX(0x142, 0xa); // row_bcast:15 -> rows 1 and 3
+	MPC_DPP_MAX(0x143, 0xc); // row_bcast:31 -> rows 2 and 3
+#undef MPC_DPP_MAX
+	return v;
+}
 // optimisation barrier on one VGPR value (no code): stops hoisting of what is derived from it
 #define MPC_OPAQUE(v) asm volatile("" : "+v"(v))
 // value held by the first active lane, as a wave-uniform scalar (v_readfirstlane_b32 -> SGPR)

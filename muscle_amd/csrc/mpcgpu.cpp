@@ -639,9 +639,16 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 		pp.pair_x = c->d_bx.as<u32>(); pp.pair_y = c->d_by.as<u32>(); pp.seq_len = c->d_seq_len.as<u32>();
 		pp.cand = c->d_cand.as<u64>(); pp.capc = capc; pp.cand_cnt = c->d_cand_cnt.as<u32>();
 		pp.use_fma = c->use_fma;
-		pp.sort_cap = std::min<u32>(next_pow2(capc), 2048u);
+		// LDS sort buffer capacity (entries, power of two): pairs with more candidates sort in the
+		// global scratch. The kernel is latency-bound (one wave per pair), so LDS per workgroup trades
+		// against resident waves; MPCGPU_POST_SORT_CAP overrides for tuning.
+		pp.sort_cap = std::min<u32>(next_pow2(capc), next_pow2((u32)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2)));
 		pp.srow_cap = std::min<u32>(LYmax + 1, 2048u);
-		const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * 8);
+		const size_t psmem0 = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
+		int pocc = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_kernel, 64, psmem0) != hipSuccess || pocc < 1) pocc = 8;
+		const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
+		if (trace_on()) { fprintf(stderr, "[mpcgpu] post: sort_cap=%u lds=%zu B blocks/CU=%d grid=%u\n", pp.sort_cap, psmem0, pocc, pgrid); fflush(stderr); }
 		pp.sort_stride = next_pow2(capc);
 		pp.srow_stride = 2 * ((u64)LYmax + 1);
 		const bool need_sort_scr = next_pow2(capc) > pp.sort_cap, need_srow_scr = LYmax + 1 > pp.srow_cap;

@@ -82,6 +82,16 @@ template <class T> static inline T __shfl_up(T v, unsigned d) { return emu_xchg(
 template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xchg(v, (int)d, false); }
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
 #define MPC_OPAQUE(v) ((void)0)
+template <class T> static inline T mpc_lane_up1(T v) { return __shfl_up(v, 1); }
+template <class T> static inline T mpc_lane_down1(T v) { return __shfl_down(v, 1); }
+static inline float mpc_wave_scan_max_nonneg(float v)
+{
+	for (int d = 1; d < 64; d <<= 1) {
+		const float o = __shfl_up(v, d);
+		if ((int)emu::t_lane >= d) v = v > o ? v : o;
+	}
+	return v;
+}
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
 static inline unsigned long long __ballot(int pred)
 {
