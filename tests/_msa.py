@@ -17,8 +17,29 @@ EMU_MUSCLE = os.path.join(ROOT, "hostcxx", "_build", "muscle_gpu_emu")
 GOLDEN = os.path.join(ROOT, "tests", "golden", "msa_md5.json")
 
 
+def _balanced_newick(lo, hi):
+    if hi - lo == 1:
+        return "s%d:0.1" % lo
+    mid = (lo + hi) // 2
+    return "(%s,%s):0.1" % (_balanced_newick(lo, mid), _balanced_newick(mid, hi))
+
+
+def command(name):
+    """The muscle command of a set: -align (MPCFlat::Run on everything), or for super7_* the
+    BASELINE config-5 path (super7.cpp:9-137: guide tree -> shrubs -> MPCFlat::Run per shrub ->
+    PProg joins), driven by a balanced guide tree so no distance matrix is needed."""
+    if name.startswith("super7_"):  # super7_<n>x<L>_b<shrub size>
+        n = int(name[7:].split("x")[0])
+        shrub = name.split("_b")[1]
+        return "-super7", ["-guidetreein", "tree.nwk", "-shrub_size", shrub], {"tree.nwk": _balanced_newick(0, n) + ";\n"}
+    return "-align", [], {}
+
+
 def input_set(name):
     """-> (seqs, labels, extra command-line args)"""
+    if name.startswith("super7_"):
+        n, L = name[7:].split("_b")[0].split("x")
+        return make_family(int(n), int(L), seed=13), None, []
     if name.startswith("synth"):  # synth_<n>x<L>_s<seed>
         n, rest = name[6:].split("x")
         L, seed = rest.split("_s")
@@ -37,10 +58,14 @@ def input_set(name):
 
 def run_muscle(binary, name, threads=4, timeout=900):
     seqs, labels, extra = input_set(name)
+    cmd, cmd_extra, files = command(name)
     with tempfile.TemporaryDirectory() as d:
         fa, out = os.path.join(d, "in.fa"), os.path.join(d, "out.afa")
         write_fasta(fa, seqs, labels)
-        subprocess.run([binary, "-align", fa, "-output", out, "-threads", str(threads), "-quiet"] + extra,
+        for fn, text in files.items():
+            with open(os.path.join(d, fn), "w") as f:
+                f.write(text)
+        subprocess.run([binary, cmd, fa, "-output", out, "-threads", str(threads), "-quiet"] + cmd_extra + extra,
                        check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         with open(out, "rb") as f:
             data = f.read()

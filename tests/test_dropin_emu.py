@@ -29,7 +29,7 @@ def emu_muscle():
     return _msa.EMU_MUSCLE
 
 
-@pytest.mark.parametrize("name", ["n2_L40", "n3_L30", "synth_6x40_s2", "dupes", "consiters0", "perturb_small"])
+@pytest.mark.parametrize("name", ["n2_L40", "n3_L30", "synth_6x40_s2", "dupes", "consiters0", "perturb_small", "super7_16x36_b8"])
 def test_final_msa_identical(emu_muscle, name):
     md5, _ = _msa.run_muscle(emu_muscle, name, threads=3)
     assert md5 == _msa.golden_md5()[name]
