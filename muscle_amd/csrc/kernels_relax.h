@@ -26,8 +26,8 @@
 
 #define MPC_RT_THREADS 1024 // default workgroup size (MPCGPU_RELAX_WG=512: two 512-thread workgroups per CU on 4x2 blocks)
 #define MPC_RT_SLOTS 16
-#define MPC_RT_ROW 4          // entries of each row handled per merge step
-#define MPC_RT_MAXLEN 8191u   // cell descriptor packs x:13 | y:13 | matrix of X:3 | matrix of Y:3
+#define MPC_RT_ROW MPC_PAD_ROW // entries of each row handled per merge step (= the block size of the padded layout)
+#define MPC_RT_MAXLEN 8191u   // cell descriptor packs x:13 | y:13 | matrix of X:3 | matrix of Y:3; columns < MPC_PAD_SENTINEL
 
 struct RelaxTileParams {
 	StoreParams s;    // s.pad / s.pad_stride / s.lcap1 / s.ecap describe the padded records
@@ -179,57 +179,46 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 				nx_oa = __umul24((c >> 26) & 7u, mat_dwords);
 				nx_ob = __umul24(c >> 29, mat_dwords);
 				const u32 *ma = lds + nx_oa, *mb = lds + nx_ob;
-				nx_a = ma[x]; nx_b = mb[y];
-				nx_na = ma[x + 1] - nx_a; nx_nb = mb[y + 1] - nx_b;
+				nx_a = ma[x]; nx_b = mb[y];               // first block of each row
+				nx_na = ma[x + 1] - nx_a; nx_nb = mb[y + 1] - nx_b; // blocks in each row
 			};
 			if (wave_first < total) fetch_rows(0);
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
 				if ((u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
-					const u32 a = nx_a, b = nx_b, na = nx_na, nb = nx_nb;
-					// lcap1 is a multiple of 4 and the LDS base 16-byte aligned: entries are 8-byte aligned
-					const MpcEnt *ea = (const MpcEnt *)__builtin_assume_aligned(lds + nx_oa + lcap1, 8);
-					const MpcEnt *eb = (const MpcEnt *)__builtin_assume_aligned(lds + nx_ob + lcap1, 8);
+					const u32 na = nx_na, nb = nx_nb;
+					// blocks are 32 bytes and the entry region starts 16-byte aligned: two ds_read_b128 per block
+					const MpcU4 *ea = (const MpcU4 *)__builtin_assume_aligned(lds + nx_oa + lcap1, 16) + 2 * (u64)nx_a;
+					const MpcU4 *eb = (const MpcU4 *)__builtin_assume_aligned(lds + nx_ob + lcap1, 16) + 2 * (u64)nx_b;
 					if (q + 1 < MPC_RT_SLOTS && (u32)(q + 1) * THREADS + wave_first < total) fetch_rows(q + 1);
-					// Block merge of the two sorted rows, MPC_RT_ROW entries of each per step: all LDS reads
-					// of a step are in flight together and the match is done in registers, so a cell costs
-					// ceil(na/4)+ceil(nb/4)-1 dependent LDS round trips (1 for ~97 % of the rows) instead of
-					// one per merged entry. Row a is walked in ascending z; the partner of an entry in row b
-					// (columns are distinct within a row: at most one) is picked by compares. Entries read
-					// past a row end are neutralised through their probability (0.0f), not their column:
-					// a valid entry of row a can only pick up a real partner or a zeroed one, and if both
-					// exist the real one has the lower index and is assigned last. Columns ascend in both
-					// rows, so matches are monotone and the block order preserves the reference's order of
-					// additions (relaxflat.cpp:16-29 / :41-58 / :78-92: z ascending). An unmatched or
-					// absent entry contributes pa * 0.0f = +0.0f, which leaves the strictly positive sum
+					// Block merge of the two sorted rows, one block of MPC_PAD_ROW = 4 entries of each per
+					// step (rows are stored in whole blocks, tails filled with {0.0f, sentinel column}): both
+					// blocks are fetched with aligned 16-byte LDS reads in flight together and matched in
+					// registers — ceil(na/4)+ceil(nb/4)-1 dependent LDS round trips per cell (1 for ~97 % of
+					// the rows). Row a is walked in ascending z; the partner of an entry in row b (columns
+					// are distinct within a row: at most one) is picked by compares. No validity masks: a
+					// sentinel only ever equals another sentinel and both carry P = 0.0f. Columns ascend in
+					// both rows, so matches are monotone and the block order preserves the reference's order
+					// of additions (relaxflat.cpp:16-29 / :41-58 / :78-92: z ascending). An unmatched entry
+					// (and a sentinel) contributes pa * 0.0f = +0.0f, which leaves the strictly positive sum
 					// bit-for-bit unchanged (the XZ_YZ form of the reference adds such zeros itself).
 					float sum = acc[q];
 					u32 ia = 0, ib = 0;
 					while (ia < na && ib < nb) {
-						const u32 ra = na - ia, rb = nb - ib; // entries left in each row (>= 1)
-						MpcEnt va[MPC_RT_ROW], vb[MPC_RT_ROW];
+						const MpcU4 a01 = ea[2 * ia], a23 = ea[2 * ia + 1], b01 = eb[2 * ib], b23 = eb[2 * ib + 1];
+						const u32 ca[4] = {a01.y, a01.w, a23.y, a23.w}, cb[4] = {b01.y, b01.w, b23.y, b23.w};
+						const float pa[4] = {__uint_as_float(a01.x), __uint_as_float(a01.z), __uint_as_float(a23.x), __uint_as_float(a23.z)};
+						const float pbv[4] = {__uint_as_float(b01.x), __uint_as_float(b01.z), __uint_as_float(b23.x), __uint_as_float(b23.z)};
 #pragma unroll
-						for (int r = 0; r < MPC_RT_ROW; ++r) { va[r] = ea[a + ia + r]; vb[r] = eb[b + ib + r]; }
-						float pbm[MPC_RT_ROW];
-#pragma unroll
-						for (int r = 0; r < MPC_RT_ROW; ++r) pbm[r] = ((u32)r < rb) ? __uint_as_float(vb[r].p) : 0.0f;
-#pragma unroll
-						for (int r = 0; r < MPC_RT_ROW; ++r) {
+						for (int r = 0; r < 4; ++r) {
 							float pb = 0.0f;
 #pragma unroll
-							for (int t2 = MPC_RT_ROW - 1; t2 >= 0; --t2) pb = (va[r].c == vb[t2].c) ? pbm[t2] : pb;
-							const float pa = ((u32)r < ra) ? __uint_as_float(va[r].p) : 0.0f;
-							sum += pa * pb; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
+							for (int t2 = 3; t2 >= 0; --t2) pb = (ca[r] == cb[t2]) ? pbv[t2] : pb;
+							sum += pa[r] * pb; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
 						}
-						// the largest column present in each block decides which row moves on
-						u32 amax = va[0].c, bmax = vb[0].c;
-#pragma unroll
-						for (int r = 1; r < MPC_RT_ROW; ++r) {
-							amax = ((u32)r < ra) ? va[r].c : amax;
-							bmax = ((u32)r < rb) ? vb[r].c : bmax;
-						}
-						ia += (amax <= bmax) ? (u32)MPC_RT_ROW : 0u;
-						ib += (bmax <= amax) ? (u32)MPC_RT_ROW : 0u;
+						// the last column of each block (a sentinel once the row has ended) decides which row moves on
+						ia += (ca[3] <= cb[3]) ? 1u : 0u;
+						ib += (cb[3] <= ca[3]) ? 1u : 0u;
 					}
 					acc[q] = sum;
 				}

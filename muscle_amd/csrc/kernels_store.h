@@ -40,13 +40,22 @@ struct StoreParams {
 	float *vnext;
 	// padded layout for the LDS-tiled relax (kernels_relax.h), used INSTEAD of the slabs when it fits:
 	// one fixed-size record per ordered pair (A,Z) at pad + (A*n+Z)*pad_stride dwords =
-	//   [row pointers: lcap1 dwords, relative to the record's own entries][entries: ecap x {P bits, col}]
-	// A record is a straight 16-byte-aligned copy of what the kernel wants in LDS: no per-matrix
-	// metadata, no dependent address loads, one global_load_dwordx4 per thread per matrix.
+	//   [row pointers: lcap1 dwords, in BLOCKS of MPC_PAD_ROW entries][entries: ecap x {P bits, col}]
+	// Every row occupies whole 32-byte blocks of MPC_PAD_ROW = 4 entries; the tail of its last block
+	// is filled with sentinel entries {P = 0.0f, col = MPC_PAD_SENTINEL}. The merge in the kernel then
+	// needs no validity masks (a sentinel can only meet a sentinel, and 0*0 adds +0.0f) and reads each
+	// block with two aligned 16-byte LDS loads. A record is a straight 16-byte-aligned copy of what
+	// the kernel wants in LDS: no per-matrix metadata, no dependent address loads, one
+	// global_load_dwordx4 per thread per matrix. pos_f / pos_t give, per canonical entry, its entry
+	// index inside the record of (X,Y) and of (Y,X) (written by pad_build, used by commit).
 	u32 *pad;
 	u32 pad_stride; // dwords per record = lcap1 + 2*ecap (multiple of 4)
 	u32 lcap1, ecap;
+	unsigned short *pos_f, *pos_t;
 };
+
+#define MPC_PAD_ROW 4
+#define MPC_PAD_SENTINEL 0x1fffu // larger than any column: sequences in the padded layout are <= 8191 long
 
 __device__ __forceinline__ u64 mpc_pair_index(u32 n, u32 i, u32 j) // i<j, mpcflat.cpp:145-155 order
 {
@@ -100,9 +109,36 @@ __global__ void __launch_bounds__(64) slab_build_kernel(StoreParams s)
 	}
 }
 
+// Blocks of MPC_PAD_ROW entries the largest record needs: max over (A,Z) of sum_a ceil(cnt[a]/4).
+__global__ void __launch_bounds__(64) pad_size_kernel(StoreParams s, u32 *max_blocks)
+{
+	const int t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	u32 best = 0;
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		if (A == Z) continue;
+		const u32 LA = s.seq_len[A];
+		const bool fwd = A < Z;
+		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 *cnt = fwd ? rec : rec + s.seq_len[Z];
+		u32 mine = 0;
+		for (u32 a = t; a < LA; a += 64) mine += (cnt[a] + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
+		for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
+		mine = __shfl(mine, 0);
+		best = mine > best ? mine : best;
+	}
+	if (t == 0 && best) atomicMax(max_blocks, best);
+}
+
 // Padded layout: one 64-thread workgroup per ordered pair (A,Z), same sources as slab_build_kernel.
+// Dynamic LDS: 2*lcap1 u32 (exclusive scans of the per-row entry counts and block counts).
 __global__ void __launch_bounds__(64) pad_build_kernel(StoreParams s)
 {
+	MPC_DYN_SMEM(smem_raw);
+	u32 *s_start = (u32 *)smem_raw; // entries before row a in the packed (unpadded) order
+	u32 *s_blk = s_start + s.lcap1; // blocks before row a in the padded record (copy of its row pointers)
 	const int t = threadIdx.x;
 	const u64 total = (u64)s.n * s.n;
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
@@ -110,8 +146,10 @@ __global__ void __launch_bounds__(64) pad_build_kernel(StoreParams s)
 		const u32 LA = s.seq_len[A];
 		u32 *rec_out = s.pad + b * (u64)s.pad_stride;
 		MpcEnt *dst = (MpcEnt *)(rec_out + s.lcap1);
+		MpcEnt sentinel; sentinel.p = 0u; sentinel.c = MPC_PAD_SENTINEL;
 		if (A == Z) { // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
-			for (u32 q = t; q < s.pad_stride; q += 64) rec_out[q] = 0;
+			for (u32 q = t; q < s.lcap1; q += 64) rec_out[q] = 0;
+			for (u32 q = t; q < s.ecap; q += 64) dst[q] = sentinel;
 			continue;
 		}
 		const bool fwd = A < Z;
@@ -121,28 +159,42 @@ __global__ void __launch_bounds__(64) pad_build_kernel(StoreParams s)
 		const u32 LY = fwd ? s.seq_len[Z] : LA;
 		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
 		const u32 *cnt = fwd ? rec : rec + LX; // rowcnt or colcnt, LA entries
-		u32 carry = 0;
+		u32 carry = 0, carry_b = 0;
 		for (u32 a0 = 0; a0 < s.lcap1; a0 += 64) {
 			const u32 a = a0 + t;
 			const u32 v = (a < LA) ? cnt[a] : 0;
-			u32 incl = v;
+			const u32 vb = (v + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
+			u32 incl = v, incl_b = vb;
 			for (int d = 1; d < 64; d <<= 1) {
-				const u32 o = __shfl_up(incl, d);
-				if (t >= d) incl += o;
+				const u32 o = __shfl_up(incl, d), ob = __shfl_up(incl_b, d);
+				if (t >= d) { incl += o; incl_b += ob; }
 			}
-			if (a < s.lcap1) rec_out[a] = carry + incl - v; // rows past LA repeat the total
+			if (a < s.lcap1) { // rows past LA repeat the total
+				s_start[a] = carry + incl - v;
+				s_blk[a] = carry_b + incl_b - vb;
+				rec_out[a] = carry_b + incl_b - vb;
+			}
 			carry += __shfl(incl, 63);
+			carry_b += __shfl(incl_b, 63);
 		}
+		for (u32 q = t; q < s.ecap; q += 64) dst[q] = sentinel;
+		__syncthreads(); // sentinels and row pointers are in place (and visible to this workgroup) before the entries go in
 		const u32 *e = rec + LX + LY;
 		const u32 *rowv = e + 2 * (u64)nnz;
 		const u32 *tperm = rowv + nnz;
+		unsigned short *pos = (fwd ? s.pos_f : s.pos_t) + s.vbase[k];
 		for (u32 q = t; q < nnz; q += 64) {
 			MpcEnt v;
 			v.p = e[2 * (u64)q];
-			if (fwd) { v.c = e[2 * (u64)q + 1]; dst[q] = v; }
-			else { v.c = rowv[q]; dst[tperm[q]] = v; }
+			const u32 col = e[2 * (u64)q + 1], row = rowv[q];
+			const u32 r = fwd ? row : col;          // row of this entry in M(A,Z)
+			const u32 rank = fwd ? q : tperm[q];    // its rank in M(A,Z)'s row-major order
+			v.c = fwd ? col : row;
+			const u32 at = s_blk[r] * MPC_PAD_ROW + (rank - s_start[r]);
+			dst[at] = v;
+			pos[q] = (unsigned short)at;
 		}
-		for (u32 q = nnz + t; q < s.ecap; q += 64) { MpcEnt v; v.p = 0; v.c = 0; dst[q] = v; }
+		__syncthreads(); // s_start is reused by the next record
 	}
 }
 
@@ -238,8 +290,9 @@ __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
 		const u32 pb = __float_as_uint(s.vnext[e]);
 		const u32 tq = ent[3 * (u64)nnz + idx];
 		ent[2 * (u64)idx] = pb;
-		s.pad[((u64)X * s.n + Y) * s.pad_stride + s.lcap1 + 2 * (u64)idx] = pb;
-		s.pad[((u64)Y * s.n + X) * s.pad_stride + s.lcap1 + 2 * (u64)tq] = pb;
+		(void)tq;
+		s.pad[((u64)X * s.n + Y) * s.pad_stride + s.lcap1 + 2 * (u64)s.pos_f[e]] = pb;
+		s.pad[((u64)Y * s.n + X) * s.pad_stride + s.lcap1 + 2 * (u64)s.pos_t[e]] = pb;
 	}
 }
 

@@ -96,7 +96,7 @@ struct mpcgpu_ctx {
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
-	DevBuf d_tiles, d_pad, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
+	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // padded layout + LDS-tiled relax (else: slabs + gather relax)
 	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0, pad_threads = MPC_RT_THREADS;
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
@@ -261,16 +261,19 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.lcap1 = c->pad_lcap1;
 	s.ecap = c->pad_ecap;
 	s.pad_stride = c->pad_lcap1 + 2 * c->pad_ecap;
+	s.pos_f = c->d_pos.as<unsigned short>();
+	s.pos_t = c->d_pos.as<unsigned short>() + c->total_entries;
 }
 
 // Padded-layout geometry for the LDS-tiled relax; false when a tile cannot fit the CU's LDS (or the
 // cell coordinates do not pack into 16:16): the caller then builds the slabs for the gather kernel.
-bool pad_geometry(const mpcgpu_ctx *c, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by, u32 *threads)
+bool pad_geometry(const mpcgpu_ctx *c, u32 max_blocks, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by, u32 *threads)
 {
 	*threads = env_int("MPCGPU_RELAX_WG", MPC_RT_THREADS) == 512 ? 512u : 1024u;
 	if (c->max_len > MPC_RT_MAXLEN) return false; // cell descriptors pack x and y into 13 bits each
 	*lcap1 = (c->max_len + 1 + 3) & ~3u;                 // >= Lmax+1, multiple of 4 dwords
-	*ecap = (std::max<u32>(c->max_nnz, 1) + 1) & ~1u;    // even: the record is a multiple of 16 bytes
+	*ecap = std::max<u32>(max_blocks, 1) * MPC_PAD_ROW;   // whole 32-byte blocks (kernels_store.h)
+	if (*ecap > 65535u) return false;                    // pos_f / pos_t are 16-bit
 	const u64 rec_bytes = ((u64)*lcap1 + 2 * (u64)*ecap) * 4;
 	if (rec_bytes > 2 * 16 * (u64)*threads) return false; // at most two 16-byte loads per thread per matrix
 	// 1024-thread workgroups own the whole LDS of a CU; 512-thread ones share it two per CU
@@ -421,7 +424,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_shard, &c->d_pbase, &c->d_vbase, &c->d_rp, &c->d_rp_base, &c->d_ent, &c->d_ent_base, &c->d_mbase,
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
-		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
+		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_pos, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
 		&c->d_aln_out};
 	for (DevBuf *b : all) b->release();
 	(void)hipStreamDestroy(c->stream);
@@ -789,15 +792,29 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	{
 		const char *mode = getenv("MPCGPU_RELAX");
 		u32 lcap1 = 0, ecap = 0, bx = 0, by = 0, threads = 0;
-		if (!(mode && !strcmp(mode, "gather")) && pad_geometry(c, &lcap1, &ecap, &bx, &by, &threads)) {
-			const u64 pad_bytes = (u64)n * n * ((u64)lcap1 + 2 * (u64)ecap) * 4;
-			size_t freeb = 0, totb = 0;
-			HIPCHK(c, hipMemGetInfo(&freeb, &totb));
-			if (pad_bytes <= c->d_pad.cap || pad_bytes + ((u64)2 << 30) <= (u64)freeb) {
-				c->have_pad = true;
-				c->pad_lcap1 = lcap1; c->pad_ecap = ecap; c->pad_bx = bx; c->pad_by = by; c->pad_threads = threads;
-				c->d_rp.release(); c->d_ent.release(); c->d_mbase.release(); // slabs of an earlier run are not needed
-				HIPCHK(c, c->d_pad.ensure(pad_bytes));
+		if (!(mode && !strcmp(mode, "gather")) && c->max_len <= MPC_RT_MAXLEN) {
+			// size of the largest padded record: rows occupy whole blocks of MPC_PAD_ROW entries
+			StoreParams sp0;
+			fill_store_params(c, sp0);
+			HIPCHK(c, c->d_aln_out.ensure(8));
+			HIPCHK(c, hipMemsetAsync(c->d_aln_out.p, 0, 4, c->stream));
+			MPC_LAUNCH(pad_size_kernel, (u32)std::min<u64>((u64)n * n, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp0,
+				c->d_aln_out.as<u32>());
+			HIPCHK(c, hipGetLastError());
+			u32 max_blocks = 0;
+			HIPCHK(c, hipMemcpyAsync(&max_blocks, c->d_aln_out.p, 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			if (pad_geometry(c, max_blocks, &lcap1, &ecap, &bx, &by, &threads)) {
+				const u64 pad_bytes = (u64)n * n * ((u64)lcap1 + 2 * (u64)ecap) * 4 + 4 * std::max<u64>(c->total_entries, 1);
+				size_t freeb = 0, totb = 0;
+				HIPCHK(c, hipMemGetInfo(&freeb, &totb));
+				if (pad_bytes <= c->d_pad.cap + c->d_pos.cap || pad_bytes + ((u64)2 << 30) <= (u64)freeb) {
+					c->have_pad = true;
+					c->pad_lcap1 = lcap1; c->pad_ecap = ecap; c->pad_bx = bx; c->pad_by = by; c->pad_threads = threads;
+					c->d_rp.release(); c->d_ent.release(); c->d_mbase.release(); // slabs of an earlier run are not needed
+					HIPCHK(c, c->d_pad.ensure((u64)n * n * ((u64)lcap1 + 2 * (u64)ecap) * 4));
+					HIPCHK(c, c->d_pos.ensure(4 * std::max<u64>(c->total_entries, 1))); // pos_f then pos_t, u16 each
+				}
 			}
 		}
 	}
@@ -812,7 +829,7 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 		}
 		if (span_begin(c, 2, &ts)) return 1;
 		const u64 blocks = (u64)n * n;
-		MPC_LAUNCH(pad_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp);
+		MPC_LAUNCH(pad_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)sp.lcap1 * 8, c->stream, sp);
 		HIPCHK(c, hipGetLastError());
 		if (span_end(c, &ts)) return 1;
 		HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -820,6 +837,7 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 		return 0;
 	}
 	c->d_pad.release();
+	c->d_pos.release();
 	// ---- slab geometry: per ordered pair entry counts -> mbase (within slab), slab bases
 	std::vector<u32> mbase((size_t)n * (n + 1), 0);
 	std::vector<u64> ent_base(n + 1, 0), rp_base(n + 1, 0);
