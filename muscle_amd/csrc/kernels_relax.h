@@ -187,38 +187,32 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
 				if ((u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
 					const u32 na = nx_na, nb = nx_nb;
-					// blocks are 32 bytes and the entry region starts 16-byte aligned: two ds_read_b128 per block
-					const MpcU4 *ea = (const MpcU4 *)__builtin_assume_aligned(lds + nx_oa + lcap1, 16) + 2 * (u64)nx_a;
-					const MpcU4 *eb = (const MpcU4 *)__builtin_assume_aligned(lds + nx_ob + lcap1, 16) + 2 * (u64)nx_b;
+					// a block is 16 bytes and the entry region starts 16-byte aligned: one ds_read_b128 per block
+					const MpcU4 *ea = (const MpcU4 *)__builtin_assume_aligned(lds + nx_oa + lcap1, 16) + nx_a;
+					const MpcU4 *eb = (const MpcU4 *)__builtin_assume_aligned(lds + nx_ob + lcap1, 16) + nx_b;
 					if (q + 1 < MPC_RT_SLOTS && (u32)(q + 1) * THREADS + wave_first < total) fetch_rows(q + 1);
-					// Block merge of the two sorted rows, one block of MPC_PAD_ROW = 4 entries of each per
-					// step (rows are stored in whole blocks, tails filled with {0.0f, sentinel column}): both
-					// blocks are fetched with aligned 16-byte LDS reads in flight together and matched in
-					// registers — ceil(na/4)+ceil(nb/4)-1 dependent LDS round trips per cell (1 for ~97 % of
-					// the rows). Row a is walked in ascending z; the partner of an entry in row b (columns
-					// are distinct within a row: at most one) is picked by compares. No validity masks: a
-					// sentinel only ever equals another sentinel and both carry P = 0.0f. Columns ascend in
-					// both rows, so matches are monotone and the block order preserves the reference's order
-					// of additions (relaxflat.cpp:16-29 / :41-58 / :78-92: z ascending). An unmatched entry
-					// (and a sentinel) contributes pa * 0.0f = +0.0f, which leaves the strictly positive sum
-					// bit-for-bit unchanged (the XZ_YZ form of the reference adds such zeros itself).
+					// Block merge of the two sorted rows, one block of MPC_PAD_ROW = 2 entries of each per
+					// step (rows are stored in whole blocks, an odd tail is filled with {0.0f, sentinel
+					// column}): both blocks are fetched with one aligned 16-byte LDS read each, in flight
+					// together, and matched in registers. Row a is walked in ascending z; the partner of an
+					// entry in row b (columns are distinct within a row: at most one) is picked by compares.
+					// No validity masks: a sentinel only ever equals another sentinel and both carry
+					// P = 0.0f. Columns ascend in both rows, so matches are monotone and the block order
+					// preserves the reference's order of additions (relaxflat.cpp:16-29 / :41-58 / :78-92:
+					// z ascending). An unmatched entry (and a sentinel) contributes pa * 0.0f = +0.0f, which
+					// leaves the strictly positive sum bit-for-bit unchanged (the XZ_YZ form of the
+					// reference adds such zeros itself).
 					float sum = acc[q];
 					u32 ia = 0, ib = 0;
 					while (ia < na && ib < nb) {
-						const MpcU4 a01 = ea[2 * ia], a23 = ea[2 * ia + 1], b01 = eb[2 * ib], b23 = eb[2 * ib + 1];
-						const u32 ca[4] = {a01.y, a01.w, a23.y, a23.w}, cb[4] = {b01.y, b01.w, b23.y, b23.w};
-						const float pa[4] = {__uint_as_float(a01.x), __uint_as_float(a01.z), __uint_as_float(a23.x), __uint_as_float(a23.z)};
-						const float pbv[4] = {__uint_as_float(b01.x), __uint_as_float(b01.z), __uint_as_float(b23.x), __uint_as_float(b23.z)};
-#pragma unroll
-						for (int r = 0; r < 4; ++r) {
-							float pb = 0.0f;
-#pragma unroll
-							for (int t2 = 3; t2 >= 0; --t2) pb = (ca[r] == cb[t2]) ? pbv[t2] : pb;
-							sum += pa[r] * pb; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
-						}
+						const MpcU4 va = ea[ia], vb = eb[ib]; // {p0, c0, p1, c1}
+						const float pb0 = (va.y == vb.y) ? __uint_as_float(vb.x) : ((va.y == vb.w) ? __uint_as_float(vb.z) : 0.0f);
+						const float pb1 = (va.w == vb.y) ? __uint_as_float(vb.x) : ((va.w == vb.w) ? __uint_as_float(vb.z) : 0.0f);
+						sum += __uint_as_float(va.x) * pb0; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
+						sum += __uint_as_float(va.z) * pb1;
 						// the last column of each block (a sentinel once the row has ended) decides which row moves on
-						ia += (ca[3] <= cb[3]) ? 1u : 0u;
-						ib += (cb[3] <= ca[3]) ? 1u : 0u;
+						ia += (va.w <= vb.w) ? 1u : 0u;
+						ib += (vb.w <= va.w) ? 1u : 0u;
 					}
 					acc[q] = sum;
 				}

@@ -41,10 +41,10 @@ struct StoreParams {
 	// padded layout for the LDS-tiled relax (kernels_relax.h), used INSTEAD of the slabs when it fits:
 	// one fixed-size record per ordered pair (A,Z) at pad + (A*n+Z)*pad_stride dwords =
 	//   [row pointers: lcap1 dwords, in BLOCKS of MPC_PAD_ROW entries][entries: ecap x {P bits, col}]
-	// Every row occupies whole 32-byte blocks of MPC_PAD_ROW = 4 entries; the tail of its last block
+	// Every row occupies whole 16-byte blocks of MPC_PAD_ROW = 2 entries; the tail of its last block
 	// is filled with sentinel entries {P = 0.0f, col = MPC_PAD_SENTINEL}. The merge in the kernel then
 	// needs no validity masks (a sentinel can only meet a sentinel, and 0*0 adds +0.0f) and reads each
-	// block with two aligned 16-byte LDS loads. A record is a straight 16-byte-aligned copy of what
+	// block with one aligned 16-byte LDS load. A record is a straight 16-byte-aligned copy of what
 	// the kernel wants in LDS: no per-matrix metadata, no dependent address loads, one
 	// global_load_dwordx4 per thread per matrix. pos_f / pos_t give, per canonical entry, its entry
 	// index inside the record of (X,Y) and of (Y,X) (written by pad_build, used by commit).
@@ -54,7 +54,8 @@ struct StoreParams {
 	unsigned short *pos_f, *pos_t;
 };
 
-#define MPC_PAD_ROW 4
+#define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128). 4 was tried: records grow past the 16 KiB a 1024-thread
+                      // workgroup stages with one load per thread (+45 % HBM traffic, spills in the two-load variant): slower.
 #define MPC_PAD_SENTINEL 0x1fffu // larger than any column: sequences in the padded layout are <= 8191 long
 
 __device__ __forceinline__ u64 mpc_pair_index(u32 n, u32 i, u32 j) // i<j, mpcflat.cpp:145-155 order
