@@ -10,7 +10,12 @@
 //   MPCFlat::ConsIter(uint)        replaces consflat.cpp:5-23            (called per iteration from
 //                                  MPCFlat::Consistency, mpcflat.cpp:173-181)
 //
-// Build: every reference object except consflat.o, calcposteriorflat.o with its CalcPosterior
+//   MPCFlat::AlignAlns(MSA1,MSA2) replaces alnalnsflat.cpp:7-52: BuildPost (buildpostflat.cpp:18-106) +
+//                                  CalcAlnFlat/TraceBackFlat (calcalnflat.cpp:6, tracebackflat.cpp:3) run on
+//                                  the device store, so the progressive stage and the 100 refinement
+//                                  rounds never need the sparse matrices on the host
+//
+// Build: every reference object except consflat.o and alnalnsflat.o, calcposteriorflat.o with its CalcPosterior
 // symbol weakened (the same object also defines CalcPostFlat and the two vestigial virtuals that
 // other translation units / the vtable need), plus this file, plus -lmpcgpu
 // (hostcxx/build_muscle_gpu.sh; INTEGRATION.md shows the two-line change a maintainer would make
@@ -55,6 +60,21 @@ mpcgpu_ctx *GetCtx()
 	}
 
 // MUSCLE_GPU_DEBUG=1: FNV-1a digests of what crosses the boundary, on stderr (diagnostics)
+// The sparse matrices are only read by BuildPost, which AlignAlns below keeps on the device; they
+// are copied back to MySparseMx objects only on request (MUSCLE_GPU_DOWNLOAD=1, or MUSCLE_GPU_DEBUG=1
+// for the digests).
+bool DownloadOn()
+	{
+	static int On = -1;
+	if (On < 0)
+		{
+		const char *s = getenv("MUSCLE_GPU_DOWNLOAD");
+		const char *d = getenv("MUSCLE_GPU_DEBUG");
+		On = ((s != 0 && *s != 0 && *s != '0') || (d != 0 && *d != 0 && *d != '0')) ? 1 : 0;
+		}
+	return On == 1;
+	}
+
 bool DebugOn()
 	{
 	static int On = -1;
@@ -203,7 +223,7 @@ void MPCFlat::CalcPosterior(uint PairIndex)
 		if (B.m_Seqs != m_MyInputSeqs || B.m_PairCount != SIZE(m_Pairs) || B.m_Served >= B.m_PairCount)
 			{
 			StartBatch(*this, B);
-			if (B.m_Materialise)
+			if (B.m_Materialise && DownloadOn())
 				Download(g_Ctx, *this, B.m_PairCount, [this](uint k) -> MySparseMx & { return GetSparsePost(k); });
 			}
 		asserta(PairIndex < B.m_PairCount);
@@ -224,10 +244,82 @@ void MPCFlat::ConsIter(uint Iter)
 		mpcgpu_ctx *Ctx = GetCtx();
 		GPUCHK(mpcgpu_cons_iter(Ctx, 0, PairCount));
 		GPUCHK(mpcgpu_cons_commit(Ctx));
-// Only the matrices of the last iteration are read by the host (ProgressiveAlign/Refine ->
-// BuildPost, buildpostflat.cpp:18); intermediate iterations stay on the device.
-		if (Iter + 1 == m_ConsistencyIterCount)
+// Nothing on the host reads the matrices any more (ProgressiveAlign/Refine -> AlignAlns below);
+// they are downloaded after the last iteration only on request.
+		if (Iter + 1 == m_ConsistencyIterCount && DownloadOn())
 			Download(Ctx, *this, PairCount, [this](uint k) -> MySparseMx & { return GetUpdatedSparsePost(k); });
 		}
 	swap(m_ptrSparsePosts, m_ptrUpdatedSparsePosts); // consflat.cpp:22
+	}
+
+MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
+  const MultiSequence &MSA2, float *ptrScore)
+	{
+	const uint SeqCount1 = MSA1.GetSeqCount();
+	const uint SeqCount2 = MSA2.GetSeqCount();
+	const uint ColCount1 = MSA1.GetColCount();
+	const uint ColCount2 = MSA2.GetColCount();
+
+// alnalnsflat.cpp:16-20
+	const uint SeqCount = GetSeqCount();
+	if (SIZE(m_Weights) != SeqCount)
+		m_Weights.assign(SeqCount, 1.0f);
+// BuildPost multiplies by w1*w2 (buildpostflat.cpp:41,52,74); MPCFlat::Run overwrites every weight
+// with 1.0f (mpcflat.cpp:324). The device path implements exactly that case.
+	for (uint i = 0; i < SeqCount; ++i)
+		if (m_Weights[i] != 1.0f)
+			Die("GPU posterior stage: sequence weights other than 1 are not supported");
+
+	vector<uint32_t> Seqs1(SeqCount1), Seqs2(SeqCount2);
+	vector<uint32_t> Map1, Map2;
+	vector<uint> PosToCol;
+	for (uint i = 0; i < SeqCount1; ++i)
+		{
+		const Sequence *Seq = MSA1.GetSequence(i);
+		uint SMI = GetMyInputSeqIndex(Seq->m_Label);
+		asserta(SMI != UINT_MAX);
+		Seqs1[i] = SMI;
+		Seq->GetPosToCol(PosToCol);
+		asserta(SIZE(PosToCol) == GetSeqLength(SMI));
+		Map1.insert(Map1.end(), PosToCol.begin(), PosToCol.end());
+		}
+	for (uint i = 0; i < SeqCount2; ++i)
+		{
+		const Sequence *Seq = MSA2.GetSequence(i);
+		uint SMI = GetMyInputSeqIndex(Seq->m_Label);
+		asserta(SMI != UINT_MAX);
+		Seqs2[i] = SMI;
+		Seq->GetPosToCol(PosToCol);
+		asserta(SIZE(PosToCol) == GetSeqLength(SMI));
+		Map2.insert(Map2.end(), PosToCol.begin(), PosToCol.end());
+		}
+
+	string Path(ColCount1 + ColCount2, '?');
+	uint32_t PathLen = 0;
+	float Score = 0;
+		{
+		std::lock_guard<std::mutex> Guard(g_Mu);
+		mpcgpu_ctx *Ctx = GetCtx();
+		GPUCHK(mpcgpu_align_alns(Ctx, SeqCount1, Seqs1.data(), SeqCount2, Seqs2.data(), ColCount1, ColCount2,
+		  Map1.data(), Map2.data(), &Path[0], &PathLen, &Score));
+		}
+	Path.resize(PathLen);
+	if (ptrScore != 0)
+		*ptrScore = Score;
+
+// alnalnsflat.cpp:36-50
+	MultiSequence *result = new MultiSequence();
+	for (uint SeqIndex1 = 0; SeqIndex1 < SeqCount1; ++SeqIndex1)
+		{
+		const Sequence *InputRow = MSA1.GetSequence(SeqIndex1);
+		Sequence *AlignedRow = InputRow->AddGapsPath(Path, 'X');
+		result->AddSequence(AlignedRow, true);
+		}
+	for (uint SeqIndex2 = 0; SeqIndex2 < SeqCount2; ++SeqIndex2)
+		{
+		const Sequence *InputRow = MSA2.GetSequence(SeqIndex2);
+		Sequence *AlignedRow = InputRow->AddGapsPath(Path, 'Y');
+		result->AddSequence(AlignedRow, true);
+		}
+	return result;
 	}

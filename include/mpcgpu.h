@@ -117,6 +117,19 @@ int mpcgpu_get_sparse_range(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1, uint32_t 
 int mpcgpu_calc_aln(mpcgpu_ctx *ctx, const float *post, uint32_t LX, uint32_t LY,
                     char *path, uint32_t *pathlen, float *score);
 
+/* Alignment of two alignments on the device: replaces MPCFlat::AlignAlns' numeric part
+ * (alnalnsflat.cpp:7-52) = MPCFlat::BuildPost (buildpostflat.cpp:18-106: dense C1 x C2 matrix, sum over
+ * s in MSA1 (outer), t in MSA2 (inner) of the CURRENT pairwise posteriors of the device store scattered
+ * through the position->column maps, weights 1.0f as set at mpcflat.cpp:324) followed by CalcAlnFlat +
+ * TraceBackFlat (calcalnflat.cpp:6-46, tracebackflat.cpp:3-37) on it. Bit-exact: every cell receives
+ * its contributions in the reference's (s,t) order.
+ * seq1[n1] / seq2[n2]: sequence indices (InitPairs numbering) of the rows of MSA1 / MSA2, in row order;
+ * pos2col1 / pos2col2: Sequence::GetPosToCol (sequence.cpp:144-154) of every row, concatenated
+ * (row a contributes len(seq a) entries); C1, C2: column counts. path: B/X/Y string, capacity C1+C2. */
+int mpcgpu_align_alns(mpcgpu_ctx *ctx, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2,
+                      uint32_t C1, uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2,
+                      char *path, uint32_t *pathlen, float *score);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 /* Kernel time in ms measured with hipEvents on the library's own stream, accumulated since the
  * last reset, per kernel family: 0 = fwd/bwd (fb), 1 = posterior finish (sort/EA/pack),

@@ -1,0 +1,76 @@
+// kernels_prog.h — alignment of two alignments on the device: MSA x MSA posterior build.
+//
+// Replaces MPCFlat::BuildPost (buildpostflat.cpp:18-106): for all s in MSA1 (outer loop), t in
+// MSA2 (inner loop) and every stored entry (i,j,P) of their pairwise matrix,
+//     Post[col1(i) * C2 + col2(j)] += w1*w2*P        (w == 1.0f: mpcflat.cpp:324)
+// with the roles of row/column swapped when the stored orientation is (t,s)
+// (buildpostflat.cpp:78-100). CalcAlnFlat then runs on that dense matrix (kernels_aln.h).
+//
+// Float addition is not associative and the alignment DP breaks ties on exact values, so every
+// output cell must receive its contributions in the reference's order: s ascending (position in
+// MSA1), then t ascending (position in MSA2); one pair contributes at most once to a cell. The
+// device form: (1) every stored entry of every (s,t) pair becomes a (key, P) record with
+// key = cell << (ba+bb) | rank(s) << bb | rank(t); (2) one radix sort of the records (rocPRIM via
+// hipCUB — bulk data movement, not arithmetic); (3) one thread per output cell finds its run by
+// binary search and adds it up front to back, starting from 0.0f like the reference's zeroed
+// matrix. The probabilities are the current ones of the packed records (after the last commit).
+#pragma once
+#include "kernels_store.h"
+
+struct BuildPostParams {
+	StoreParams s;
+	const u32 *seq1, *seq2; // sequence index (InitPairs numbering) of every row of MSA1 / MSA2
+	u32 n1, n2;
+	const u32 *p2c1, *p2c2;         // position -> column maps, concatenated per row
+	const u64 *p2c1_off, *p2c2_off; // start of each row's map
+	u32 C2;
+	const u64 *coff; // n1*n2+1: first record of pair (a,b)
+	u64 *keys;
+	float *vals;
+	u32 bits_a, bits_b; // key = cell << (bits_a+bits_b) | a << bits_b | b
+};
+
+// one 64-thread workgroup per (a,b)
+__global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
+{
+	const u64 total = (u64)p.n1 * p.n2;
+	for (u64 ab = blockIdx.x; ab < total; ab += gridDim.x) {
+		const u32 a = (u32)(ab / p.n2), b = (u32)(ab % p.n2);
+		const u32 S = p.seq1[a], T = p.seq2[b];
+		const bool fwd = S < T;
+		const u64 k = fwd ? mpc_pair_index(p.s.n, S, T) : mpc_pair_index(p.s.n, T, S);
+		const u32 LX = p.s.seq_len[fwd ? S : T], LY = p.s.seq_len[fwd ? T : S];
+		const u32 *rec = p.s.packed + p.s.pbase[k];
+		const u32 nnz = (u32)(p.s.vbase[k + 1] - p.s.vbase[k]);
+		const u32 *ent = rec + LX + LY;
+		const u32 *rowv = ent + 2 * (u64)nnz;
+		const u32 *m1 = p.p2c1 + p.p2c1_off[a], *m2 = p.p2c2 + p.p2c2_off[b];
+		u64 *keys = p.keys + p.coff[ab];
+		float *vals = p.vals + p.coff[ab];
+		for (u32 q = threadIdx.x; q < nnz; q += 64) {
+			const u32 row = rowv[q], col = ent[2 * (u64)q + 1];
+			// stored (S,T): rows are positions of S (MSA1); stored (T,S): rows are positions of T (MSA2)
+			const u32 c1 = fwd ? m1[row] : m1[col];
+			const u32 c2 = fwd ? m2[col] : m2[row];
+			const u64 cell = (u64)c1 * p.C2 + c2;
+			keys[q] = (cell << (p.bits_a + p.bits_b)) | ((u64)a << p.bits_b) | (u64)b;
+			vals[q] = __uint_as_float(ent[2 * (u64)q]);
+		}
+	}
+}
+
+// one thread per output cell: in-order sum of its run in the sorted records
+__global__ void __launch_bounds__(256) build_post_reduce_kernel(const u64 *keys, const float *vals, u64 count, u32 shift,
+	float *post, u64 cells)
+{
+	for (u64 cell = (u64)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (u64)gridDim.x * blockDim.x) {
+		u64 lo = 0, hi = count; // first record with key >> shift >= cell
+		while (lo < hi) {
+			const u64 mid = (lo + hi) >> 1;
+			if ((keys[mid] >> shift) < cell) lo = mid + 1; else hi = mid;
+		}
+		float acc = 0.0f; // the reference zeroes Post first (buildpostflat.cpp:27-30)
+		while (lo < count && (keys[lo] >> shift) == cell) { acc += vals[lo]; ++lo; } // buildpostflat.cpp:74 / :96 (w1*w2 == 1.0f)
+		post[cell] = acc;
+	}
+}

@@ -7,6 +7,10 @@
 #include "kernels_store.h"
 #include "kernels_relax.h"
 #include "kernels_aln.h"
+#include "kernels_prog.h"
+#ifndef MPC_EMU
+#include <hipcub/hipcub.hpp>
+#endif
 
 #include <algorithm>
 #include <climits>
@@ -96,6 +100,7 @@ struct mpcgpu_ctx {
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
+	DevBuf d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp;
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // padded layout + LDS-tiled relax (else: slabs + gather relax)
 	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0, pad_threads = MPC_RT_THREADS;
@@ -424,7 +429,8 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_shard, &c->d_pbase, &c->d_vbase, &c->d_rp, &c->d_rp_base, &c->d_ent, &c->d_ent_base, &c->d_mbase,
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
-		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_pos, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
+		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_pos, &c->d_bp_seq, &c->d_bp_map, &c->d_bp_off, &c->d_bp_coff,
+		&c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
 		&c->d_aln_out};
 	for (DevBuf *b : all) b->release();
 	(void)hipStreamDestroy(c->stream);
@@ -1022,24 +1028,19 @@ int mpcgpu_get_sparse(mpcgpu_ctx *c, uint64_t k, uint32_t *offsets, void *values
 	return mpcgpu_get_sparse_range(c, k, k + 1, offsets, values);
 }
 
-int mpcgpu_calc_aln(mpcgpu_ctx *c, const float *post, uint32_t LX, uint32_t LY, char *path, uint32_t *pathlen, float *score)
+// CalcAlnFlat + TraceBackFlat on a dense LX x LY matrix already in device memory
+static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_t LY, char *path, uint32_t *pathlen, float *score)
 {
-	if (!c) return 1;
-	if (!post || !path || !pathlen) return fail(c, "mpcgpu_calc_aln: NULL argument");
-	if (LX == 0 || LY == 0) return fail(c, "mpcgpu_calc_aln: empty matrix (%u x %u)", LX, LY);
 	const u64 W = (u64)LY + 1;
 	const size_t smem = (size_t)(2 * W + MPC_ALN_THREADS / 64 + 4) * 4;
 	if (smem > 160u * 1024u)
 		return fail(c, "mpcgpu_calc_aln: %u columns exceed the LDS-resident DP rows of this build", LY);
-	HIPCHK(c, hipSetDevice(c->device));
-	HIPCHK(c, c->d_aln_post.ensure((u64)LX * LY * 4));
 	HIPCHK(c, c->d_aln_tb.ensure(((u64)LX + 1) * W));
 	HIPCHK(c, c->d_aln_rev.ensure((u64)LX + LY));
 	HIPCHK(c, c->d_aln_path.ensure((u64)LX + LY));
 	HIPCHK(c, c->d_aln_out.ensure(8));
-	HIPCHK(c, hipMemcpyAsync(c->d_aln_post.p, post, (u64)LX * LY * 4, hipMemcpyHostToDevice, c->stream));
 	AlnParams ap;
-	ap.post = c->d_aln_post.as<float>(); ap.LX = LX; ap.LY = LY;
+	ap.post = d_post; ap.LX = LX; ap.LY = LY;
 	ap.tb = c->d_aln_tb.as<char>(); ap.rev = c->d_aln_rev.as<char>(); ap.path = c->d_aln_path.as<char>();
 	ap.pathlen = c->d_aln_out.as<u32>(); ap.score = c->d_aln_out.as<float>() + 1;
 	(void)hipFuncSetAttribute((const void *)calc_aln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1047,13 +1048,106 @@ int mpcgpu_calc_aln(mpcgpu_ctx *c, const float *post, uint32_t LX, uint32_t LY, 
 	HIPCHK(c, hipGetLastError());
 	u32 out[2] = {0, 0};
 	HIPCHK(c, hipMemcpyAsync(out, c->d_aln_out.p, 8, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream)); // also: the H2D source (caller's buffer) is done with
+	HIPCHK(c, hipStreamSynchronize(c->stream));
 	if (out[0] > LX + LY) return fail(c, "mpcgpu_calc_aln: path length %u out of range (internal error)", out[0]);
 	*pathlen = out[0];
 	if (score) memcpy(score, &out[1], 4);
 	if (out[0]) HIPCHK(c, hipMemcpyAsync(path, c->d_aln_path.p, out[0], hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return 0;
+}
+
+int mpcgpu_calc_aln(mpcgpu_ctx *c, const float *post, uint32_t LX, uint32_t LY, char *path, uint32_t *pathlen, float *score)
+{
+	if (!c) return 1;
+	if (!post || !path || !pathlen) return fail(c, "mpcgpu_calc_aln: NULL argument");
+	if (LX == 0 || LY == 0) return fail(c, "mpcgpu_calc_aln: empty matrix (%u x %u)", LX, LY);
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, c->d_aln_post.ensure((u64)LX * LY * 4));
+	HIPCHK(c, hipMemcpyAsync(c->d_aln_post.p, post, (u64)LX * LY * 4, hipMemcpyHostToDevice, c->stream));
+	return run_calc_aln(c, c->d_aln_post.as<float>(), LX, LY, path, pathlen, score); // syncs: the caller's buffer is done with
+}
+
+static u32 bits_for(u64 v) { u32 b = 1; while ((v >> b) != 0) ++b; return b; } // bits to hold values 0..v
+
+int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
+	uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, char *path, uint32_t *pathlen, float *score)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_align_alns: no store (call mpcgpu_build_store / mpcgpu_store_import)");
+	if (!seq1 || !seq2 || !pos2col1 || !pos2col2 || !path || !pathlen) return fail(c, "mpcgpu_align_alns: NULL argument");
+	if (n1 == 0 || n2 == 0 || C1 == 0 || C2 == 0) return fail(c, "mpcgpu_align_alns: empty alignment");
+	HIPCHK(c, hipSetDevice(c->device));
+	const u32 n = c->n;
+	// ---- host: maps, pair record offsets
+	std::vector<u32> seqs(seq1, seq1 + n1);
+	seqs.insert(seqs.end(), seq2, seq2 + n2);
+	std::vector<u64> off(n1 + n2 + 1, 0);
+	for (u32 a = 0; a < n1 + n2; ++a) {
+		if (seqs[a] >= n) return fail(c, "mpcgpu_align_alns: sequence index %u out of range", seqs[a]);
+		off[a + 1] = off[a] + c->len[seqs[a]];
+	}
+	const u64 len1 = off[n1], len2 = off[n1 + n2] - off[n1];
+	std::vector<u32> maps(len1 + len2);
+	memcpy(maps.data(), pos2col1, len1 * 4);
+	memcpy(maps.data() + len1, pos2col2, len2 * 4);
+	for (u64 q = 0; q < len1; ++q) if (maps[q] >= C1) return fail(c, "mpcgpu_align_alns: column map of MSA1 out of range");
+	for (u64 q = len1; q < len1 + len2; ++q) if (maps[q] >= C2) return fail(c, "mpcgpu_align_alns: column map of MSA2 out of range");
+	std::vector<u64> coff((u64)n1 * n2 + 1, 0);
+	for (u32 a = 0; a < n1; ++a)
+		for (u32 b = 0; b < n2; ++b) {
+			const u32 S = seqs[a], T = seqs[n1 + b];
+			if (S == T) return fail(c, "mpcgpu_align_alns: sequence %u is in both alignments", S);
+			const u64 k = S < T ? (u64)S * n - ((u64)S * (S + 1)) / 2 + (T - S - 1) : (u64)T * n - ((u64)T * (T + 1)) / 2 + (S - T - 1);
+			coff[(u64)a * n2 + b + 1] = coff[(u64)a * n2 + b] + c->all_nnz[k];
+		}
+	const u64 M = coff[(u64)n1 * n2];
+	const u64 cells = (u64)C1 * C2;
+	const u32 ba = bits_for(n1 - 1), bb = bits_for(n2 - 1), bc = bits_for(cells - 1);
+	if (ba + bb + bc > 64) return fail(c, "mpcgpu_align_alns: key does not fit 64 bits (%u x %u rows, %llu cells)", n1, n2, (u64)cells);
+	if (M > 0x7fffffffull) return fail(c, "mpcgpu_align_alns: %llu contributions exceed this build's sort size", (u64)M);
+	if (upload(c, c->d_bp_seq, seqs) || upload(c, c->d_bp_off, off) || upload(c, c->d_bp_map, maps) || upload(c, c->d_bp_coff, coff))
+		return 1;
+	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 8 * 2));
+	HIPCHK(c, c->d_bp_vals.ensure(std::max<u64>(M, 1) * 4 * 2));
+	HIPCHK(c, c->d_aln_post.ensure(cells * 4));
+	u64 *keys_in = c->d_bp_keys.as<u64>(), *keys_out = keys_in + std::max<u64>(M, 1);
+	float *vals_in = c->d_bp_vals.as<float>(), *vals_out = vals_in + std::max<u64>(M, 1);
+	BuildPostParams bp;
+	fill_store_params(c, bp.s);
+	bp.seq1 = c->d_bp_seq.as<u32>(); bp.seq2 = bp.seq1 + n1; bp.n1 = n1; bp.n2 = n2;
+	bp.p2c1 = c->d_bp_map.as<u32>(); bp.p2c2 = bp.p2c1; // offsets below are into the one concatenated array
+	bp.p2c1_off = c->d_bp_off.as<u64>(); bp.p2c2_off = bp.p2c1_off + n1;
+	bp.C2 = C2; bp.coff = c->d_bp_coff.as<u64>(); bp.keys = keys_in; bp.vals = vals_in; bp.bits_a = ba; bp.bits_b = bb;
+	const u64 npairs12 = (u64)n1 * n2;
+	MPC_LAUNCH(build_post_gen_kernel, (u32)std::min<u64>(npairs12, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, bp);
+	HIPCHK(c, hipGetLastError());
+	const u64 *keys_sorted = keys_in;
+	const float *vals_sorted = vals_in;
+	if (M > 1) {
+#ifdef MPC_EMU
+		{ // emulator build (tests only): "device" memory is host memory
+			std::vector<u64> idx(M);
+			for (u64 q = 0; q < M; ++q) idx[q] = q;
+			std::sort(idx.begin(), idx.end(), [&](u64 x, u64 y) { return keys_in[x] < keys_in[y]; });
+			for (u64 q = 0; q < M; ++q) { keys_out[q] = keys_in[idx[q]]; vals_out[q] = vals_in[idx[q]]; }
+		}
+#else
+		size_t tmp_bytes = 0;
+		HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)M, 0,
+			(int)(ba + bb + bc), c->stream));
+		HIPCHK(c, c->d_bp_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+		HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->d_bp_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)M, 0,
+			(int)(ba + bb + bc), c->stream));
+#endif
+		keys_sorted = keys_out;
+		vals_sorted = vals_out;
+	}
+	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((cells + 255) / 256, (u64)c->prop.multiProcessorCount * 64), 256, 0,
+		c->stream, keys_sorted, vals_sorted, (u64)M, (u32)(ba + bb), c->d_aln_post.as<float>(), (u64)cells);
+	HIPCHK(c, hipGetLastError());
+	// the uploads above came from vectors that die with this call: drain before returning (run_calc_aln syncs)
+	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score);
 }
 
 int mpcgpu_timers_reset(mpcgpu_ctx *c)

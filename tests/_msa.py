@@ -28,6 +28,7 @@ def command(name):
     """The muscle command of a set: -align (MPCFlat::Run on everything), or for super7_* the
     BASELINE config-5 path (super7.cpp:9-137: guide tree -> shrubs -> MPCFlat::Run per shrub ->
     PProg joins), driven by a balanced guide tree so no distance matrix is needed."""
+    name = name.split("+r")[0]
     if name.startswith("super7_"):  # super7_<n>x<L>_b<shrub size>
         n = int(name[7:].split("x")[0])
         shrub = name.split("_b")[1]
@@ -36,7 +37,12 @@ def command(name):
 
 
 def input_set(name):
-    """-> (seqs, labels, extra command-line args)"""
+    """-> (seqs, labels, extra command-line args). A "+rK" suffix adds -refineiters K (the emulator
+    runs of the drop-in use it: every refinement round is one emulated device alignment)."""
+    if "+r" in name:
+        base, k = name.split("+r")
+        seqs, labels, extra = input_set(base)
+        return seqs, labels, extra + ["-refineiters", k]
     if name.startswith("super7_"):
         n, L = name[7:].split("_b")[0].split("x")
         return make_family(int(n), int(L), seed=13), None, []

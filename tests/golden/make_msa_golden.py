@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import _msa  # noqa: E402
 
 SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "bb11001", "bb11005", "n32_L150", "dupes", "consiters0", "perturb", "perturb_small",
-        "synth_6x40_s2", "synth_64x200_s1", "synth_128x300_s1", "super7_16x36_b8", "super7_200x120_b32"]
+        "synth_6x40_s2", "synth_64x200_s1", "synth_128x300_s1", "super7_200x120_b32",
+        "n2_L40+r2", "n3_L30+r2", "synth_6x40_s2+r2", "dupes+r2", "consiters0+r2", "perturb_small+r2"]
 out = {}
 for s in SETS:
     out[s] = _msa.run_muscle(_msa.REF_MUSCLE, s, threads=os.cpu_count() or 4)[0]

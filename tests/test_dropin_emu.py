@@ -3,7 +3,8 @@ own `muscle` is linked with the drop-in and the SIMT-emulator build of libmpcgpu
 infrastructure) and must write byte-identical final MSAs to the committed golden MD5s of the
 unmodified reference (tests/golden/msa_md5.json). Checks lazy batching from the OpenMP loop, the
 HMM-table hand-over, Derep/InsertDupes around the stage, the <3-sequence / -consiters 0 paths and
-the final download + buffer swap. Needs the reference objects (oracle/_ref/obj): skipped where
+the buffer swap, and MPCFlat::AlignAlns on the device store (progressive joins + refinement rounds,
+limited with -refineiters because every round is an emulated 1024-thread kernel). Needs the reference objects (oracle/_ref/obj): skipped where
 /root/reference was never available."""
 import os
 import subprocess
@@ -29,7 +30,7 @@ def emu_muscle():
     return _msa.EMU_MUSCLE
 
 
-@pytest.mark.parametrize("name", ["n2_L40", "n3_L30", "synth_6x40_s2", "dupes", "consiters0", "perturb_small", "super7_16x36_b8"])
+@pytest.mark.parametrize("name", ["n2_L40+r2", "n3_L30+r2", "synth_6x40_s2+r2", "dupes+r2", "consiters0+r2", "perturb_small+r2"])
 def test_final_msa_identical(emu_muscle, name):
     md5, _ = _msa.run_muscle(emu_muscle, name, threads=3)
     assert md5 == _msa.golden_md5()[name]

@@ -107,3 +107,35 @@ def test_emu_calc_aln(emu):
         assert path == path0, M.shape
         assert P.bits(sc) == P.bits(sc0)
     g.close()
+
+
+def test_emu_align_alns(emu):
+    """Device BuildPost + CalcAlnFlat (mpcgpu_align_alns) vs the numpy restatement of
+    buildpostflat.cpp + the oracle's CalcAlnFlat: same path, same score bits; both orientations
+    (s<t and s>t), after two relax iterations (current probabilities of the store)."""
+    import _buildpost as BP
+    import _oracle as O
+    from muscle_amd._lib import MpcGpu
+    rng = np.random.default_rng(3)
+    seqs = make_family(7, 22, seed=23)
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, emu)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    g.build_store()
+    for _ in range(2):
+        g.cons_iter()
+        g.cons_commit()
+    stage = g.get_sparse_range()
+    pidx = {p: k for k, p in enumerate((a, b) for a in range(7) for b in range(a + 1, 7))}
+    for grp1, grp2 in (([0, 2, 5], [1, 3, 4, 6]), ([6, 1], [0]), ([3], [2]), ([4, 5, 6], [0, 1, 2, 3])):
+        rows1, C1 = BP.random_msa(seqs, grp1, rng)
+        rows2, C2 = BP.random_msa(seqs, grp2, rng)
+        m1 = [BP.pos_to_col(r) for r in rows1]
+        m2 = [BP.pos_to_col(r) for r in rows2]
+        post = BP.build_post(stage, pidx, grp1, grp2, m1, m2, C1, C2)
+        sc0, path0 = O.calc_aln(post)
+        path, sc = g.align_alns(grp1, grp2, m1, m2, C1, C2)
+        assert path == path0 and P.bits(sc) == P.bits(sc0), (grp1, grp2)
+    g.close()
