@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out; mkdir -p $OUT; LOG=$OUT/quick4.log; : > $LOG
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+step() { echo "=== $* (t=$SECONDS)" | tee -a $LOG; "$@" 2>&1 | tee -a $LOG | tail -${TAILN:-30}; rc=${PIPESTATUS[0]}; echo "=== rc=$rc (t=$SECONDS)" | tee -a $LOG; return $rc; }
+TAILN=12 step timeout 300 python -u -m pytest tests -m gpu -q
+step timeout 200 python -u diag/e2e.py 256 300

@@ -189,6 +189,40 @@ def test_calc_aln_paths():
     g.close()
 
 
+def test_align_alns_vs_restatement():
+    """mpcgpu_align_alns (device BuildPost by sorted in-order reduction + CalcAlnFlat + traceback) vs the
+    numpy restatement of buildpostflat.cpp and the oracle's CalcAlnFlat on random gapped alignments of
+    a 12-sequence family after two relax iterations: identical path strings and score bits."""
+    import _buildpost as BP
+    import _oracle as O
+    rng = np.random.default_rng(4)
+    n = 12
+    seqs = make_family(n, 70, seed=29)
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    g.build_store()
+    for _ in range(2):
+        g.cons_iter()
+        g.cons_commit()
+    stage = g.get_sparse_range()
+    pidx = {p: k for k, p in enumerate((a, b) for a in range(n) for b in range(a + 1, n))}
+    order = list(rng.permutation(n))
+    for cut in (1, 5, 6, 11):
+        grp1, grp2 = [int(x) for x in order[:cut]], [int(x) for x in order[cut:]]
+        rows1, C1 = BP.random_msa(seqs, grp1, rng)
+        rows2, C2 = BP.random_msa(seqs, grp2, rng)
+        m1 = [BP.pos_to_col(r) for r in rows1]
+        m2 = [BP.pos_to_col(r) for r in rows2]
+        post = BP.build_post(stage, pidx, grp1, grp2, m1, m2, C1, C2)
+        sc0, path0 = O.calc_aln(post)
+        path, sc = g.align_alns(grp1, grp2, m1, m2, C1, C2)
+        assert path == path0 and P.bits(sc) == P.bits(sc0), cut
+    g.close()
+
+
 def test_errors_are_loud():
     s, t, m, i, thr = G.hmm_tables()
     g = MpcGpu(0)
