@@ -276,6 +276,7 @@ bool pad_geometry(const mpcgpu_ctx *c, u32 max_blocks, u32 *lcap1, u32 *ecap, u3
 {
 	*threads = env_int("MPCGPU_RELAX_WG", MPC_RT_THREADS) == 512 ? 512u : 1024u;
 	if (c->max_len > MPC_RT_MAXLEN) return false; // cell descriptors pack x and y into 13 bits each
+	if ((u64)c->max_nnz > (u64)MPC_RT_SLOTS * *threads) return false; // one pair must fit the slots of a tile
 	*lcap1 = (c->max_len + 1 + 3) & ~3u;                 // >= Lmax+1, multiple of 4 dwords
 	*ecap = std::max<u32>(max_blocks, 1) * MPC_PAD_ROW;   // whole 32-byte blocks (kernels_store.h)
 	if (*ecap > 65535u) return false;                    // pos_f / pos_t are 16-bit
