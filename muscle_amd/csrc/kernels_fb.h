@@ -47,7 +47,8 @@ struct FbParams {
 	// scratch / outputs
 	float *fm_scratch; // forward M plane, one slot per resident wave
 	u64 fm_stride;     // floats per slot
-	u64 *cand;         // candidates, capc per batch-local pair: (flat index << 32) | score bits
+	u64 *cand;         // candidates, capc per batch-local pair: (cell key << 32) | score bits
+	int cand_rc;       // cell key: 0 = flat index (i-1)*LY+(j-1) (post_kernel), 1 = (i-1) << 16 | (j-1) (post_rows_kernel)
 	u32 capc;
 	u32 *cand_cnt; // per batch-local pair (may exceed capc: overflow, detected by the host)
 	float *total;  // per batch-local pair: log total probability (diagnostic / tests)
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 					if (bal) {
 						const u32 pos = ncand + (u32)__popcll(bal & ((1ull << t) - 1ull));
 						if (hit && pos < p.capc) {
-							const u32 idx = (u32)(i - 1) * (u32)LY + (u32)(j - 1);
+							const u32 idx = p.cand_rc ? (((u32)(i - 1) << 16) | (u32)(j - 1)) : ((u32)(i - 1) * (u32)LY + (u32)(j - 1));
 							cand[pos] = ((u64)idx << 32) | (u64)__float_as_uint(sc[r]);
 						}
 						ncand += (u32)__popcll(bal);

@@ -199,3 +199,233 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 		__syncthreads();
 	}
 }
+
+// ---------------------------------------------------------------------------------------------
+// post_rows_kernel — same outputs as post_kernel, without the two bitonic sorts and with an EA DP
+// that touches LDS three times per row instead of a dozen. Used when the candidate keys are
+// (row << 16 | col) (FbParams::cand_rc) and LY fits the LDS arrays; post_kernel stays the general path.
+//
+//  * Row-major order by a counting sort on the row (LDS histogram -> scan -> scatter through a per-row
+//    cursor) and a tiny insertion sort inside each row (a lane per row, ~3 cells per row); the
+//    column-major rank (tperm) the same way on the column.
+//  * EA score (calcalnscoreflat.cpp:4-32): PM[j] holds S(i,j) of the current row (non-decreasing in
+//    j). Unrolling the recurrence over j gives S(i,j) = max(S(i-1,j), max over stored cells (i,c),
+//    c <= j, of S(i-1,c-1) + P(i,c)); cells with P == 0 change nothing because S(i-1,.) is
+//    non-decreasing. So a row needs: one LDS read of PM[c-1] per stored cell (all cells of the row at
+//    once, from the previous row's values), one add each, a running maximum over the cells in column
+//    order, and one pass "PM[j] = max(PM[j], V(j))" over the columns right of the first cell. The
+//    only rounding is the one add per stored cell, max is exact: bit-identical to the sequential DP.
+struct PostRowsParams {
+	const u32 *pair_x, *pair_y;
+	const u32 *seq_len;
+	u64 *cand;        // in: (row << 16 | col) << 32 | score bits; probability bits replace the score in place
+	u32 capc;
+	const u32 *cand_cnt;
+	int use_fma;
+	u32 lx_cap, ly_cap; // LDS array sizes (entries): rows+1, cols+1
+	u32 sort_cap;       // LDS entries for the row-sorted list; larger pairs use sort_scratch
+	u32 batch;          // cells of one row handled per EA pass: 64 (a smaller value only to test the multi-pass path)
+	u64 *sort_scratch;
+	u64 sort_stride;
+	u32 *res;
+	u64 res_stride;
+	u32 *nnz;
+	float *ea;
+	u32 *flags;
+	u32 count;
+};
+
+__global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
+{
+	MPC_DYN_SMEM(smem_raw);
+	u32 *s_rend = (u32 *)smem_raw;            // lx_cap: per-row counts, then row ENDS (cursor after the scatter)
+	u32 *s_cend = s_rend + p.lx_cap;          // ly_cap: same per column
+	float *s_pm = (float *)(s_cend + p.ly_cap); // ly_cap: PM[0..LY]
+	u64 *s_sorted = (u64 *)(smem_raw + ((((size_t)p.lx_cap + 2 * (size_t)p.ly_cap) * 4 + 7) & ~(size_t)7)); // sort_cap: (col << 32 | P bits), row-major
+	const int t = threadIdx.x;
+
+	for (u32 pid = blockIdx.x; pid < p.count; pid += gridDim.x) {
+		const u32 LX = p.seq_len[p.pair_x[pid]], LY = p.seq_len[p.pair_y[pid]];
+		u32 *rec = p.res + (u64)pid * p.res_stride;
+		const u32 c = p.cand_cnt[pid];
+		if (c > p.capc) { // overflow: reported to the host, which retries with a larger capacity
+			if (t == 0) { p.flags[pid] = 1u; p.nnz[pid] = 0; p.ea[pid] = 0.0f; }
+			continue;
+		}
+		if (t == 0) p.flags[pid] = 0u;
+		u64 *cand = p.cand + (u64)pid * p.capc;
+		u64 *sorted = (c <= p.sort_cap) ? s_sorted : (p.sort_scratch + (u64)blockIdx.x * p.sort_stride);
+		for (u32 q = t; q <= LX; q += 64) s_rend[q] = 0;
+		for (u32 q = t; q <= LY; q += 64) { s_cend[q] = 0; s_pm[q] = 0.0f; }
+		for (u32 q = t; q < LX + LY; q += 64) rec[q] = 0;
+		__syncthreads();
+		// ---- probabilities (calcposteriorflat.cpp:16-22) and the row histogram
+		for (u32 q = t; q < c; q += 64) {
+			const u64 v = cand[q];
+			const float pr = mpc_score_to_prob(__uint_as_float((u32)v), p.use_fma);
+			cand[q] = (v & 0xffffffff00000000ull) | (u64)__float_as_uint(pr);
+			atomicAdd(&s_rend[(u32)(v >> 48)], 1u);
+		}
+		__syncthreads();
+		// exclusive scan of the row counts (in place: s_rend[i] = first slot of row i)
+		{
+			u32 carry = 0;
+			for (u32 a0 = 0; a0 <= LX; a0 += 64) {
+				const u32 a = a0 + t;
+				const u32 v = (a <= LX) ? s_rend[a] : 0;
+				u32 incl = v;
+				for (int d = 1; d < 64; d <<= 1) {
+					const u32 o = __shfl_up(incl, d);
+					if (t >= d) incl += o;
+				}
+				if (a <= LX) s_rend[a] = carry + incl - v;
+				carry += __shfl(incl, 63);
+			}
+		}
+		__syncthreads();
+		// scatter through the per-row cursor: afterwards s_rend[i] = END of row i (start of row i+1)
+		for (u32 q = t; q < c; q += 64) {
+			const u64 v = cand[q];
+			const u32 at = atomicAdd(&s_rend[(u32)(v >> 48)], 1u);
+			sorted[at] = ((v >> 32) & 0xffffull) << 32 | (v & 0xffffffffull);
+		}
+		__syncthreads();
+		// columns ascending inside each row (a lane per row; rows hold a handful of cells)
+		for (u32 i = t; i < LX; i += 64) {
+			const u32 b = i ? s_rend[i - 1] : 0u, e = s_rend[i];
+			for (u32 x = b + 1; x < e; ++x) {
+				const u64 key = sorted[x];
+				u32 y = x;
+				while (y > b && sorted[y - 1] > key) { sorted[y] = sorted[y - 1]; --y; }
+				sorted[y] = key;
+			}
+		}
+		__syncthreads();
+		// ---- EA score
+		for (u32 i = 0; i < LX; ++i) {
+			const u32 b = i ? s_rend[i - 1] : 0u, e = s_rend[i]; // wave-uniform
+			if (e == b) continue;
+			const bool wide = e - b > p.batch; // more than one batch of cells: every B must still come from the previous row's PM
+			if (wide) {
+				for (u32 x = b + (u32)t; x < e; x += 64) {
+					const u64 key = sorted[x];
+					s_cend[x - b] = __float_as_uint(s_pm[(u32)(key >> 32)] + __uint_as_float((u32)key)); // s_cend is free until the sparsify step
+				}
+				__syncthreads();
+			}
+			float vprev = 0.0f; // maximum over the cells of this row handled so far
+			for (u32 c0 = b; c0 < e; c0 += p.batch) {
+				const u32 me = c0 + (u32)t;
+				const bool have = me < e && (u32)t < p.batch;
+				const u64 key = have ? sorted[me] : 0ull;
+				const u32 col = (u32)(key >> 32);
+				float val = 0.0f; // B = S(i-1,j-1) + P with j = col+1 (calcalnscoreflat.cpp:20)
+				if (have) val = wide ? __uint_as_float(s_cend[me - b]) : s_pm[col] + __uint_as_float((u32)key);
+				const float V = fmaxf(mpc_wave_scan_max_nonneg(val), vprev); // running maximum in column order
+				const u32 k = (e - c0 < p.batch) ? (e - c0) : p.batch;
+				for (u32 j0 = mpc_wave_first(col) + 1u; j0 <= LY; j0 += 64) {
+					const u32 j = j0 + (u32)t;
+					float cur = 0.0f;
+					for (u32 l = 0; l < k; ++l) { // cells ascend in column: the last one with col+1 <= j wins
+						const u32 cj = mpc_read_lane(col, l) + 1u;
+						const float vj = mpc_read_lane(V, l);
+						cur = (j >= cj) ? vj : cur;
+					}
+					if (j <= LY) s_pm[j] = fmaxf(s_pm[j], cur); // max(X, Y-chain) of the recurrence
+				}
+				vprev = mpc_read_lane(V, k - 1);
+				__syncthreads();
+			}
+			if (wide) {
+				for (u32 x = b + (u32)t; x < e; x += 64) s_cend[x - b] = 0;
+				__syncthreads();
+			}
+		}
+		const float score = s_pm[LY];
+		const u32 mn = LX < LY ? LX : LY;
+		const float ea = score / (float)mn; // calcposteriorflat.cpp:89 (uint -> float, IEEE divide)
+		__syncthreads();
+		// ---- sparsify (mysparsemx.cpp:115-152): keep P >= 0.01f, row-major rank among the kept
+		u32 kept = 0;
+		for (u32 q0 = 0; q0 < c; q0 += 64) {
+			const u32 q = q0 + t;
+			const bool k = q < c && __uint_as_float((u32)sorted[q]) >= MPC_MIN_SPARSE_PROB;
+			kept += (u32)__popcll(__ballot(k));
+		}
+		const u32 nnz = kept;
+		u32 *rowcnt = rec, *colcnt = rec + LX;
+		u32 *ent = rec + LX + LY;
+		u32 *rowv = ent + 2 * (u64)nnz;
+		u32 *tperm = rowv + nnz;
+		// row of every sorted slot: slots of row i are [s_rend[i-1], s_rend[i])
+		u32 base = 0;
+		for (u32 i0 = 0; i0 < LX; i0 += 64) { // a lane per row writes that row's kept cells
+			const u32 i = i0 + (u32)t;
+			u32 mycnt = 0;
+			u32 b = 0, e = 0;
+			if (i < LX) {
+				b = i ? s_rend[i - 1] : 0u; e = s_rend[i];
+				for (u32 x = b; x < e; ++x) mycnt += (__uint_as_float((u32)sorted[x]) >= MPC_MIN_SPARSE_PROB) ? 1u : 0u;
+			}
+			u32 incl = mycnt;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d);
+				if (t >= d) incl += o;
+			}
+			u32 at = base + incl - mycnt;
+			if (i < LX) {
+				rowcnt[i] = mycnt;
+				for (u32 x = b; x < e; ++x) {
+					const u64 key = sorted[x];
+					if (__uint_as_float((u32)key) >= MPC_MIN_SPARSE_PROB) {
+						const u32 col = (u32)(key >> 32);
+						ent[2 * (u64)at] = (u32)key;
+						ent[2 * (u64)at + 1] = col;
+						rowv[at] = i;
+						atomicAdd(&s_cend[col], 1u);
+						++at;
+					}
+				}
+			}
+			base += __shfl(incl, 63);
+		}
+		__syncthreads();
+		// ---- column-major rank of every kept entry: counting sort on the column, rows ascending inside
+		for (u32 q = t; q < LY; q += 64) colcnt[q] = s_cend[q];
+		{
+			u32 carry = 0;
+			for (u32 a0 = 0; a0 <= LY; a0 += 64) {
+				const u32 a = a0 + t;
+				const u32 v = (a <= LY) ? s_cend[a] : 0;
+				u32 incl = v;
+				for (int d = 1; d < 64; d <<= 1) {
+					const u32 o = __shfl_up(incl, d);
+					if (t >= d) incl += o;
+				}
+				if (a <= LY) s_cend[a] = carry + incl - v;
+				carry += __shfl(incl, 63);
+			}
+		}
+		__syncthreads();
+		u32 *csorted = (u32 *)sorted; // entry ranks in column-major order (the row-sorted list is no longer needed)
+		__syncthreads();
+		for (u32 q = t; q < nnz; q += 64) {
+			const u32 at = atomicAdd(&s_cend[ent[2 * (u64)q + 1]], 1u);
+			csorted[at] = q; // entry rank (row-major); rows ascend with the rank
+		}
+		__syncthreads();
+		for (u32 j = t; j < LY; j += 64) { // ranks ascending inside each column = rows ascending
+			const u32 b = j ? s_cend[j - 1] : 0u, e = s_cend[j];
+			for (u32 x = b + 1; x < e; ++x) {
+				const u32 key = csorted[x];
+				u32 y = x;
+				while (y > b && csorted[y - 1] > key) { csorted[y] = csorted[y - 1]; --y; }
+				csorted[y] = key;
+			}
+		}
+		__syncthreads();
+		for (u32 q = t; q < nnz; q += 64) tperm[csorted[q]] = q;
+		if (t == 0) { p.nnz[pid] = nnz; p.ea[pid] = ea; }
+		__syncthreads();
+	}
+}

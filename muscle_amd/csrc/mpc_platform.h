@@ -32,6 +32,9 @@ __device__ __forceinline__ float mpc_wave_scan_max_nonneg(float v)
 #undef MPC_DPP_MAX
 	return v;
 }
+// value of lane `l` (wave-uniform index) as a scalar: v_readlane_b32, no LDS
+__device__ __forceinline__ unsigned mpc_read_lane(unsigned v, unsigned l) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ float mpc_read_lane(float v, unsigned l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l)); }
 // optimisation barrier on one VGPR value (no code): stops hoisting of what is derived from it
 #define MPC_OPAQUE(v) asm volatile("" : "+v"(v))
 // value held by the first active lane, as a wave-uniform scalar (v_readfirstlane_b32 -> SGPR)

@@ -618,6 +618,10 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 		fp.pair_x = c->d_bx.as<u32>(); fp.pair_y = c->d_by.as<u32>();
 		fp.cand = c->d_cand.as<u64>(); fp.capc = capc; fp.cand_cnt = c->d_cand_cnt.as<u32>();
 		fp.total = c->d_total.as<float>();
+		// row-list post kernel (no sorts, 3 LDS trips per EA row) when LY fits its LDS arrays; MPCGPU_POST=sort forces the general one
+		const char *post_mode = getenv("MPCGPU_POST");
+		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) && LYmax + 1 <= 2048u && LXmax <= 65535u && LYmax <= 65535u;
+		fp.cand_rc = post_rows ? 1 : 0;
 
 		TimedSpan sp;
 		u32 pos = 0;
@@ -645,6 +649,30 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 			pos += cnt;
 		}
 		// ---- finish: probabilities, sort, EA, sparsify
+		if (post_rows) {
+			PostRowsParams pr;
+			pr.pair_x = c->d_bx.as<u32>(); pr.pair_y = c->d_by.as<u32>(); pr.seq_len = c->d_seq_len.as<u32>();
+			pr.cand = c->d_cand.as<u64>(); pr.capc = capc; pr.cand_cnt = c->d_cand_cnt.as<u32>();
+			pr.use_fma = c->use_fma;
+			pr.lx_cap = LXmax + 2; pr.ly_cap = LYmax + 2;
+			pr.sort_cap = std::min<u32>(capc, (u32)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2));
+			pr.sort_stride = capc;
+			pr.batch = (u32)std::min(std::max(env_int("MPCGPU_POST_BATCH", 64), 1), 64);
+			const size_t smem = ((((size_t)pr.lx_cap + 2 * (size_t)pr.ly_cap) * 4 + 7) & ~(size_t)7) + (size_t)pr.sort_cap * 8;
+			int pocc = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_rows_kernel, 64, smem) != hipSuccess || pocc < 1) pocc = 8;
+			const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
+			HIPCHK(c, c->d_sort_scratch.ensure(capc > pr.sort_cap ? (u64)pgrid * pr.sort_stride * 8 : 8));
+			pr.sort_scratch = c->d_sort_scratch.as<u64>();
+			pr.res = c->d_res.as<u32>(); pr.res_stride = res_stride;
+			pr.nnz = c->d_nnz.as<u32>(); pr.ea = c->d_ea.as<float>(); pr.flags = c->d_flags.as<u32>();
+			pr.count = (u32)B;
+			if (trace_on()) { fprintf(stderr, "[mpcgpu] post rows: lds=%zu B blocks/CU=%d grid=%u\n", smem, pocc, pgrid); fflush(stderr); }
+			if (span_begin(c, 1, &sp)) return 1;
+			MPC_LAUNCH(post_rows_kernel, pgrid, 64, smem, c->stream, pr);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &sp)) return 1;
+		} else {
 		PostParams pp;
 		pp.pair_x = c->d_bx.as<u32>(); pp.pair_y = c->d_by.as<u32>(); pp.seq_len = c->d_seq_len.as<u32>();
 		pp.cand = c->d_cand.as<u64>(); pp.capc = capc; pp.cand_cnt = c->d_cand_cnt.as<u32>();
@@ -673,6 +701,7 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 		MPC_LAUNCH(post_kernel, pgrid, 64, psmem, c->stream, pp);
 		HIPCHK(c, hipGetLastError());
 		if (span_end(c, &sp)) return 1;
+		}
 		// ---- sizes back, overflow check, pack
 		std::vector<u32> flags(B);
 		HIPCHK(c, hipMemcpyAsync(&c->sh_nnz[done], c->d_nnz.p, B * 4, hipMemcpyDeviceToHost, c->stream));

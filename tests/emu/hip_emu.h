@@ -82,6 +82,7 @@ template <class T> static inline T __shfl_up(T v, unsigned d) { return emu_xchg(
 template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xchg(v, (int)d, false); }
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
 #define MPC_OPAQUE(v) ((void)0)
+template <class T> static inline T mpc_read_lane(T v, unsigned l) { return __shfl(v, (int)l); }
 template <class T> static inline T mpc_lane_up1(T v) { return __shfl_up(v, 1); }
 template <class T> static inline T mpc_lane_down1(T v) { return __shfl_down(v, 1); }
 static inline float mpc_wave_scan_max_nonneg(float v)

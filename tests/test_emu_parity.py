@@ -109,6 +109,17 @@ def test_emu_calc_aln(emu):
     g.close()
 
 
+def test_emu_post_kernels(emu):
+    """Both post kernels (row lists: default; bitonic sort: general path) and the multi-pass EA path of
+    the row-list kernel (forced with a batch of 3 cells) give the oracle's store and EA."""
+    seqs = ["AC" * 30, "CA" * 28, "ACAC" * 13 + "A", make_family(1, 50, seed=3)[0], "M"]
+    want = P.run_oracle(seqs)
+    P.assert_same(P.run_lib(seqs, lib_path=emu), want, "rows")
+    P.assert_same(_with_env({"MPCGPU_POST": "sort"}, lambda: P.run_lib(seqs, lib_path=emu)), want, "sort")
+    P.assert_same(_with_env({"MPCGPU_POST_BATCH": "3"}, lambda: P.run_lib(seqs, lib_path=emu)), want, "batch 3")
+    P.assert_same(_with_env({"MPCGPU_POST_SORT_CAP": "8"}, lambda: P.run_lib(seqs, lib_path=emu)), want, "global scratch list")
+
+
 def test_emu_align_alns(emu):
     """Device BuildPost + CalcAlnFlat (mpcgpu_align_alns) vs the numpy restatement of
     buildpostflat.cpp + the oracle's CalcAlnFlat: same path, same score bits; both orientations
