@@ -26,6 +26,8 @@
 #include "device_math.h"
 
 #define MPC_HMAX 16
+#define MPC_KEY_ROW_SHIFT 22 // rows < 64*MPC_HMAX = 2^10, columns < 2^22 (checked in mpcgpu_set_seqs)
+#define MPC_KEY_COL_MASK ((1u << MPC_KEY_ROW_SHIFT) - 1u)
 #define MPC_FB_COEF_BYTES (MPC_COEF_ENTRIES * 16)
 
 struct FbParams {
@@ -47,8 +49,8 @@ struct FbParams {
 	// scratch / outputs
 	float *fm_scratch; // forward M plane, one slot per resident wave
 	u64 fm_stride;     // floats per slot
-	u64 *cand;         // candidates, capc per batch-local pair: (cell key << 32) | score bits
-	int cand_rc;       // cell key: 0 = flat index (i-1)*LY+(j-1) (post_kernel), 1 = (i-1) << 16 | (j-1) (post_rows_kernel)
+	u64 *cand;         // candidates, capc per batch-local pair: (cell key << 32) | score bits,
+	                   // cell key = (i-1) << MPC_KEY_ROW_SHIFT | (j-1): row-major order, no division to unpack
 	u32 capc;
 	u32 *cand_cnt; // per batch-local pair (may exceed capc: overflow, detected by the host)
 	float *total;  // per batch-local pair: log total probability (diagnostic / tests)
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 					if (bal) {
 						const u32 pos = ncand + (u32)__popcll(bal & ((1ull << t) - 1ull));
 						if (hit && pos < p.capc) {
-							const u32 idx = p.cand_rc ? (((u32)(i - 1) << 16) | (u32)(j - 1)) : ((u32)(i - 1) * (u32)LY + (u32)(j - 1));
+							const u32 idx = ((u32)(i - 1) << MPC_KEY_ROW_SHIFT) | (u32)(j - 1);
 							cand[pos] = ((u64)idx << 32) | (u64)__float_as_uint(sc[r]);
 						}
 						ncand += (u32)__popcll(bal);

@@ -19,6 +19,7 @@
 // sequential recurrence bit for bit (the only rounding is the one float add per stored entry).
 #pragma once
 #include "device_math.h"
+#include "kernels_fb.h" // MPC_KEY_ROW_SHIFT: layout of the candidate keys
 
 struct PostParams {
 	const u32 *pair_x, *pair_y; // per batch-local pair
@@ -112,9 +113,10 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 		const u32 c0 = t * C;
 		u32 e = 0; // wave-uniform cursor into the sorted candidates
 		for (u32 i = 0; i < LX; ++i) {
-			const u32 rlo = i * LY, rhi = rlo + LY; // flat-index range of posterior row i
+			const u32 rlo = i << MPC_KEY_ROW_SHIFT; // key range of posterior row i: [rlo, rhi) (64-bit: row 1023 ends at 2^32)
+			const u64 rhi = (u64)(i + 1) << MPC_KEY_ROW_SHIFT;
 			u32 e1 = e;
-			while (e1 < c && (u32)(buf[e1] >> 32) < rhi) ++e1;
+			while (e1 < c && (buf[e1] >> 32) < rhi) ++e1;
 			if (e1 > e) {
 				u32 kk = e; // first stored cell of this row at or right of my first column
 				while (kk < e1 && (u32)(buf[kk] >> 32) - rlo + 1 < c0) ++kk;
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 			if (k) {
 				const u32 rank = base + (u32)__popcll(bal & ((1ull << t) - 1ull));
 				const u32 idx = (u32)(key >> 32);
-				const u32 row = idx / LY, col = idx - row * LY;
+				const u32 row = idx >> MPC_KEY_ROW_SHIFT, col = idx & MPC_KEY_COL_MASK;
 				ent[2 * (u64)rank] = (u32)key;
 				ent[2 * (u64)rank + 1] = col;
 				rowv[rank] = row;
@@ -202,8 +204,8 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 
 // ---------------------------------------------------------------------------------------------
 // post_rows_kernel — same outputs as post_kernel, without the two bitonic sorts and with an EA DP
-// that touches LDS three times per row instead of a dozen. Used when the candidate keys are
-// (row << 16 | col) (FbParams::cand_rc) and LY fits the LDS arrays; post_kernel stays the general path.
+// that touches LDS three times per row instead of a dozen. Used when LY fits the LDS arrays;
+// post_kernel stays the general path.
 //
 //  * Row-major order by a counting sort on the row (LDS histogram -> scan -> scatter through a per-row
 //    cursor) and a tiny insertion sort inside each row (a lane per row, ~3 cells per row); the
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 struct PostRowsParams {
 	const u32 *pair_x, *pair_y;
 	const u32 *seq_len;
-	u64 *cand;        // in: (row << 16 | col) << 32 | score bits; probability bits replace the score in place
+	u64 *cand;        // in: (row << MPC_KEY_ROW_SHIFT | col) << 32 | score bits; probability bits replace the score in place
 	u32 capc;
 	const u32 *cand_cnt;
 	int use_fma;
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			const u64 v = cand[q];
 			const float pr = mpc_score_to_prob(__uint_as_float((u32)v), p.use_fma);
 			cand[q] = (v & 0xffffffff00000000ull) | (u64)__float_as_uint(pr);
-			atomicAdd(&s_rend[(u32)(v >> 48)], 1u);
+			atomicAdd(&s_rend[(u32)(v >> (32 + MPC_KEY_ROW_SHIFT))], 1u);
 		}
 		__syncthreads();
 		// exclusive scan of the row counts (in place: s_rend[i] = first slot of row i)
@@ -286,8 +288,8 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 		// scatter through the per-row cursor: afterwards s_rend[i] = END of row i (start of row i+1)
 		for (u32 q = t; q < c; q += 64) {
 			const u64 v = cand[q];
-			const u32 at = atomicAdd(&s_rend[(u32)(v >> 48)], 1u);
-			sorted[at] = ((v >> 32) & 0xffffull) << 32 | (v & 0xffffffffull);
+			const u32 at = atomicAdd(&s_rend[(u32)(v >> (32 + MPC_KEY_ROW_SHIFT))], 1u);
+			sorted[at] = ((v >> 32) & (u64)MPC_KEY_COL_MASK) << 32 | (v & 0xffffffffull);
 		}
 		__syncthreads();
 		// columns ascending inside each row (a lane per row; rows hold a handful of cells)

@@ -486,6 +486,7 @@ int mpcgpu_set_seqs(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const
 	u32 maxl = 0, max2 = 0;
 	for (u32 i = 0; i < n; ++i) {
 		if (lens[i] == 0) return fail(c, "mpcgpu_set_seqs: sequence %u is empty", i);
+		if (lens[i] > MPC_KEY_COL_MASK) return fail(c, "mpcgpu_set_seqs: sequence %u is longer than %u", i, MPC_KEY_COL_MASK);
 		c->raw[i].assign(seqs[i], seqs[i] + lens[i]);
 		for (u8 b : c->raw[i]) {
 			if (b >= 128) return fail(c, "mpcgpu_set_seqs: sequence %u holds non-ASCII byte %u", i, (unsigned)b);
@@ -620,8 +621,7 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 		fp.total = c->d_total.as<float>();
 		// row-list post kernel (no sorts, 3 LDS trips per EA row) when LY fits its LDS arrays; MPCGPU_POST=sort forces the general one
 		const char *post_mode = getenv("MPCGPU_POST");
-		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) && LYmax + 1 <= 2048u && LXmax <= 65535u && LYmax <= 65535u;
-		fp.cand_rc = post_rows ? 1 : 0;
+		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) && LYmax + 1 <= 2048u;
 
 		TimedSpan sp;
 		u32 pos = 0;

@@ -34,7 +34,8 @@ def test_wildcards_and_lowercase():
 
 
 def test_ragged_and_extremes():
-    seqs = ["M", "W", "MKVLA", make_family(1, 900, seed=2)[0], make_family(1, 1000, seed=3)[0][:1024],
+    long1024 = (make_family(1, 1100, seed=5)[0] * 2)[:1024]  # exactly the longest row sequence this build takes
+    seqs = ["M", "W", "MKVLA", make_family(1, 900, seed=2)[0], make_family(1, 1000, seed=3)[0][:1024], long1024,
             "ACDEFGHIKLMNPQRSTVWY" * 10, make_family(1, 333, seed=4)[0]]
     P.assert_same(P.run_lib(seqs), P.run_oracle(seqs, threads=0), "ragged")
 
