@@ -5,7 +5,8 @@
 # of the reference is copied into the repo, and the combined (GPL-3.0) binary is git-ignored; it
 # travels to the GPU box as a built artefact.
 #
-#   reference objects  - consflat.o, alnalnsflat.o       (MPCFlat::ConsIter and MPCFlat::AlignAlns are ours)
+#   reference objects  - consflat.o, alnalnsflat.o, alnmsasflat.o  (MPCFlat::ConsIter, MPCFlat::AlignAlns and
+#                        PProg::AlignMSAsFlat are ours)
 #                      - calcposteriorflat.o's CalcPosterior symbol, weakened with objcopy so that
 #                        hostcxx/mpcflat_gpu.cpp's strong definition wins while CalcPostFlat and the
 #                        two vestigial virtuals in the same object stay available
@@ -26,7 +27,7 @@ CXXFLAGS="-std=c++17 -O3 -fopenmp -DNDEBUG -pthread -fPIC -w -I$ROOT/oracle/_ref
 g++ $CXXFLAGS -c "$HERE/mpcflat_gpu.cpp" -o "$OUT/mpcflat_gpu.o"
 g++ $CXXFLAGS -c "$HERE/rand_isolate.cpp" -o "$OUT/rand_isolate.o"
 objcopy --weaken-symbol=_ZN7MPCFlat13CalcPosteriorEj "$REFOBJ/calcposteriorflat.o" "$OUT/calcposteriorflat_weak.o"
-OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/calcposteriorflat\.o$')
+OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$')
 # The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
 # MPCGPU_LIBDIR/MPCGPU_LIBNAME pointing at the SIMT-emulator build of the same library sources
 # (tests/emu, test infrastructure) to check the host-side plumbing of this file without a GPU.

@@ -15,7 +15,11 @@
 //                                  the device store, so the progressive stage and the 100 refinement
 //                                  rounds never need the sparse matrices on the host
 //
-// Build: every reference object except consflat.o and alnalnsflat.o, calcposteriorflat.o with its CalcPosterior
+//   PProg::AlignMSAsFlat(...)      replaces alnmsasflat.cpp:4-50: the join of two MSAs in the super5/super7
+//                                  drivers — GetPostPairsAlignedFlat (getpostpairsalignedflat.cpp:5-98: fwd/bwd/
+//                                  posterior per sampled cross pair) + CalcPosteriorFlat3 + CalcAlnFlat
+//
+// Build: every reference object except consflat.o, alnalnsflat.o and alnmsasflat.o, calcposteriorflat.o with its CalcPosterior
 // symbol weakened (the same object also defines CalcPostFlat and the two vestigial virtuals that
 // other translation units / the vtable need), plus this file, plus -lmpcgpu
 // (hostcxx/build_muscle_gpu.sh; INTEGRATION.md shows the two-line change a maintainer would make
@@ -26,6 +30,7 @@
 #include "muscle.h"
 #include "mpcflat.h"
 #include "pairhmm.h"
+#include "pprog.h"
 #include "mpcgpu.h"
 
 #include <map>
@@ -44,6 +49,7 @@ struct Batch
 
 std::mutex g_Mu;
 mpcgpu_ctx *g_Ctx = 0;
+mpcgpu_ctx *g_CtxJoin = 0; // PProg joins: their own context, so a join never disturbs the store of an MPCFlat run
 std::map<const MPCFlat *, Batch> g_Batches;
 
 mpcgpu_ctx *GetCtx()
@@ -322,4 +328,101 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 		result->AddSequence(AlignedRow, true);
 		}
 	return result;
+	}
+
+float PProg::AlignMSAsFlat(const string &ProgressStr,
+  const MultiSequence &MSA1, const MultiSequence &MSA2,
+  uint TargetPairCount, string &Path)
+	{
+// alnmsasflat.cpp:8-25
+	const uint SeqCount1 = MSA1.GetNumSequences();
+	const uint SeqCount2 = MSA2.GetNumSequences();
+	asserta(SeqCount1 > 0);
+	asserta(SeqCount2 > 0);
+	asserta(MSA1.IsAligned());
+	asserta(MSA2.IsAligned());
+	const uint ColCount1 = MSA1.GetColCount();
+	const uint ColCount2 = MSA2.GetColCount();
+
+	vector<uint> SeqIndexes1;
+	vector<uint> SeqIndexes2;
+	GetPairs(SeqCount1, SeqCount2, TargetPairCount, SeqIndexes1, SeqIndexes2);
+	const uint PairCount = SIZE(SeqIndexes1);
+	asserta(SIZE(SeqIndexes2) == PairCount);
+	asserta(PairCount > 0);
+	ProgressStep(0, 1, "%s [%u x %u, %u pairs]", ProgressStr.substr(0, 20).c_str(),
+	  min(SeqCount1, SeqCount2), max(SeqCount1, SeqCount2), PairCount);
+
+// The ungapped sequences come from the global input registry by label, like CalcPost does
+// (calcpost.cpp:4-36, getpostpairsalignedflat.cpp:43-46); the ones this join touches are handed to
+// the library as its registry for this call.
+	std::map<const Sequence *, uint32_t> SeqToIndex;
+	vector<const uint8_t *> Ptrs;
+	vector<uint32_t> Lens;
+	auto Register = [&](const string &Label) -> uint32_t
+		{
+		const Sequence &Seq = GetGlobalInputSeqByLabel(Label);
+		std::map<const Sequence *, uint32_t>::const_iterator p = SeqToIndex.find(&Seq);
+		if (p != SeqToIndex.end())
+			return p->second;
+		uint32_t Index = (uint32_t) Ptrs.size();
+		SeqToIndex[&Seq] = Index;
+		Ptrs.push_back(Seq.GetBytePtr());
+		Lens.push_back(Seq.GetLength());
+		return Index;
+		};
+
+	vector<uint32_t> Seqs1(PairCount), Seqs2(PairCount);
+	vector<uint32_t> Map1, Map2;
+	vector<uint> PosToCol;
+	for (uint PairIndex = 0; PairIndex < PairCount; ++PairIndex)
+		{
+		const uint SeqIndex1 = SeqIndexes1[PairIndex];
+		const uint SeqIndex2 = SeqIndexes2[PairIndex];
+		asserta(SeqIndex1 < SeqCount1);
+		asserta(SeqIndex2 < SeqCount2);
+		Seqs1[PairIndex] = Register(MSA1.GetLabelStr(SeqIndex1));
+		Seqs2[PairIndex] = Register(MSA2.GetLabelStr(SeqIndex2));
+// buildposterior3flat.cpp:46-66
+		const Sequence *Row1 = MSA1.GetSequence(SeqIndex1);
+		const Sequence *Row2 = MSA2.GetSequence(SeqIndex2);
+		asserta(Row1->GetLength() == ColCount1);
+		asserta(Row2->GetLength() == ColCount2);
+		Row1->GetPosToCol(PosToCol);
+		asserta(SIZE(PosToCol) == Lens[Seqs1[PairIndex]]);
+		Map1.insert(Map1.end(), PosToCol.begin(), PosToCol.end());
+		Row2->GetPosToCol(PosToCol);
+		asserta(SIZE(PosToCol) == Lens[Seqs2[PairIndex]]);
+		Map2.insert(Map2.end(), PosToCol.begin(), PosToCol.end());
+		}
+
+	Path.assign(ColCount1 + ColCount2, '?');
+	uint32_t PathLen = 0;
+	float Score = 0;
+	vector<float> EA(PairCount);
+		{
+		std::lock_guard<std::mutex> Guard(g_Mu);
+		if (g_CtxJoin == 0)
+			{
+			int Device = 0;
+			const char *s = getenv("MUSCLE_GPU_DEVICE");
+			if (s != 0 && *s != 0)
+				Device = atoi(s);
+			if (mpcgpu_create(&g_CtxJoin, Device) != 0)
+				Die("GPU posterior stage: %s", mpcgpu_last_error(0));
+			}
+		mpcgpu_ctx *Ctx = g_CtxJoin;
+		GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
+		  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
+		GPUCHK(mpcgpu_set_seqs_registry(Ctx, (uint32_t) Ptrs.size(), Ptrs.data(), Lens.data()));
+		GPUCHK(mpcgpu_align_msas(Ctx, PairCount, Seqs1.data(), Seqs2.data(), ColCount1, ColCount2,
+		  Map1.data(), Map2.data(), &Path[0], &PathLen, &Score, EA.data()));
+		}
+	Path.resize(PathLen);
+
+// getpostpairsalignedflat.cpp:90-96: the reference adds the EAs in thread-arrival order; here in pair order
+	float SumEA = 0;
+	for (uint PairIndex = 0; PairIndex < PairCount; ++PairIndex)
+		SumEA += EA[PairIndex];
+	return SumEA/PairCount;
 	}

@@ -130,6 +130,21 @@ int mpcgpu_align_alns(mpcgpu_ctx *ctx, uint32_t n1, const uint32_t *seq1, uint32
                       uint32_t C1, uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2,
                       char *path, uint32_t *pathlen, float *score);
 
+/* The MSA x MSA join of PProg (pprog2.cpp:7-56 -> PProg::AlignMSAsFlat, alnmsasflat.cpp:4-50) for an
+ * explicit list of cross pairs (getpairs.cpp:33-69 samples at most 2000): per pair
+ * PProg::GetPostPairsAlignedFlat (getpostpairsalignedflat.cpp:5-98) = CalcPost + MySparseMx::FromPost
+ * + the alignment score (EA = Score / min(L1,L2)), then CalcPosteriorFlat3
+ * (buildposterior3flat.cpp:19-85, contributions in pair-list order) and CalcAlnFlat + TraceBackFlat.
+ * Sequences are indices into the set given to mpcgpu_set_seqs_registry (the reference's global input
+ * registry, globalinputms.cpp:11-143: any sequence may pair with any other, no all-pairs tables);
+ * pair q aligns seq1[q] (a row of MSA1, X) with seq2[q] (a row of MSA2, Y); pos2col1 / pos2col2 hold
+ * the position->column map of seq1[q] / seq2[q] for q = 0..npairs-1, concatenated. ea_out (may be
+ * NULL) receives EA per pair. */
+int mpcgpu_set_seqs_registry(mpcgpu_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens);
+int mpcgpu_align_msas(mpcgpu_ctx *ctx, uint32_t npairs, const uint32_t *seq1, const uint32_t *seq2, uint32_t C1,
+                      uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, char *path, uint32_t *pathlen,
+                      float *score, float *ea_out);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 /* Kernel time in ms measured with hipEvents on the library's own stream, accumulated since the
  * last reset, per kernel family: 0 = fwd/bwd (fb), 1 = posterior finish (sort/EA/pack),

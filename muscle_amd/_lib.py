@@ -19,7 +19,7 @@ SYMBOLS = [
     "mpcgpu_set_seqs", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
-    "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_timers_reset", "mpcgpu_timers_get",
+    "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize",
 ]
 
@@ -67,6 +67,8 @@ def load(lib_path=None):
     L.mpcgpu_get_sparse_range.argtypes = [vp, u64, u64, vp, vp]
     L.mpcgpu_calc_aln.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.mpcgpu_align_alns.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float)]
+    L.mpcgpu_set_seqs_registry.argtypes = [vp, u32, vp, vp]
+    L.mpcgpu_align_msas.argtypes = [vp, u32, vp, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float), vp]
     L.mpcgpu_timers_reset.argtypes = [vp]
     L.mpcgpu_timers_get.argtypes = [vp, vp, vp]
     L.mpcgpu_work_get.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
@@ -107,6 +109,29 @@ class MpcGpu:
         assert a[0].size == 5 and a[1].size == 25 and a[2].size == 65536 and a[3].size == 256
         self._ck(self.L.mpcgpu_set_hmm(self.h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
                                         a[3].ctypes.data, float(min_sparse_score), expf_variant))
+
+    def set_seqs_registry(self, seqs):
+        """all sequences any explicit pair list may refer to (no all-pairs tables)"""
+        bufs = [np.frombuffer(s.encode() if isinstance(s, str) else bytes(s), np.uint8).copy() for s in seqs]
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        lens = np.array([len(b) for b in bufs], np.uint32)
+        self._ck(self.L.mpcgpu_set_seqs_registry(self.h, len(bufs), ptrs, lens.ctypes.data))
+        self.n = len(bufs)
+        self.lens = lens
+        self.pairs = None
+
+    def align_msas(self, seq1, seq2, p2c1, p2c2, C1, C2):
+        """pair q aligns sequence seq1[q] (row of MSA1) with seq2[q] (row of MSA2); p2c1[q] / p2c2[q] are
+        their position->column maps -> (path, score, EA per pair)"""
+        s1, s2 = np.asarray(seq1, np.uint32), np.asarray(seq2, np.uint32)
+        m1 = np.concatenate([np.asarray(x, np.uint32) for x in p2c1]).astype(np.uint32)
+        m2 = np.concatenate([np.asarray(x, np.uint32) for x in p2c2]).astype(np.uint32)
+        path = np.empty(C1 + C2, np.uint8)
+        ea = np.empty(len(s1), np.float32)
+        n, sc = C.c_uint32(), C.c_float()
+        self._ck(self.L.mpcgpu_align_msas(self.h, len(s1), s1.ctypes.data, s2.ctypes.data, C1, C2, m1.ctypes.data,
+                                           m2.ctypes.data, path.ctypes.data, C.byref(n), C.byref(sc), ea.ctypes.data))
+        return path[:n.value].tobytes().decode(), float(np.float32(sc.value)), ea
 
     def set_seqs(self, seqs):
         bufs = [np.frombuffer(s.encode() if isinstance(s, str) else bytes(s), np.uint8).copy() for s in seqs]

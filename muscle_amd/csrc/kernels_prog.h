@@ -74,3 +74,40 @@ __global__ void __launch_bounds__(256) build_post_reduce_kernel(const u64 *keys,
 		post[cell] = acc;
 	}
 }
+
+// ---- list form: CalcPosteriorFlat3 (buildposterior3flat.cpp:19-85) over an explicit pair list whose
+// packed records (kernels_post.h) lie back to back in one shard, X = the MSA1 sequence of the pair.
+// Contributions are added in pair-list order (buildposterior3flat.cpp:41, :81): key = cell << bits_q | q.
+struct BuildPostListParams {
+	const u32 *seq_len;
+	const u32 *packed;
+	const u32 *seq1, *seq2; // per pair: sequence indices
+	u32 npairs;
+	const u32 *p2c1, *p2c2; // per pair: position -> column maps, concatenated
+	const u64 *off1, *off2; // start of each pair's map
+	const u64 *coff;        // first record of each pair in keys/vals
+	const u64 *rbase;       // word offset of each pair's packed record
+	const u32 *nnz;
+	u32 C2;
+	u64 *keys;
+	float *vals;
+	u32 bits_q;
+};
+
+__global__ void __launch_bounds__(64) build_post_list_gen_kernel(BuildPostListParams p)
+{
+	for (u32 q = blockIdx.x; q < p.npairs; q += gridDim.x) {
+		const u32 LX = p.seq_len[p.seq1[q]], LY = p.seq_len[p.seq2[q]];
+		const u32 nnz = (u32)(p.coff[q + 1] - p.coff[q]);
+		const u32 *ent = p.packed + p.rbase[q] + LX + LY;
+		const u32 *rowv = ent + 2 * (u64)nnz;
+		const u32 *m1 = p.p2c1 + p.off1[q], *m2 = p.p2c2 + p.off2[q];
+		u64 *keys = p.keys + p.coff[q];
+		float *vals = p.vals + p.coff[q];
+		for (u32 e = threadIdx.x; e < nnz; e += 64) {
+			const u64 cell = (u64)m1[rowv[e]] * p.C2 + m2[ent[2 * (u64)e + 1]];
+			keys[e] = (cell << p.bits_q) | (u64)q;
+			vals[e] = __uint_as_float(ent[2 * (u64)e]);
+		}
+	}
+}

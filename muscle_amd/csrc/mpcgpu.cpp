@@ -85,6 +85,7 @@ struct mpcgpu_ctx {
 
 	// shard state (stage A output of this context)
 	bool have_shard = false;
+	bool shard_is_list = false; // the shard holds an explicit pair list (mpcgpu_align_msas), not a range of InitPairs
 	u64 sh_k0 = 0, sh_k1 = 0;
 	DevBuf d_shard;             // [header][records]
 	u64 shard_bytes = 0;
@@ -470,12 +471,12 @@ int mpcgpu_set_hmm(mpcgpu_ctx *c, const float start[5], const float trans[25], c
 	return 0;
 }
 
-int mpcgpu_set_seqs(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens)
+static int set_seqs_impl(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens, bool with_pairs)
 {
 	if (!c) return 1;
 	if (!c->have_hmm) return fail(c, "mpcgpu_set_seqs: call mpcgpu_set_hmm first");
 	if (n < 2) return fail(c, "mpcgpu_set_seqs: need at least 2 sequences (got %u)", n);
-	if ((u64)n * n > 0xffffffffull) return fail(c, "mpcgpu_set_seqs: too many sequences (%u)", n);
+	if (with_pairs && (u64)n * n > 0xffffffffull) return fail(c, "mpcgpu_set_seqs: too many sequences (%u)", n);
 	HIPCHK(c, hipSetDevice(c->device));
 	c->have_shard = c->have_store = false;
 	c->n = n;
@@ -515,6 +516,12 @@ int mpcgpu_set_seqs(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const
 	if (upload(c, c->d_seq_code, code) || upload(c, c->d_seq_off, off) || upload(c, c->d_seq_len, c->len) ||
 		upload(c, c->d_match, cm) || upload(c, c->d_ins, ci))
 		return 1;
+	c->npairs = 0;
+	c->h_pair_x.clear(); c->h_pair_y.clear();
+	if (!with_pairs) { // explicit pair lists only (mpcgpu_align_msas)
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		return 0;
+	}
 	// MPCFlat::InitPairs (mpcflat.cpp:139-159)
 	c->npairs = (u64)n * (n - 1) / 2;
 	c->h_pair_x.resize(c->npairs);
@@ -527,17 +534,26 @@ int mpcgpu_set_seqs(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const
 	return 0;
 }
 
+int mpcgpu_set_seqs(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens)
+{
+	return set_seqs_impl(c, n, seqs, lens, true);
+}
+
+int mpcgpu_set_seqs_registry(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens)
+{
+	return set_seqs_impl(c, n, seqs, lens, false);
+}
+
 uint64_t mpcgpu_pair_count(const mpcgpu_ctx *c) { return c ? c->npairs : 0; }
 
-int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
+// Stage A over an explicit list of (x,y) sequence-index pairs (host arrays of np entries): the packed
+// shard of those pairs, in list order, ends up in c->d_shard with sh_nnz / sh_ea.
+static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 {
-	if (!c) return 1;
-	if (c->n == 0) return fail(c, "mpcgpu_calc_posteriors: call mpcgpu_set_seqs first");
-	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_calc_posteriors: bad pair range [%llu,%llu)", (u64)k0, (u64)k1);
 	HIPCHK(c, hipSetDevice(c->device));
 	c->have_shard = c->have_store = false;
-	const u64 np = k1 - k0;
-	c->sh_k0 = k0; c->sh_k1 = k1;
+	c->shard_is_list = true;
+	c->sh_k0 = 0; c->sh_k1 = np;
 	c->sh_nnz.assign(np, 0);
 	c->sh_ea.assign(np, 0.0f);
 	c->work_cells = 0;
@@ -553,8 +569,8 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	}
 	// geometry of the shard
 	u32 LXmax = 0, LYmax = 0;
-	for (u64 k = k0; k < k1; ++k) {
-		const u32 LX = c->len[c->h_pair_x[k]], LY = c->len[c->h_pair_y[k]];
+	for (u64 k = 0; k < np; ++k) {
+		const u32 LX = c->len[px[k]], LY = c->len[py[k]];
 		LXmax = std::max(LXmax, LX); LYmax = std::max(LYmax, LY);
 		c->work_cells += (u64)(LX + 1) * (LY + 1);
 	}
@@ -579,14 +595,14 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 		u64 budget = std::min<u64>((u64)env_int("MPCGPU_SCRATCH_GB", 16) << 30, (u64)(freeb * 0.4));
 		u64 B = std::max<u64>(1, std::min<u64>(np - done, budget / per_pair));
 		B = std::min<u64>(B, 1u << 22);
-		const u64 b0 = k0 + done;
+		const u64 b0 = done;
 		// ---- bin by H, order by work (longest first)
 		std::vector<u32> bx(B), by(B), hh(B);
 		std::vector<u32> order(B);
 		std::vector<u64> wk(B);
 		u32 hcount[MPC_HMAX + 1] = {0};
 		for (u64 q = 0; q < B; ++q) {
-			bx[q] = c->h_pair_x[b0 + q]; by[q] = c->h_pair_y[b0 + q];
+			bx[q] = px[b0 + q]; by[q] = py[b0 + q];
 			const u32 LX = c->len[bx[q]], LY = c->len[by[q]];
 			const u32 H = (LX + 63) / 64;
 			hh[q] = H; hcount[H]++;
@@ -748,6 +764,17 @@ int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	c->shard_bytes = hdr + words_done * 4;
 	c->have_shard = true;
 	return 0;
+}
+
+int mpcgpu_calc_posteriors(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
+{
+	if (!c) return 1;
+	if (c->n == 0) return fail(c, "mpcgpu_calc_posteriors: call mpcgpu_set_seqs first");
+	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_calc_posteriors: bad pair range [%llu,%llu)", (u64)k0, (u64)k1);
+	const int rc = stage_a(c, k1 - k0, c->h_pair_x.data() + k0, c->h_pair_y.data() + k0);
+	c->shard_is_list = false;
+	c->sh_k0 = k0; c->sh_k1 = k1;
+	return rc;
 }
 
 int mpcgpu_shard_info(mpcgpu_ctx *c, uint64_t *bytes, void **dev_ptr)
@@ -918,7 +945,7 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 int mpcgpu_build_store(mpcgpu_ctx *c)
 {
 	if (!c) return 1;
-	if (!c->have_shard || c->sh_k0 != 0 || c->sh_k1 != c->npairs)
+	if (!c->have_shard || c->shard_is_list || c->sh_k0 != 0 || c->sh_k1 != c->npairs)
 		return fail(c, "mpcgpu_build_store: needs this context's shard to cover all pairs "
 			"(multi-GPU callers use mpcgpu_store_import)");
 	const uint64_t k0 = 0, k1 = c->npairs, bytes = c->shard_bytes;
@@ -1015,7 +1042,7 @@ int mpcgpu_get_ea(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, float *ea)
 	if (!c) return 1;
 	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_get_ea: bad pair range");
 	if (c->have_store) { memcpy(ea, &c->all_ea[k0], (k1 - k0) * 4); return 0; }
-	if (c->have_shard && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(ea, &c->sh_ea[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
+	if (c->have_shard && !c->shard_is_list && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(ea, &c->sh_ea[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
 	return fail(c, "mpcgpu_get_ea: range [%llu,%llu) not available", (u64)k0, (u64)k1);
 }
 
@@ -1024,7 +1051,7 @@ int mpcgpu_get_nnz(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, uint32_t *nnz)
 	if (!c) return 1;
 	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_get_nnz: bad pair range");
 	if (c->have_store) { memcpy(nnz, &c->all_nnz[k0], (k1 - k0) * 4); return 0; }
-	if (c->have_shard && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(nnz, &c->sh_nnz[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
+	if (c->have_shard && !c->shard_is_list && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(nnz, &c->sh_nnz[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
 	return fail(c, "mpcgpu_get_nnz: range [%llu,%llu) not available", (u64)k0, (u64)k1);
 }
 
@@ -1178,6 +1205,88 @@ int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t
 	HIPCHK(c, hipGetLastError());
 	// the uploads above came from vectors that die with this call: drain before returning (run_calc_aln syncs)
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score);
+}
+
+int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, const uint32_t *seq2, uint32_t C1, uint32_t C2,
+	const uint32_t *pos2col1, const uint32_t *pos2col2, char *path, uint32_t *pathlen, float *score, float *ea_out)
+{
+	if (!c) return 1;
+	if (c->n == 0) return fail(c, "mpcgpu_align_msas: call mpcgpu_set_seqs / mpcgpu_set_seqs_registry first");
+	if (!seq1 || !seq2 || !pos2col1 || !pos2col2 || !path || !pathlen) return fail(c, "mpcgpu_align_msas: NULL argument");
+	if (npairs == 0 || C1 == 0 || C2 == 0) return fail(c, "mpcgpu_align_msas: empty input");
+	for (u32 q = 0; q < npairs; ++q)
+		if (seq1[q] >= c->n || seq2[q] >= c->n) return fail(c, "mpcgpu_align_msas: sequence index out of range in pair %u", q);
+	// ---- stage A on the listed pairs (X = the MSA1 sequence, Y = the MSA2 sequence: calcpost.cpp:4-36)
+	if (stage_a(c, npairs, seq1, seq2)) return 1;
+	if (ea_out) memcpy(ea_out, c->sh_ea.data(), (size_t)npairs * 4);
+	// ---- CalcPosteriorFlat3 (buildposterior3flat.cpp:19-85): Flat[col1*C2+col2] += Prob in pair-list order
+	std::vector<u64> off1(npairs + 1, 0), off2(npairs + 1, 0), coff(npairs + 1, 0), rbase(npairs + 1, 0);
+	rbase[0] = shard_header_bytes(npairs) / 4; // records follow the shard header (words)
+	for (u32 q = 0; q < npairs; ++q) {
+		off1[q + 1] = off1[q] + c->len[seq1[q]];
+		off2[q + 1] = off2[q] + c->len[seq2[q]];
+		coff[q + 1] = coff[q] + c->sh_nnz[q];
+		rbase[q + 1] = rbase[q] + rec_words(c->len[seq1[q]], c->len[seq2[q]], c->sh_nnz[q]);
+	}
+	for (u64 x = 0; x < off1[npairs]; ++x) if (pos2col1[x] >= C1) return fail(c, "mpcgpu_align_msas: column map of MSA1 out of range");
+	for (u64 x = 0; x < off2[npairs]; ++x) if (pos2col2[x] >= C2) return fail(c, "mpcgpu_align_msas: column map of MSA2 out of range");
+	const u64 M = coff[npairs];
+	const u64 cells = (u64)C1 * C2;
+	const u32 bq = bits_for(npairs - 1), bc = bits_for(cells - 1);
+	if (bq + bc > 64) return fail(c, "mpcgpu_align_msas: key does not fit 64 bits");
+	if (M > 0x7fffffffull) return fail(c, "mpcgpu_align_msas: %llu contributions exceed this build's sort size", (u64)M);
+	std::vector<u32> maps(off1[npairs] + off2[npairs]);
+	memcpy(maps.data(), pos2col1, off1[npairs] * 4);
+	memcpy(maps.data() + off1[npairs], pos2col2, off2[npairs] * 4);
+	std::vector<u64> offs(off1);
+	offs.insert(offs.end(), off2.begin(), off2.end());
+	std::vector<u32> seqs(seq1, seq1 + npairs);
+	seqs.insert(seqs.end(), seq2, seq2 + npairs);
+	std::vector<u64> bases(coff);
+	bases.insert(bases.end(), rbase.begin(), rbase.end());
+	if (upload(c, c->d_bp_seq, seqs) || upload(c, c->d_bp_off, offs) || upload(c, c->d_bp_map, maps) || upload(c, c->d_bp_coff, bases))
+		return 1;
+	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 8 * 2));
+	HIPCHK(c, c->d_bp_vals.ensure(std::max<u64>(M, 1) * 4 * 2));
+	HIPCHK(c, c->d_aln_post.ensure(cells * 4));
+	u64 *keys_in = c->d_bp_keys.as<u64>(), *keys_out = keys_in + std::max<u64>(M, 1);
+	float *vals_in = c->d_bp_vals.as<float>(), *vals_out = vals_in + std::max<u64>(M, 1);
+	BuildPostListParams lp;
+	lp.seq_len = c->d_seq_len.as<u32>();
+	lp.packed = c->d_shard.as<u32>();
+	lp.seq1 = c->d_bp_seq.as<u32>(); lp.seq2 = lp.seq1 + npairs; lp.npairs = npairs;
+	lp.p2c1 = c->d_bp_map.as<u32>(); lp.p2c2 = lp.p2c1 + off1[npairs];
+	lp.off1 = c->d_bp_off.as<u64>(); lp.off2 = lp.off1 + (npairs + 1);
+	lp.coff = c->d_bp_coff.as<u64>(); lp.rbase = lp.coff + (npairs + 1);
+	lp.nnz = nullptr; // counts come from coff
+	lp.C2 = C2; lp.keys = keys_in; lp.vals = vals_in; lp.bits_q = bq;
+	MPC_LAUNCH(build_post_list_gen_kernel, (u32)std::min<u64>(npairs, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, lp);
+	HIPCHK(c, hipGetLastError());
+	const u64 *keys_sorted = keys_in;
+	const float *vals_sorted = vals_in;
+	if (M > 1) {
+#ifdef MPC_EMU
+		{
+			std::vector<u64> idx(M);
+			for (u64 q = 0; q < M; ++q) idx[q] = q;
+			std::sort(idx.begin(), idx.end(), [&](u64 x, u64 y) { return keys_in[x] < keys_in[y]; });
+			for (u64 q = 0; q < M; ++q) { keys_out[q] = keys_in[idx[q]]; vals_out[q] = vals_in[idx[q]]; }
+		}
+#else
+		size_t tmp_bytes = 0;
+		HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)M, 0, (int)(bq + bc),
+			c->stream));
+		HIPCHK(c, c->d_bp_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
+		HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->d_bp_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)M, 0,
+			(int)(bq + bc), c->stream));
+#endif
+		keys_sorted = keys_out;
+		vals_sorted = vals_out;
+	}
+	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((cells + 255) / 256, (u64)c->prop.multiProcessorCount * 64), 256, 0,
+		c->stream, keys_sorted, vals_sorted, (u64)M, bq, c->d_aln_post.as<float>(), (u64)cells);
+	HIPCHK(c, hipGetLastError());
+	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // syncs before the vectors above die
 }
 
 int mpcgpu_timers_reset(mpcgpu_ctx *c)

@@ -33,6 +33,8 @@ def command(name):
         n = int(name[7:].split("x")[0])
         shrub = name.split("_b")[1]
         return "-super7", ["-guidetreein", "tree.nwk", "-shrub_size", shrub], {"tree.nwk": _balanced_newick(0, n) + ";\n"}
+    if name.startswith("super5_"):  # super5_<n>x<L>: UCLUST split + MPCFlat per cluster + PProg joins (super5.cpp)
+        return "-super5", [], {}
     return "-align", [], {}
 
 
@@ -46,6 +48,9 @@ def input_set(name):
     if name.startswith("super7_"):
         n, L = name[7:].split("_b")[0].split("x")
         return make_family(int(n), int(L), seed=13), None, []
+    if name.startswith("super5_"):
+        n, L = name[7:].split("x")
+        return make_family(int(n), int(L), seed=4), None, []
     if name.startswith("synth"):  # synth_<n>x<L>_s<seed>
         n, rest = name[6:].split("x")
         L, seed = rest.split("_s")
@@ -65,6 +70,10 @@ def input_set(name):
 def run_muscle(binary, name, threads=4, timeout=900):
     seqs, labels, extra = input_set(name)
     cmd, cmd_extra, files = command(name)
+    if cmd == "-super5":
+        # PProg::Run picks joins by the average EA of AlignMSAsFlat (pprog.cpp:286,394), which the reference
+        # sums in thread-arrival order (getpostpairsalignedflat.cpp:92-95): only one thread is deterministic
+        threads = 1
     with tempfile.TemporaryDirectory() as d:
         fa, out = os.path.join(d, "in.fa"), os.path.join(d, "out.afa")
         write_fasta(fa, seqs, labels)

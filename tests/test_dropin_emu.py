@@ -4,7 +4,8 @@ infrastructure) and must write byte-identical final MSAs to the committed golden
 unmodified reference (tests/golden/msa_md5.json). Checks lazy batching from the OpenMP loop, the
 HMM-table hand-over, Derep/InsertDupes around the stage, the <3-sequence / -consiters 0 paths and
 the buffer swap, and MPCFlat::AlignAlns on the device store (progressive joins + refinement rounds,
-limited with -refineiters because every round is an emulated 1024-thread kernel). Needs the reference objects (oracle/_ref/obj): skipped where
+limited with -refineiters because every round is an emulated kernel), and PProg::AlignMSAsFlat
+(the MSA x MSA joins of the -super7 / -super5 drivers) on explicit pair lists. Needs the reference objects (oracle/_ref/obj): skipped where
 /root/reference was never available."""
 import os
 import subprocess
@@ -30,7 +31,7 @@ def emu_muscle():
     return _msa.EMU_MUSCLE
 
 
-@pytest.mark.parametrize("name", ["n2_L40+r2", "n3_L30+r2", "synth_6x40_s2+r2", "dupes+r2", "consiters0+r2", "perturb_small+r2"])
+@pytest.mark.parametrize("name", ["n2_L40+r2", "n3_L30+r2", "synth_6x40_s2+r2", "dupes+r2", "consiters0+r2", "perturb_small+r2", "super7_8x18_b4", "super5_14x20"])
 def test_final_msa_identical(emu_muscle, name):
     md5, _ = _msa.run_muscle(emu_muscle, name, threads=3)
     assert md5 == _msa.golden_md5()[name]
