@@ -224,6 +224,45 @@ def test_align_alns_vs_restatement():
     g.close()
 
 
+def test_align_msas_vs_restatement():
+    """mpcgpu_align_msas (PProg join: stage A on an explicit pair list in both index orders,
+    CalcPosteriorFlat3 in pair-list order, CalcAlnFlat + traceback) vs the oracle per pair and the numpy
+    restatement of buildposterior3flat.cpp:19-85: identical path, score bits and per-pair EA bits."""
+    import _buildpost as BP
+    import _oracle as O
+    rng = np.random.default_rng(19)
+    seqs = make_family(14, 90, seed=37)
+    s, t, m, i, thr = G.hmm_tables()
+    h = O.make_hmm(s, t, m, i)
+    g = MpcGpu(0)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs_registry(seqs)
+    grp1, grp2 = [9, 0, 3, 12, 5], [7, 1, 2, 6, 4, 13, 8, 10, 11]
+    rows1, C1 = BP.random_msa(seqs, grp1, rng)
+    rows2, C2 = BP.random_msa(seqs, grp2, rng)
+    pairs = [(a, b) for a in range(len(grp1)) for b in range(len(grp2)) if (a * 7 + b) % 5 != 2]
+    seq1 = [grp1[a] for a, b in pairs]
+    seq2 = [grp2[b] for a, b in pairs]
+    m1 = [BP.pos_to_col(rows1[a]) for a, b in pairs]
+    m2 = [BP.pos_to_col(rows2[b]) for a, b in pairs]
+    post = np.zeros((C1, C2), np.float32)
+    ea_want = []
+    for q, (X, Y) in enumerate(zip(seq1, seq2)):
+        x, y = seqs[X].encode(), seqs[Y].encode()
+        Pd = O.post(O.fwd(h, x, y), O.bwd(h, x, y), len(x), len(y))
+        ea_want.append(np.float32(O.aln_score(Pd)) / np.float32(min(len(x), len(y))))
+        off, val = O.sparse_from_post(Pd)
+        p, col = val[0::2].view(np.float32), val[1::2]
+        for r in range(len(off) - 1):
+            for k in range(off[r], off[r + 1]):
+                post[m1[q][r], m2[q][col[k]]] += p[k]  # buildposterior3flat.cpp:81
+    sc0, path0 = O.calc_aln(post)
+    path, sc, ea = g.align_msas(seq1, seq2, m1, m2, C1, C2)
+    assert path == path0 and P.bits(sc) == P.bits(sc0)
+    assert np.array_equal(P.bits(ea), P.bits(np.array(ea_want, np.float32)))
+    g.close()
+
+
 def test_errors_are_loud():
     s, t, m, i, thr = G.hmm_tables()
     g = MpcGpu(0)
