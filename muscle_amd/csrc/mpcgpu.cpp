@@ -1,6 +1,11 @@
 // mpcgpu.cpp — host side of libmpcgpu.so: the C ABI of include/mpcgpu.h over the HIP kernels in
-// kernels_fb.h / kernels_post.h / kernels_store.h. Built by hipcc (-x hip) for gfx950. There is
-// no CPU implementation behind this API: without a HIP device mpcgpu_create() fails.
+// kernels_fb.h (pair-HMM forward/backward), kernels_post.h (probabilities, sparsify, EA),
+// kernels_store.h (packed records, padded / slab stores, gather relax, commit, export),
+// kernels_relax.h (LDS-tiled relax), kernels_aln.h (posterior-DP alignment + traceback) and
+// kernels_prog.h (MSA x MSA posterior build). Built by hipcc (-x hip) for gfx950. There is no CPU
+// implementation behind this API: without a HIP device mpcgpu_create() fails. rocPRIM's radix sort
+// (through hipCUB) is used for one bulk data-movement step (kernels_prog.h); everything else is
+// hand-written.
 #include "../../include/mpcgpu.h"
 #include "kernels_fb.h"
 #include "kernels_post.h"
