@@ -91,52 +91,117 @@ float orc_log_add(float x, float y) { return la2(x, y); }
 	const float tJM = (h)->trans[S_JX][S_M];
 
 /*
- * Forward, fwdflat3.cpp:12-153. F is the flat (LX+1)(LY+1)x5 array.
- * Border initialisation :35-93, interior :100-152. The reference indexes the tables with a
- * (signed) char; inputs here are 7-bit ASCII so byte indexing is identical.
+ * Emission scores. Two sources, selected exactly where the reference selects them (calcpost.cpp:14-29):
+ *  - byte sequences: PairHMM::m_InsScore[c] / m_MatchScore[x][y] (fwdflat3.cpp:102-109);
+ *  - "mega" structure profiles (a .mega input, loadinput.cpp:5-9): per position one letter for each of
+ *    nfeat features; Mega::GetInsScore (mega.cpp:273-285) = sum over features, in feature order and
+ *    starting from 0, of LogProbs_f[letter_f] * Weight_f; Mega::GetMatchScore (mega.cpp:341-363) = the
+ *    same fold over LogProbMx_f[letterX_f][letterY_f] * Weight_f.
  */
-void orc_fwd(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY, float *F)
+typedef struct {
+	uint nfeat;
+	const uint *alpha;   /* [nfeat] alphabet size of each feature (Mega::m_AlphaSizes) */
+	const float *weight; /* [nfeat] Mega::m_Weights */
+	const float *lp;     /* Mega::m_LogProbsVec, features back to back */
+	const uint *lp_off;  /* [nfeat] start of feature f in lp */
+	const float *mx;     /* Mega::m_LogProbMxVec, A_f x A_f row-major, features back to back */
+	const uint *mx_off;  /* [nfeat] start of feature f in mx */
+} orc_mega;
+
+typedef struct {
+	const orc_hmm *h;
+	const byte *X, *Y;   /* byte sequences, or (mega) profiles: position-major, nfeat letters per position */
+	const orc_mega *g;   /* NULL: byte sequences */
+} emit_t;
+
+/* mega.cpp:273-285 */
+static float mega_ins(const orc_mega *g, const byte *prof, uint pos)
 {
+	float score = 0;
+	for (uint f = 0; f < g->nfeat; ++f)
+		score += g->lp[g->lp_off[f] + prof[(size_t)pos * g->nfeat + f]] * g->weight[f];
+	return score;
+}
+
+/* mega.cpp:341-363 */
+static float mega_match(const orc_mega *g, const byte *px, uint posx, const byte *py, uint posy)
+{
+	float score = 0;
+	for (uint f = 0; f < g->nfeat; ++f) {
+		const uint lx = px[(size_t)posx * g->nfeat + f], ly = py[(size_t)posy * g->nfeat + f];
+		score += g->mx[g->mx_off[f] + (size_t)lx * g->alpha[f] + ly] * g->weight[f];
+	}
+	return score;
+}
+
+float orc_mega_ins(const orc_mega *g, const byte *prof, uint pos) { return mega_ins(g, prof, pos); }
+float orc_mega_match(const orc_mega *g, const byte *px, uint posx, const byte *py, uint posy) { return mega_match(g, px, posx, py, posy); }
+
+/* 0-based positions. "past the end" (bwdflat3.cpp:46,64 use the letter 0; bwdflat_mega.cpp:55,78-80 use a 0 score):
+ * the value never reaches a result (it is only ever added to LOG_ZERO), kept per source anyway. */
+static inline float e_ins_x(const emit_t *e, uint i, uint LX)
+{
+	if (e->g) return i >= LX ? 0.0f : mega_ins(e->g, e->X, i);
+	return e->h->ins[i >= LX ? 0 : e->X[i]];
+}
+static inline float e_ins_y(const emit_t *e, uint j, uint LY)
+{
+	if (e->g) return j >= LY ? 0.0f : mega_ins(e->g, e->Y, j);
+	return e->h->ins[j >= LY ? 0 : e->Y[j]];
+}
+static inline float e_match(const emit_t *e, uint i, uint LX, uint j, uint LY)
+{
+	if (e->g) return (i >= LX || j >= LY) ? 0.0f : mega_match(e->g, e->X, i, e->Y, j);
+	return e->h->match[i >= LX ? 0 : e->X[i]][j >= LY ? 0 : e->Y[j]];
+}
+
+/*
+ * Forward, fwdflat3.cpp:12-153 (byte sequences) / fwdflat_mega.cpp:14-165 (profiles: the same statements
+ * with the emission lookups replaced, fwdflat_mega.cpp:29-31,80,95,113,120-121). F is the flat
+ * (LX+1)(LY+1)x5 array. Border initialisation :35-93, interior :100-152. The reference indexes the
+ * tables with a (signed) char; inputs here are 7-bit ASCII so byte indexing is identical.
+ */
+static void fwd_any(const emit_t *e, uint LX, uint LY, float *F)
+{
+	const orc_hmm *h = e->h;
 	BIND_T(h)
 	/* (0,0): all five states log-zero (:35-39) */
 	for (int s = 0; s < NS; ++s)
 		F[FIX(s, 0, 0, LY)] = LOG_ZERO;
 	/* column 0 (:48-55, :42-43, :67-79) */
 	for (uint i = 1; i <= LX; ++i) {
-		float e = h->ins[X[i - 1]];
+		float ex = e_ins_x(e, i - 1, LX);
 		F[FIX(S_M, i, 0, LY)] = LOG_ZERO;
 		F[FIX(S_IY, i, 0, LY)] = LOG_ZERO;
 		F[FIX(S_JY, i, 0, LY)] = LOG_ZERO;
 		if (i == 1) {
-			F[FIX(S_IX, 1, 0, LY)] = tSI + e;
-			F[FIX(S_JX, 1, 0, LY)] = tSJ + e;
+			F[FIX(S_IX, 1, 0, LY)] = tSI + ex;
+			F[FIX(S_JX, 1, 0, LY)] = tSJ + ex;
 		} else {
-			F[FIX(S_IX, i, 0, LY)] = F[FIX(S_IX, i - 1, 0, LY)] + tII + e;
-			F[FIX(S_JX, i, 0, LY)] = F[FIX(S_JX, i - 1, 0, LY)] + tJJ + e;
+			F[FIX(S_IX, i, 0, LY)] = F[FIX(S_IX, i - 1, 0, LY)] + tII + ex;
+			F[FIX(S_JX, i, 0, LY)] = F[FIX(S_JX, i - 1, 0, LY)] + tJJ + ex;
 		}
 	}
 	/* row 0 (:57-65, :44-45, :81-93) */
 	for (uint j = 1; j <= LY; ++j) {
-		float e = h->ins[Y[j - 1]];
+		float ey = e_ins_y(e, j - 1, LY);
 		F[FIX(S_M, 0, j, LY)] = LOG_ZERO;
 		F[FIX(S_IX, 0, j, LY)] = LOG_ZERO;
 		F[FIX(S_JX, 0, j, LY)] = LOG_ZERO;
 		if (j == 1) {
-			F[FIX(S_IY, 0, 1, LY)] = tSI + e;
-			F[FIX(S_JY, 0, 1, LY)] = tSJ + e;
+			F[FIX(S_IY, 0, 1, LY)] = tSI + ey;
+			F[FIX(S_JY, 0, 1, LY)] = tSJ + ey;
 		} else {
-			F[FIX(S_IY, 0, j, LY)] = F[FIX(S_IY, 0, j - 1, LY)] + tII + e;
-			F[FIX(S_JY, 0, j, LY)] = F[FIX(S_JY, 0, j - 1, LY)] + tJJ + e;
+			F[FIX(S_IY, 0, j, LY)] = F[FIX(S_IY, 0, j - 1, LY)] + tII + ey;
+			F[FIX(S_JY, 0, j, LY)] = F[FIX(S_JY, 0, j - 1, LY)] + tJJ + ey;
 		}
 	}
 	/* interior (:100-152) */
 	for (uint i = 1; i <= LX; ++i) {
-		const byte x = X[i - 1];
-		const float ex = h->ins[x];
+		const float ex = e_ins_x(e, i - 1, LX);
 		for (uint j = 1; j <= LY; ++j) {
-			const byte y = Y[j - 1];
-			const float ey = h->ins[y];
-			const float exy = h->match[x][y];
+			const float ey = e_ins_y(e, j - 1, LY);
+			const float exy = e_match(e, i - 1, LX, j - 1, LY);
 			const float *D = F + FIX(0, i - 1, j - 1, LY); /* diagonal predecessor */
 			const float *U = F + FIX(0, i - 1, j, LY);     /* (i-1, j) */
 			const float *L = F + FIX(0, i, j - 1, LY);     /* (i, j-1) */
@@ -154,15 +219,15 @@ void orc_fwd(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY, f
 }
 
 /*
- * Backward, bwdflat3.cpp:10-184. Corner :53-61, interior :73-130, right column :132-153,
- * bottom row :155-176; all (i,j) in [0,LX]x[0,LY] are written.
+ * Backward, bwdflat3.cpp:10-184 / bwdflat_mega.cpp:13-193. Corner :53-61, interior :73-130, right
+ * column :132-153, bottom row :155-176; all (i,j) in [0,LX]x[0,LY] are written.
  */
-void orc_bwd(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY, float *B)
+static void bwd_any(const emit_t *e, uint LX, uint LY, float *B)
 {
+	const orc_hmm *h = e->h;
 	BIND_T(h)
 	for (int i = (int)LX; i >= 0; --i) {
-		const byte xn = (i == (int)LX) ? 0 : X[i]; /* x_{i+1} */
-		const float ex = h->ins[xn];
+		const float ex = e_ins_x(e, (uint)i, LX); /* x_{i+1} */
 		for (int j = (int)LY; j >= 0; --j) {
 			float *C = B + FIX(0, i, j, LY);
 			if (i == (int)LX && j == (int)LY) {
@@ -173,10 +238,9 @@ void orc_bwd(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY, f
 				C[S_JY] = tSJ;
 				continue;
 			}
-			const byte yn = (j == (int)LY) ? 0 : Y[j]; /* y_{j+1} */
-			const float ey = h->ins[yn];
+			const float ey = e_ins_y(e, (uint)j, LY); /* y_{j+1} */
 			if (i < (int)LX && j < (int)LY) {
-				const float nM = B[FIX(S_M, i + 1, j + 1, LY)] + h->match[xn][yn];
+				const float nM = B[FIX(S_M, i + 1, j + 1, LY)] + e_match(e, (uint)i, LX, (uint)j, LY);
 				const float nIX = B[FIX(S_IX, i + 1, j, LY)] + ex;
 				const float nJX = B[FIX(S_JX, i + 1, j, LY)] + ex;
 				const float nIY = B[FIX(S_IY, i, j + 1, LY)] + ey;
@@ -232,6 +296,28 @@ void orc_bwd(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY, f
 			}
 		}
 	}
+}
+
+void orc_fwd(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY, float *F)
+{
+	const emit_t e = {h, X, Y, NULL};
+	fwd_any(&e, LX, LY, F);
+}
+void orc_bwd(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY, float *B)
+{
+	const emit_t e = {h, X, Y, NULL};
+	bwd_any(&e, LX, LY, B);
+}
+/* Mega::CalcFwdFlat_mega / CalcBwdFlat_mega (fwdflat_mega.cpp:14, bwdflat_mega.cpp:13); PX/PY are profiles */
+void orc_fwd_mega(const orc_hmm *h, const orc_mega *g, const byte *PX, uint LX, const byte *PY, uint LY, float *F)
+{
+	const emit_t e = {h, PX, PY, g};
+	fwd_any(&e, LX, LY, F);
+}
+void orc_bwd_mega(const orc_hmm *h, const orc_mega *g, const byte *PX, uint LX, const byte *PY, uint LY, float *B)
+{
+	const emit_t e = {h, PX, PY, g};
+	bwd_any(&e, LX, LY, B);
 }
 
 /* totalprobflat.cpp:3-16: left fold over the five end states */
@@ -509,15 +595,15 @@ void orc_cons_pair(const orc_store *s, uint X, uint Y, byte *out_val)
  * orc_store_free.
  */
 /* calcposteriorflat.cpp:45-92 + calcpost.cpp:4-36 for one pair */
-void orc_pair_posterior(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY,
+static void pair_posterior_any(const emit_t *e, uint LX, uint LY,
 	uint **off_out, byte **val_out, uint *nnz_out, float *ea_out)
 {
 	const size_t fb = (size_t)NS * ((size_t)LX + 1) * ((size_t)LY + 1);
 	float *F = (float *)malloc(fb * sizeof(float));
 	float *B = (float *)malloc(fb * sizeof(float));
 	float *Post = (float *)malloc(nz1((size_t)LX * LY) * sizeof(float));
-	orc_fwd(h, X, LX, Y, LY, F);
-	orc_bwd(h, X, LX, Y, LY, B);
+	fwd_any(e, LX, LY, F);
+	bwd_any(e, LX, LY, B);
 	orc_post(F, B, LX, LY, Post);
 	free(F); free(B);
 	uint *off = (uint *)malloc(((size_t)LX + 1) * sizeof(uint));
@@ -527,6 +613,13 @@ void orc_pair_posterior(const orc_hmm *h, const byte *X, uint LX, const byte *Y,
 	*ea_out = orc_ea(orc_aln_score(Post, LX, LY), LX, LY);
 	free(Post);
 	*off_out = off; *val_out = val; *nnz_out = nnz;
+}
+
+void orc_pair_posterior(const orc_hmm *h, const byte *X, uint LX, const byte *Y, uint LY,
+	uint **off_out, byte **val_out, uint *nnz_out, float *ea_out)
+{
+	const emit_t e = {h, X, Y, NULL};
+	pair_posterior_any(&e, LX, LY, off_out, val_out, nnz_out, ea_out);
 }
 
 orc_store *orc_store_new(uint n, const uint *len)
@@ -573,7 +666,7 @@ void orc_store_set(orc_store *s, uint k, uint LX, const uint *off, const byte *v
 }
 
 /* MPCFlat::CalcPosteriors (mpcflat.cpp:214-252): all pairs (or the sub-range [k0,k1)), ea[k] per pair */
-void orc_calc_posteriors(const orc_hmm *h, orc_store *s, const byte *const *seqs, float *ea,
+static void calc_posteriors_any(const orc_hmm *h, const orc_mega *g, orc_store *s, const byte *const *seqs, float *ea,
 	uint k0, uint k1, int threads)
 {
 	const uint n = s->n;
@@ -590,9 +683,24 @@ void orc_calc_posteriors(const orc_hmm *h, orc_store *s, const byte *const *seqs
 	for (int q = (int)k0; q < (int)k1; ++q) {
 		uint i = pi[q], j = pj[q];
 		free(s->off[q]); free(s->val[q]);
-		orc_pair_posterior(h, seqs[i], s->len[i], seqs[j], s->len[j], &s->off[q], &s->val[q], &s->nnz[q], &ea[q]);
+		const emit_t e = {h, seqs[i], seqs[j], g};
+		pair_posterior_any(&e, s->len[i], s->len[j], &s->off[q], &s->val[q], &s->nnz[q], &ea[q]);
 	}
 	free(pi); free(pj);
+}
+
+void orc_calc_posteriors(const orc_hmm *h, orc_store *s, const byte *const *seqs, float *ea,
+	uint k0, uint k1, int threads)
+{
+	calc_posteriors_any(h, NULL, s, seqs, ea, k0, k1, threads);
+}
+
+/* the same loop when a .mega input is loaded: CalcPost takes the profile branch (calcpost.cpp:14-22);
+ * profs[i] = profile of sequence i, position-major, g->nfeat letters per position */
+void orc_calc_posteriors_mega(const orc_hmm *h, const orc_mega *g, orc_store *s, const byte *const *profs, float *ea,
+	uint k0, uint k1, int threads)
+{
+	calc_posteriors_any(h, g, s, profs, ea, k0, k1, threads);
 }
 
 /* MPCFlat::ConsIter (consflat.cpp:5-23): Jacobi update of pairs [k0,k1) into a fresh store `dst`

@@ -10,6 +10,7 @@
 #include "mpcflat.h"
 #include "pairhmm.h"
 #include "hmmparams.h"
+#include "mega.h"
 #include <cstring>
 
 string g_Arg1; // normally defined in main.cpp:4 (main.o is not linked)
@@ -123,6 +124,69 @@ int ref_mpc_begin(uint n, const char **seqs, uint threads)
 	M.m_Weights.assign(n, 1.0f); // read (then overwritten by 1.0f) at conspairflat.cpp:41-42
 	return 0;
 	}
+
+// The same, for a .mega input (structure profiles): Mega::FromFile (mega.cpp:119-270) + the label/sequence
+// registry LoadInput builds from it (loadinput.cpp:5-9); CalcPost then takes the profile branch
+// (calcpost.cpp:14-22). ONE call per process (mega.cpp:125-127 asserts an empty state).
+int ref_mpc_begin_mega(const char *path, uint threads)
+	{
+	if (g_M != 0)
+		return -1;
+	opt_quiet = true; optset_quiet = true;
+	if (threads > 0)
+		ref_set_threads(threads);
+	Mega::FromFile(path);
+	g_MS = new MultiSequence;
+	g_MS->FromStrings(Mega::m_Labels, Mega::m_Seqs);
+	SetGlobalInputMS(*g_MS);
+	const uint n = g_MS->GetSeqCount();
+	g_M = new MPCFlat;
+	MPCFlat &M = *g_M;
+	M.Clear();
+	M.AllocPairCount((n*(n-1))/2);
+	M.InitSeqs(g_MS);
+	M.InitPairs();
+	M.InitDistMx();
+	M.m_Weights.assign(n, 1.0f);
+	return 0;
+	}
+
+// Copies of the Mega statics (mega.h:9-33)
+uint ref_mega_feature_count() { return Mega::m_FeatureCount; }
+uint ref_mega_profile_count() { return Mega::GetProfileCount(); }
+uint ref_mega_alpha(uint f) { return Mega::GetAlphaSize(f); }
+float ref_mega_weight(uint f) { return Mega::GetWeight(f); }
+void ref_mega_logprobs(uint f, float *out)
+	{
+	const vector<float> &v = Mega::m_LogProbsVec[f];
+	memcpy(out, v.data(), sizeof(float)*v.size());
+	}
+void ref_mega_logprobmx(uint f, float *out) // A x A row-major
+	{
+	const vector<vector<float> > &m = Mega::m_LogProbMxVec[f];
+	const uint A = SIZE(m);
+	for (uint a = 0; a < A; ++a)
+		memcpy(out + (size_t) a*A, m[a].data(), sizeof(float)*A);
+	}
+uint ref_mega_length(uint idx) { return SIZE(Mega::GetProfile(idx)); }
+void ref_mega_profile(uint idx, byte *out) // position-major, feature_count letters per position
+	{
+	const vector<vector<byte> > &P = Mega::GetProfile(idx);
+	const uint F = Mega::m_FeatureCount;
+	for (uint Pos = 0; Pos < SIZE(P); ++Pos)
+		for (uint f = 0; f < F; ++f)
+			out[(size_t) Pos*F + f] = P[Pos][f];
+	}
+void ref_mega_seq(uint idx, char *out) { memcpy(out, Mega::m_Seqs[idx].data(), Mega::m_Seqs[idx].size()); }
+// Mega::GetInsScore / GetMatchScore (mega.cpp:273, :341) on loaded profiles
+float ref_mega_ins(uint idx, uint pos) { return Mega::GetInsScore(Mega::GetProfile(idx), pos); }
+float ref_mega_match(uint idx1, uint pos1, uint idx2, uint pos2)
+	{
+	return Mega::GetMatchScore(Mega::GetProfile(idx1), pos1, Mega::GetProfile(idx2), pos2);
+	}
+// Mega::CalcFwdFlat_mega / CalcBwdFlat_mega (fwdflat_mega.cpp:14, bwdflat_mega.cpp:13)
+void ref_mega_fwd(uint idx1, uint idx2, float *Flat) { Mega::CalcFwdFlat_mega(Mega::GetProfile(idx1), Mega::GetProfile(idx2), Flat); }
+void ref_mega_bwd(uint idx1, uint idx2, float *Flat) { Mega::CalcBwdFlat_mega(Mega::GetProfile(idx1), Mega::GetProfile(idx2), Flat); }
 
 void ref_mpc_calc_posteriors() { g_M->CalcPosteriors(); }     // mpcflat.cpp:214
 void ref_mpc_cons_iter(uint iter) { g_M->ConsIter(iter); }     // consflat.cpp:5

@@ -57,3 +57,31 @@ def mpc(name):
         else:
             out["stage"].append(None)
     return out
+
+
+MEGA_SETS = ["mega_bb11001", "mega_synth_6x40_s2", "mega_synth_3x25_s5_f3", "mega_synth_2x70_s7"]
+
+
+def mega(name):
+    """-> dict(seqs, alpha, weight, lp, mx, profs[list of u8 arrays], ea, stage[s], probes...) of a mega_<name>.npz"""
+    z = load(name)
+    seqs = [str(s) for s in z["seqs"]]
+    n, F = len(seqs), len(z["alpha"])
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    profs, po = [], 0
+    for s in seqs:
+        profs.append(z["profs"][po:po + len(s) * F].copy())
+        po += len(s) * F
+    out = {"seqs": seqs, "alpha": z["alpha"], "weight": z["weight"], "lp": z["lp"], "mx": z["mx"], "profs": profs,
+           "ea": z["ea"], "nstages": int(z["nstages"]), "stage": [], "digest": [], "z": z}
+    for s in range(out["nstages"]):
+        out["digest"].append(str(z["digest%d" % s]))
+        nnz, offs, vals = z["nnz%d" % s], z["off%d" % s], z["val%d" % s]
+        st, o, v = [], 0, 0
+        for k, (i, j) in enumerate(pairs):
+            L = len(seqs[i]) + 1
+            st.append((offs[o:o + L], vals[v:v + 2 * int(nnz[k])]))
+            o += L
+            v += 2 * int(nnz[k])
+        out["stage"].append(st)
+    return out

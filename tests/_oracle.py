@@ -177,3 +177,66 @@ def val_probs(val):
 
 def val_cols(val):
     return val[1::2]
+
+
+# ---- structure-profile ("mega") emissions: orc_mega / orc_*_mega ---------------------------------------------
+class Mega(C.Structure):
+    _fields_ = [("nfeat", C.c_uint), ("alpha", C.c_void_p), ("weight", C.c_void_p), ("lp", C.c_void_p),
+                ("lp_off", C.c_void_p), ("mx", C.c_void_p), ("mx_off", C.c_void_p)]
+
+
+def make_mega(alpha, weight, lp, mx):
+    """alpha[F] u32, weight[F] f32, lp = log-probabilities of every feature back to back, mx = A_f x A_f
+    log-probability matrices back to back (the reference's parsed Mega statics). Keeps the arrays alive."""
+    g = Mega()
+    keep = {"alpha": np.ascontiguousarray(alpha, np.uint32), "weight": np.ascontiguousarray(weight, np.float32),
+            "lp": np.ascontiguousarray(lp, np.float32), "mx": np.ascontiguousarray(mx, np.float32)}
+    a = keep["alpha"].astype(np.uint64)
+    keep["lp_off"] = np.concatenate([[0], np.cumsum(a)[:-1]]).astype(np.uint32)
+    keep["mx_off"] = np.concatenate([[0], np.cumsum(a * a)[:-1]]).astype(np.uint32)
+    g.nfeat = len(keep["alpha"])
+    for k in ("alpha", "weight", "lp", "lp_off", "mx", "mx_off"):
+        setattr(g, k, keep[k].ctypes.data)
+    g._keep = keep
+    return g
+
+
+def mega_ins(g, prof, pos):
+    lib().orc_mega_ins.restype = C.c_float
+    return lib().orc_mega_ins(C.byref(g), prof.ctypes.data_as(u8p), pos)
+
+
+def mega_match(g, px, i, py, j):
+    lib().orc_mega_match.restype = C.c_float
+    return lib().orc_mega_match(C.byref(g), px.ctypes.data_as(u8p), i, py.ctypes.data_as(u8p), j)
+
+
+def fwd_mega(h, g, px, py):
+    LX, LY = len(px) // g.nfeat, len(py) // g.nfeat
+    F = np.empty(5 * (LX + 1) * (LY + 1), np.float32)
+    lib().orc_fwd_mega(C.byref(h), C.byref(g), px.ctypes.data_as(u8p), LX, py.ctypes.data_as(u8p), LY, F.ctypes.data_as(f32p))
+    return F
+
+
+def bwd_mega(h, g, px, py):
+    LX, LY = len(px) // g.nfeat, len(py) // g.nfeat
+    B = np.empty(5 * (LX + 1) * (LY + 1), np.float32)
+    lib().orc_bwd_mega(C.byref(h), C.byref(g), px.ctypes.data_as(u8p), LX, py.ctypes.data_as(u8p), LY, B.ctypes.data_as(f32p))
+    return B
+
+
+class MegaStore(Store):
+    """Store whose stage A runs on structure profiles (calcpost.cpp:14-22); relax is unchanged."""
+
+    def __init__(self, seqs, profs):
+        Store.__init__(self, seqs)
+        self.profs = [np.ascontiguousarray(p, np.uint8) for p in profs]
+        self._pptrs = (C.c_void_p * self.n)(*[p.ctypes.data for p in self.profs])
+
+    def calc_posteriors_mega(self, hmm, g, k0=0, k1=None, threads=0):
+        ea = np.zeros(max(self.npairs, 1), np.float32)
+        lib().orc_calc_posteriors_mega.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_uint, C.c_uint, C.c_int]
+        lib().orc_calc_posteriors_mega(C.byref(hmm), C.byref(g), self.h, self._pptrs, ea.ctypes.data, k0,
+                                       self.npairs if k1 is None else k1, threads)
+        return ea[:self.npairs]

@@ -138,3 +138,70 @@ def mpc_run(seqs, iters=2, threads=0, nucleo=False, perturb_seed=0):
             L.ref_mpc_cons_iter(it)
             stages.append(snap())
     return stages, ea
+
+
+def mpc_run_mega(path, iters=2, threads=0):
+    """The same through a .mega input (structure profiles): Mega::FromFile + MPCFlat on its chains; CalcPost
+    takes the profile branch (calcpost.cpp:14-22). ONE call per process. Returns (tables, stages, ea, probes):
+    tables = the reference's own parsed Mega statics (what a caller hands to mpcgpu_set_mega / the oracle)."""
+    init_hmm(False, 0)
+    L = lib()
+    L.ref_mega_weight.restype = C.c_float
+    L.ref_mega_ins.restype = C.c_float
+    L.ref_mega_match.restype = C.c_float
+    rc = L.ref_mpc_begin_mega(path.encode(), threads)
+    if rc != 0:
+        raise RuntimeError("ref_mpc_begin_mega may only be called once per process")
+    F, n = L.ref_mega_feature_count(), L.ref_mega_profile_count()
+    alpha = np.array([L.ref_mega_alpha(f) for f in range(F)], np.uint32)
+    weight = np.array([L.ref_mega_weight(f) for f in range(F)], np.float32)
+    lp, mx = [], []
+    for f in range(F):
+        a = np.empty(int(alpha[f]), np.float32)
+        L.ref_mega_logprobs(f, a.ctypes.data_as(f32p))
+        m = np.empty(int(alpha[f]) ** 2, np.float32)
+        L.ref_mega_logprobmx(f, m.ctypes.data_as(f32p))
+        lp.append(a)
+        mx.append(m)
+    lens = [L.ref_mega_length(i) for i in range(n)]
+    profs, seqs = [], []
+    for i in range(n):
+        p = np.empty(lens[i] * F, np.uint8)
+        L.ref_mega_profile(i, p.ctypes.data_as(u8p))
+        profs.append(p)
+        buf = C.create_string_buffer(lens[i] + 1)
+        L.ref_mega_seq(i, buf)
+        seqs.append(buf.raw[:lens[i]].decode())
+    tables = {"alpha": alpha, "weight": weight, "lp": np.concatenate(lp), "mx": np.concatenate(mx),
+              "profs": profs, "seqs": seqs}
+    # direct probes of the reference's emission functions and DP on the first pair (pins the oracle's pieces)
+    probes = {}
+    if n >= 2:
+        l0, l1 = lens[0], lens[1]
+        probes["ins0"] = np.array([L.ref_mega_ins(0, p) for p in range(l0)], np.float32)
+        probes["match01"] = np.array([[L.ref_mega_match(0, a, 1, b) for b in range(l1)] for a in range(l0)], np.float32)
+        Fw = np.empty(5 * (l0 + 1) * (l1 + 1), np.float32)
+        Bw = np.empty(5 * (l0 + 1) * (l1 + 1), np.float32)
+        L.ref_mega_fwd(0, 1, Fw.ctypes.data_as(f32p))
+        L.ref_mega_bwd(0, 1, Bw.ctypes.data_as(f32p))
+        probes["F01"], probes["B01"] = Fw, Bw
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+
+    def snap():
+        out = []
+        for k, (i, j) in enumerate(pairs):
+            nnz = L.ref_mpc_nnz(k)
+            off = np.empty(lens[i] + 1, np.uint32)
+            val = np.empty(max(nnz, 1) * 2, np.uint32)
+            L.ref_mpc_sparse(k, off.ctypes.data_as(u32p), val.ctypes.data_as(u8p))
+            out.append((off, val[:2 * nnz].copy()))
+        return out
+
+    L.ref_mpc_calc_posteriors()
+    ea = np.array([L.ref_mpc_ea(i, j) for (i, j) in pairs], np.float32)
+    stages = [snap()]
+    if n >= 3:
+        for it in range(iters):
+            L.ref_mpc_cons_iter(it)
+            stages.append(snap())
+    return tables, stages, ea, probes

@@ -12,6 +12,10 @@ Fixtures
                                    CalcPostFlat/FromPost/CalcAlnScoreFlat/CalcAlnFlat for the short
                                    pairs of the reference's disabled unit test (testfb.cpp:369-375)
                                    and edge cases; F/B M-planes in full, sha256 of the full 5-state arrays
+  mega_<name>.npz                : the same stage for a .mega input (structure profiles, calcpost.cpp:14-22):
+                                   the reference's parsed Mega tables + profiles, the stage snapshots in
+                                   full, and probes of Mega::GetInsScore/GetMatchScore/CalcFwdFlat_mega/
+                                   CalcBwdFlat_mega on the first pair
   mpc_<name>.npz                 : whole stage through the reference's MPCFlat::CalcPosteriors +
                                    ConsIter x2 (one subprocess per data set): EA per pair and, per
                                    stage, the MySparseMx arrays in full (small sets) or their sha256
@@ -144,8 +148,51 @@ def gen_mpc():
             print(pool.map(_mpc_worker, [job])[0])
 
 
+def _mega_worker(name):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tempfile
+    import _mega
+    import _ref as R
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "in.mega")
+        with open(path, "w") as f:
+            f.write(_mega.mega_text(name))
+        tables, stages, ea, probes = R.mpc_run_mega(path, iters=2, threads=0)
+    d = {"seqs": np.array(tables["seqs"]), "alpha": tables["alpha"], "weight": tables["weight"],
+         "lp": tables["lp"], "mx": tables["mx"], "profs": np.concatenate(tables["profs"]),
+         "ea": ea, "nstages": np.int32(len(stages))}
+    for k, v in probes.items():
+        if k in ("F01", "B01"):  # M planes in full, digest of all five
+            l0, l1 = len(tables["seqs"][0]), len(tables["seqs"][1])
+            d[k + "_M"] = v.reshape(l0 + 1, l1 + 1, 5)[:, :, 0].copy()
+            d[k + "_sha"] = np.array(sha(v))
+        else:
+            d[k] = v
+    for s, st in enumerate(stages):
+        d["digest%d" % s] = np.array(stage_digest(st))
+        d["nnz%d" % s] = np.array([len(v) // 2 for _, v in st], np.uint32)
+        d["off%d" % s] = np.concatenate([o for o, _ in st])
+        d["val%d" % s] = np.concatenate([v for _, v in st]) if st else np.zeros(0, np.uint32)
+    np.savez_compressed(os.path.join(HERE, "%s.npz" % name), **d)
+    return name, len(tables["seqs"]), [int(sum(len(v) // 2 for _, v in st)) for st in stages]
+
+
+MEGA_SETS = ["mega_bb11001", "mega_synth_6x40_s2", "mega_synth_3x25_s5_f3", "mega_synth_2x70_s7"]
+
+
+def gen_mega():
+    ctx = mp.get_context("spawn")
+    for name in MEGA_SETS:  # one process per data set: Mega::FromFile / SetGlobalInputMS are once-per-process
+        with ctx.Pool(1) as pool:
+            print(pool.map(_mega_worker, [name])[0])
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["mega"]:
+        gen_mega()
+        sys.exit(0)
     gen_hmm()
     gen_pairs_small()
     gen_mpc()
+    gen_mega()
     print("golden fixtures written to", HERE)

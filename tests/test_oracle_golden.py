@@ -53,6 +53,35 @@ def test_mpc_stage(hmm, name):
                 assert np.array_equal(o1, o2) and np.array_equal(v1, v2)
 
 
+@pytest.mark.parametrize("name", G.MEGA_SETS)
+def test_mega_stage(hmm, name):
+    """Structure-profile emissions (calcpost.cpp:14-22 -> fwdflat_mega.cpp / bwdflat_mega.cpp / mega.cpp:273-363):
+    the oracle on the reference's parsed tables vs the reference's own outputs."""
+    m = G.mega(name)
+    z = m["z"]
+    g = O.make_mega(m["alpha"], m["weight"], m["lp"], m["mx"])
+    p0, p1 = m["profs"][0], m["profs"][1]
+    l0, l1 = len(m["seqs"][0]), len(m["seqs"][1])
+    ins0 = np.array([O.mega_ins(g, p0, p) for p in range(l0)], np.float32)
+    assert np.array_equal(bits(ins0), bits(z["ins0"]))
+    mt = np.array([[O.mega_match(g, p0, a, p1, b) for b in range(l1)] for a in range(l0)], np.float32)
+    assert np.array_equal(bits(mt), bits(z["match01"]))
+    F, B = O.fwd_mega(hmm, g, p0, p1), O.bwd_mega(hmm, g, p0, p1)
+    assert G.sha(F) == str(z["F01_sha"]) and G.sha(B) == str(z["B01_sha"])
+    assert np.array_equal(bits(F.reshape(l0 + 1, l1 + 1, 5)[:, :, 0]), bits(z["F01_M"]))
+    st = O.MegaStore(m["seqs"], m["profs"])
+    ea = st.calc_posteriors_mega(hmm, g)
+    assert np.array_equal(bits(ea), bits(m["ea"]))
+    cur = st
+    for s in range(m["nstages"]):
+        if s > 0:
+            cur = cur.cons_iter()
+        stage = [cur.get(k) for k in range(st.npairs)]
+        assert G.stage_digest(stage) == m["digest"][s], "stage %d" % s
+        for (o1, v1), (o2, v2) in zip(stage, m["stage"][s]):
+            assert np.array_equal(o1, o2) and np.array_equal(v1, v2)
+
+
 def test_expf_emulation_matches_libm():
     """The glibc-2.35 expf restatement (both ifunc variants) vs this host's libm over the only
     range the path uses, [logf(0.01f), 0): the variant the host resolves to must be bit-identical."""
