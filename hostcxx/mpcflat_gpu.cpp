@@ -25,12 +25,17 @@
 // (hostcxx/build_muscle_gpu.sh; INTEGRATION.md shows the two-line change a maintainer would make
 // in the source tree instead of the objcopy step).
 //
+// A .mega input (structure profiles, loadinput.cpp:5-9) makes the reference's CalcPost take its profile
+// branch (calcpost.cpp:14-22): here the Mega statics are handed to the library (mpcgpu_set_mega) right
+// after the sequences, in MPCFlat::CalcPosterior and in PProg::AlignMSAsFlat alike.
+//
 // There is no CPU path in here: if libmpcgpu cannot create a device context the run Die()s, like
 // every other fatal condition in the reference (myutils.cpp:883-927).
 #include "muscle.h"
 #include "mpcflat.h"
 #include "pairhmm.h"
 #include "pprog.h"
+#include "mega.h"
 #include "mpcgpu.h"
 
 #include <map>
@@ -169,6 +174,53 @@ template<class GETMX> void Download(mpcgpu_ctx *Ctx, MPCFlat &M, uint PairCount,
 		}
 	}
 
+// calcpost.cpp:14-22: with a .mega input loaded the emissions come from the structure profiles of the
+// sequences (looked up by label, like CalcPost does), not from the PairHMM letter tables. Labels[i] is
+// the label of sequence i of the set just given to mpcgpu_set_seqs / mpcgpu_set_seqs_registry.
+void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_t> &Lens)
+	{
+	if (!Mega::m_Loaded)
+		return; // set_seqs already switched the context back to letter emissions
+	const uint FeatureCount = Mega::GetFeatureCount();
+	vector<uint32_t> AlphaSizes(FeatureCount);
+	vector<float> Weights(FeatureCount);
+	vector<vector<float> > Mxs(FeatureCount);
+	vector<const float *> LogProbPtrs(FeatureCount), MxPtrs(FeatureCount);
+	for (uint f = 0; f < FeatureCount; ++f)
+		{
+		const uint A = Mega::GetAlphaSize(f);
+		AlphaSizes[f] = A;
+		Weights[f] = Mega::GetWeight(f);
+		asserta(SIZE(Mega::m_LogProbsVec[f]) == A);
+		LogProbPtrs[f] = Mega::m_LogProbsVec[f].data();
+		const vector<vector<float> > &Mx = Mega::m_LogProbMxVec[f];
+		asserta(SIZE(Mx) == A);
+		for (uint a = 0; a < A; ++a)
+			{
+			asserta(SIZE(Mx[a]) == A);
+			Mxs[f].insert(Mxs[f].end(), Mx[a].begin(), Mx[a].end());
+			}
+		MxPtrs[f] = Mxs[f].data();
+		}
+	const uint SeqCount = SIZE(Labels);
+	vector<vector<uint8_t> > Profs(SeqCount);
+	vector<const uint8_t *> ProfPtrs(SeqCount);
+	for (uint i = 0; i < SeqCount; ++i)
+		{
+		const vector<vector<byte> > &Profile = *Mega::GetProfileByLabel(Labels[i]);
+		asserta(SIZE(Profile) == Lens[i]); // calcpost.cpp:18-19
+		Profs[i].reserve(size_t(Lens[i])*FeatureCount);
+		for (uint Pos = 0; Pos < Lens[i]; ++Pos)
+			{
+			asserta(SIZE(Profile[Pos]) == FeatureCount);
+			Profs[i].insert(Profs[i].end(), Profile[Pos].begin(), Profile[Pos].end());
+			}
+		ProfPtrs[i] = Profs[i].data();
+		}
+	GPUCHK(mpcgpu_set_mega(Ctx, FeatureCount, AlphaSizes.data(), Weights.data(), LogProbPtrs.data(),
+	  MxPtrs.data(), ProfPtrs.data()));
+	}
+
 // First CalcPosterior call of a run: the whole all-pairs stage A on the device.
 void StartBatch(MPCFlat &M, Batch &B)
 	{
@@ -183,13 +235,16 @@ void StartBatch(MPCFlat &M, Batch &B)
 
 	vector<const uint8_t *> Ptrs(SeqCount);
 	vector<uint32_t> Lens(SeqCount);
+	vector<string> Labels(SeqCount);
 	for (uint i = 0; i < SeqCount; ++i)
 		{
 		Ptrs[i] = M.GetBytePtr(i);
 		Lens[i] = M.GetSeqLength(i);
+		Labels[i] = string(M.GetLabel(i)); // calcposteriorflat.cpp:63-64
 		}
 // (the "HMM overflow" length check of calcposteriorflat.cpp:54-61 is made by the library)
 	GPUCHK(mpcgpu_set_seqs(Ctx, SeqCount, Ptrs.data(), Lens.data()));
+	SetMega(Ctx, Labels, Lens);
 	GPUCHK(mpcgpu_calc_posteriors(Ctx, 0, PairCount));
 	GPUCHK(mpcgpu_build_store(Ctx));
 
@@ -359,6 +414,7 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 	std::map<const Sequence *, uint32_t> SeqToIndex;
 	vector<const uint8_t *> Ptrs;
 	vector<uint32_t> Lens;
+	vector<string> Labels;
 	auto Register = [&](const string &Label) -> uint32_t
 		{
 		const Sequence &Seq = GetGlobalInputSeqByLabel(Label);
@@ -369,6 +425,7 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 		SeqToIndex[&Seq] = Index;
 		Ptrs.push_back(Seq.GetBytePtr());
 		Lens.push_back(Seq.GetLength());
+		Labels.push_back(Label);
 		return Index;
 		};
 
@@ -415,6 +472,7 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 		GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
 		  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
 		GPUCHK(mpcgpu_set_seqs_registry(Ctx, (uint32_t) Ptrs.size(), Ptrs.data(), Lens.data()));
+		SetMega(Ctx, Labels, Lens);
 		GPUCHK(mpcgpu_align_msas(Ctx, PairCount, Seqs1.data(), Seqs2.data(), ColCount1, ColCount2,
 		  Map1.data(), Map2.data(), &Path[0], &PathLen, &Score, EA.data()));
 		}

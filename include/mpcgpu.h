@@ -56,6 +56,23 @@ int mpcgpu_set_hmm(mpcgpu_ctx *ctx, const float start[5], const float trans[25],
  * calcposteriorflat.cpp:54-61 (LX*LY*5+100 > INT_MAX) is preserved as an error. */
 int mpcgpu_set_seqs(mpcgpu_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens);
 
+/* Structure-profile ("mega") emissions for stage A. Replaces the Mega statics a .mega input fills
+ * (Mega::FromFile, mega.cpp:119-270; mega.h:9-33) as CalcPost uses them when Mega::m_Loaded
+ * (calcpost.cpp:14-22): Mega::CalcFwdFlat_mega / CalcBwdFlat_mega (fwdflat_mega.cpp:14-165,
+ * bwdflat_mega.cpp:13-193) with Mega::GetInsScore (mega.cpp:273-285) and Mega::GetMatchScore
+ * (mega.cpp:341-363) in place of the PairHMM emission tables; transitions still come from set_hmm.
+ *   nfeat                 Mega::m_FeatureCount (<= 8 in this build); 0 switches back to byte sequences
+ *   alpha[f], weight[f]   Mega::m_AlphaSizes, Mega::m_Weights
+ *   logprobs[f]           Mega::m_LogProbsVec[f]: alpha[f] floats
+ *   logprob_mx[f]         Mega::m_LogProbMxVec[f]: alpha[f] x alpha[f] floats, row-major
+ *   profiles[i]           profile of sequence i of the last set_seqs/set_seqs_registry (Mega::m_Profiles
+ *                         via GetProfileByLabel): len[i] positions x nfeat letters, position-major
+ * Call after every set_seqs (which drops the previous profiles). Everything downstream of the
+ * emissions (posterior, sparsify, EA, relax, joins) is unchanged. */
+int mpcgpu_set_mega(mpcgpu_ctx *ctx, uint32_t nfeat, const uint32_t *alpha, const float *weight,
+                    const float *const *logprobs, const float *const *logprob_mx,
+                    const uint8_t *const *profiles);
+
 uint64_t mpcgpu_pair_count(const mpcgpu_ctx *ctx); /* n(n-1)/2 */
 
 /* Stage A for the pair range [k0,k1): replaces MPCFlat::CalcPosteriors' OpenMP loop

@@ -48,6 +48,7 @@ def load(lib_path=None):
     L.mpcgpu_version.restype = C.c_char_p
     L.mpcgpu_set_hmm.argtypes = [vp, vp, vp, vp, vp, C.c_float, i32]
     L.mpcgpu_set_seqs.argtypes = [vp, u32, vp, vp]
+    L.mpcgpu_set_mega.argtypes = [vp, u32, vp, vp, vp, vp, vp]
     L.mpcgpu_pair_count.argtypes = [vp]
     L.mpcgpu_pair_count.restype = u64
     L.mpcgpu_calc_posteriors.argtypes = [vp, u64, u64]
@@ -141,6 +142,31 @@ class MpcGpu:
         self.n = len(bufs)
         self.lens = lens
         self.pairs = [(i, j) for i in range(self.n) for j in range(i + 1, self.n)] if self.n <= 4096 else None
+
+    def set_mega(self, alpha, weight, lp, mx, profiles):
+        """Structure-profile emissions for stage A (call after set_seqs / set_seqs_registry): alpha[F], weight[F],
+        lp = per-feature log-probabilities back to back, mx = per-feature A x A log-probability matrices back to
+        back, profiles[i] = len[i] x F letters (position-major). alpha=None switches back to byte sequences."""
+        if alpha is None:
+            self._ck(self.L.mpcgpu_set_mega(self.h, 0, None, None, None, None, None))
+            return
+        alpha = np.ascontiguousarray(alpha, np.uint32)
+        weight = np.ascontiguousarray(weight, np.float32)
+        lp, mx = np.ascontiguousarray(lp, np.float32), np.ascontiguousarray(mx, np.float32)
+        F = len(alpha)
+        lp_parts, mx_parts, a, b = [], [], 0, 0
+        for f in range(F):
+            A = int(alpha[f])
+            lp_parts.append(lp[a:a + A].copy())
+            mx_parts.append(mx[b:b + A * A].copy())
+            a += A
+            b += A * A
+        profs = [np.ascontiguousarray(p, np.uint8) for p in profiles]
+        assert len(profs) == self.n and all(len(p) == int(self.lens[i]) * F for i, p in enumerate(profs))
+        lpp = (C.c_void_p * F)(*[x.ctypes.data for x in lp_parts])
+        mxp = (C.c_void_p * F)(*[x.ctypes.data for x in mx_parts])
+        pp = (C.c_void_p * self.n)(*[x.ctypes.data for x in profs])
+        self._ck(self.L.mpcgpu_set_mega(self.h, F, alpha.ctypes.data, weight.ctypes.data, lpp, mxp, pp))
 
     @property
     def npairs(self):

@@ -16,6 +16,15 @@
 // leads, data flows t+1 -> t) and emits every cell with Score >= MIN_SPARSE_SCORE as an 8-byte
 // candidate {flat index, score} through a wave-aggregated append.
 //
+// Structure-profile ("mega") emissions, MEGA = true: when a .mega input is loaded the reference's CalcPost
+// runs Mega::CalcFwdFlat_mega / CalcBwdFlat_mega (calcpost.cpp:14-22; fwdflat_mega.cpp:14-165,
+// bwdflat_mega.cpp:13-193) — the same recurrences with Emit = Mega::GetInsScore (mega.cpp:273-285) /
+// Mega::GetMatchScore (mega.cpp:341-363): a left fold, from 0, over the features f of
+// Table_f[letter(s)] * Weight_f. Here the products are formed once (mega_prepare_kernel: the fold of the
+// insert score per sequence position, and the pair tables pre-multiplied by their weight — each product
+// is one rounded multiply either way), every position carries its <= 8 feature letters packed in a
+// u64, and a cell's match score is the in-order sum of <= 8 LDS lookups.
+//
 // Every cell value is a fixed expression of its three neighbours, so the wavefront order does
 // not change results: outputs are bit-identical to the row-major CPU sweep (given no FMA
 // contraction, -ffp-contract=off). Border handling: the reference's special-cased border
@@ -29,6 +38,7 @@
 #define MPC_KEY_ROW_SHIFT 22 // rows < 64*MPC_HMAX = 2^10, columns < 2^22 (checked in mpcgpu_set_seqs)
 #define MPC_KEY_COL_MASK ((1u << MPC_KEY_ROW_SHIFT) - 1u)
 #define MPC_FB_COEF_BYTES (MPC_COEF_ENTRIES * 16)
+#define MPC_MEGA_FMAX 8 // features per position (one byte each in a u64)
 
 struct FbParams {
 	// sequences (compact alphabet codes 0..A-1)
@@ -54,21 +64,47 @@ struct FbParams {
 	u32 capc;
 	u32 *cand_cnt; // per batch-local pair (may exceed capc: overflow, detected by the host)
 	float *total;  // per batch-local pair: log total probability (diagnostic / tests)
+	// structure-profile emissions (MEGA kernels only); positions are indexed like seq_code
+	const u64 *mg_prof;  // letters of feature f in bits [8f, 8f+8)
+	const float *mg_ins; // Mega::GetInsScore of the position
+	const float *mg_tab; // weight-multiplied pair tables back to back + one 0.0f (what unused features read)
+	u32 mg_tab_floats;   // including the trailing zero
+	u32 mg_base[MPC_MEGA_FMAX];  // first float of feature f's table
+	u32 mg_alpha[MPC_MEGA_FMAX]; // its row length (0 for unused features: every lookup hits the zero)
 };
 
-template <int H>
+// Mega::GetMatchScore (mega.cpp:341-363): Score = 0; Score += LogProbMx_f[lx][ly] * Weight_f for f ascending.
+// yi[f] = mg_base[f] + letter_f(y). Unused features add the table's 0.0f, which leaves the sum unchanged
+// (it can never be -0.0f: it starts at +0.0f).
+__device__ __forceinline__ float mpc_mega_match(const float *s_tab, const u32 *alpha, u64 xl, const u32 *yi)
+{
+	float m = 0.0f;
+#pragma unroll
+	for (int f = 0; f < MPC_MEGA_FMAX; ++f) {
+		const u32 xf = (u32)(xl >> (8 * f)) & 0xffu;
+		m += s_tab[xf * alpha[f] + yi[f]];
+	}
+	return m;
+}
+
+template <int H, bool MEGA>
 __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
 	MpcCoef *s_coef = (MpcCoef *)smem_raw;                        // LOGEXP1 coefficient table, LDS offset 0
-	float *s_match = (float *)(smem_raw + MPC_FB_COEF_BYTES);    // A*A
-	float *s_ins = s_match + p.A * p.A;                          // A
+	float *s_match = (float *)(smem_raw + MPC_FB_COEF_BYTES);    // A*A (MEGA: the feature tables)
+	float *s_ins = s_match + p.A * p.A;                          // A   (MEGA: unused)
 	if (threadIdx.x < MPC_COEF_ENTRIES)
 		mpc_coef_table_init(s_coef, (int)threadIdx.x);
-	for (int q = threadIdx.x; q < p.A * p.A; q += blockDim.x)
-		s_match[q] = p.match[q];
-	for (int q = threadIdx.x; q < p.A; q += blockDim.x)
-		s_ins[q] = p.ins[q];
+	if (MEGA) {
+		for (u32 q = threadIdx.x; q < p.mg_tab_floats; q += blockDim.x)
+			s_match[q] = p.mg_tab[q];
+	} else {
+		for (int q = threadIdx.x; q < p.A * p.A; q += blockDim.x)
+			s_match[q] = p.match[q];
+		for (int q = threadIdx.x; q < p.A; q += blockDim.x)
+			s_ins[q] = p.ins[q];
+	}
 	__syncthreads();
 
 	const int t = threadIdx.x & 63;
@@ -79,6 +115,9 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 	const float tSM = p.tSM, tSI = p.tSI, tSJ = p.tSJ, tMM = p.tMM, tMI = p.tMI, tMJ = p.tMJ;
 	const float tII = p.tII, tIM = p.tIM, tJJ = p.tJJ, tJM = p.tJM;
 	const int A = p.A;
+	u32 mg_base[MPC_MEGA_FMAX], mg_alpha[MPC_MEGA_FMAX]; // wave-uniform (SGPRs)
+#pragma unroll
+	for (int f = 0; f < MPC_MEGA_FMAX; ++f) { mg_base[f] = MEGA ? p.mg_base[f] : 0u; mg_alpha[f] = MEGA ? p.mg_alpha[f] : 0u; }
 
 	for (;;) {
 		// Work queue: lane 0 adds 1, the other lanes add 0 (branch-free; the compiler's atomic optimizer
@@ -102,17 +141,28 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 		float cM[H], cIX[H], cJX[H], cIY[H], cJY[H]; // own rows at the previous column
 		float insx[H];
 		int mrow[H];
+		u64 xl[MEGA ? H : 1];
+		// MEGA: packed letters and insert score of every position
+		const u64 *PX = MEGA ? p.mg_prof + p.seq_off[sx] : nullptr, *PY = MEGA ? p.mg_prof + p.seq_off[sy] : nullptr;
+		const float *IX = MEGA ? p.mg_ins + p.seq_off[sx] : nullptr, *IY = MEGA ? p.mg_ins + p.seq_off[sy] : nullptr;
 #pragma unroll
 		for (int r = 0; r < H; ++r) {
 			const int i = t * H + r + 1;
-			const int xc = (i <= LX) ? (int)X[i - 1] : 0;
-			insx[r] = s_ins[xc];
-			mrow[r] = xc * A;
+			if (MEGA) {
+				xl[MEGA ? r : 0] = (i <= LX) ? PX[i - 1] : 0ull;
+				insx[r] = (i <= LX) ? IX[i - 1] : 0.0f; // fwdflat_mega.cpp:113
+			} else {
+				const int xc = (i <= LX) ? (int)X[i - 1] : 0;
+				insx[r] = s_ins[xc];
+				mrow[r] = xc * A;
+			}
 			cM[r] = cIX[r] = cJX[r] = cIY[r] = cJY[r] = LZ;
 		}
 		float uM = LZ, uIX = LZ, uJX = LZ, uIY = LZ, uJY = LZ; // row t*H at column j-1 (diagonal of r=0)
 		float gIY = LZ, gJY = LZ;                              // lane 0: row-0 chain (fwdflat3.cpp:81-93)
 		int yprev = 0;
+		u32 ylo_prev = 0, yhi_prev = 0; // MEGA: the column's packed letters and insert score travel with it
+		float insy_prev = 0.0f;
 		const int nsteps = LY + T;
 		for (int s = 0; s < nsteps; ++s) {
 			const int j = s - t;
@@ -122,11 +172,28 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			float nJX = mpc_lane_up1(cJX[H - 1]);
 			float nIY = mpc_lane_up1(cIY[H - 1]);
 			float nJY = mpc_lane_up1(cJY[H - 1]);
-			int yc = mpc_lane_up1(yprev);
-			const int yload = (s >= 1 && s <= LY) ? (int)Y[s - 1] : 0; // lane 0: letter of column j = s
-			if (t == 0)
-				yc = yload;
-			const float insy = s_ins[yc];
+			int yc = 0;
+			u32 ylo = 0, yhi = 0;
+			float insy;
+			u32 yi[MEGA ? MPC_MEGA_FMAX : 1];
+			if (MEGA) {
+				ylo = (u32)mpc_lane_up1((int)ylo_prev);
+				yhi = (u32)mpc_lane_up1((int)yhi_prev);
+				insy = mpc_lane_up1(insy_prev);
+				const bool incol = (s >= 1 && s <= LY);
+				const u64 yload = incol ? PY[s - 1] : 0ull; // lane 0: column j = s
+				const float iload = incol ? IY[s - 1] : 0.0f; // fwdflat_mega.cpp:120
+				if (t == 0) { ylo = (u32)yload; yhi = (u32)(yload >> 32); insy = iload; }
+#pragma unroll
+				for (int f = 0; f < MPC_MEGA_FMAX; ++f)
+					yi[f] = mg_base[f] + (((f < 4 ? ylo : yhi) >> (8 * (f & 3))) & 0xffu);
+			} else {
+				yc = mpc_lane_up1(yprev);
+				const int yload = (s >= 1 && s <= LY) ? (int)Y[s - 1] : 0; // lane 0: letter of column j = s
+				if (t == 0)
+					yc = yload;
+				insy = s_ins[yc];
+			}
 			if (t == 0) {
 				// row 0 (fwdflat3.cpp:35-39, :44-45, :57-65, :81-93): M=IX=JX=LOG_ZERO,
 				// IY(0,1)=tSI+Ins(y1), IY(0,j)=IY(0,j-1)+tII+Ins(yj)
@@ -142,7 +209,8 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 #pragma unroll
 			for (int r = 0; r < H; ++r) {
 				const float oM = cM[r], oIX = cIX[r], oJX = cJX[r], oIY = cIY[r], oJY = cJY[r]; // (i, j-1)
-				const float m = s_match[mrow[r] + yc];
+				const float m = MEGA ? mpc_mega_match(s_match, mg_alpha, xl[MEGA ? r : 0], yi) // fwdflat_mega.cpp:121
+				                     : s_match[mrow[r] + yc];
 				// fwdflat3.cpp:116-145. No per-cell border tests: for j <= 0 (column 0 and the columns a
 				// lane "computes" before it has started) every input that should be LOG_ZERO is exactly
 				// LOG_ZERO, LOG_ZERO + score == LOG_ZERO and LOG_ADD(LOG_ZERO, v) == v, so the same
@@ -167,6 +235,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			}
 			uM = nM; uIX = nIX; uJX = nJX; uIY = nIY; uJY = nJY;
 			yprev = yc;
+			ylo_prev = ylo; yhi_prev = yhi; insy_prev = insy;
 		}
 		// F(LX,LY,*) sits in lane T-1, row (LX-1)%H, after its last step (column LY).
 		float eM = LZ, eIX = LZ, eJX = LZ, eIY = LZ, eJY = LZ;
@@ -194,15 +263,21 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 #pragma unroll
 		for (int r = 0; r < H; ++r) {
 			const int i = t * H + r + 1;
-			const int xc = (i < LX) ? (int)X[i] : 0;
-			insx[r] = s_ins[xc];
-			mrow[r] = xc * A;
+			if (MEGA) {
+				xl[MEGA ? r : 0] = (i < LX) ? PX[i] : 0ull;
+				insx[r] = (i < LX) ? IX[i] : 0.0f; // bwdflat_mega.cpp:55
+			} else {
+				const int xc = (i < LX) ? (int)X[i] : 0;
+				insx[r] = s_ins[xc];
+				mrow[r] = xc * A;
+			}
 			cM[r] = cIX[r] = cJX[r] = cIY[r] = cJY[r] = LZ; // virtual column LY+1
 		}
 		float gM = LZ; // row (t+1)*H+1 at column j+1: diagonal of r=H-1
 		u64 *cand = p.cand + (u64)pid * p.capc;
 		u32 ncand = 0;
 		int ynext_prev = 0;
+		ylo_prev = 0; yhi_prev = 0; insy_prev = 0.0f;
 		const int bsteps = LY + T - 1;
 		for (int s = 0; s < bsteps; ++s) {
 			const int j = LY - s + (T - 1 - t);
@@ -211,12 +286,29 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			float nIX = mpc_lane_down1(cIX[0]);
 			float nJX = mpc_lane_down1(cJX[0]);
 			if (t == 63) { nM = LZ; nIX = LZ; nJX = LZ; } // nothing below the wave: virtual row
-			int yc = mpc_lane_down1(ynext_prev);
 			const int jl = LY - s; // column of the leading lane T-1
-			const int yload = (jl >= 0 && jl < LY) ? (int)Y[jl] : 0;
-			if (t >= T - 1)
-				yc = yload; // leading lane (and idle lanes beyond it)
-			const float insy = s_ins[yc];
+			int yc = 0;
+			u32 ylo = 0, yhi = 0;
+			float insy;
+			u32 yi[MEGA ? MPC_MEGA_FMAX : 1];
+			if (MEGA) {
+				ylo = (u32)mpc_lane_down1((int)ylo_prev);
+				yhi = (u32)mpc_lane_down1((int)yhi_prev);
+				insy = mpc_lane_down1(insy_prev);
+				const bool incol = (jl >= 0 && jl < LY);
+				const u64 yload = incol ? PY[jl] : 0ull;      // y_{j+1} of the leading lane's column
+				const float iload = incol ? IY[jl] : 0.0f;    // bwdflat_mega.cpp:78
+				if (t >= T - 1) { ylo = (u32)yload; yhi = (u32)(yload >> 32); insy = iload; }
+#pragma unroll
+				for (int f = 0; f < MPC_MEGA_FMAX; ++f)
+					yi[f] = mg_base[f] + (((f < 4 ? ylo : yhi) >> (8 * (f & 3))) & 0xffu);
+			} else {
+				yc = mpc_lane_down1(ynext_prev);
+				const int yload = (jl >= 0 && jl < LY) ? (int)Y[jl] : 0;
+				if (t >= T - 1)
+					yc = yload; // leading lane (and idle lanes beyond it)
+				insy = s_ins[yc];
+			}
 			const int sf = j + t; // forward step that stored column j of this lane (uniform: LY-s+T-1)
 			const float *fmrow = fm + ((u64)(sf < 0 ? 0 : sf) * H) * 64 + t;
 			float dgM = gM;                           // M(i+1, j+1)
@@ -229,7 +321,8 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 				const int i = t * H + r + 1;
 				const float oM = cM[r], oIY = cIY[r], oJY = cJY[r]; // (i, j+1)
 				// bwdflat3.cpp:75-79
-				const float xM = dgM + s_match[mrow[r] + yc];
+				const float xM = dgM + (MEGA ? mpc_mega_match(s_match, mg_alpha, xl[MEGA ? r : 0], yi) // bwdflat_mega.cpp:79-80
+				                             : s_match[mrow[r] + yc]);
 				const float xIX = dnIX + insx[r];
 				const float xJX = dnJX + insx[r];
 				const float xIY = oIY + insy;
@@ -261,6 +354,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			(void)newfirstM;
 			gM = nM;
 			ynext_prev = yc;
+			ylo_prev = ylo; yhi_prev = yhi; insy_prev = insy;
 			if (__ballot(anyhit)) {
 #pragma unroll
 				for (int r = 0; r < H; ++r) {
@@ -280,5 +374,44 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 		}
 		if (t == 0)
 			p.cand_cnt[pid] = ncand;
+	}
+}
+
+// ---- preparation of the structure-profile tables (once per mpcgpu_set_mega) ---------------------------------
+struct MegaPrepParams {
+	u32 nfeat;
+	const u32 *alpha;    // [nfeat]
+	const float *weight; // [nfeat]
+	const float *lp;     // log-probabilities per feature, back to back
+	const u32 *lp_off;   // [nfeat]
+	const float *mx;     // A_f x A_f log-probability matrices, back to back
+	const u32 *mx_off;   // [nfeat + 1]
+	const u8 *letters;   // all positions of all sequences, nfeat letters per position
+	u64 npos;
+	u64 *prof;           // out: packed letters per position
+	float *ins;          // out: Mega::GetInsScore per position
+	float *tab;          // out: mx[q] * weight[f(q)], then one 0.0f
+};
+
+__global__ void __launch_bounds__(256) mega_prepare_kernel(MegaPrepParams p)
+{
+	const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x, stride = (u64)gridDim.x * blockDim.x;
+	const u32 ntab = p.mx_off[p.nfeat];
+	for (u64 q = gid; q <= ntab; q += stride) {
+		if (q == ntab) { p.tab[q] = 0.0f; continue; }
+		u32 f = 0;
+		while (f + 1 < p.nfeat && q >= p.mx_off[f + 1]) ++f;
+		p.tab[q] = p.mx[q] * p.weight[f]; // mega.cpp:359-360 (the product; the fold is mpc_mega_match)
+	}
+	for (u64 pos = gid; pos < p.npos; pos += stride) {
+		const u8 *l = p.letters + pos * p.nfeat;
+		u64 packed = 0;
+		float score = 0.0f; // mega.cpp:277-284
+		for (u32 f = 0; f < p.nfeat; ++f) {
+			packed |= (u64)l[f] << (8 * f);
+			score += p.lp[p.lp_off[f] + l[f]] * p.weight[f];
+		}
+		p.prof[pos] = packed;
+		p.ins[pos] = score;
 	}
 }

@@ -84,6 +84,10 @@ struct mpcgpu_ctx {
 	int A = 0;
 	int code_of[256];
 	DevBuf d_seq_code, d_seq_off, d_seq_len, d_match, d_ins;
+	// structure-profile emissions (mpcgpu_set_mega); reset by every set_seqs
+	bool have_mega = false;
+	u32 mg_nfeat = 0, mg_tab_floats = 0, mg_base[MPC_MEGA_FMAX], mg_alpha[MPC_MEGA_FMAX];
+	DevBuf d_mg_prof, d_mg_ins, d_mg_tab, d_mg_in;
 	u64 npairs = 0;
 	DevBuf d_pair_x, d_pair_y; // all pairs
 	std::vector<u32> h_pair_x, h_pair_y;
@@ -213,23 +217,24 @@ int env_int(const char *name, int dflt)
 	return (s && *s) ? atoi(s) : dflt;
 }
 
-template <int H> void launch_fb(const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+template <int H, bool MEGA> void launch_fb(const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
-	MPC_LAUNCH(HIP_KERNEL_NAME(fb_kernel<H>), grid, block, smem, st, p);
+	auto kern = fb_kernel<H, MEGA>;
+	MPC_LAUNCH(kern, grid, block, smem, st, p);
 }
 
-template <int H> int occ_fb(u32 block, size_t smem)
+template <int H, bool MEGA> int occ_fb(u32 block, size_t smem)
 {
 	int nb = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_kernel<H>, (int)block, smem) != hipSuccess || nb < 1)
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_kernel<H, MEGA>, (int)block, smem) != hipSuccess || nb < 1)
 		nb = 1;
 	return nb;
 }
 
-int occ_fb_h(int H, u32 block, size_t smem)
+int occ_fb_h(int H, bool mega, u32 block, size_t smem)
 {
 	switch (H) {
-#define MPC_CASE(h) case h: return occ_fb<h>(block, smem);
+#define MPC_CASE(h) case h: return mega ? occ_fb<h, true>(block, smem) : occ_fb<h, false>(block, smem);
 	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
 	MPC_CASE(9) MPC_CASE(10) MPC_CASE(11) MPC_CASE(12) MPC_CASE(13) MPC_CASE(14) MPC_CASE(15) MPC_CASE(16)
 #undef MPC_CASE
@@ -237,10 +242,10 @@ int occ_fb_h(int H, u32 block, size_t smem)
 	}
 }
 
-void launch_fb_h(int H, const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+void launch_fb_h(int H, bool mega, const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
 	switch (H) {
-#define MPC_CASE(h) case h: launch_fb<h>(p, grid, block, smem, st); break;
+#define MPC_CASE(h) case h: if (mega) launch_fb<h, true>(p, grid, block, smem, st); else launch_fb<h, false>(p, grid, block, smem, st); break;
 	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
 	MPC_CASE(9) MPC_CASE(10) MPC_CASE(11) MPC_CASE(12) MPC_CASE(13) MPC_CASE(14) MPC_CASE(15) MPC_CASE(16)
 #undef MPC_CASE
@@ -433,6 +438,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 	(void)hipStreamSynchronize(c->stream);
 	for (auto &sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
 	DevBuf *all[] = {&c->d_seq_code, &c->d_seq_off, &c->d_seq_len, &c->d_match, &c->d_ins, &c->d_pair_x, &c->d_pair_y,
+		&c->d_mg_prof, &c->d_mg_ins, &c->d_mg_tab, &c->d_mg_in,
 		&c->d_shard, &c->d_pbase, &c->d_vbase, &c->d_rp, &c->d_rp_base, &c->d_ent, &c->d_ent_base, &c->d_mbase,
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
@@ -484,6 +490,7 @@ static int set_seqs_impl(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, 
 	if (with_pairs && (u64)n * n > 0xffffffffull) return fail(c, "mpcgpu_set_seqs: too many sequences (%u)", n);
 	HIPCHK(c, hipSetDevice(c->device));
 	c->have_shard = c->have_store = false;
+	c->have_mega = false;
 	c->n = n;
 	c->raw.assign(n, {});
 	c->len.assign(lens, lens + n);
@@ -549,6 +556,85 @@ int mpcgpu_set_seqs_registry(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *se
 	return set_seqs_impl(c, n, seqs, lens, false);
 }
 
+int mpcgpu_set_mega(mpcgpu_ctx *c, uint32_t nfeat, const uint32_t *alpha, const float *weight,
+	const float *const *logprobs, const float *const *logprob_mx, const uint8_t *const *profiles)
+{
+	if (!c) return 1;
+	if (c->n == 0) return fail(c, "mpcgpu_set_mega: call mpcgpu_set_seqs first");
+	HIPCHK(c, hipSetDevice(c->device));
+	c->have_shard = c->have_store = false;
+	c->have_mega = false;
+	if (nfeat == 0) return 0; // back to byte-sequence emissions
+	if (nfeat > MPC_MEGA_FMAX) return fail(c, "mpcgpu_set_mega: %u features; this build supports at most %d", nfeat, MPC_MEGA_FMAX);
+	if (!alpha || !weight || !logprobs || !logprob_mx || !profiles) return fail(c, "mpcgpu_set_mega: NULL argument");
+	// one upload: [alpha | weight | lp_off | mx_off | lp | mx | letters]
+	std::vector<u32> lp_off(nfeat), mx_off(nfeat + 1);
+	u32 nlp = 0, nmx = 0;
+	for (u32 f = 0; f < nfeat; ++f) {
+		if (alpha[f] == 0 || alpha[f] > 256) return fail(c, "mpcgpu_set_mega: feature %u has alphabet size %u", f, alpha[f]);
+		lp_off[f] = nlp; mx_off[f] = nmx;
+		nlp += alpha[f]; nmx += alpha[f] * alpha[f];
+	}
+	mx_off[nfeat] = nmx;
+	const size_t fb_lds = MPC_FB_COEF_BYTES + ((size_t)nmx + 1) * sizeof(float);
+	if (fb_lds > 64 * 1024) return fail(c, "mpcgpu_set_mega: the feature tables (%u floats) do not fit the kernel's LDS budget", nmx);
+	u64 npos = 0;
+	for (u32 i = 0; i < c->n; ++i) npos += c->len[i];
+	std::vector<u8> blob;
+	auto put = [&](const void *src, size_t bytes) {
+		const size_t at = blob.size();
+		blob.resize(at + ((bytes + 15) & ~(size_t)15));
+		memcpy(blob.data() + at, src, bytes);
+		return at;
+	};
+	const size_t o_alpha = put(alpha, 4ull * nfeat), o_weight = put(weight, 4ull * nfeat);
+	const size_t o_lpoff = put(lp_off.data(), 4ull * nfeat), o_mxoff = put(mx_off.data(), 4ull * (nfeat + 1));
+	std::vector<float> lp(nlp), mx(nmx);
+	for (u32 f = 0; f < nfeat; ++f) {
+		if (!logprobs[f] || !logprob_mx[f]) return fail(c, "mpcgpu_set_mega: NULL table of feature %u", f);
+		memcpy(lp.data() + lp_off[f], logprobs[f], 4ull * alpha[f]);
+		memcpy(mx.data() + mx_off[f], logprob_mx[f], 4ull * alpha[f] * alpha[f]);
+	}
+	const size_t o_lp = put(lp.data(), 4ull * nlp), o_mx = put(mx.data(), 4ull * nmx);
+	std::vector<u8> letters((size_t)npos * nfeat);
+	size_t at = 0;
+	for (u32 i = 0; i < c->n; ++i) {
+		if (!profiles[i]) return fail(c, "mpcgpu_set_mega: NULL profile of sequence %u", i);
+		const size_t bytes = (size_t)c->len[i] * nfeat;
+		for (size_t q = 0; q < bytes; ++q)
+			if (profiles[i][q] >= alpha[q % nfeat])
+				return fail(c, "mpcgpu_set_mega: sequence %u position %zu: letter %u of feature %zu is outside its alphabet (%u)",
+					i, q / nfeat, (unsigned)profiles[i][q], q % nfeat, alpha[q % nfeat]);
+		memcpy(letters.data() + at, profiles[i], bytes);
+		at += bytes;
+	}
+	const size_t o_let = put(letters.data(), letters.size());
+	if (upload(c, c->d_mg_in, blob)) return 1;
+	HIPCHK(c, c->d_mg_prof.ensure(npos * 8));
+	HIPCHK(c, c->d_mg_ins.ensure(npos * 4));
+	HIPCHK(c, c->d_mg_tab.ensure(((u64)nmx + 1) * 4));
+	MegaPrepParams mp;
+	const u8 *base = c->d_mg_in.as<u8>();
+	mp.nfeat = nfeat;
+	mp.alpha = (const u32 *)(base + o_alpha); mp.weight = (const float *)(base + o_weight);
+	mp.lp = (const float *)(base + o_lp); mp.lp_off = (const u32 *)(base + o_lpoff);
+	mp.mx = (const float *)(base + o_mx); mp.mx_off = (const u32 *)(base + o_mxoff);
+	mp.letters = base + o_let; mp.npos = npos;
+	mp.prof = c->d_mg_prof.as<u64>(); mp.ins = c->d_mg_ins.as<float>(); mp.tab = c->d_mg_tab.as<float>();
+	const u32 grid = (u32)std::min<u64>((std::max<u64>(npos, nmx + 1) + 255) / 256, 4096);
+	MPC_LAUNCH(mega_prepare_kernel, grid, 256, 0, c->stream, mp);
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->mg_nfeat = nfeat;
+	c->mg_tab_floats = nmx + 1;
+	for (u32 f = 0; f < MPC_MEGA_FMAX; ++f) {
+		c->mg_base[f] = f < nfeat ? mx_off[f] : nmx; // unused features read the trailing 0.0f
+		c->mg_alpha[f] = f < nfeat ? alpha[f] : 0;
+	}
+	c->have_mega = true;
+	return 0;
+}
+
 uint64_t mpcgpu_pair_count(const mpcgpu_ctx *c) { return c ? c->npairs : 0; }
 
 // Stage A over an explicit list of (x,y) sequence-index pairs (host arrays of np entries): the packed
@@ -587,7 +673,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	capc = std::max(capc, 1024u);
 	const int waves_per_block = 4, block = 64 * waves_per_block;
 	const u32 cus = (u32)c->prop.multiProcessorCount;
-	const size_t fb_smem = MPC_FB_COEF_BYTES + ((size_t)c->A * c->A + c->A) * sizeof(float);
+	const bool mega = c->have_mega;
+	const size_t fb_smem = MPC_FB_COEF_BYTES + (mega ? (size_t)c->mg_tab_floats : (size_t)c->A * c->A + c->A) * sizeof(float);
 
 	u64 words_done = 0; // record words packed so far
 	u64 done = 0;
@@ -640,6 +727,9 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		fp.pair_x = c->d_bx.as<u32>(); fp.pair_y = c->d_by.as<u32>();
 		fp.cand = c->d_cand.as<u64>(); fp.capc = capc; fp.cand_cnt = c->d_cand_cnt.as<u32>();
 		fp.total = c->d_total.as<float>();
+		fp.mg_prof = mega ? c->d_mg_prof.as<u64>() : nullptr; fp.mg_ins = mega ? c->d_mg_ins.as<float>() : nullptr;
+		fp.mg_tab = mega ? c->d_mg_tab.as<float>() : nullptr; fp.mg_tab_floats = mega ? c->mg_tab_floats : 0;
+		for (u32 f = 0; f < MPC_MEGA_FMAX; ++f) { fp.mg_base[f] = mega ? c->mg_base[f] : 0; fp.mg_alpha[f] = mega ? c->mg_alpha[f] : 0; }
 		// row-list post kernel (no sorts, 3 LDS trips per EA row) when LY fits its LDS arrays; MPCGPU_POST=sort forces the general one
 		const char *post_mode = getenv("MPCGPU_POST");
 		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) && LYmax + 1 <= 2048u;
@@ -650,7 +740,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			if (!hcount[H]) continue;
 			const u32 cnt = hcount[H];
 			// persistent waves: exactly as many workgroups as the chip keeps resident (VGPR-limited)
-			const u32 occ = (u32)occ_fb_h((int)H, block, fb_smem);
+			const u32 occ = (u32)occ_fb_h((int)H, mega, block, fb_smem);
 			u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ);
 			grid = std::max(grid, 1u);
 			const u64 fm_stride = (u64)(LYmax + 64) * H * 64;
@@ -664,7 +754,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			fp.queue = c->d_queue.as<u32>() + H;
 			fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride;
 			if (span_begin(c, 0, &sp)) return 1;
-			launch_fb_h((int)H, fp, grid, block, fb_smem, c->stream);
+			launch_fb_h((int)H, mega, fp, grid, block, fb_smem, c->stream);
 			HIPCHK(c, hipGetLastError());
 			if (span_end(c, &sp)) return 1;
 			pos += cnt;

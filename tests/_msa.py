@@ -8,6 +8,7 @@ import subprocess
 import tempfile
 
 import _golden as G
+import _mega
 from muscle_amd.synth import make_family, write_fasta
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +30,8 @@ def command(name):
     BASELINE config-5 path (super7.cpp:9-137: guide tree -> shrubs -> MPCFlat::Run per shrub ->
     PProg joins), driven by a balanced guide tree so no distance matrix is needed."""
     name = name.split("+r")[0]
+    if name.startswith("mega_"):
+        name = name[5:]
     if name.startswith("super7_"):  # super7_<n>x<L>_b<shrub size>
         n = int(name[7:].split("x")[0])
         shrub = name.split("_b")[1]
@@ -67,16 +70,37 @@ def input_set(name):
     return G.mpc(name)["seqs"], None, []
 
 
+def mega_input(name):
+    """mega_* sets: the input is a .mega file (structure profiles; loadinput.cpp:5-9 keys on the extension), so
+    CalcPost runs its profile branch (calcpost.cpp:14-22). -> (file text, extra args)"""
+    base, extra = name, []
+    if "+r" in name:
+        base, k = name.split("+r")
+        extra = ["-refineiters", k]
+    if base.startswith("mega_super7_"):  # mega_super7_<n>x<L>_b<shrub size>: labels s0.. match the balanced tree
+        n, L = base[12:].split("_b")[0].split("x")
+        return _mega.synth_mega_text(int(n), int(L), seed=13), extra
+    return _mega.mega_text(base), extra
+
+
 def run_muscle(binary, name, threads=4, timeout=900):
-    seqs, labels, extra = input_set(name)
+    mega = name.startswith("mega_")
+    if mega:
+        text, extra = mega_input(name)
+    else:
+        seqs, labels, extra = input_set(name)
     cmd, cmd_extra, files = command(name)
     if cmd == "-super5":
         # PProg::Run picks joins by the average EA of AlignMSAsFlat (pprog.cpp:286,394), which the reference
         # sums in thread-arrival order (getpostpairsalignedflat.cpp:92-95): only one thread is deterministic
         threads = 1
     with tempfile.TemporaryDirectory() as d:
-        fa, out = os.path.join(d, "in.fa"), os.path.join(d, "out.afa")
-        write_fasta(fa, seqs, labels)
+        fa, out = os.path.join(d, "in.mega" if mega else "in.fa"), os.path.join(d, "out.afa")
+        if mega:
+            with open(fa, "w") as f:
+                f.write(text)
+        else:
+            write_fasta(fa, seqs, labels)
         for fn, text in files.items():
             with open(os.path.join(d, fn), "w") as f:
                 f.write(text)

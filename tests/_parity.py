@@ -11,11 +11,14 @@ def bits(a):
     return np.asarray(a, np.float32).view(np.uint32)
 
 
-def run_lib(seqs, iters=2, lib_path=None, hmm_name="hmm_amino", expf_variant=-1):
+def run_lib(seqs, iters=2, lib_path=None, hmm_name="hmm_amino", expf_variant=-1, mega=None):
+    """mega = dict(alpha, weight, lp, mx, profs): stage A on structure profiles (mpcgpu_set_mega)"""
     s, t, m, i, thr = G.hmm_tables(hmm_name)
     g = MpcGpu(0, lib_path)
     g.set_hmm(s, t, m, i, thr, expf_variant)
     g.set_seqs(seqs)
+    if mega is not None:
+        g.set_mega(mega["alpha"], mega["weight"], mega["lp"], mega["mx"], mega["profs"])
     g.calc_posteriors()
     ea = g.get_ea().copy()
     g.build_store()
@@ -29,11 +32,41 @@ def run_lib(seqs, iters=2, lib_path=None, hmm_name="hmm_amino", expf_variant=-1)
     return stages, ea
 
 
-def run_oracle(seqs, iters=2, hmm_name="hmm_amino", threads=0):
+def random_mega(seqs, seed, nfeat=8):
+    """Random structure-profile tables + profiles for the given sequences (library vs oracle runs: any finite
+    negative log-probabilities will do; the reference-parsed ones are in the mega_* golden fixtures)."""
+    rng = np.random.default_rng(seed)
+    alpha = np.array([20] + [int(rng.choice([2, 5, 9, 16])) for _ in range(nfeat - 1)], np.uint32)[:nfeat]
+    weight = rng.uniform(0.05, 0.5, nfeat).astype(np.float32)
+    lp = np.concatenate([np.log(rng.dirichlet(np.ones(int(a)))).astype(np.float32) for a in alpha])
+    mxs = []
+    for a in alpha:
+        a = int(a)
+        j = rng.uniform(0.2, 1.0, (a, a)) + 5.0 * np.eye(a)
+        j = (j + j.T) / 2
+        mxs.append(np.log(j / j.sum()).astype(np.float32).ravel())
+    amino = "ACDEFGHIKLMNPQRSTVWY"
+    profs = []
+    for sq in seqs:
+        p = np.empty((len(sq), nfeat), np.uint8)
+        for pos, c in enumerate(sq):
+            base = amino.index(c) if c in amino else 0
+            p[pos, 0] = base
+            for f in range(1, nfeat):
+                p[pos, f] = (base * 5 + f) % int(alpha[f]) if rng.random() > 0.3 else rng.integers(int(alpha[f]))
+        profs.append(p.ravel())
+    return {"alpha": alpha, "weight": weight, "lp": lp, "mx": np.concatenate(mxs), "profs": profs}
+
+
+def run_oracle(seqs, iters=2, hmm_name="hmm_amino", threads=0, mega=None):
     s, t, m, i, thr = G.hmm_tables(hmm_name)
     h = O.make_hmm(s, t, m, i)
-    st = O.Store(seqs)
-    ea = st.calc_posteriors(h, threads=threads)
+    if mega is not None:
+        st = O.MegaStore(seqs, mega["profs"])
+        ea = st.calc_posteriors_mega(h, O.make_mega(mega["alpha"], mega["weight"], mega["lp"], mega["mx"]), threads=threads)
+    else:
+        st = O.Store(seqs)
+        ea = st.calc_posteriors(h, threads=threads)
     stages = [[st.get(k) for k in range(st.npairs)]]
     cur = st
     if len(seqs) >= 3:

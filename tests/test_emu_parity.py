@@ -190,3 +190,57 @@ def test_emu_align_msas(emu):
     assert path == path0 and P.bits(sc) == P.bits(sc0)
     assert np.array_equal(P.bits(ea), P.bits(np.array(ea_want, np.float32)))
     g.close()
+
+
+# ---- structure-profile ("mega") emissions: fb_kernel<H, true> + mega_prepare_kernel -------------------------
+@pytest.mark.parametrize("name", ["mega_synth_3x25_s5_f3", "mega_synth_2x70_s7"])
+def test_emu_mega_vs_golden(emu, name):
+    """the reference's own parsed tables and outputs (calcpost.cpp:14-22 branch)"""
+    m = G.mega(name)
+    stages, ea = P.run_lib(m["seqs"], lib_path=emu, mega=m)
+    assert np.array_equal(P.bits(ea), P.bits(m["ea"]))
+    for s in range(m["nstages"]):
+        assert G.stage_digest(stages[s]) == m["digest"][s]
+
+
+def test_emu_mega_vs_oracle(emu):
+    # ragged lengths incl. length 1 and H = 2 rows per lane; random tables with all 8 features
+    seqs = ["M", "MKVLA", make_family(1, 80, seed=3)[0], make_family(1, 33, seed=4)[0]]
+    mega = P.random_mega(seqs, seed=11)
+    P.assert_same(P.run_lib(seqs, lib_path=emu, mega=mega), P.run_oracle(seqs, mega=mega), "mega ragged")
+    # and the switch back to byte sequences on the same context state is covered by every other test
+
+
+def test_emu_mega_rejects_bad_input(emu):
+    from muscle_amd._lib import MpcGpu
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, emu)
+    g.set_hmm(s, t, m, i, thr)
+    seqs = ["MKVLA", "MKILA"]
+    g.set_seqs(seqs)
+    mega = P.random_mega(seqs, seed=2, nfeat=3)
+    mega["profs"][1][4] = 200  # letter outside its alphabet
+    with pytest.raises(RuntimeError, match="outside its alphabet"):
+        g.set_mega(mega["alpha"], mega["weight"], mega["lp"], mega["mx"], mega["profs"])
+    g.close()
+
+
+def test_emu_mega_then_letters_on_one_context(emu):
+    """set_seqs drops the profiles: the same context goes back to letter emissions"""
+    from muscle_amd._lib import MpcGpu
+    s, t, m, i, thr = G.hmm_tables()
+    seqs = make_family(3, 24, seed=31)
+    mega = P.random_mega(seqs, seed=5, nfeat=4)
+    g = MpcGpu(0, emu)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.set_mega(mega["alpha"], mega["weight"], mega["lp"], mega["mx"], mega["profs"])
+    g.calc_posteriors()
+    ea_mega = g.get_ea().copy()
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    ea_plain = g.get_ea().copy()
+    g.close()
+    assert np.array_equal(P.bits(ea_mega), P.bits(P.run_oracle(seqs, iters=0, mega=mega)[1]))
+    assert np.array_equal(P.bits(ea_plain), P.bits(P.run_oracle(seqs, iters=0)[1]))
+    assert not np.array_equal(P.bits(ea_mega), P.bits(ea_plain))

@@ -22,6 +22,47 @@ def test_golden_sets(name):
         assert G.stage_digest(stages[s]) == g["digest"][s], "stage %d" % s
 
 
+@pytest.mark.parametrize("name", G.MEGA_SETS)
+def test_mega_golden_sets(name):
+    """Structure-profile emissions (mpcgpu_set_mega; calcpost.cpp:14-22 -> fwdflat_mega.cpp / bwdflat_mega.cpp):
+    the reference's parsed tables in, the reference's own stage outputs expected."""
+    m = G.mega(name)
+    stages, ea = P.run_lib(m["seqs"], mega=m)
+    assert np.array_equal(P.bits(ea), P.bits(m["ea"]))
+    for s in range(m["nstages"]):
+        assert G.stage_digest(stages[s]) == m["digest"][s], "stage %d" % s
+        for (o1, v1), (o2, v2) in zip(stages[s], m["stage"][s]):
+            assert np.array_equal(o1, o2) and np.array_equal(v1, v2)
+
+
+@pytest.mark.parametrize("nfeat", [8, 5, 1])
+def test_mega_vs_oracle_ragged(nfeat):
+    """random tables; lengths 1 .. 700 (H = 1 .. 11 rows per lane), fewer than 8 features (unused ones read the 0 entry)"""
+    seqs = ["M", "MKVLA", make_family(1, 700, seed=2)[0], make_family(1, 420, seed=3)[0], make_family(1, 64, seed=4)[0],
+            make_family(1, 65, seed=5)[0], make_family(1, 129, seed=6)[0]]
+    mega = P.random_mega(seqs, seed=20 + nfeat, nfeat=nfeat)
+    P.assert_same(P.run_lib(seqs, mega=mega), P.run_oracle(seqs, mega=mega), "mega ragged F=%d" % nfeat)
+
+
+def test_mega_then_letters_on_one_context():
+    """set_seqs drops the profiles: the same context must go back to letter emissions"""
+    s, t, m, i, thr = G.hmm_tables()
+    seqs = make_family(4, 70, seed=31)
+    mega = P.random_mega(seqs, seed=5)
+    g = MpcGpu(0)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.set_mega(mega["alpha"], mega["weight"], mega["lp"], mega["mx"], mega["profs"])
+    g.calc_posteriors()
+    ea_mega = g.get_ea().copy()
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    ea_plain = g.get_ea().copy()
+    g.close()
+    assert np.array_equal(P.bits(ea_mega), P.bits(P.run_oracle(seqs, iters=0, mega=mega)[1]))
+    assert np.array_equal(P.bits(ea_plain), P.bits(P.run_oracle(seqs, iters=0)[1]))
+
+
 def test_nucleotide_tables():
     rng = np.random.default_rng(3)
     seqs = ["".join(rng.choice(list("ACGU" if k % 2 else "ACGT"), size=int(rng.integers(20, 120)))) for k in range(7)]
