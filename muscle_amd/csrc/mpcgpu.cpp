@@ -1,5 +1,5 @@
 // mpcgpu.cpp — host side of libmpcgpu.so: the C ABI of include/mpcgpu.h over the HIP kernels in
-// kernels_fb.h (pair-HMM forward/backward), kernels_post.h (probabilities, sparsify, EA),
+// kernels_fb.h (pair-HMM forward/backward, letter and structure-profile emissions), kernels_post.h (probabilities, sparsify, EA),
 // kernels_store.h (packed records, padded / slab stores, gather relax, commit, export),
 // kernels_relax.h (LDS-tiled relax), kernels_aln.h (posterior-DP alignment + traceback) and
 // kernels_prog.h (MSA x MSA posterior build). Built by hipcc (-x hip) for gfx950. There is no CPU
