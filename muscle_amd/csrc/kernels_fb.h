@@ -25,6 +25,15 @@
 // is one rounded multiply either way), every position carries its <= 8 feature letters packed in a
 // u64, and a cell's match score is the in-order sum of <= 8 LDS lookups.
 //
+// Row blocks, LONG = true (X longer than 64*MPC_HMAX rows): the rows are cut into blocks of 64*H; the
+// forward sweep runs block after block, lane 63's last row (all five states, every column) going through
+// a small HBM line buffer to lane 0 of the next block, which reads it back 64 columns at a time (one
+// coalesced load per state every 64 steps + one v_readlane per step). The backward sweep runs the blocks
+// in reverse with lane 0's first row (M, IX, JX) as the line buffer for lane 63 of the block above. The
+// forward M plane keeps one region per block. Cells, expressions and results are the same; candidate keys
+// use 16 bits for the column (MPC_KEY_ROW_SHIFT_LONG). The line buffers alternate by block parity and a
+// workgroup-scope fence separates a block's stores from the next block's loads.
+//
 // Every cell value is a fixed expression of its three neighbours, so the wavefront order does
 // not change results: outputs are bit-identical to the row-major CPU sweep (given no FMA
 // contraction, -ffp-contract=off). Border handling: the reference's special-cased border
@@ -37,6 +46,8 @@
 #define MPC_HMAX 16
 #define MPC_KEY_ROW_SHIFT 22 // rows < 64*MPC_HMAX = 2^10, columns < 2^22 (checked in mpcgpu_set_seqs)
 #define MPC_KEY_COL_MASK ((1u << MPC_KEY_ROW_SHIFT) - 1u)
+#define MPC_KEY_ROW_SHIFT_LONG 16 // row-block (LONG) kernels: rows and columns < 2^16 (checked by the host)
+#define MPC_KEY_COL_MASK_LONG ((1u << MPC_KEY_ROW_SHIFT_LONG) - 1u)
 #define MPC_FB_COEF_BYTES (MPC_COEF_ENTRIES * 16)
 #define MPC_MEGA_FMAX 8 // features per position (one byte each in a u64)
 
@@ -64,6 +75,11 @@ struct FbParams {
 	u32 capc;
 	u32 *cand_cnt; // per batch-local pair (may exceed capc: overflow, detected by the host)
 	float *total;  // per batch-local pair: log total probability (diagnostic / tests)
+	// row blocks (LONG kernels only)
+	float *bnd;      // line buffers, one slot per resident wave: [2 parities][5 fwd + 3 bwd states][bnd_ld]
+	u64 bnd_stride;  // floats per slot
+	u32 bnd_ld;      // >= LYmax + 2
+	u64 fm_block;    // floats of fm_scratch per row block
 	// structure-profile emissions (MEGA kernels only); positions are indexed like seq_code
 	const u64 *mg_prof;  // letters of feature f in bits [8f, 8f+8)
 	const float *mg_ins; // Mega::GetInsScore of the position
@@ -87,7 +103,7 @@ __device__ __forceinline__ float mpc_mega_match(const float *s_tab, const u32 *a
 	return m;
 }
 
-template <int H, bool MEGA>
+template <int H, bool MEGA, bool LONG>
 __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
@@ -135,7 +151,11 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 		const int LX = (int)p.seq_len[sx], LY = (int)p.seq_len[sy];
 		const u8 *X = p.seq_code + p.seq_off[sx];
 		const u8 *Y = p.seq_code + p.seq_off[sy];
-		const int T = (LX + H - 1) / H; // lanes that own at least one row
+		constexpr int R = 64 * H;                   // rows per block
+		const int NB = LONG ? (LX + R - 1) / R : 1; // row blocks (1 unless LONG)
+		float *bnd = LONG ? p.bnd + (u64)slot * p.bnd_stride : nullptr;
+		const u32 ld = LONG ? p.bnd_ld : 0u;
+		int T = (LX + H - 1) / H; // lanes that own at least one row (LONG: of the current block)
 
 		// ------------------------------------------------------------------ forward
 		float cM[H], cIX[H], cJX[H], cIY[H], cJY[H]; // own rows at the previous column
@@ -145,9 +165,18 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 		// MEGA: packed letters and insert score of every position
 		const u64 *PX = MEGA ? p.mg_prof + p.seq_off[sx] : nullptr, *PY = MEGA ? p.mg_prof + p.seq_off[sy] : nullptr;
 		const float *IX = MEGA ? p.mg_ins + p.seq_off[sx] : nullptr, *IY = MEGA ? p.mg_ins + p.seq_off[sy] : nullptr;
+		u32 ylo_prev = 0, yhi_prev = 0; // MEGA: the column's packed letters and insert score travel with it
+		float insy_prev = 0.0f;
+		for (int b = 0; b < NB; ++b) { // row block b: rows i0+1 .. i0+R (one pass unless LONG)
+		const int i0 = LONG ? b * R : 0;
+		if (LONG) T = ((LX - i0 < R ? LX - i0 : R) + H - 1) / H;
+		float *fmb = LONG ? fm + (u64)b * p.fm_block : fm;
+		const float *bnd_in = LONG ? bnd + (u64)(b & 1) * 8 * ld : nullptr; // row i0, written by block b-1
+		float *bnd_out = LONG ? bnd + (u64)((b + 1) & 1) * 8 * ld : nullptr; // row i0+R, for block b+1
+		float pfM = LZ, pfIX = LZ, pfJX = LZ, pfIY = LZ, pfJY = LZ;          // LONG: 64 columns of row i0, one per lane
 #pragma unroll
 		for (int r = 0; r < H; ++r) {
-			const int i = t * H + r + 1;
+			const int i = i0 + t * H + r + 1;
 			if (MEGA) {
 				xl[MEGA ? r : 0] = (i <= LX) ? PX[i - 1] : 0ull;
 				insx[r] = (i <= LX) ? IX[i - 1] : 0.0f; // fwdflat_mega.cpp:113
@@ -161,8 +190,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 		float uM = LZ, uIX = LZ, uJX = LZ, uIY = LZ, uJY = LZ; // row t*H at column j-1 (diagonal of r=0)
 		float gIY = LZ, gJY = LZ;                              // lane 0: row-0 chain (fwdflat3.cpp:81-93)
 		int yprev = 0;
-		u32 ylo_prev = 0, yhi_prev = 0; // MEGA: the column's packed letters and insert score travel with it
-		float insy_prev = 0.0f;
+		ylo_prev = 0; yhi_prev = 0; insy_prev = 0.0f;
 		const int nsteps = LY + T;
 		for (int s = 0; s < nsteps; ++s) {
 			const int j = s - t;
@@ -194,6 +222,18 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 					yc = yload;
 				insy = s_ins[yc];
 			}
+			if (LONG && b > 0) {
+				// row i0, the last row of the block above, comes back from the line buffer
+				if ((s & 63) == 0) {
+					const int jj = s + t;
+					const bool in = jj <= LY;
+					pfM = in ? bnd_in[0 * ld + jj] : LZ; pfIX = in ? bnd_in[1 * ld + jj] : LZ; pfJX = in ? bnd_in[2 * ld + jj] : LZ;
+					pfIY = in ? bnd_in[3 * ld + jj] : LZ; pfJY = in ? bnd_in[4 * ld + jj] : LZ;
+				}
+				const float bM = mpc_read_lane(pfM, s & 63), bIX = mpc_read_lane(pfIX, s & 63), bJX = mpc_read_lane(pfJX, s & 63);
+				const float bIY = mpc_read_lane(pfIY, s & 63), bJY = mpc_read_lane(pfJY, s & 63);
+				if (t == 0) { nM = bM; nIX = bIX; nJX = bJX; nIY = bIY; nJY = bJY; }
+			} else
 			if (t == 0) {
 				// row 0 (fwdflat3.cpp:35-39, :44-45, :57-65, :81-93): M=IX=JX=LOG_ZERO,
 				// IY(0,1)=tSI+Ins(y1), IY(0,j)=IY(0,j-1)+tII+Ins(yj)
@@ -205,7 +245,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			}
 			float dM = uM, dIX = uIX, dJX = uJX, dIY = uIY, dJY = uJY; // (i-1, j-1)
 			float upM = nM, upIX = nIX, upJX = nJX;                     // (i-1, j)
-			float *fmrow = fm + ((u64)s * H) * 64 + t;
+			float *fmrow = fmb + ((u64)s * H) * 64 + t;
 #pragma unroll
 			for (int r = 0; r < H; ++r) {
 				const float oM = cM[r], oIX = cIX[r], oJX = cJX[r], oIY = cIY[r], oJY = cJY[r]; // (i, j-1)
@@ -224,7 +264,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 				float vIY = mpc_la2t(oIY + tII, oM + tMI, s_coef) + insy;
 				float vJY = mpc_la2t(oJY + tJJ, oM + tMJ, s_coef) + insy;
 				if (r == 0) {
-					const bool row1 = (t == 0);
+					const bool row1 = (t == 0) && (!LONG || b == 0);
 					if (row1 && j == 0) { vIX = tSI + insx[0]; vJX = tSJ + insx[0]; } // fwdflat3.cpp:42-43
 					if (row1 && j == 1) vM = tSM + m;                                 // fwdflat3.cpp:111-112
 				}
@@ -236,7 +276,13 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			uM = nM; uIX = nIX; uJX = nJX; uIY = nIY; uJY = nJY;
 			yprev = yc;
 			ylo_prev = ylo; yhi_prev = yhi; insy_prev = insy;
+			if (LONG && b + 1 < NB && t == 63 && j >= 0 && j <= LY) { // row i0+R for the next block (column j = s-63)
+				bnd_out[0 * ld + j] = cM[H - 1]; bnd_out[1 * ld + j] = cIX[H - 1]; bnd_out[2 * ld + j] = cJX[H - 1];
+				bnd_out[3 * ld + j] = cIY[H - 1]; bnd_out[4 * ld + j] = cJY[H - 1];
+			}
 		}
+		if (LONG) MPC_WAVE_FENCE();
+		} // row blocks (forward)
 		// F(LX,LY,*) sits in lane T-1, row (LX-1)%H, after its last step (column LY).
 		float eM = LZ, eIX = LZ, eJX = LZ, eIY = LZ, eJY = LZ;
 		{
@@ -260,9 +306,19 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 
 		// ------------------------------------------------------------------ backward + posterior
 		// Row i uses the emissions of x_{i+1}=X[i] and y_{j+1}=Y[j] (bwdflat3.cpp:46,64).
+		u64 *cand = p.cand + (u64)pid * p.capc;
+		u32 ncand = 0;
+		for (int bb = 0; bb < NB; ++bb) { // row blocks bottom-up (one pass unless LONG)
+		const int b = NB - 1 - bb;
+		const int i0 = LONG ? b * R : 0;
+		if (LONG) T = ((LX - i0 < R ? LX - i0 : R) + H - 1) / H;
+		const float *fmb = LONG ? fm + (u64)b * p.fm_block : fm;
+		const float *bnd_in = LONG ? bnd + ((u64)(bb & 1) * 8 + 5) * ld : nullptr; // row i0+R+1 (M, IX, JX), written by block b+1
+		float *bnd_out = LONG ? bnd + ((u64)((bb + 1) & 1) * 8 + 5) * ld : nullptr; // row i0+1, for block b-1
+		float pfM = LZ, pfIX = LZ, pfJX = LZ; // LONG: 64 columns of the row below the block, one per lane
 #pragma unroll
 		for (int r = 0; r < H; ++r) {
-			const int i = t * H + r + 1;
+			const int i = i0 + t * H + r + 1;
 			if (MEGA) {
 				xl[MEGA ? r : 0] = (i < LX) ? PX[i] : 0ull;
 				insx[r] = (i < LX) ? IX[i] : 0.0f; // bwdflat_mega.cpp:55
@@ -274,8 +330,6 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			cM[r] = cIX[r] = cJX[r] = cIY[r] = cJY[r] = LZ; // virtual column LY+1
 		}
 		float gM = LZ; // row (t+1)*H+1 at column j+1: diagonal of r=H-1
-		u64 *cand = p.cand + (u64)pid * p.capc;
-		u32 ncand = 0;
 		int ynext_prev = 0;
 		ylo_prev = 0; yhi_prev = 0; insy_prev = 0.0f;
 		const int bsteps = LY + T - 1;
@@ -285,6 +339,16 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			float nM = mpc_lane_down1(cM[0]);
 			float nIX = mpc_lane_down1(cIX[0]);
 			float nJX = mpc_lane_down1(cJX[0]);
+			if (LONG && bb > 0) {
+				// the first row of the block below comes back from the line buffer (lane 63 is at column LY - s)
+				if ((s & 63) == 0) {
+					const int jj = LY - s - t;
+					const bool in = jj >= 1;
+					pfM = in ? bnd_in[0 * ld + jj] : LZ; pfIX = in ? bnd_in[1 * ld + jj] : LZ; pfJX = in ? bnd_in[2 * ld + jj] : LZ;
+				}
+				const float bM = mpc_read_lane(pfM, s & 63), bIX = mpc_read_lane(pfIX, s & 63), bJX = mpc_read_lane(pfJX, s & 63);
+				if (t == 63) { nM = bM; nIX = bIX; nJX = bJX; }
+			} else
 			if (t == 63) { nM = LZ; nIX = LZ; nJX = LZ; } // nothing below the wave: virtual row
 			const int jl = LY - s; // column of the leading lane T-1
 			int yc = 0;
@@ -310,7 +374,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 				insy = s_ins[yc];
 			}
 			const int sf = j + t; // forward step that stored column j of this lane (uniform: LY-s+T-1)
-			const float *fmrow = fm + ((u64)(sf < 0 ? 0 : sf) * H) * 64 + t;
+			const float *fmrow = fmb + ((u64)(sf < 0 ? 0 : sf) * H) * 64 + t;
 			float dgM = gM;                           // M(i+1, j+1)
 			float dnIX = nIX, dnJX = nJX;             // (i+1, j)
 			float newfirstM = LZ;
@@ -318,7 +382,7 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			float sc[H];
 #pragma unroll
 			for (int r = H - 1; r >= 0; --r) {
-				const int i = t * H + r + 1;
+				const int i = i0 + t * H + r + 1;
 				const float oM = cM[r], oIY = cIY[r], oJY = cJY[r]; // (i, j+1)
 				// bwdflat3.cpp:75-79
 				const float xM = dgM + (MEGA ? mpc_mega_match(s_match, mg_alpha, xl[MEGA ? r : 0], yi) // bwdflat_mega.cpp:79-80
@@ -355,16 +419,19 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 			gM = nM;
 			ynext_prev = yc;
 			ylo_prev = ylo; yhi_prev = yhi; insy_prev = insy;
+			if (LONG && b > 0 && t == 0 && j >= 1 && j <= LY) { // row i0+1 for the block above
+				bnd_out[0 * ld + j] = cM[0]; bnd_out[1 * ld + j] = cIX[0]; bnd_out[2 * ld + j] = cJX[0];
+			}
 			if (__ballot(anyhit)) {
 #pragma unroll
 				for (int r = 0; r < H; ++r) {
-					const int i = t * H + r + 1;
+					const int i = i0 + t * H + r + 1;
 					const bool hit = (i <= LX) && (j >= 1) && (j <= LY) && (sc[r] >= p.thr);
 					const u64 bal = __ballot(hit);
 					if (bal) {
 						const u32 pos = ncand + (u32)__popcll(bal & ((1ull << t) - 1ull));
 						if (hit && pos < p.capc) {
-							const u32 idx = ((u32)(i - 1) << MPC_KEY_ROW_SHIFT) | (u32)(j - 1);
+							const u32 idx = ((u32)(i - 1) << (LONG ? MPC_KEY_ROW_SHIFT_LONG : MPC_KEY_ROW_SHIFT)) | (u32)(j - 1);
 							cand[pos] = ((u64)idx << 32) | (u64)__float_as_uint(sc[r]);
 						}
 						ncand += (u32)__popcll(bal);
@@ -372,6 +439,8 @@ __global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 				}
 			}
 		}
+		if (LONG) MPC_WAVE_FENCE();
+		} // row blocks (backward)
 		if (t == 0)
 			p.cand_cnt[pid] = ncand;
 	}

@@ -40,7 +40,11 @@ struct PostParams {
 	float *ea;      // per batch-local pair
 	u32 *flags;     // per batch-local pair: bit0 = candidate overflow
 	u32 count;      // pairs in this batch
+	u32 long_min;   // pairs with LX >= long_min came from a row-block (LONG) fb kernel: 16-bit column keys
 };
+
+// candidate key layout of a pair (kernels_fb.h): row << shift | column
+__device__ __forceinline__ u32 mpc_key_shift(u32 LX, u32 long_min) { return LX >= long_min ? MPC_KEY_ROW_SHIFT_LONG : MPC_KEY_ROW_SHIFT; }
 
 __device__ __forceinline__ u32 mpc_next_pow2(u32 v)
 {
@@ -76,6 +80,7 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 
 	for (u32 pid = blockIdx.x; pid < p.count; pid += gridDim.x) {
 		const u32 LX = p.seq_len[p.pair_x[pid]], LY = p.seq_len[p.pair_y[pid]];
+		const u32 kshift = mpc_key_shift(LX, p.long_min);
 		u32 *rec = p.res + (u64)pid * p.res_stride;
 		u32 c = p.cand_cnt[pid];
 		if (c > p.capc) { // overflow: reported to the host, which fails loudly
@@ -113,8 +118,8 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 		const u32 c0 = t * C;
 		u32 e = 0; // wave-uniform cursor into the sorted candidates
 		for (u32 i = 0; i < LX; ++i) {
-			const u32 rlo = i << MPC_KEY_ROW_SHIFT; // key range of posterior row i: [rlo, rhi) (64-bit: row 1023 ends at 2^32)
-			const u64 rhi = (u64)(i + 1) << MPC_KEY_ROW_SHIFT;
+			const u32 rlo = i << kshift; // key range of posterior row i: [rlo, rhi) (64-bit: the last row ends at 2^32)
+			const u64 rhi = (u64)(i + 1) << kshift;
 			u32 e1 = e;
 			while (e1 < c && (buf[e1] >> 32) < rhi) ++e1;
 			if (e1 > e) {
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 			if (k) {
 				const u32 rank = base + (u32)__popcll(bal & ((1ull << t) - 1ull));
 				const u32 idx = (u32)(key >> 32);
-				const u32 row = idx >> MPC_KEY_ROW_SHIFT, col = idx & MPC_KEY_COL_MASK;
+				const u32 row = idx >> kshift, col = idx & ((1u << kshift) - 1u);
 				ent[2 * (u64)rank] = (u32)key;
 				ent[2 * (u64)rank + 1] = col;
 				rowv[rank] = row;
@@ -235,6 +240,7 @@ struct PostRowsParams {
 	float *ea;
 	u32 *flags;
 	u32 count;
+	u32 long_min; // as in PostParams
 };
 
 __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
@@ -248,6 +254,7 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 
 	for (u32 pid = blockIdx.x; pid < p.count; pid += gridDim.x) {
 		const u32 LX = p.seq_len[p.pair_x[pid]], LY = p.seq_len[p.pair_y[pid]];
+		const u32 kshift = mpc_key_shift(LX, p.long_min);
 		u32 *rec = p.res + (u64)pid * p.res_stride;
 		const u32 c = p.cand_cnt[pid];
 		if (c > p.capc) { // overflow: reported to the host, which retries with a larger capacity
@@ -266,7 +273,7 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			const u64 v = cand[q];
 			const float pr = mpc_score_to_prob(__uint_as_float((u32)v), p.use_fma);
 			cand[q] = (v & 0xffffffff00000000ull) | (u64)__float_as_uint(pr);
-			atomicAdd(&s_rend[(u32)(v >> (32 + MPC_KEY_ROW_SHIFT))], 1u);
+			atomicAdd(&s_rend[(u32)(v >> (32 + kshift))], 1u);
 		}
 		__syncthreads();
 		// exclusive scan of the row counts (in place: s_rend[i] = first slot of row i)
@@ -288,8 +295,8 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 		// scatter through the per-row cursor: afterwards s_rend[i] = END of row i (start of row i+1)
 		for (u32 q = t; q < c; q += 64) {
 			const u64 v = cand[q];
-			const u32 at = atomicAdd(&s_rend[(u32)(v >> (32 + MPC_KEY_ROW_SHIFT))], 1u);
-			sorted[at] = ((v >> 32) & (u64)MPC_KEY_COL_MASK) << 32 | (v & 0xffffffffull);
+			const u32 at = atomicAdd(&s_rend[(u32)(v >> (32 + kshift))], 1u);
+			sorted[at] = ((v >> 32) & (u64)((1u << kshift) - 1u)) << 32 | (v & 0xffffffffull);
 		}
 		__syncthreads();
 		// columns ascending inside each row (a lane per row; rows hold a handful of cells)

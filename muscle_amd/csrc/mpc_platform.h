@@ -37,6 +37,9 @@ __device__ __forceinline__ unsigned mpc_read_lane(unsigned v, unsigned l) { retu
 __device__ __forceinline__ float mpc_read_lane(float v, unsigned l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l)); }
 // optimisation barrier on one VGPR value (no code): stops hoisting of what is derived from it
 #define MPC_OPAQUE(v) asm volatile("" : "+v"(v))
+// orders this wave's earlier global stores before its later global loads (other lanes' data): s_waitcnt only,
+// the waves of a workgroup share the CU's L1
+#define MPC_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
 // value held by the first active lane, as a wave-uniform scalar (v_readfirstlane_b32 -> SGPR)
 __device__ __forceinline__ unsigned mpc_wave_first(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 #endif

@@ -120,6 +120,7 @@ struct mpcgpu_ctx {
 	u32 tiles_bx = 0, tiles_by = 0;
 
 	// scratch
+	DevBuf d_bnd;
 	DevBuf d_queue, d_order, d_bx, d_by, d_fm, d_cand, d_cand_cnt, d_total, d_res, d_nnz, d_ea, d_flags,
 		d_sort_scratch, d_srow_scratch, d_dstbase, d_recwords, d_exp_off, d_exp_val, d_exp_offbase;
 
@@ -217,18 +218,34 @@ int env_int(const char *name, int dflt)
 	return (s && *s) ? atoi(s) : dflt;
 }
 
-template <int H, bool MEGA> void launch_fb(const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+template <int H, bool MEGA, bool LONG = false> void launch_fb(const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
-	auto kern = fb_kernel<H, MEGA>;
+	auto kern = fb_kernel<H, MEGA, LONG>;
 	MPC_LAUNCH(kern, grid, block, smem, st, p);
 }
 
-template <int H, bool MEGA> int occ_fb(u32 block, size_t smem)
+template <int H, bool MEGA, bool LONG = false> int occ_fb(u32 block, size_t smem)
 {
 	int nb = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_kernel<H, MEGA>, (int)block, smem) != hipSuccess || nb < 1)
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_kernel<H, MEGA, LONG>, (int)block, smem) != hipSuccess || nb < 1)
 		nb = 1;
 	return nb;
+}
+
+// Row-block kernels (sequences X longer than 64*MPC_HMAX): H = MPC_LONG_H rows per lane; H = 1 exists so that
+// tests reach several blocks with short sequences (MPCGPU_FB_LONG_H=1 MPCGPU_FB_LONG_MIN=<rows>).
+#define MPC_LONG_H 7
+int occ_fb_long(int H, bool mega, u32 block, size_t smem)
+{
+	if (H == 1) return mega ? occ_fb<1, true, true>(block, smem) : occ_fb<1, false, true>(block, smem);
+	return mega ? occ_fb<MPC_LONG_H, true, true>(block, smem) : occ_fb<MPC_LONG_H, false, true>(block, smem);
+}
+
+void launch_fb_long(int H, bool mega, const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+{
+	if (H == 1) { if (mega) launch_fb<1, true, true>(p, grid, block, smem, st); else launch_fb<1, false, true>(p, grid, block, smem, st); }
+	else if (mega) launch_fb<MPC_LONG_H, true, true>(p, grid, block, smem, st);
+	else launch_fb<MPC_LONG_H, false, true>(p, grid, block, smem, st);
 }
 
 int occ_fb_h(int H, bool mega, u32 block, size_t smem)
@@ -438,7 +455,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 	(void)hipStreamSynchronize(c->stream);
 	for (auto &sp : c->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
 	DevBuf *all[] = {&c->d_seq_code, &c->d_seq_off, &c->d_seq_len, &c->d_match, &c->d_ins, &c->d_pair_x, &c->d_pair_y,
-		&c->d_mg_prof, &c->d_mg_ins, &c->d_mg_tab, &c->d_mg_in,
+		&c->d_mg_prof, &c->d_mg_ins, &c->d_mg_tab, &c->d_mg_in, &c->d_bnd,
 		&c->d_shard, &c->d_pbase, &c->d_vbase, &c->d_rp, &c->d_rp_base, &c->d_ent, &c->d_ent_base, &c->d_mbase,
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
@@ -665,9 +682,17 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		LXmax = std::max(LXmax, LX); LYmax = std::max(LYmax, LY);
 		c->work_cells += (u64)(LX + 1) * (LY + 1);
 	}
-	if (LXmax > 64u * MPC_HMAX)
-		return fail(c, "mpcgpu_calc_posteriors: row sequence length %u exceeds %u (row-block tiling for longer "
-			"sequences is not implemented in this build)", LXmax, 64u * MPC_HMAX);
+	// X longer than 64*MPC_HMAX rows: row-block (LONG) kernels, 16-bit row/column candidate keys
+	const u32 long_h = env_int("MPCGPU_FB_LONG_H", MPC_LONG_H) == 1 ? 1u : (u32)MPC_LONG_H;
+	const u32 long_min = (u32)std::min(std::max(env_int("MPCGPU_FB_LONG_MIN", 64 * MPC_HMAX + 1), 2), 64 * MPC_HMAX + 1);
+	u32 LXlong = 0, LYlong = 0; // extents over the LONG pairs
+	for (u64 k = 0; k < np; ++k) {
+		const u32 LX = c->len[px[k]], LY = c->len[py[k]];
+		if (LX >= long_min) { LXlong = std::max(LXlong, LX); LYlong = std::max(LYlong, LY); }
+	}
+	if (LXlong > MPC_KEY_COL_MASK_LONG || LYlong > MPC_KEY_COL_MASK_LONG)
+		return fail(c, "mpcgpu_calc_posteriors: a pair of %u x %u positions is beyond this build's limit of %u per sequence "
+			"once the row sequence is longer than %u", LXlong, LYlong, MPC_KEY_COL_MASK_LONG, long_min - 1);
 	const u32 Lmax = std::max(LXmax, LYmax);
 	u32 capc = (u32)std::max(env_int("MPCGPU_CAND_PER_ROW", 12), 1) * Lmax;
 	capc = std::max(capc, 1024u);
@@ -692,13 +717,14 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		std::vector<u32> bx(B), by(B), hh(B);
 		std::vector<u32> order(B);
 		std::vector<u64> wk(B);
-		u32 hcount[MPC_HMAX + 1] = {0};
+		u32 hcount[MPC_HMAX + 2] = {0}; // bin MPC_HMAX+1: the row-block (LONG) pairs
 		for (u64 q = 0; q < B; ++q) {
 			bx[q] = px[b0 + q]; by[q] = py[b0 + q];
 			const u32 LX = c->len[bx[q]], LY = c->len[by[q]];
-			const u32 H = (LX + 63) / 64;
+			const bool lng = LX >= long_min;
+			const u32 H = lng ? MPC_HMAX + 1 : (LX + 63) / 64;
 			hh[q] = H; hcount[H]++;
-			wk[q] = (u64)(LY + (LX + H - 1) / H) * H;
+			wk[q] = lng ? (u64)LX * LY : (u64)(LY + (LX + H - 1) / H) * H;
 			order[q] = (u32)q;
 		}
 		std::sort(order.begin(), order.end(), [&](u32 a, u32 b) {
@@ -714,8 +740,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		HIPCHK(c, c->d_nnz.ensure(B * 4));
 		HIPCHK(c, c->d_ea.ensure(B * 4));
 		HIPCHK(c, c->d_flags.ensure(B * 4));
-		HIPCHK(c, c->d_queue.ensure(4 * (MPC_HMAX + 1)));
-		HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (MPC_HMAX + 1), c->stream));
+		HIPCHK(c, c->d_queue.ensure(4 * (MPC_HMAX + 2)));
+		HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (MPC_HMAX + 2), c->stream));
 
 		FbParams fp;
 		fp.seq_code = c->d_seq_code.as<u8>(); fp.seq_off = c->d_seq_off.as<u64>(); fp.seq_len = c->d_seq_len.as<u32>();
@@ -730,12 +756,50 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		fp.mg_prof = mega ? c->d_mg_prof.as<u64>() : nullptr; fp.mg_ins = mega ? c->d_mg_ins.as<float>() : nullptr;
 		fp.mg_tab = mega ? c->d_mg_tab.as<float>() : nullptr; fp.mg_tab_floats = mega ? c->mg_tab_floats : 0;
 		for (u32 f = 0; f < MPC_MEGA_FMAX; ++f) { fp.mg_base[f] = mega ? c->mg_base[f] : 0; fp.mg_alpha[f] = mega ? c->mg_alpha[f] : 0; }
+		fp.bnd = nullptr; fp.bnd_stride = 0; fp.bnd_ld = 0; fp.fm_block = 0;
 		// row-list post kernel (no sorts, 3 LDS trips per EA row) when LY fits its LDS arrays; MPCGPU_POST=sort forces the general one
 		const char *post_mode = getenv("MPCGPU_POST");
-		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) && LYmax + 1 <= 2048u;
+		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) && LYmax + 1 <= 2048u &&
+			((size_t)LXmax + 2 + 2 * ((size_t)LYmax + 2)) * 4 + 8 + 8 * (size_t)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2) <= 64 * 1024;
 
 		TimedSpan sp;
 		u32 pos = 0;
+		if (hcount[MPC_HMAX + 1]) { // ---- row-block pairs (the order lists them last: bins ascend)
+			const u32 cnt = hcount[MPC_HMAX + 1];
+			u32 first = 0;
+			for (u32 H = 1; H <= MPC_HMAX; ++H) first += hcount[H];
+			const u32 nbmax = (LXlong + 64 * long_h - 1) / (64 * long_h);
+			const u64 fm_block = (u64)(LYlong + 64) * long_h * 64;
+			const u64 fm_stride = fm_block * nbmax;
+			const u32 ld = (LYlong + 2 + 63) & ~63u;
+			// resident waves are bounded by the forward M planes they keep (LX*LY floats each)
+			size_t freeb2 = 0, totb2 = 0;
+			HIPCHK(c, hipMemGetInfo(&freeb2, &totb2));
+			const u64 fm_budget = std::min<u64>((u64)env_int("MPCGPU_SCRATCH_GB", 16) << 30, (u64)(freeb2 * 0.5));
+			const u64 max_waves = fm_budget / (fm_stride * 4 + 16ull * ld * 4);
+			if (max_waves < 1)
+				return fail(c, "mpcgpu_calc_posteriors: not enough device memory for the forward plane of a %u x %u pair", LXlong, LYlong);
+			const u32 occ = (u32)occ_fb_long((int)long_h, mega, block, fb_smem);
+			u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ);
+			grid = (u32)std::max<u64>(std::min<u64>(grid, max_waves / waves_per_block), 1);
+			const u32 wpb = max_waves < (u64)waves_per_block ? (u32)max_waves : (u32)waves_per_block; // fewer waves per workgroup when memory is that tight
+			HIPCHK(c, c->d_fm.ensure((u64)grid * wpb * fm_stride * 4));
+			HIPCHK(c, c->d_bnd.ensure((u64)grid * wpb * 16 * ld * 4));
+			if (trace_on()) {
+				fprintf(stderr, "[mpcgpu] fb row blocks: H=%u pairs=%u blocks<=%u grid=%u x %u waves occ=%u fm=%.1f MB\n", long_h, cnt, nbmax,
+					grid, wpb, occ, (double)grid * wpb * fm_stride * 4 / 1048576.0);
+				fflush(stderr);
+			}
+			fp.order = c->d_order.as<u32>() + first; fp.count = cnt;
+			fp.queue = c->d_queue.as<u32>() + MPC_HMAX + 1;
+			fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride; fp.fm_block = fm_block;
+			fp.bnd = c->d_bnd.as<float>(); fp.bnd_stride = 16ull * ld; fp.bnd_ld = ld;
+			if (span_begin(c, 0, &sp)) return 1;
+			launch_fb_long((int)long_h, mega, fp, grid, 64 * wpb, fb_smem, c->stream);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &sp)) return 1;
+			fp.bnd = nullptr; fp.bnd_stride = 0; fp.bnd_ld = 0; fp.fm_block = 0;
+		}
 		for (u32 H = 1; H <= MPC_HMAX; ++H) {
 			if (!hcount[H]) continue;
 			const u32 cnt = hcount[H];
@@ -778,6 +842,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			pr.res = c->d_res.as<u32>(); pr.res_stride = res_stride;
 			pr.nnz = c->d_nnz.as<u32>(); pr.ea = c->d_ea.as<float>(); pr.flags = c->d_flags.as<u32>();
 			pr.count = (u32)B;
+			pr.long_min = long_min;
 			if (trace_on()) { fprintf(stderr, "[mpcgpu] post rows: lds=%zu B blocks/CU=%d grid=%u\n", smem, pocc, pgrid); fflush(stderr); }
 			if (span_begin(c, 1, &sp)) return 1;
 			MPC_LAUNCH(post_rows_kernel, pgrid, 64, smem, c->stream, pr);
@@ -807,6 +872,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		pp.res = c->d_res.as<u32>(); pp.res_stride = res_stride;
 		pp.nnz = c->d_nnz.as<u32>(); pp.ea = c->d_ea.as<float>(); pp.flags = c->d_flags.as<u32>();
 		pp.count = (u32)B;
+		pp.long_min = long_min;
 		const size_t psmem = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
 		if (span_begin(c, 1, &sp)) return 1;
 		MPC_LAUNCH(post_kernel, pgrid, 64, psmem, c->stream, pp);

@@ -1,56 +1,155 @@
 // tests/emu/hip_emu.cpp — TEST INFRASTRUCTURE ONLY. See hip_emu.h.
 #include "hip_emu.h"
 
+#include <sys/mman.h>
+
 thread_local dim3 threadIdx;
 thread_local dim3 blockIdx;
 dim3 blockDim;
 dim3 gridDim;
 
+// Context switch between fibers of one OS thread (System V x86-64): callee-saved registers and the
+// stack pointer; the floating-point control state is the same everywhere and is left alone.
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+asm(R"(
+	.text
+	.globl emu_switch
+	.type emu_switch, @function
+emu_switch:
+	pushq %rbp
+	pushq %rbx
+	pushq %r12
+	pushq %r13
+	pushq %r14
+	pushq %r15
+	movq %rsp, (%rdi)
+	movq %rsi, %rsp
+	popq %r15
+	popq %r14
+	popq %r13
+	popq %r12
+	popq %rbx
+	popq %rbp
+	ret
+	.size emu_switch, .-emu_switch
+)");
+
 namespace emu {
-BlockState *g_block = nullptr;
+thread_local BlockState *g_block = nullptr;
 thread_local WaveState *t_wave = nullptr;
 thread_local unsigned t_lane = 0;
 
-void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()> &body)
+namespace {
+constexpr size_t STACK_BYTES = 256 * 1024; // mapped lazily: only touched pages cost memory
+
+struct Fiber {
+	void *sp = nullptr;
+	char *stack = nullptr;
+	unsigned tid = 0;
+	bool done = false;
+};
+
+struct Worker {
+	std::vector<Fiber> fibers;
+	Fiber *cur = nullptr;
+	void *sched_sp = nullptr;
+	const std::function<void()> *body = nullptr;
+	~Worker()
+	{
+		for (Fiber &f : fibers)
+			if (f.stack) munmap(f.stack, STACK_BYTES);
+	}
+};
+thread_local Worker *t_worker = nullptr;
+
+void fiber_entry()
+{
+	Worker *w = t_worker;
+	(*w->body)();
+	w->cur->done = true;
+	emu_switch(&w->cur->sp, w->sched_sp); // never resumed
+	abort();
+}
+
+void run_block(Worker &w, unsigned bid, dim3 block, size_t smem)
 {
 	const unsigned nthreads = block.x;
-	if (nthreads == 0 || grid.x == 0)
-		return;
 	BlockState bs;
-	pthread_barrier_init(&bs.bar, nullptr, nthreads);
+	bs.bar.n = (int)nthreads;
 	const unsigned nwaves = (nthreads + 63) / 64;
-	for (unsigned w = 0; w < nwaves; ++w) {
-		WaveState *ws = new WaveState;
-		ws->nthreads = (int)std::min(64u, nthreads - w * 64);
-		pthread_barrier_init(&ws->bar, nullptr, ws->nthreads);
-		bs.waves.push_back(ws);
+	bs.waves.resize(nwaves);
+	for (unsigned k = 0; k < nwaves; ++k) {
+		bs.waves[k].nthreads = (int)std::min(64u, nthreads - k * 64);
+		bs.waves[k].bar.n = bs.waves[k].nthreads;
 	}
 	std::vector<unsigned char> dyn(smem + 64);
 	bs.dyn_smem = (unsigned char *)(((uintptr_t)dyn.data() + 15) & ~(uintptr_t)15);
 	g_block = &bs;
+	if (w.fibers.size() < nthreads) w.fibers.resize(nthreads);
+	for (unsigned t = 0; t < nthreads; ++t) {
+		Fiber &f = w.fibers[t];
+		if (!f.stack) {
+			void *m = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+			if (m == MAP_FAILED) { perror("emu: mmap fiber stack"); abort(); }
+			f.stack = (char *)m;
+		}
+		f.tid = t;
+		f.done = false;
+		// initial frame: six callee-saved registers, then the entry point as the return address; after the
+		// `ret` the stack pointer is 8 modulo 16, as at any function entry
+		uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15;
+		void **sp = (void **)(top - 8);
+		*sp = nullptr;                // "return address" of fiber_entry (it never returns)
+		*--sp = (void *)&fiber_entry; // popped by emu_switch's ret
+		for (int k = 0; k < 6; ++k) *--sp = nullptr;
+		f.sp = sp;
+	}
+	unsigned remaining = nthreads;
+	while (remaining) {
+		for (unsigned t = 0; t < nthreads; ++t) {
+			Fiber &f = w.fibers[t];
+			if (f.done) continue;
+			w.cur = &f;
+			threadIdx = dim3(t, 0, 0);
+			blockIdx = dim3(bid, 0, 0);
+			t_wave = &bs.waves[t / 64];
+			t_lane = t % 64;
+			emu_switch(&w.sched_sp, f.sp);
+			if (f.done) --remaining;
+		}
+	}
+	g_block = nullptr;
+}
+} // namespace
+
+void yield()
+{
+	Worker *w = t_worker;
+	emu_switch(&w->cur->sp, w->sched_sp);
+}
+
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()> &body)
+{
+	if (block.x == 0 || grid.x == 0)
+		return;
 	blockDim = block;
 	gridDim = grid;
+	static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+	const unsigned nworkers = std::min(hw, grid.x);
+	auto work = [&](unsigned wi) {
+		Worker w;
+		w.body = &body;
+		t_worker = &w;
+		for (unsigned b = wi; b < grid.x; b += nworkers)
+			run_block(w, b, block, smem);
+		t_worker = nullptr;
+	};
+	if (nworkers == 1) { // no OS thread at all for single-block launches
+		work(0);
+		return;
+	}
 	std::vector<std::thread> th;
-	th.reserve(nthreads);
-	for (unsigned t = 0; t < nthreads; ++t) {
-		th.emplace_back([&, t]() {
-			threadIdx = dim3(t, 0, 0);
-			t_wave = bs.waves[t / 64];
-			t_lane = t % 64;
-			for (unsigned b = 0; b < grid.x; ++b) {
-				blockIdx = dim3(b, 0, 0);
-				body();
-				pthread_barrier_wait(&bs.bar); // all threads of the block finish before the next block
-			}
-		});
-	}
-	for (auto &t : th)
-		t.join();
-	for (auto *w : bs.waves) {
-		pthread_barrier_destroy(&w->bar);
-		delete w;
-	}
-	pthread_barrier_destroy(&bs.bar);
-	g_block = nullptr;
+	for (unsigned wi = 0; wi < nworkers; ++wi) th.emplace_back(work, wi);
+	for (auto &t : th) t.join();
 }
 } // namespace emu

@@ -3,9 +3,10 @@
 // A tiny SIMT emulator: just enough of the HIP runtime + device intrinsics for the sources in
 // muscle_amd/csrc to be compiled by g++ (-DMPC_EMU) into tests/emu/libmpcgpu_emu.so, so kernel
 // logic (indexing, skew schedules, boundary cases, orchestration, buffer sizing) can be checked
-// against the oracle in this GPU-less container BEFORE a gpurun call is spent. One OS thread per
-// GPU thread of the running block; wave collectives (shuffles, ballot) and __syncthreads are
-// pthread barriers; blocks run one after another. Slow by design: tiny inputs only.
+// against the oracle in this GPU-less container BEFORE a gpurun call is spent. Every GPU thread of a
+// block is a fiber (own stack, hand-written x86-64 context switch, no system calls) of one OS thread;
+// wave collectives (shuffles, ballot) and __syncthreads are cooperative barriers: a fiber that has to wait
+// yields to the next one. Blocks are spread over a few OS threads. Slow by design: tiny inputs only.
 // The product path (muscle_amd/csrc/libmpcgpu.so, hipcc --offload-arch=gfx950) never sees this.
 #pragma once
 #include <algorithm>
@@ -17,7 +18,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -35,25 +35,37 @@ struct dim3 {
 };
 
 namespace emu {
+struct Barrier {
+	int n = 0, count = 0;
+	unsigned gen = 0;
+};
 struct WaveState {
-	pthread_barrier_t bar;
+	Barrier bar;
 	uint64_t xbuf[64];
 	int nthreads;
 };
 struct BlockState {
-	pthread_barrier_t bar;
-	std::vector<WaveState *> waves;
+	Barrier bar;
+	std::vector<WaveState> waves;
 	unsigned char *dyn_smem;
 };
-extern BlockState *g_block;
-extern thread_local WaveState *t_wave;
+extern thread_local BlockState *g_block; // the block this OS thread is running
+extern thread_local WaveState *t_wave;   // of the running fiber
 extern thread_local unsigned t_lane;
+void yield(); // give the OS thread to the next fiber of the block
+// all fibers of a barrier live on one OS thread: plain counters
+static inline void barrier_wait(Barrier &b)
+{
+	const unsigned g = b.gen;
+	if (++b.count == b.n) { b.count = 0; ++b.gen; }
+	else while (b.gen == g) yield();
+}
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()> &body);
 } // namespace emu
 
 extern thread_local dim3 threadIdx;
 extern thread_local dim3 blockIdx;
-extern dim3 blockDim;
+extern dim3 blockDim; // one launch at a time
 extern dim3 gridDim;
 
 #define MPC_LAUNCH(kern, grid, block, smem, stream, ...) \
@@ -61,7 +73,7 @@ extern dim3 gridDim;
 #define MPC_DYN_SMEM(name) unsigned char *name = emu::g_block->dyn_smem
 
 // ---- device intrinsics -------------------------------------------------------------------
-static inline void __syncthreads() { pthread_barrier_wait(&emu::g_block->bar); }
+static inline void __syncthreads() { emu::barrier_wait(emu::g_block->bar); }
 
 template <class T> static inline T emu_xchg(T v, int src_lane_delta, bool absolute)
 {
@@ -70,18 +82,19 @@ template <class T> static inline T emu_xchg(T v, int src_lane_delta, bool absolu
 	uint64_t raw = 0;
 	memcpy(&raw, &v, sizeof(T));
 	w->xbuf[emu::t_lane] = raw;
-	pthread_barrier_wait(&w->bar);
+	emu::barrier_wait(w->bar);
 	int src = absolute ? src_lane_delta : (int)emu::t_lane + src_lane_delta;
 	T r = v;
 	if (src >= 0 && src < w->nthreads)
 		memcpy(&r, &w->xbuf[src], sizeof(T));
-	pthread_barrier_wait(&w->bar);
+	emu::barrier_wait(w->bar);
 	return r;
 }
 template <class T> static inline T __shfl_up(T v, unsigned d) { return emu_xchg(v, -(int)d, false); }
 template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xchg(v, (int)d, false); }
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
 #define MPC_OPAQUE(v) ((void)0)
+#define MPC_WAVE_FENCE() ((void)0) // emulated lanes meet at every shuffle
 template <class T> static inline T mpc_read_lane(T v, unsigned l) { return __shfl(v, (int)l); }
 template <class T> static inline T mpc_lane_up1(T v) { return __shfl_up(v, 1); }
 template <class T> static inline T mpc_lane_down1(T v) { return __shfl_down(v, 1); }
@@ -98,11 +111,11 @@ static inline unsigned long long __ballot(int pred)
 {
 	emu::WaveState *w = emu::t_wave;
 	w->xbuf[emu::t_lane] = pred ? 1 : 0;
-	pthread_barrier_wait(&w->bar);
+	emu::barrier_wait(w->bar);
 	unsigned long long m = 0;
 	for (int i = 0; i < w->nthreads; ++i)
 		if (w->xbuf[i]) m |= (1ull << i);
-	pthread_barrier_wait(&w->bar);
+	emu::barrier_wait(w->bar);
 	return m;
 }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }

@@ -244,3 +244,22 @@ def test_emu_mega_then_letters_on_one_context(emu):
     assert np.array_equal(P.bits(ea_mega), P.bits(P.run_oracle(seqs, iters=0, mega=mega)[1]))
     assert np.array_equal(P.bits(ea_plain), P.bits(P.run_oracle(seqs, iters=0)[1]))
     assert not np.array_equal(P.bits(ea_mega), P.bits(ea_plain))
+
+
+# ---- row blocks: fb_kernel<H, MEGA, LONG=true> (sequences X longer than 64*MPC_HMAX rows) -------------------
+# H = 1 and a low threshold reach several 64-row blocks with short sequences (the GPU tests use real lengths).
+def test_emu_row_blocks(emu):
+    seqs = [make_family(1, 131, seed=21)[0], make_family(1, 66, seed=22)[0], make_family(1, 64, seed=24)[0], "MKV"]
+    # every pair through the row-block kernel: 3, 2 and 1 blocks (LX = 131, 66, 64, 3)
+    got = _with_env({"MPCGPU_FB_LONG_H": "1", "MPCGPU_FB_LONG_MIN": "2"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "row blocks")
+
+
+def test_emu_row_blocks_general_post_and_mega(emu):
+    seqs = [make_family(1, 130, seed=31)[0], make_family(1, 66, seed=33)[0]]
+    env = {"MPCGPU_FB_LONG_H": "1", "MPCGPU_FB_LONG_MIN": "65"}
+    got = _with_env(dict(env, MPCGPU_POST="sort"), lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "row blocks + general post kernel")
+    mega = P.random_mega(seqs, seed=9)
+    got = _with_env(env, lambda: P.run_lib(seqs, lib_path=emu, mega=mega))
+    P.assert_same(got, P.run_oracle(seqs, mega=mega), "row blocks + mega")

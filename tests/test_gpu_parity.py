@@ -81,6 +81,24 @@ def test_ragged_and_extremes():
     P.assert_same(P.run_lib(seqs), P.run_oracle(seqs, threads=0), "ragged")
 
 
+def test_long_rows_row_blocks():
+    """X longer than 64*16 rows: the row-block kernel (fb_kernel<7, MEGA, LONG>: 448-row blocks chained through
+    the line buffers). 1024 is the last single-block length, 1025 the first with blocks; 2049 columns also
+    sends the batch to the general post kernel; the relax of such records takes the gather fallback."""
+    seqs = [make_family(1, 1500, seed=41)[0][:1500], (make_family(1, 1100, seed=42)[0] * 2)[:1025],
+            (make_family(1, 1100, seed=43)[0] * 2)[:1024], make_family(1, 333, seed=44)[0],
+            (make_family(1, 2300, seed=45)[0] * 2)[:2049]]
+    P.assert_same(P.run_lib(seqs), P.run_oracle(seqs, threads=0), "row blocks")
+
+
+def test_long_rows_row_lists_and_mega():
+    """row-block pairs through the default post kernel (16-bit column keys), then with structure profiles"""
+    seqs = [make_family(1, 1400, seed=51)[0], make_family(1, 1030, seed=52)[0], make_family(1, 200, seed=53)[0]]
+    P.assert_same(P.run_lib(seqs), P.run_oracle(seqs, threads=0), "row blocks, row lists")
+    mega = P.random_mega(seqs, seed=13)
+    P.assert_same(P.run_lib(seqs, mega=mega), P.run_oracle(seqs, mega=mega, threads=0), "row blocks, mega")
+
+
 def test_identical_sequences_saturate():
     s = make_family(1, 120, seed=8)[0]
     seqs = [s, s, s[:100], s[10:]]
