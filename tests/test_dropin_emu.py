@@ -33,7 +33,11 @@ def emu_muscle():
 
 @pytest.mark.parametrize("name", ["n2_L40+r2", "n3_L30+r2", "synth_6x40_s2+r2", "dupes+r2", "consiters0+r2", "perturb_small+r2", "super7_8x18_b4", "super5_14x20",
                                   # .mega inputs: structure-profile emissions in MPCFlat::CalcPosterior and in the PProg joins
-                                  "mega_bb11001+r2", "mega_synth_6x40_s2+r2", "mega_super7_6x16_b3"])
+                                  "mega_bb11001+r2", "mega_synth_6x40_s2+r2", "mega_super7_6x16_b3",
+                                  # full runs (100 refinement rounds): affordable since the emulator runs GPU threads as fibers
+                                  "n8_L60", "bb11001", "mega_bb11001", "perturb",
+                                  # sequences longer than 1024: row-block fb kernel + gather relax fallback
+                                  "synth_5x1300_s3"])
 def test_final_msa_identical(emu_muscle, name):
     md5, _ = _msa.run_muscle(emu_muscle, name, threads=3)
     assert md5 == _msa.golden_md5()[name]

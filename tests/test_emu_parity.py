@@ -263,3 +263,9 @@ def test_emu_row_blocks_general_post_and_mega(emu):
     mega = P.random_mega(seqs, seed=9)
     got = _with_env(env, lambda: P.run_lib(seqs, lib_path=emu, mega=mega))
     P.assert_same(got, P.run_oracle(seqs, mega=mega), "row blocks + mega")
+
+
+def test_emu_row_blocks_real_lengths(emu):
+    """the shipped configuration: LX >= 1025 -> fb_kernel<7, MEGA, LONG> with 448-row blocks (3 and 4 blocks here)"""
+    seqs = [make_family(1, 1400, seed=51)[0], make_family(1, 1030, seed=52)[0], make_family(1, 200, seed=53)[0]]
+    P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "row blocks, real lengths")
