@@ -1,6 +1,7 @@
 // tests/emu/hip_emu.cpp — TEST INFRASTRUCTURE ONLY. See hip_emu.h.
 #include "hip_emu.h"
 
+#include <mutex>
 #include <sys/mman.h>
 
 thread_local dim3 threadIdx;
@@ -132,6 +133,8 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()> &bod
 {
 	if (block.x == 0 || grid.x == 0)
 		return;
+	static std::mutex one_launch; // blockDim/gridDim are process globals: launches of different host threads take turns
+	std::lock_guard<std::mutex> guard(one_launch);
 	blockDim = block;
 	gridDim = grid;
 	static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));

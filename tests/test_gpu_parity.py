@@ -191,6 +191,24 @@ def test_sharded_equals_whole():
     hip.hipFree(dptr)
 
 
+def test_two_rank_exchange_through_torch_tensors():
+    """bench.py's N>1 code (muscle_amd.mpcflat.run_stage + TorchExchange) with two ranks as two threads on this
+    one GPU and an in-process stand-in for the collectives: shards and values travel through torch CUDA tensors
+    (allocator/pointer interop with the library), store_import reads them, both ranks end bit-identical to a
+    single context. Fresh process: torch has to be imported before the library (tests/_torch_exchange_check.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(here) + os.pathsep + here)
+    env.pop("TEC_DEVICE", None)
+    env.pop("TEC_LIB", None)
+    r = subprocess.run([sys.executable, "-u", os.path.join(here, "_torch_exchange_check.py")], env=env, cwd=here,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240, text=True)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and "OK two-rank exchange" in r.stdout, r.stdout[-3000:]
+
+
 def test_back_to_back_iterations_without_sync():
     """The drop-in (hostcxx/mpcflat_gpu.cpp) and bench.py queue both relax iterations without reading
     anything back in between; the result must not depend on host-side synchronisation (regression:

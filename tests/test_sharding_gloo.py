@@ -170,3 +170,18 @@ def test_run_stage_world2_gloo_real_kernels():
         assert np.array_equal(P.bits(ea), P.bits(want_ea)), "rank %d EA" % rank
         for k, ((o1, v1), (o2, v2)) in enumerate(zip(final, want_stages[2])):
             assert np.array_equal(o1, o2) and np.array_equal(v1, v2), "rank %d pair %d" % (rank, k)
+
+
+def test_two_rank_thread_exchange_dry_run():
+    """tests/_torch_exchange_check.py (the -m gpu check of run_stage's exchange through torch tensors) on the SIMT
+    emulator with CPU tensors, so the script itself is known to work before it meets a GPU."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    emu_dir = os.path.join(here, "emu")
+    subprocess.check_call(["make", "-C", emu_dir], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(here) + os.pathsep + here, TEC_DEVICE="cpu",
+               TEC_LIB=os.path.join(emu_dir, "libmpcgpu_emu.so"))
+    r = subprocess.run([sys.executable, "-u", os.path.join(here, "_torch_exchange_check.py")], env=env, cwd=here,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240, text=True)
+    assert r.returncode == 0 and "OK two-rank exchange" in r.stdout, r.stdout[-3000:]
