@@ -269,3 +269,24 @@ def test_emu_row_blocks_real_lengths(emu):
     """the shipped configuration: LX >= 1025 -> fb_kernel<7, MEGA, LONG> with 448-row blocks (3 and 4 blocks here)"""
     seqs = [make_family(1, 1400, seed=51)[0], make_family(1, 1030, seed=52)[0], make_family(1, 200, seed=53)[0]]
     P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "row blocks, real lengths")
+
+
+# ---- host-side paths that only special sizes reach -------------------------------------------------------------
+def test_emu_candidate_overflow_retry(emu):
+    """a pair with more candidates than the buffer (floor 1024 entries) makes the batch run again with twice the room"""
+    seqs = make_family(3, 700, seed=61)
+    got = _with_env({"MPCGPU_CAND_PER_ROW": "1"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "overflow retry")
+
+
+def test_emu_one_pair_per_batch(emu):
+    """no scratch budget -> every pair is its own stage-A batch: the packed shard grows batch by batch"""
+    seqs = make_family(5, 40, seed=62) + ["MKV"]
+    got = _with_env({"MPCGPU_SCRATCH_GB": "0"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "one pair per batch")
+
+
+def test_emu_relax_512_thread_workgroups(emu):
+    seqs = make_family(7, 24, seed=63)
+    got = _with_env({"MPCGPU_RELAX_WG": "512"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "512-thread relax workgroups")
