@@ -161,7 +161,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 			}
 		};
 
-		const u32 wave_first = tid & ~63u; // first lane of my wave
+		// first lane of my wave, as a scalar: the "does my wave hold cells of slot q" tests below become scalar
+		// branches instead of exec-mask regions (the value is the same in all 64 lanes)
+		const u32 wave_first = mpc_wave_first(tid & ~63u);
 		stage_load(0);
 		for (u32 Z = 0; Z < n; ++Z) {
 			__syncthreads(); // every wave is done reading step Z-1 from LDS
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 				nx_a = ma[x]; nx_b = mb[y];               // first block of each row
 				nx_na = ma[x + 1] - nx_a; nx_nb = mb[y + 1] - nx_b; // blocks in each row
 			};
-			if (wave_first < total) fetch_rows(0);
+			fetch_rows(0); // unconditional: a lane without a cell holds the dummy descriptor (valid LDS reads)
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
 				if ((u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 					// a block is 16 bytes and the entry region starts 16-byte aligned: one ds_read_b128 per block
 					const MpcU4 *ea = (const MpcU4 *)__builtin_assume_aligned(lds + nx_oa + lcap1, 16) + nx_a;
 					const MpcU4 *eb = (const MpcU4 *)__builtin_assume_aligned(lds + nx_ob + lcap1, 16) + nx_b;
-					if (q + 1 < MPC_RT_SLOTS && (u32)(q + 1) * THREADS + wave_first < total) fetch_rows(q + 1);
+					if (q + 1 < MPC_RT_SLOTS) fetch_rows(q + 1); // unconditional, see fetch_rows(0)
 					// Block merge of the two sorted rows, one block of MPC_PAD_ROW = 2 entries of each per
 					// step (rows are stored in whole blocks, an odd tail is filled with {0.0f, sentinel
 					// column}): both blocks are fetched with one aligned 16-byte LDS read each, in flight
