@@ -190,9 +190,11 @@ def main():
             # one launch = one relax iteration over this rank's pairs
             per_launch = stage_b_bytes(lens, nnz) * my_frac
             achieved = per_launch / avg_s / 1e9
-            roof = {"kernel": "relax_tile_kernel (consistency relax: sampled sparse product over the all-pairs store, LDS-tiled)",
+            # the library's default is the dense record layout (relax_dense_kernel); MPCGPU_PAD=rows selects the older one
+            kname = "relax_tile_kernel" if os.environ.get("MPCGPU_PAD") == "rows" else "relax_dense_kernel"
+            roof = {"kernel": kname + " (consistency relax: sampled sparse product over the all-pairs store, LDS-tiled)",
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic("relax_tile_kernel", a.n, a.len),
+                    "traffic": pmc_traffic(kname, a.n, a.len),
                     "algorithmic_bytes_per_launch": per_launch,
                     "note": "algorithmic bytes per launch (= one relax iteration) = operands of every (pair,Z) read once: sum "
                             "over pairs and Z of 8*(nnz_XZ+nnz_YZ)+4*(LX+LY+2), + 4*nnz written (SURVEY.md 8d stage B), divided "

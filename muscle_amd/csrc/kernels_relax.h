@@ -232,3 +232,167 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 		__syncthreads();
 	}
 }
+
+// ---- dense-record variant (the default; MPCGPU_PAD=rows selects relax_tile_kernel above) ----------------------
+// Same tiles, slots, staging and arithmetic as relax_tile_kernel; only the way a cell finds its two rows differs.
+// In the dense padded layout (kernels_store.h) row a of a record starts at block a, so a cell keeps the LDS block
+// indices of its two rows (matrix slot * blocks per record + row, 16 bits each) and a merge step is: two aligned
+// 16-byte LDS reads, a 2x2 column compare, two products, two adds, and one test whether the row that has to move on
+// has another block (the distance to it rides in the upper half of the block's first column word). No row
+// pointers, no block counts, no matrix-base arithmetic: rows of up to two entries — most rows — take one step.
+template <int MAXSEQ, int NLD, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_kernel(RelaxTileParams p)
+{
+	MPC_DYN_SMEM(smem_raw);
+	const StoreParams &s = p.s;
+	const u32 tid = threadIdx.x;
+	const u32 n = s.n;
+	const u32 mat_dwords = s.pad_stride;
+	const u32 rec_units = mat_dwords >> 2; // 16-byte blocks per record
+	u32 *lds = (u32 *)smem_raw;
+
+	const u32 G = gridDim.x < 8u ? gridDim.x : 8u;
+	const u32 xcd = blockIdx.x % G, lb = blockIdx.x / G, per_xcd = (gridDim.x - xcd + G - 1u) / G;
+	const u32 chunk = (p.ntiles + G - 1u) / G;
+	const u32 t_begin = xcd * chunk, t_end = (t_begin + chunk < p.ntiles) ? t_begin + chunk : p.ntiles;
+
+	for (u32 tl = t_begin + lb; tl < t_end; tl += per_xcd) {
+		const u32 x0 = p.tiles[4 * tl], nx = p.tiles[4 * tl + 1], y0 = p.tiles[4 * tl + 2], ny = p.tiles[4 * tl + 3];
+		u32 seq[MAXSEQ];
+		u32 nseq = 0;
+#pragma unroll
+		for (int i = 0; i < MAXSEQ; ++i) seq[i] = 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			if ((u32)i < nx && nseq < (u32)MAXSEQ) {
+#pragma unroll
+				for (int q = 0; q < MAXSEQ; ++q) if ((u32)q == nseq) seq[q] = x0 + i;
+				++nseq;
+			}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const u32 Y = y0 + i;
+			if ((u32)i < ny && !(Y >= x0 && Y < x0 + nx) && nseq < (u32)MAXSEQ) {
+#pragma unroll
+				for (int q = 0; q < MAXSEQ; ++q) if ((u32)q == nseq) seq[q] = Y;
+				++nseq;
+			}
+		}
+		float acc[MPC_RT_SLOTS];
+		u32 ab[MPC_RT_SLOTS]; // LDS block index of row x of M(X,.) | of row y of M(Y,.) << 16; 0 = the dummy cell
+#pragma unroll
+		for (int q = 0; q < MPC_RT_SLOTS; ++q) { acc[q] = 1.0f; ab[q] = 0u; }
+		auto for_each_pair = [&](auto &&fn) {
+			u32 base = 0;
+			for (u32 ix = 0; ix < nx; ++ix) {
+				for (u32 iy = 0; iy < ny; ++iy) {
+					const u32 X = x0 + ix, Y = y0 + iy;
+					if (X >= Y) continue;
+					const u64 k = mpc_pair_index(n, X, Y);
+					if (k < p.k0 || k >= p.k1) continue;
+					const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+					u32 mb = 0; // LDS matrix slot of Y
+					if (Y >= x0 && Y < x0 + nx) mb = Y - x0;
+					else {
+						u32 before = 0;
+						for (u32 j = 0; j < iy; ++j) { const u32 Yj = y0 + j; if (!(Yj >= x0 && Yj < x0 + nx)) ++before; }
+						mb = nx + before;
+					}
+					fn(k, X, Y, nnz, base, ix * rec_units, mb * rec_units);
+					base += nnz;
+				}
+			}
+			return base;
+		};
+		const u32 total = for_each_pair([&](u64 k, u32 X, u32 Y, u32 nnz, u32 base, u32 ua, u32 ub) {
+			const u32 *ent = s.packed + s.pbase[k] + s.seq_len[X] + s.seq_len[Y];
+#pragma unroll
+			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
+				const u32 g = (u32)q * THREADS + tid;
+				if (g >= base && g - base < nnz) {
+					const u32 idx = g - base;
+					acc[q] = __uint_as_float(ent[2 * (u64)idx]) * 2.0f; // conspairflat.cpp:29-30
+					ab[q] = (ua + ent[2 * (u64)nnz + idx]) | ((ub + ent[2 * (u64)idx + 1]) << 16);
+				}
+			}
+		});
+
+		MpcU4 st[MAXSEQ][NLD];
+		const u32 rec_bytes = mat_dwords * 4u;
+		auto stage_load = [&](u32 Z) {
+#pragma unroll
+			for (int i = 0; i < MAXSEQ; ++i) {
+				if ((u32)i < nseq) {
+					const unsigned char *src = (const unsigned char *)(s.pad + ((u64)seq[i] * n + Z) * (u64)mat_dwords);
+#pragma unroll
+					for (int r = 0; r < NLD; ++r) {
+						const u32 off = (tid + (u32)r * THREADS) * 16u;
+						MpcU4 v; v.x = 0; v.y = 0; v.z = 0; v.w = 0;
+						if (off < rec_bytes) v = *(const MpcU4 *)(src + off);
+						st[i][r] = v;
+					}
+				}
+			}
+		};
+		auto stage_store = [&]() {
+#pragma unroll
+			for (int i = 0; i < MAXSEQ; ++i) {
+				if ((u32)i < nseq) {
+					unsigned char *m = (unsigned char *)(lds + (u32)i * mat_dwords);
+#pragma unroll
+					for (int r = 0; r < NLD; ++r) {
+						const u32 off = (tid + (u32)r * THREADS) * 16u;
+						if (off < rec_bytes) *(MpcU4 *)(m + off) = st[i][r];
+					}
+				}
+			}
+		};
+
+		const u32 wave_first = mpc_wave_first(tid & ~63u); // scalar: slot tests are scalar branches
+		const MpcU4 *blocks = (const MpcU4 *)__builtin_assume_aligned(lds, 16);
+		stage_load(0);
+		for (u32 Z = 0; Z < n; ++Z) {
+			__syncthreads(); // every wave is done reading step Z-1 from LDS
+			stage_store();
+			__syncthreads();
+			if (Z + 1 < n) stage_load(Z + 1); // in flight while step Z is computed
+#pragma unroll
+			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
+				if ((u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
+					u32 c = ab[q];
+					MPC_OPAQUE(c); // one register per slot: the two block indices are unpacked per step
+					u32 ia = c & 0xffffu, ib = c >> 16;
+					float sum = acc[q];
+					// Block merge of the two sorted rows (see relax_tile_kernel for the order-of-additions argument: z
+					// ascending, unmatched entries and sentinels add +0.0f). The row whose last column is not larger
+					// moves to its next block; when that row has none the merge is over (everything left in the other
+					// row lies beyond it).
+					for (;;) {
+						const MpcU4 va = blocks[ia], vb = blocks[ib]; // {p0, c0 | delta << 16, p1, c1}
+						const u32 ca0 = va.y & 0xffffu, cb0 = vb.y & 0xffffu;
+						const float pb0 = (ca0 == cb0) ? __uint_as_float(vb.x) : ((ca0 == vb.w) ? __uint_as_float(vb.z) : 0.0f);
+						const float pb1 = (va.w == cb0) ? __uint_as_float(vb.x) : ((va.w == vb.w) ? __uint_as_float(vb.z) : 0.0f);
+						sum += __uint_as_float(va.x) * pb0; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
+						sum += __uint_as_float(va.z) * pb1;
+						const bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
+						const u32 da = va.y >> 16, db = vb.y >> 16; // blocks to the next block of the row, 0: none
+						if ((adv_a && da == 0u) || (adv_b && db == 0u)) break;
+						ia += adv_a ? da : 0u;
+						ib += adv_b ? db : 0u;
+					}
+					acc[q] = sum;
+				}
+			}
+		}
+		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern
+		for_each_pair([&](u64 k, u32, u32, u32 nnz, u32 base, u32, u32) {
+#pragma unroll
+			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
+				const u32 g = (u32)q * THREADS + tid;
+				if (g >= base && g - base < nnz)
+					s.vnext[s.vbase[k] + (g - base)] = acc[q] / (float)n; // uint -> float, IEEE divide (mysparsemx.cpp:108)
+			}
+		});
+		__syncthreads();
+	}
+}

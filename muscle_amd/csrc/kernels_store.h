@@ -52,6 +52,13 @@ struct StoreParams {
 	u32 pad_stride; // dwords per record = lcap1 + 2*ecap (multiple of 4)
 	u32 lcap1, ecap;
 	unsigned short *pos_f, *pos_t;
+	// dense variant of the padded layout (the default; relax_dense_kernel. MPCGPU_PAD=rows selects the one above): a record is
+	//   [first block of every row: lcap1 blocks, row a at block a][overflow blocks: ecap blocks]
+	// block = 16 bytes = {P0 bits, col0 | delta << 16, P1 bits, col1}: delta = distance in blocks to the next block of
+	// the same row, 0 in its last block; unused entries are sentinels as above. A row is reached by its index alone
+	// (no row pointers), rows of up to MPC_PAD_ROW entries — most of them — never leave the first-block region.
+	u32 pad_dense;   // 0: row-pointer layout above, 1: dense
+	u32 pad_ent_off; // dword offset of entry 0 inside a record (lcap1 for the row-pointer layout, 0 for the dense one)
 };
 
 #define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128). 4 was tried: records grow past the 16 KiB a 1024-thread
@@ -199,6 +206,100 @@ __global__ void __launch_bounds__(64) pad_build_kernel(StoreParams s)
 	}
 }
 
+// ---- dense variant ----------------------------------------------------------------------------------------------
+// Overflow blocks the largest record needs: max over (A,Z) of sum_a max(ceil(cnt[a]/MPC_PAD_ROW) - 1, 0).
+__global__ void __launch_bounds__(64) pad_size_dense_kernel(StoreParams s, u32 *max_blocks)
+{
+	const int t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	u32 best = 0;
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		if (A == Z) continue;
+		const u32 LA = s.seq_len[A];
+		const bool fwd = A < Z;
+		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 *cnt = fwd ? rec : rec + s.seq_len[Z];
+		u32 mine = 0;
+		for (u32 a = t; a < LA; a += 64) {
+			const u32 nb = (cnt[a] + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
+			mine += nb > 1 ? nb - 1 : 0;
+		}
+		for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
+		mine = __shfl(mine, 0);
+		best = mine > best ? mine : best;
+	}
+	if (t == 0 && best) atomicMax(max_blocks, best);
+}
+
+// One 64-thread workgroup per ordered pair (A,Z). Dynamic LDS: 2*lcap1 u32.
+__global__ void __launch_bounds__(64) pad_build_dense_kernel(StoreParams s)
+{
+	MPC_DYN_SMEM(smem_raw);
+	u32 *s_start = (u32 *)smem_raw; // entries before row a in the packed (unpadded) order
+	u32 *s_ovf = s_start + s.lcap1; // overflow blocks before row a
+	const int t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	const u32 units = s.lcap1 + s.ecap; // blocks per record
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		const u32 LA = s.seq_len[A];
+		u32 *rec_out = s.pad + b * (u64)s.pad_stride;
+		for (u32 q = t; q < units; q += 64) { // every block starts as an empty one
+			rec_out[4 * q] = 0u; rec_out[4 * q + 1] = MPC_PAD_SENTINEL; rec_out[4 * q + 2] = 0u; rec_out[4 * q + 3] = MPC_PAD_SENTINEL;
+		}
+		if (A == Z) continue; // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
+		const bool fwd = A < Z;
+		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 LX = fwd ? LA : s.seq_len[Z]; // rows of the stored (unordered) pair
+		const u32 LY = fwd ? s.seq_len[Z] : LA;
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		const u32 *cnt = fwd ? rec : rec + LX; // rowcnt or colcnt, LA entries
+		u32 carry = 0, carry_o = 0;
+		for (u32 a0 = 0; a0 < s.lcap1; a0 += 64) {
+			const u32 a = a0 + t;
+			const u32 v = (a < LA) ? cnt[a] : 0;
+			const u32 nb = (v + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
+			const u32 vo = nb > 1 ? nb - 1 : 0;
+			u32 incl = v, incl_o = vo;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d), oo = __shfl_up(incl_o, d);
+				if (t >= d) { incl += o; incl_o += oo; }
+			}
+			if (a < s.lcap1) {
+				s_start[a] = carry + incl - v;
+				s_ovf[a] = carry_o + incl_o - vo;
+			}
+			carry += __shfl(incl, 63);
+			carry_o += __shfl(incl_o, 63);
+		}
+		__syncthreads(); // empty blocks and scans are in place before the entries go in
+		const u32 *e = rec + LX + LY;
+		const u32 *rowv = e + 2 * (u64)nnz;
+		const u32 *tperm = rowv + nnz;
+		unsigned short *pos = (fwd ? s.pos_f : s.pos_t) + s.vbase[k];
+		for (u32 q = t; q < nnz; q += 64) {
+			const u32 pbits = e[2 * (u64)q];
+			const u32 col = e[2 * (u64)q + 1], row = rowv[q];
+			const u32 r = fwd ? row : col;       // row of this entry in M(A,Z)
+			const u32 rank = fwd ? q : tperm[q]; // its rank in M(A,Z)'s row-major order
+			const u32 c = fwd ? col : row;
+			const u32 within = rank - s_start[r];
+			const u32 j = within / MPC_PAD_ROW, slot = within % MPC_PAD_ROW;
+			const u32 nb = (cnt[r] + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
+			const u32 ovf0 = s.lcap1 + s_ovf[r]; // first overflow block of this row
+			const u32 unit = j == 0 ? r : ovf0 + (j - 1);
+			const u32 delta = j + 1 < nb ? (j == 0 ? ovf0 - r : 1u) : 0u; // blocks to the row's next block
+			rec_out[4 * unit + 2 * slot] = pbits;
+			rec_out[4 * unit + 2 * slot + 1] = slot == 0 ? (c | (delta << 16)) : c;
+			pos[q] = (unsigned short)(unit * MPC_PAD_ROW + slot);
+		}
+		__syncthreads(); // s_start is reused by the next record
+	}
+}
+
 __device__ __forceinline__ u64 mpc_find_pair(const u64 *vbase, u64 lo, u64 hi, u64 e)
 {
 	// largest k in [lo,hi) with vbase[k] <= e (pairs without entries are skipped naturally)
@@ -292,8 +393,8 @@ __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
 		const u32 tq = ent[3 * (u64)nnz + idx];
 		ent[2 * (u64)idx] = pb;
 		(void)tq;
-		s.pad[((u64)X * s.n + Y) * s.pad_stride + s.lcap1 + 2 * (u64)s.pos_f[e]] = pb;
-		s.pad[((u64)Y * s.n + X) * s.pad_stride + s.lcap1 + 2 * (u64)s.pos_t[e]] = pb;
+		s.pad[((u64)X * s.n + Y) * s.pad_stride + s.pad_ent_off + 2 * (u64)s.pos_f[e]] = pb;
+		s.pad[((u64)Y * s.n + X) * s.pad_stride + s.pad_ent_off + 2 * (u64)s.pos_t[e]] = pb;
 	}
 }
 

@@ -114,6 +114,8 @@ struct mpcgpu_ctx {
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // padded layout + LDS-tiled relax (else: slabs + gather relax)
 	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0, pad_threads = MPC_RT_THREADS;
+	bool pad_dense = false;      // dense records + relax_dense_kernel (default), else row-pointer records + relax_tile_kernel (MPCGPU_PAD=rows)
+	u32 pad_stride_dw() const { return pad_dense ? 4 * (pad_lcap1 + pad_ecap) : pad_lcap1 + 2 * pad_ecap; }
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
 	std::vector<u32> h_tiles;
 	u64 tiles_k0 = ~0ull, tiles_k1 = ~0ull;
@@ -293,22 +295,33 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.pad = c->d_pad.as<u32>();
 	s.lcap1 = c->pad_lcap1;
 	s.ecap = c->pad_ecap;
-	s.pad_stride = c->pad_lcap1 + 2 * c->pad_ecap;
+	s.pad_stride = c->pad_stride_dw();
+	s.pad_dense = c->pad_dense ? 1u : 0u;
+	s.pad_ent_off = c->pad_dense ? 0u : c->pad_lcap1;
 	s.pos_f = c->d_pos.as<unsigned short>();
 	s.pos_t = c->d_pos.as<unsigned short>() + c->total_entries;
 }
 
 // Padded-layout geometry for the LDS-tiled relax; false when a tile cannot fit the CU's LDS (or the
 // cell coordinates do not pack into 16:16): the caller then builds the slabs for the gather kernel.
-bool pad_geometry(const mpcgpu_ctx *c, u32 max_blocks, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by, u32 *threads)
+bool pad_geometry(const mpcgpu_ctx *c, bool dense, u32 max_blocks, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by, u32 *threads)
 {
 	*threads = env_int("MPCGPU_RELAX_WG", MPC_RT_THREADS) == 512 ? 512u : 1024u;
 	if (c->max_len > MPC_RT_MAXLEN) return false; // cell descriptors pack x and y into 13 bits each
 	if ((u64)c->max_nnz > (u64)MPC_RT_SLOTS * *threads) return false; // one pair must fit the slots of a tile
-	*lcap1 = (c->max_len + 1 + 3) & ~3u;                 // >= Lmax+1, multiple of 4 dwords
-	*ecap = std::max<u32>(max_blocks, 1) * MPC_PAD_ROW;   // whole 32-byte blocks (kernels_store.h)
-	if (*ecap > 65535u) return false;                    // pos_f / pos_t are 16-bit
-	const u64 rec_bytes = ((u64)*lcap1 + 2 * (u64)*ecap) * 4;
+	u64 rec_bytes;
+	if (dense) {
+		*lcap1 = c->max_len;  // one first block per row
+		*ecap = max_blocks;   // overflow blocks of the largest record
+		const u64 units = (u64)*lcap1 + *ecap;
+		if (8 * units > 65535u) return false; // a cell keeps two block indices over <= 8 resident records in 16 bits each
+		rec_bytes = units * 16;
+	} else {
+		*lcap1 = (c->max_len + 1 + 3) & ~3u;                 // >= Lmax+1, multiple of 4 dwords
+		*ecap = std::max<u32>(max_blocks, 1) * MPC_PAD_ROW;   // whole 32-byte blocks (kernels_store.h)
+		if (*ecap > 65535u) return false;                    // pos_f / pos_t are 16-bit
+		rec_bytes = ((u64)*lcap1 + 2 * (u64)*ecap) * 4;
+	}
 	if (rec_bytes > 2 * 16 * (u64)*threads) return false; // at most two 16-byte loads per thread per matrix
 	// 1024-thread workgroups own the whole LDS of a CU; 512-thread ones share it two per CU
 	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", *threads == 1024 ? 160 : 80) * 1024;
@@ -326,14 +339,21 @@ template <int MS, int NLD, int TH> void launch_relax_tile(const RelaxTileParams 
 	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
 }
 
+template <int MS, int NLD, int TH> void launch_relax_dense(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
+{
+	auto kern = relax_dense_kernel<MS, NLD, TH>;
+	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
+}
+
 // LDS-tiled relax (kernels_relax.h) over the padded layout; 0 = launched, 1 = error.
 int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 {
 	const u32 n = c->n;
 	const u32 bx = c->pad_bx, by = c->pad_by;
-	const u64 mat_bytes = ((u64)c->pad_lcap1 + 2 * (u64)c->pad_ecap) * 4;
+	const u64 mat_bytes = (u64)c->pad_stride_dw() * 4;
 	const u32 threads = c->pad_threads;
 	const int nld = mat_bytes <= (u64)threads * 16 ? 1 : 2;
+	const bool dense = c->pad_dense;
 	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
 	// slots a tile needs: its cells (all pairs in [k0,k1), laid end to end) in chunks of 1024
 	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
@@ -384,6 +404,10 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	rp.k0 = k0; rp.k1 = k1;
 	const size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-block reads may run past the last matrix
 	const void *fn = nullptr;
+	if (dense) {
+		if (threads == 1024) fn = nld == 1 ? (const void *)relax_dense_kernel<8, 1, 1024> : (const void *)relax_dense_kernel<8, 2, 1024>;
+		else fn = nld == 1 ? (const void *)relax_dense_kernel<6, 1, 512> : (const void *)relax_dense_kernel<6, 2, 512>;
+	} else
 	if (threads == 1024) fn = nld == 1 ? (const void *)relax_tile_kernel<8, 1, 1024> : (const void *)relax_tile_kernel<8, 2, 1024>;
 	else fn = nld == 1 ? (const void *)relax_tile_kernel<6, 1, 512> : (const void *)relax_tile_kernel<6, 2, 512>;
 	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -392,12 +416,21 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	u32 grid = std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ);
 	grid = std::max(grid, 1u);
 	if (trace_on()) {
-		fprintf(stderr, "[mpcgpu] relax tiled: tiles=%u block=%ux%u wg=%u nld=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n", rp.ntiles, bx, by,
-			threads, nld, c->max_nnz, smem, occ, grid);
+		fprintf(stderr, "[mpcgpu] relax tiled (%s records): tiles=%u block=%ux%u wg=%u nld=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n",
+			dense ? "dense" : "row-pointer", rp.ntiles, bx, by, threads, nld, c->max_nnz, smem, occ, grid);
 		fflush(stderr);
 	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
+	if (dense) {
+		if (threads == 1024) {
+			if (nld == 1) launch_relax_dense<8, 1, 1024>(rp, grid, smem, c->stream);
+			else launch_relax_dense<8, 2, 1024>(rp, grid, smem, c->stream);
+		} else {
+			if (nld == 1) launch_relax_dense<6, 1, 512>(rp, grid, smem, c->stream);
+			else launch_relax_dense<6, 2, 512>(rp, grid, smem, c->stream);
+		}
+	} else
 	if (threads == 1024) {
 		if (nld == 1) launch_relax_tile<8, 1, 1024>(rp, grid, smem, c->stream);
 		else launch_relax_tile<8, 2, 1024>(rp, grid, smem, c->stream);
@@ -1016,27 +1049,36 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	{
 		const char *mode = getenv("MPCGPU_RELAX");
 		u32 lcap1 = 0, ecap = 0, bx = 0, by = 0, threads = 0;
+		const char *padmode = getenv("MPCGPU_PAD");
+		const bool dense = !(padmode && !strcmp(padmode, "rows")); // default: dense records; MPCGPU_PAD=rows: row-pointer records
 		if (!(mode && !strcmp(mode, "gather")) && c->max_len <= MPC_RT_MAXLEN) {
 			// size of the largest padded record: rows occupy whole blocks of MPC_PAD_ROW entries
 			StoreParams sp0;
 			fill_store_params(c, sp0);
 			HIPCHK(c, c->d_aln_out.ensure(8));
 			HIPCHK(c, hipMemsetAsync(c->d_aln_out.p, 0, 4, c->stream));
+			if (dense)
+				MPC_LAUNCH(pad_size_dense_kernel, (u32)std::min<u64>((u64)n * n, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp0,
+					c->d_aln_out.as<u32>());
+			else
 			MPC_LAUNCH(pad_size_kernel, (u32)std::min<u64>((u64)n * n, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp0,
 				c->d_aln_out.as<u32>());
 			HIPCHK(c, hipGetLastError());
 			u32 max_blocks = 0;
 			HIPCHK(c, hipMemcpyAsync(&max_blocks, c->d_aln_out.p, 4, hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(c, hipStreamSynchronize(c->stream));
-			if (pad_geometry(c, max_blocks, &lcap1, &ecap, &bx, &by, &threads)) {
-				const u64 pad_bytes = (u64)n * n * ((u64)lcap1 + 2 * (u64)ecap) * 4 + 4 * std::max<u64>(c->total_entries, 1);
+			if (pad_geometry(c, dense, max_blocks, &lcap1, &ecap, &bx, &by, &threads)) {
+				const u64 rec_dw = dense ? 4 * ((u64)lcap1 + ecap) : (u64)lcap1 + 2 * (u64)ecap;
+				const u64 pad_bytes = (u64)n * n * rec_dw * 4 + 4 * std::max<u64>(c->total_entries, 1);
 				size_t freeb = 0, totb = 0;
 				HIPCHK(c, hipMemGetInfo(&freeb, &totb));
 				if (pad_bytes <= c->d_pad.cap + c->d_pos.cap || pad_bytes + ((u64)2 << 30) <= (u64)freeb) {
 					c->have_pad = true;
 					c->pad_lcap1 = lcap1; c->pad_ecap = ecap; c->pad_bx = bx; c->pad_by = by; c->pad_threads = threads;
+					c->pad_dense = dense;
+					c->tiles_k0 = c->tiles_k1 = ~0ull; // the tile list depends on the block shape
 					c->d_rp.release(); c->d_ent.release(); c->d_mbase.release(); // slabs of an earlier run are not needed
-					HIPCHK(c, c->d_pad.ensure((u64)n * n * ((u64)lcap1 + 2 * (u64)ecap) * 4));
+					HIPCHK(c, c->d_pad.ensure((u64)n * n * rec_dw * 4));
 					HIPCHK(c, c->d_pos.ensure(4 * std::max<u64>(c->total_entries, 1))); // pos_f then pos_t, u16 each
 				}
 			}
@@ -1047,12 +1089,15 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 		StoreParams sp;
 		fill_store_params(c, sp);
 		if (trace_on()) {
-			fprintf(stderr, "[mpcgpu] store: padded layout, %u x %u records of %u B (%.2f GB), tile block %ux%u\n", n, n,
-				sp.pad_stride * 4, (double)n * n * sp.pad_stride * 4 / 1e9, c->pad_bx, c->pad_by);
+			fprintf(stderr, "[mpcgpu] store: padded layout (%s), %u x %u records of %u B (%.2f GB), tile block %ux%u\n",
+				c->pad_dense ? "dense" : "row pointers", n, n, sp.pad_stride * 4, (double)n * n * sp.pad_stride * 4 / 1e9, c->pad_bx, c->pad_by);
 			fflush(stderr);
 		}
 		if (span_begin(c, 2, &ts)) return 1;
 		const u64 blocks = (u64)n * n;
+		if (c->pad_dense)
+			MPC_LAUNCH(pad_build_dense_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)sp.lcap1 * 8, c->stream, sp);
+		else
 		MPC_LAUNCH(pad_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)sp.lcap1 * 8, c->stream, sp);
 		HIPCHK(c, hipGetLastError());
 		if (span_end(c, &ts)) return 1;

@@ -290,3 +290,17 @@ def test_emu_relax_512_thread_workgroups(emu):
     seqs = make_family(7, 24, seed=63)
     got = _with_env({"MPCGPU_RELAX_WG": "512"}, lambda: P.run_lib(seqs, lib_path=emu))
     P.assert_same(got, P.run_oracle(seqs), "512-thread relax workgroups")
+
+
+@pytest.mark.parametrize("env", [{}, {"MPCGPU_RELAX_SLOTS": "3"}, {"MPCGPU_RELAX_LDS_KB": "2"}, {"MPCGPU_RELAX_WG": "512"}])
+def test_emu_relax_row_pointer_records(emu, env):
+    """MPCGPU_PAD=rows: the row-pointer record layout + relax_tile_kernel (the default is the dense layout)"""
+    seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0], "MKV"]
+    got = _with_env(dict(env, MPCGPU_PAD="rows"), lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "row-pointer records %s" % env)
+
+
+def test_emu_dense_records_long_rows(emu):
+    """rows with many entries (weakly related sequences: several blocks per row chained through the overflow region)"""
+    seqs = make_family(6, 60, seed=8, p_sub=0.7) + make_family(2, 50, seed=9, p_sub=0.6)
+    P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "dense records, long rows")

@@ -232,8 +232,8 @@ def test_back_to_back_iterations_without_sync():
 
 
 def test_relax_gather_equals_tiled():
-    """Both relax kernels (LDS-tiled default, one-cell-per-thread gather fallback) are device code
-    with the reference's accumulation order: identical bits."""
+    """All relax kernels (LDS-tiled over dense records = default, LDS-tiled over row-pointer records, one-cell-per-thread
+    gather fallback) are device code with the reference's accumulation order: identical bits."""
     import os
     seqs = make_family(21, 120, seed=41)
     a = P.run_lib(seqs)
@@ -244,6 +244,13 @@ def test_relax_gather_equals_tiled():
         del os.environ["MPCGPU_RELAX"]
     P.assert_same(a, b, "gather vs tiled")
     P.assert_same(a, P.run_oracle(seqs), "tiled vs oracle")
+    # the row-pointer record layout + relax_tile_kernel (the default is the dense layout + relax_dense_kernel)
+    os.environ["MPCGPU_PAD"] = "rows"
+    try:
+        r = P.run_lib(seqs)
+    finally:
+        del os.environ["MPCGPU_PAD"]
+    P.assert_same(a, r, "row-pointer records vs dense records")
 
 
 def test_calc_aln_paths():
