@@ -1,4 +1,6 @@
-// kernels_relax.h — consistency relax, LDS-tiled ("relax_tile_kernel").
+// kernels_relax.h — consistency relax, LDS-tiled: relax_dense_kernel (default, dense records: at the end of this
+// file) and relax_tile_kernel (row-pointer records, MPCGPU_PAD=rows; described first because the dense kernel only
+// changes how a cell reaches its two rows).
 //
 // Replaces MPCFlat::ConsPair (conspairflat.cpp:10-110) -> RelaxFlat_{XZ_ZY,ZX_ZY,XZ_YZ}
 // (relaxflat.cpp:4-94) -> MySparseMx::UpdateFromPost (mysparsemx.cpp:87-113) for a TILE of pairs
