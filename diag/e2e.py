@@ -27,7 +27,8 @@ with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, name + ".afa")
         t0 = time.perf_counter()
         subprocess.run([binary, "-align", fa, "-output", out, "-threads", str(th), "-quiet"], check=True, cwd=d,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=3000)
+                       stdout=subprocess.DEVNULL,
+                       stderr=None if os.environ.get("MUSCLE_GPU_TIMING") else subprocess.DEVNULL, timeout=3000)
         dt = time.perf_counter() - t0
         res[name] = (dt, hashlib.md5(open(out, "rb").read()).hexdigest())
         print("%s: %d x L~%d, %d threads: %.2f s  md5 %s" % (name, n, L, th, dt, res[name][1]), flush=True)

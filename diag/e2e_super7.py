@@ -34,7 +34,8 @@ with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, name + ".afa")
         t0 = time.perf_counter()
         subprocess.run([binary, "-super7", fa, "-output", out, "-threads", str(th), "-quiet", "-guidetreein", "tree.nwk",
-                        "-shrub_size", shrub], check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=3000)
+                        "-shrub_size", shrub], check=True, cwd=d, stdout=subprocess.DEVNULL,
+                       stderr=None if os.environ.get("MUSCLE_GPU_TIMING") else subprocess.DEVNULL, timeout=3000)
         dt = time.perf_counter() - t0
         res[name] = (dt, hashlib.md5(open(out, "rb").read()).hexdigest())
         print("%s: -super7 %d x L~%d, shrubs of %s, %d threads: %.2f s  md5 %s" % (name, n, L, shrub, th, dt, res[name][1]), flush=True)

@@ -38,6 +38,7 @@
 #include "mega.h"
 #include "mpcgpu.h"
 
+#include <chrono>
 #include <map>
 #include <mutex>
 
@@ -96,6 +97,51 @@ bool DebugOn()
 		}
 	return On == 1;
 	}
+
+// MUSCLE_GPU_TIMING=1: wall time spent inside the replaced functions, printed at exit (where does an
+// end-to-end run spend its time once the stage itself takes a few seconds).
+enum { T_STAGE_A, T_CONS_ITER, T_ALN_PREP, T_ALN_LIB, T_ALN_POST, T_JOIN_PREP, T_JOIN_LIB, T_COUNT };
+double g_Seconds[T_COUNT];
+unsigned long long g_Calls[T_COUNT];
+bool TimingOn()
+	{
+	static int On = -1;
+	if (On < 0)
+		{
+		const char *s = getenv("MUSCLE_GPU_TIMING");
+		On = (s != 0 && *s != 0 && *s != '0') ? 1 : 0;
+		if (On == 1)
+			atexit([]()
+				{
+				static const char *Names[T_COUNT] = { "stage A (all pairs)", "ConsIter", "AlignAlns: maps",
+				  "AlignAlns: library", "AlignAlns: result MSA", "AlignMSAsFlat: pairs+maps", "AlignMSAsFlat: library" };
+				for (int i = 0; i < T_COUNT; ++i)
+					fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  %8llu calls\n", Names[i], g_Seconds[i], g_Calls[i]);
+				});
+		}
+	return On == 1;
+	}
+struct Stopwatch
+	{
+	int m_Slot;
+	std::chrono::steady_clock::time_point m_T0;
+	explicit Stopwatch(int Slot) : m_Slot(Slot), m_T0(std::chrono::steady_clock::now()) {}
+	void Next(int Slot)
+		{
+		Stop();
+		m_Slot = Slot;
+		m_T0 = std::chrono::steady_clock::now();
+		}
+	void Stop()
+		{
+		if (m_Slot < 0 || !TimingOn())
+			return;
+		g_Seconds[m_Slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - m_T0).count();
+		++g_Calls[m_Slot];
+		m_Slot = -1;
+		}
+	~Stopwatch() { Stop(); }
+	};
 
 uint64_t Fnv(uint64_t h, const void *p, size_t n)
 	{
@@ -224,6 +270,7 @@ void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_
 // First CalcPosterior call of a run: the whole all-pairs stage A on the device.
 void StartBatch(MPCFlat &M, Batch &B)
 	{
+	Stopwatch SW(T_STAGE_A);
 	mpcgpu_ctx *Ctx = GetCtx();
 	const uint SeqCount = M.GetSeqCount();
 	const uint PairCount = SIZE(M.m_Pairs);
@@ -300,6 +347,7 @@ void MPCFlat::ConsIter(uint Iter)
 	uint PairCount = SIZE(m_Pairs);
 	asserta(PairCount > 0);
 	ProgressStep(0, 1, "Consistency (%u/%u)", Iter+1, m_ConsistencyIterCount);
+	Stopwatch SW(T_CONS_ITER);
 		{
 		std::lock_guard<std::mutex> Guard(g_Mu);
 		mpcgpu_ctx *Ctx = GetCtx();
@@ -331,6 +379,7 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 		if (m_Weights[i] != 1.0f)
 			Die("GPU posterior stage: sequence weights other than 1 are not supported");
 
+	Stopwatch SW(T_ALN_PREP);
 	vector<uint32_t> Seqs1(SeqCount1), Seqs2(SeqCount2);
 	vector<uint32_t> Map1, Map2;
 	vector<uint> PosToCol;
@@ -358,6 +407,7 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 	string Path(ColCount1 + ColCount2, '?');
 	uint32_t PathLen = 0;
 	float Score = 0;
+	SW.Next(T_ALN_LIB);
 		{
 		std::lock_guard<std::mutex> Guard(g_Mu);
 		mpcgpu_ctx *Ctx = GetCtx();
@@ -367,6 +417,7 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 	Path.resize(PathLen);
 	if (ptrScore != 0)
 		*ptrScore = Score;
+	SW.Next(T_ALN_POST);
 
 // alnalnsflat.cpp:36-50
 	MultiSequence *result = new MultiSequence();
@@ -411,6 +462,7 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 // The ungapped sequences come from the global input registry by label, like CalcPost does
 // (calcpost.cpp:4-36, getpostpairsalignedflat.cpp:43-46); the ones this join touches are handed to
 // the library as its registry for this call.
+	Stopwatch SW(T_JOIN_PREP);
 	std::map<const Sequence *, uint32_t> SeqToIndex;
 	vector<const uint8_t *> Ptrs;
 	vector<uint32_t> Lens;
@@ -457,6 +509,7 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 	uint32_t PathLen = 0;
 	float Score = 0;
 	vector<float> EA(PairCount);
+	SW.Next(T_JOIN_LIB);
 		{
 		std::lock_guard<std::mutex> Guard(g_Mu);
 		if (g_CtxJoin == 0)

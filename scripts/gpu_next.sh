@@ -11,3 +11,4 @@ step timeout 120 python -u diag/join_bench.py 400 300 2000 3
 step timeout 120 python -u diag/join_bench.py 400 600 2000 2
 step timeout 600 python -u diag/e2e_super7.py 2000 250 32
 step timeout 300 python -u diag/e2e.py 256 300
+MUSCLE_GPU_TIMING=1 step timeout 300 python -u diag/e2e.py 1000 400 16 gpu   # where the 15 s go (hostcxx Stopwatch)
