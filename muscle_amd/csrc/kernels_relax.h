@@ -36,6 +36,7 @@ struct RelaxTileParams {
 	const u32 *tiles; // 4 u32 per tile: x0, nx, y0, ny
 	u32 ntiles;
 	u64 k0, k1; // only pairs in [k0,k1) are relaxed (multi-GPU shard)
+	u32 buf_units; // relax_dense_kernel: 16-byte blocks between the two LDS staging buffers, 0 = one buffer
 };
 
 struct __attribute__((aligned(16))) MpcU4 { u32 x, y, z, w; };
@@ -336,11 +337,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_
 				}
 			}
 		};
-		auto stage_store = [&]() {
+		auto stage_store = [&](u32 buf_dwords) {
 #pragma unroll
 			for (int i = 0; i < MAXSEQ; ++i) {
 				if ((u32)i < nseq) {
-					unsigned char *m = (unsigned char *)(lds + (u32)i * mat_dwords);
+					unsigned char *m = (unsigned char *)(lds + buf_dwords + (u32)i * mat_dwords);
 #pragma unroll
 					for (int r = 0; r < NLD; ++r) {
 						const u32 off = (tid + (u32)r * THREADS) * 16u;
@@ -351,13 +352,28 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_
 		};
 
 		const u32 wave_first = mpc_wave_first(tid & ~63u); // scalar: slot tests are scalar branches
-		const MpcU4 *blocks = (const MpcU4 *)__builtin_assume_aligned(lds, 16);
+		const MpcU4 *blocks0 = (const MpcU4 *)__builtin_assume_aligned(lds, 16);
+		// Two LDS staging buffers when they fit (p.buf_units != 0): step Z is computed out of buffer Z&1 while the
+		// records of step Z+1, loaded into registers during that computation, go into the other buffer — one
+		// barrier per step (nobody reads that other buffer any more: its readers, step Z-1, passed the previous
+		// barrier; nobody reads it yet: its readers, step Z+1, wait at this step's barrier). With one buffer the
+		// store has to wait for all readers of the previous step and the readers for the store: two barriers.
+		const u32 bstride = p.buf_units;
 		stage_load(0);
-		for (u32 Z = 0; Z < n; ++Z) {
-			__syncthreads(); // every wave is done reading step Z-1 from LDS
-			stage_store();
+		if (bstride) {
+			__syncthreads(); // the previous tile's readers are done
+			stage_store(0);
 			__syncthreads();
-			if (Z + 1 < n) stage_load(Z + 1); // in flight while step Z is computed
+			if (n > 1) stage_load(1);
+		}
+		for (u32 Z = 0; Z < n; ++Z) {
+			if (!bstride) {
+				__syncthreads(); // every wave is done reading step Z-1 from LDS
+				stage_store(0);
+				__syncthreads();
+				if (Z + 1 < n) stage_load(Z + 1); // in flight while step Z is computed
+			}
+			const MpcU4 *blocks = blocks0 + (bstride ? (Z & 1u) * bstride : 0u);
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
 				if ((u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
@@ -384,6 +400,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_
 					}
 					acc[q] = sum;
 				}
+			}
+			if (bstride) {
+				if (Z + 1 < n) stage_store(((Z + 1) & 1u) * bstride * 4u); // records of step Z+1 -> the other buffer
+				__syncthreads();
+				if (Z + 2 < n) stage_load(Z + 2); // in flight while step Z+1 is computed
 			}
 		}
 		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern

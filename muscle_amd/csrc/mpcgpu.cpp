@@ -402,7 +402,16 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	RelaxTileParams rp;
 	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
 	rp.k0 = k0; rp.k1 = k1;
-	const size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-block reads may run past the last matrix
+	size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-block reads may run past the last matrix
+	// dense records: a second staging buffer (one barrier per step instead of two) when the CU's LDS holds both
+	rp.buf_units = 0;
+	if (dense && env_int("MPCGPU_RELAX_DBUF", 1) != 0) {
+		const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", threads == 1024 ? 160 : 80) * 1024;
+		if (2 * (u64)(bx + by) * mat_bytes + 8 * MPC_RT_ROW <= lds_cap) {
+			rp.buf_units = (u32)((u64)(bx + by) * mat_bytes / 16);
+			smem = 2 * (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW;
+		}
+	}
 	const void *fn = nullptr;
 	if (dense) {
 		if (threads == 1024) fn = nld == 1 ? (const void *)relax_dense_kernel<8, 1, 1024> : (const void *)relax_dense_kernel<8, 2, 1024>;
@@ -416,8 +425,8 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	u32 grid = std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ);
 	grid = std::max(grid, 1u);
 	if (trace_on()) {
-		fprintf(stderr, "[mpcgpu] relax tiled (%s records): tiles=%u block=%ux%u wg=%u nld=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n",
-			dense ? "dense" : "row-pointer", rp.ntiles, bx, by, threads, nld, c->max_nnz, smem, occ, grid);
+		fprintf(stderr, "[mpcgpu] relax tiled (%s records%s): tiles=%u block=%ux%u wg=%u nld=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n",
+			dense ? "dense" : "row-pointer", rp.buf_units ? ", 2 LDS buffers" : "", rp.ntiles, bx, by, threads, nld, c->max_nnz, smem, occ, grid);
 		fflush(stderr);
 	}
 	TimedSpan ts;

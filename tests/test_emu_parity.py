@@ -304,3 +304,10 @@ def test_emu_dense_records_long_rows(emu):
     """rows with many entries (weakly related sequences: several blocks per row chained through the overflow region)"""
     seqs = make_family(6, 60, seed=8, p_sub=0.7) + make_family(2, 50, seed=9, p_sub=0.6)
     P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "dense records, long rows")
+
+
+def test_emu_dense_records_single_lds_buffer(emu):
+    """MPCGPU_RELAX_DBUF=0: the one-buffer, two-barrier schedule of relax_dense_kernel (the default uses two buffers when they fit)"""
+    seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0]]
+    got = _with_env({"MPCGPU_RELAX_DBUF": "0"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "single LDS buffer")
