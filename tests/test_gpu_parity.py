@@ -251,6 +251,12 @@ def test_relax_gather_equals_tiled():
     finally:
         del os.environ["MPCGPU_PAD"]
     P.assert_same(a, r, "row-pointer records vs dense records")
+    os.environ["MPCGPU_RELAX_DBUF"] = "0"  # dense records, one LDS staging buffer (two barriers per step)
+    try:
+        d = P.run_lib(seqs)
+    finally:
+        del os.environ["MPCGPU_RELAX_DBUF"]
+    P.assert_same(a, d, "one LDS buffer vs two")
 
 
 def test_calc_aln_paths():
