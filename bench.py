@@ -114,8 +114,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1000)
-    ap.add_argument("--len", type=int, default=400)
+    ap.add_argument("--n", "--nseqs", dest="n", type=int, default=1000)  # --nseqs/--seqlen: spellings torchrun's parser does not trip over
+    ap.add_argument("--len", "--seqlen", dest="len", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -133,25 +133,37 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (a.gpus, world))
-    torch.cuda.set_device(local)
-    device = "cuda:%d" % local
+    # MPCGPU_BENCH_DRYRUN=<path of tests/emu/libmpcgpu_emu.so>: tests only (tests/test_sharding_gloo.py) — the same
+    # control flow on CPU tensors, gloo and the SIMT-emulator build of the library, so the N>1 path of this file is
+    # exercised without GPUs. The line it prints carries "dry_run": true and measures nothing.
+    dry = os.environ.get("MPCGPU_BENCH_DRYRUN") or None
+    if dry:
+        device = "cpu"
+    else:
+        torch.cuda.set_device(local)
+        device = "cuda:%d" % local
     exchange = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
         exchange = TorchExchange(dist, device)
 
     seqs = make_family(a.n, a.len, seed=a.seed)
     lens = [len(s) for s in seqs]
     npairs = a.n * (a.n - 1) // 2
-    g = MpcGpu(local)
+    g = MpcGpu(0 if dry else local, dry)
     g.set_hmm(*load_hmm())
     g.set_seqs(seqs)  # inputs resident in HBM from here on
 
     def barrier():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     for _ in range(a.warmup):
         run_stage(g, lens, exchange, torch_mod=torch)
@@ -216,7 +228,9 @@ def main():
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in timers.items()},
             "roofline": roof,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if dry:
+            out["dry_run"] = True
+        if world == 1 and not a.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(seqs, a.n)
         print(json.dumps(out), flush=True)
     g.close()

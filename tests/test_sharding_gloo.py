@@ -185,3 +185,31 @@ def test_two_rank_thread_exchange_dry_run():
     r = subprocess.run([sys.executable, "-u", os.path.join(here, "_torch_exchange_check.py")], env=env, cwd=here,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240, text=True)
     assert r.returncode == 0 and "OK two-rank exchange" in r.stdout, r.stdout[-3000:]
+
+
+def test_bench_py_world2_dry_run():
+    """bench.py itself, launched the way the driver launches it for N=2 (torch.distributed.run, one rank per "GPU"),
+    in its tests-only dry-run mode: CPU tensors, gloo, the SIMT-emulator library. Checks the N>1 control flow of the
+    file — rendezvous, sharded run_stage, barrier, max-over-ranks, the one JSON line on rank 0 — not performance."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    emu_dir = os.path.join(here, "emu")
+    subprocess.check_call(["make", "-C", emu_dir], stdout=subprocess.DEVNULL)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MPCGPU_BENCH_DRYRUN=os.path.join(emu_dir, "libmpcgpu_emu.so"), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--nseqs", "9", "--seqlen", "30"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["steps"] == 1 and d["config"]["pairs"] == 36
+    assert d["unit"] == "pairs/s" and d["value"] > 0 and d["scaling"] == "strong" and "roofline" in d and "cpu_baseline" not in d
+    assert d["config"]["parallelism"] == "pair-shard x2"
