@@ -31,7 +31,7 @@ def stage_digest(stage):
     return h.hexdigest()
 
 
-MPC_SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "bb11001", "n32_L150", "bb11005", "n48_L260"]
+MPC_SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "bb11001", "n32_L150", "bb11005", "n48_L260", "n3_L1100"]
 
 
 def mpc(name):

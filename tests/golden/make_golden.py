@@ -125,7 +125,7 @@ def _mpc_worker(args):
     return name, len(seqs), [int(sum(len(v) // 2 for _, v in st)) for st in stages]
 
 
-def gen_mpc():
+def gen_mpc(only=None):
     from muscle_amd.synth import make_family
     jobs = [
         ("n2_L40", make_family(2, 40, seed=5), True),       # N<3: consistency skipped (mpcflat.cpp:176)
@@ -135,6 +135,7 @@ def gen_mpc():
                     make_family(1, 33, seed=10)[0], "WWWWWWWW"], True),
         ("n32_L150", make_family(32, 150, seed=1), False),  # BASELINE config 0 shape
         ("n48_L260", make_family(48, 260, seed=1), False),
+        ("n3_L1100", make_family(3, 1100, seed=7), False),  # X longer than 1024: the row-block fb kernel's shape
     ]
     bb = "/root/reference/test_data/fa/BB11001"
     if os.path.exists(bb):
@@ -143,6 +144,8 @@ def gen_mpc():
     if os.path.exists(bb5):
         jobs.append(("bb11005", read_fasta(bb5), False))
     ctx = mp.get_context("spawn")
+    if only:
+        jobs = [j for j in jobs if j[0] in only]
     for job in jobs:  # one process per data set: SetGlobalInputMS is once-per-process
         with ctx.Pool(1) as pool:
             print(pool.map(_mpc_worker, [job])[0])
@@ -190,6 +193,9 @@ def gen_mega():
 if __name__ == "__main__":
     if sys.argv[1:] == ["mega"]:
         gen_mega()
+        sys.exit(0)
+    if sys.argv[1:2] == ["mpc"]:  # python make_golden.py mpc <name> ...: only these whole-stage sets
+        gen_mpc(set(sys.argv[2:]))
         sys.exit(0)
     gen_hmm()
     gen_pairs_small()

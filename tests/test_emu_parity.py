@@ -311,3 +311,13 @@ def test_emu_dense_records_single_lds_buffer(emu):
     seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0]]
     got = _with_env({"MPCGPU_RELAX_DBUF": "0"}, lambda: P.run_lib(seqs, lib_path=emu))
     P.assert_same(got, P.run_oracle(seqs), "single LDS buffer")
+
+
+def test_emu_row_blocks_vs_reference_golden(emu):
+    """the reference's own stage outputs for three sequences of ~1100 residues (X longer than 1024 rows)"""
+    g = G.mpc("n3_L1100")
+    assert min(len(s) for s in g["seqs"]) > 1024
+    stages, ea = P.run_lib(g["seqs"], lib_path=emu)
+    assert np.array_equal(P.bits(ea), P.bits(g["ea"]))
+    for s in range(g["nstages"]):
+        assert G.stage_digest(stages[s]) == g["digest"][s]
