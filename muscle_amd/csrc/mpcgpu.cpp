@@ -419,8 +419,20 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	} else
 	if (threads == 1024) fn = nld == 1 ? (const void *)relax_tile_kernel<8, 1, 1024> : (const void *)relax_tile_kernel<8, 2, 1024>;
 	else fn = nld == 1 ? (const void *)relax_tile_kernel<6, 1, 512> : (const void *)relax_tile_kernel<6, 2, 512>;
-	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 	int occ = 0;
+	if (rp.buf_units) {
+		// the doubled allocation is an optimisation: if the runtime refuses it (or reports that no workgroup fits),
+		// go back to one buffer instead of failing the launch
+		const bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess &&
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)threads, smem) == hipSuccess && occ >= 1;
+		if (!ok) {
+			(void)hipGetLastError(); // not an error of this call: clear it
+			rp.buf_units = 0;
+			smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW;
+		}
+	}
+	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	occ = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)threads, smem) != hipSuccess || occ < 1) occ = 1;
 	u32 grid = std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ);
 	grid = std::max(grid, 1u);
