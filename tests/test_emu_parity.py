@@ -321,3 +321,13 @@ def test_emu_row_blocks_vs_reference_golden(emu):
     assert np.array_equal(P.bits(ea), P.bits(g["ea"]))
     for s in range(g["nstages"]):
         assert G.stage_digest(stages[s]) == g["digest"][s]
+
+
+def test_emu_very_long_row_sequence(emu):
+    """a 9048-residue row sequence against short ones: 21 row blocks in the fb kernel, 16-bit-column candidate keys,
+    and (longer than 8191) the gather relax instead of the LDS tiles"""
+    fam = make_family(2, 50, seed=3)
+    big = make_family(1, 9000, seed=4)[0]
+    big = big[:4000] + fam[0] + big[4000:]  # related to the short ones somewhere in the middle
+    seqs = [big, fam[0], fam[1]]
+    P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "9048-long row sequence")

@@ -99,6 +99,16 @@ def test_long_rows_row_lists_and_mega():
     P.assert_same(P.run_lib(seqs, mega=mega), P.run_oracle(seqs, mega=mega, threads=0), "row blocks, mega")
 
 
+def test_very_long_row_sequence():
+    """a 9048-residue row sequence against short ones: 21 row blocks in the fb kernel, 16-bit-column candidate keys,
+    and (longer than 8191) the gather relax instead of the LDS tiles"""
+    fam = make_family(2, 50, seed=3)
+    big = make_family(1, 9000, seed=4)[0]
+    big = big[:4000] + fam[0] + big[4000:]  # related to the short ones somewhere in the middle
+    seqs = [big, fam[0], fam[1]]
+    P.assert_same(P.run_lib(seqs), P.run_oracle(seqs), "9048-long row sequence")
+
+
 def test_identical_sequences_saturate():
     s = make_family(1, 120, seed=8)[0]
     seqs = [s, s, s[:100], s[10:]]
