@@ -103,8 +103,11 @@ __device__ __forceinline__ float mpc_mega_match(const float *s_tab, const u32 *a
 	return m;
 }
 
-template <int H, bool MEGA, bool LONG>
-__global__ void __launch_bounds__(256) fb_kernel(FbParams p)
+// MINB: minimum workgroups per CU the register allocation has to allow (1 = no constraint, the default kernels;
+// 4 = 4 waves per SIMD, i.e. at most 128 VGPRs — a tuning variant for H = 5..7, MPCGPU_FB_OCC4=1, which spills a few
+// registers at H = 6 and 7).
+template <int H, bool MEGA, bool LONG, int MINB = 1>
+__global__ void __launch_bounds__(256, MINB) fb_kernel(FbParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
 	MpcCoef *s_coef = (MpcCoef *)smem_raw;                        // LOGEXP1 coefficient table, LDS offset 0

@@ -250,8 +250,27 @@ void launch_fb_long(int H, bool mega, const FbParams &p, u32 grid, u32 block, si
 	else launch_fb<MPC_LONG_H, false, true>(p, grid, block, smem, st);
 }
 
+// MPCGPU_FB_OCC4=1: letter-emission pairs with H = 5..7 rows per lane run the 128-VGPR variants (4 waves per SIMD
+// instead of 3, a few spills at H = 6 and 7) — a tuning knob, off by default.
+bool fb_occ4(int H, bool mega) { return !mega && H >= 5 && H <= 7 && env_int("MPCGPU_FB_OCC4", 0) != 0; }
+
+template <int H> void launch_fb_occ4(const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+{
+	auto kern = fb_kernel<H, false, false, 4>;
+	MPC_LAUNCH(kern, grid, block, smem, st, p);
+}
+
+template <int H> int occ_fb_occ4(u32 block, size_t smem)
+{
+	int nb = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_kernel<H, false, false, 4>, (int)block, smem) != hipSuccess || nb < 1)
+		nb = 1;
+	return nb;
+}
+
 int occ_fb_h(int H, bool mega, u32 block, size_t smem)
 {
+	if (fb_occ4(H, mega)) return H == 5 ? occ_fb_occ4<5>(block, smem) : H == 6 ? occ_fb_occ4<6>(block, smem) : occ_fb_occ4<7>(block, smem);
 	switch (H) {
 #define MPC_CASE(h) case h: return mega ? occ_fb<h, true>(block, smem) : occ_fb<h, false>(block, smem);
 	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
@@ -263,6 +282,12 @@ int occ_fb_h(int H, bool mega, u32 block, size_t smem)
 
 void launch_fb_h(int H, bool mega, const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
+	if (fb_occ4(H, mega)) {
+		if (H == 5) launch_fb_occ4<5>(p, grid, block, smem, st);
+		else if (H == 6) launch_fb_occ4<6>(p, grid, block, smem, st);
+		else launch_fb_occ4<7>(p, grid, block, smem, st);
+		return;
+	}
 	switch (H) {
 #define MPC_CASE(h) case h: if (mega) launch_fb<h, true>(p, grid, block, smem, st); else launch_fb<h, false>(p, grid, block, smem, st); break;
 	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)

@@ -331,3 +331,10 @@ def test_emu_very_long_row_sequence(emu):
     big = big[:4000] + fam[0] + big[4000:]  # related to the short ones somewhere in the middle
     seqs = [big, fam[0], fam[1]]
     P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "9048-long row sequence")
+
+
+def test_emu_fb_occ4_dispatch(emu):
+    """MPCGPU_FB_OCC4=1 routes H = 5..7 pairs to the 128-VGPR instantiations (same source; the emulator checks the dispatch)"""
+    seqs = make_family(3, 400, seed=71) + make_family(2, 330, seed=72)
+    got = _with_env({"MPCGPU_FB_OCC4": "1"}, lambda: P.run_lib(seqs, iters=0, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs, iters=0), "occ4 dispatch")
