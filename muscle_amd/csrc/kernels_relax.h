@@ -243,7 +243,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 // 16-byte LDS reads, a 2x2 column compare, two products, two adds, and one test whether the row that has to move on
 // has another block (the distance to it rides in the upper half of the block's first column word). No row
 // pointers, no block counts, no matrix-base arithmetic: rows of up to two entries — most rows — take one step.
-template <int MAXSEQ, int NLD, int THREADS>
+// PF (tuning variant, MPCGPU_RELAX_PF=1): the first blocks of slot q+1's two rows are requested from LDS before slot q's
+// arithmetic, so the round trip of the common one-step merge hides behind it (8 more VGPRs).
+template <int MAXSEQ, int NLD, int THREADS, bool PF = false>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_kernel(RelaxTileParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
@@ -374,6 +376,40 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_
 				if (Z + 1 < n) stage_load(Z + 1); // in flight while step Z is computed
 			}
 			const MpcU4 *blocks = blocks0 + (bstride ? (Z & 1u) * bstride : 0u);
+			if (PF) {
+				MpcU4 nva, nvb; // first blocks of the next slot's rows, in flight
+				u32 nia = 0, nib = 0;
+				auto prefetch = [&](int q) {
+					u32 c = ab[q];
+					MPC_OPAQUE(c);
+					nia = c & 0xffffu; nib = c >> 16;
+					nva = blocks[nia]; nvb = blocks[nib];
+				};
+				prefetch(0); // unconditional: a lane without a cell holds the dummy descriptor (block 0 of matrix 0)
+#pragma unroll
+				for (int q = 0; q < MPC_RT_SLOTS; ++q) {
+					if ((u32)q * THREADS + wave_first < total) {
+						u32 ia = nia, ib = nib;
+						MpcU4 va = nva, vb = nvb;
+						if (q + 1 < MPC_RT_SLOTS) prefetch(q + 1);
+						float sum = acc[q];
+						for (;;) { // the same merge as below, the loads moved to the end of the step
+							const u32 ca0 = va.y & 0xffffu, cb0 = vb.y & 0xffffu;
+							const float pb0 = (ca0 == cb0) ? __uint_as_float(vb.x) : ((ca0 == vb.w) ? __uint_as_float(vb.z) : 0.0f);
+							const float pb1 = (va.w == cb0) ? __uint_as_float(vb.x) : ((va.w == vb.w) ? __uint_as_float(vb.z) : 0.0f);
+							sum += __uint_as_float(va.x) * pb0;
+							sum += __uint_as_float(va.z) * pb1;
+							const bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
+							const u32 da = va.y >> 16, db = vb.y >> 16;
+							if ((adv_a && da == 0u) || (adv_b && db == 0u)) break;
+							ia += adv_a ? da : 0u;
+							ib += adv_b ? db : 0u;
+							va = blocks[ia]; vb = blocks[ib];
+						}
+						acc[q] = sum;
+					}
+				}
+			} else
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
 				if ((u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot

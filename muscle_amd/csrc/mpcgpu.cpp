@@ -364,9 +364,9 @@ template <int MS, int NLD, int TH> void launch_relax_tile(const RelaxTileParams 
 	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
 }
 
-template <int MS, int NLD, int TH> void launch_relax_dense(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
+template <int MS, int NLD, int TH, bool PF = false> void launch_relax_dense(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
 {
-	auto kern = relax_dense_kernel<MS, NLD, TH>;
+	auto kern = relax_dense_kernel<MS, NLD, TH, PF>;
 	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
 }
 
@@ -379,6 +379,8 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	const u32 threads = c->pad_threads;
 	const int nld = mat_bytes <= (u64)threads * 16 ? 1 : 2;
 	const bool dense = c->pad_dense;
+	// tuning variant of the dense kernel (next slot's first blocks prefetched); only the main shape has it
+	const bool pf = dense && threads == 1024 && nld == 1 && env_int("MPCGPU_RELAX_PF", 0) != 0;
 	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
 	// slots a tile needs: its cells (all pairs in [k0,k1), laid end to end) in chunks of 1024
 	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
@@ -438,7 +440,8 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		}
 	}
 	const void *fn = nullptr;
-	if (dense) {
+	if (pf) fn = (const void *)relax_dense_kernel<8, 1, 1024, true>;
+	else if (dense) {
 		if (threads == 1024) fn = nld == 1 ? (const void *)relax_dense_kernel<8, 1, 1024> : (const void *)relax_dense_kernel<8, 2, 1024>;
 		else fn = nld == 1 ? (const void *)relax_dense_kernel<6, 1, 512> : (const void *)relax_dense_kernel<6, 2, 512>;
 	} else
@@ -468,7 +471,8 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
-	if (dense) {
+	if (pf) launch_relax_dense<8, 1, 1024, true>(rp, grid, smem, c->stream);
+	else if (dense) {
 		if (threads == 1024) {
 			if (nld == 1) launch_relax_dense<8, 1, 1024>(rp, grid, smem, c->stream);
 			else launch_relax_dense<8, 2, 1024>(rp, grid, smem, c->stream);

@@ -338,3 +338,10 @@ def test_emu_fb_occ4_dispatch(emu):
     seqs = make_family(3, 400, seed=71) + make_family(2, 330, seed=72)
     got = _with_env({"MPCGPU_FB_OCC4": "1"}, lambda: P.run_lib(seqs, iters=0, lib_path=emu))
     P.assert_same(got, P.run_oracle(seqs, iters=0), "occ4 dispatch")
+
+
+def test_emu_dense_relax_prefetch_variant(emu):
+    """MPCGPU_RELAX_PF=1: relax_dense_kernel<8,1,1024,PF=true> (next slot's first blocks requested early)"""
+    seqs = make_family(9, 18, seed=5) + make_family(3, 60, seed=8, p_sub=0.6)
+    got = _with_env({"MPCGPU_RELAX_PF": "1"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "prefetch variant")
