@@ -471,24 +471,37 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
-	if (pf) launch_relax_dense<8, 1, 1024, true>(rp, grid, smem, c->stream);
-	else if (dense) {
+	auto launch = [&]() {
+		if (pf) launch_relax_dense<8, 1, 1024, true>(rp, grid, smem, c->stream);
+		else if (dense) {
+			if (threads == 1024) {
+				if (nld == 1) launch_relax_dense<8, 1, 1024>(rp, grid, smem, c->stream);
+				else launch_relax_dense<8, 2, 1024>(rp, grid, smem, c->stream);
+			} else {
+				if (nld == 1) launch_relax_dense<6, 1, 512>(rp, grid, smem, c->stream);
+				else launch_relax_dense<6, 2, 512>(rp, grid, smem, c->stream);
+			}
+		} else
 		if (threads == 1024) {
-			if (nld == 1) launch_relax_dense<8, 1, 1024>(rp, grid, smem, c->stream);
-			else launch_relax_dense<8, 2, 1024>(rp, grid, smem, c->stream);
+			if (nld == 1) launch_relax_tile<8, 1, 1024>(rp, grid, smem, c->stream);
+			else launch_relax_tile<8, 2, 1024>(rp, grid, smem, c->stream);
 		} else {
-			if (nld == 1) launch_relax_dense<6, 1, 512>(rp, grid, smem, c->stream);
-			else launch_relax_dense<6, 2, 512>(rp, grid, smem, c->stream);
+			if (nld == 1) launch_relax_tile<6, 1, 512>(rp, grid, smem, c->stream);
+			else launch_relax_tile<6, 2, 512>(rp, grid, smem, c->stream);
 		}
-	} else
-	if (threads == 1024) {
-		if (nld == 1) launch_relax_tile<8, 1, 1024>(rp, grid, smem, c->stream);
-		else launch_relax_tile<8, 2, 1024>(rp, grid, smem, c->stream);
-	} else {
-		if (nld == 1) launch_relax_tile<6, 1, 512>(rp, grid, smem, c->stream);
-		else launch_relax_tile<6, 2, 512>(rp, grid, smem, c->stream);
+	};
+	launch();
+	hipError_t le = hipGetLastError();
+	if (le != hipSuccess && rp.buf_units) {
+		// launch refused with the doubled LDS allocation (an optimisation): once more with one staging buffer
+		if (trace_on()) { fprintf(stderr, "[mpcgpu] relax launch with 2 LDS buffers failed (%s): retrying with one\n", hipGetErrorString(le)); fflush(stderr); }
+		rp.buf_units = 0;
+		smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW;
+		(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		launch();
+		le = hipGetLastError();
 	}
-	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, le);
 	if (span_end(c, &ts)) return 1;
 	return 0;
 }
