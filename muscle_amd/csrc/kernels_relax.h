@@ -241,7 +241,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 // In the dense padded layout (kernels_store.h) row a of a record starts at block a, so a cell keeps the LDS block
 // indices of its two rows (matrix slot * blocks per record + row, 16 bits each) and a merge step is: two aligned
 // 16-byte LDS reads, a 2x2 column compare, two products, two adds, and one test whether the row that has to move on
-// has another block (the distance to it rides in the upper half of the block's first column word). No row
+// has another block (the distance to it rides in the upper half of the block's first column word; the two
+// probabilities of a block are adjacent dwords, so the two products are one packed multiply). No row
 // pointers, no block counts, no matrix-base arithmetic: rows of up to two entries — most rows — take one step.
 // PF (tuning variant, MPCGPU_RELAX_PF=1): the first blocks of slot q+1's two rows are requested from LDS before slot q's
 // arithmetic, so the round trip of the common one-step merge hides behind it (8 more VGPRs).
@@ -394,13 +395,13 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_
 						if (q + 1 < MPC_RT_SLOTS) prefetch(q + 1);
 						float sum = acc[q];
 						for (;;) { // the same merge as below, the loads moved to the end of the step
-							const u32 ca0 = va.y & 0xffffu, cb0 = vb.y & 0xffffu;
-							const float pb0 = (ca0 == cb0) ? __uint_as_float(vb.x) : ((ca0 == vb.w) ? __uint_as_float(vb.z) : 0.0f);
-							const float pb1 = (va.w == cb0) ? __uint_as_float(vb.x) : ((va.w == vb.w) ? __uint_as_float(vb.z) : 0.0f);
+							const u32 ca0 = va.z & 0xffffu, cb0 = vb.z & 0xffffu;
+							const float pb0 = (ca0 == cb0) ? __uint_as_float(vb.x) : ((ca0 == vb.w) ? __uint_as_float(vb.y) : 0.0f);
+							const float pb1 = (va.w == cb0) ? __uint_as_float(vb.x) : ((va.w == vb.w) ? __uint_as_float(vb.y) : 0.0f);
 							sum += __uint_as_float(va.x) * pb0;
-							sum += __uint_as_float(va.z) * pb1;
+							sum += __uint_as_float(va.y) * pb1;
 							const bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
-							const u32 da = va.y >> 16, db = vb.y >> 16;
+							const u32 da = va.z >> 16, db = vb.z >> 16;
 							if ((adv_a && da == 0u) || (adv_b && db == 0u)) break;
 							ia += adv_a ? da : 0u;
 							ib += adv_b ? db : 0u;
@@ -422,14 +423,14 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_
 					// moves to its next block; when that row has none the merge is over (everything left in the other
 					// row lies beyond it).
 					for (;;) {
-						const MpcU4 va = blocks[ia], vb = blocks[ib]; // {p0, c0 | delta << 16, p1, c1}
-						const u32 ca0 = va.y & 0xffffu, cb0 = vb.y & 0xffffu;
-						const float pb0 = (ca0 == cb0) ? __uint_as_float(vb.x) : ((ca0 == vb.w) ? __uint_as_float(vb.z) : 0.0f);
-						const float pb1 = (va.w == cb0) ? __uint_as_float(vb.x) : ((va.w == vb.w) ? __uint_as_float(vb.z) : 0.0f);
+						const MpcU4 va = blocks[ia], vb = blocks[ib]; // {p0, p1, c0 | delta << 16, c1}
+						const u32 ca0 = va.z & 0xffffu, cb0 = vb.z & 0xffffu;
+						const float pb0 = (ca0 == cb0) ? __uint_as_float(vb.x) : ((ca0 == vb.w) ? __uint_as_float(vb.y) : 0.0f);
+						const float pb1 = (va.w == cb0) ? __uint_as_float(vb.x) : ((va.w == vb.w) ? __uint_as_float(vb.y) : 0.0f);
 						sum += __uint_as_float(va.x) * pb0; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
-						sum += __uint_as_float(va.z) * pb1;
+						sum += __uint_as_float(va.y) * pb1;
 						const bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
-						const u32 da = va.y >> 16, db = vb.y >> 16; // blocks to the next block of the row, 0: none
+						const u32 da = va.z >> 16, db = vb.z >> 16; // blocks to the next block of the row, 0: none
 						if ((adv_a && da == 0u) || (adv_b && db == 0u)) break;
 						ia += adv_a ? da : 0u;
 						ib += adv_b ? db : 0u;

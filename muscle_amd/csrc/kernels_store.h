@@ -54,8 +54,9 @@ struct StoreParams {
 	unsigned short *pos_f, *pos_t;
 	// dense variant of the padded layout (the default; relax_dense_kernel. MPCGPU_PAD=rows selects the one above): a record is
 	//   [first block of every row: lcap1 blocks, row a at block a][overflow blocks: ecap blocks]
-	// block = 16 bytes = {P0 bits, col0 | delta << 16, P1 bits, col1}: delta = distance in blocks to the next block of
-	// the same row, 0 in its last block; unused entries are sentinels as above. A row is reached by its index alone
+	// block = 16 bytes = {P0 bits, P1 bits, col0 | delta << 16, col1} (the two probabilities adjacent: one packed
+	// multiply in the kernel): delta = distance in blocks to the next block of the same row, 0 in its last block;
+	// unused entries are sentinels as above. A row is reached by its index alone
 	// (no row pointers), rows of up to MPC_PAD_ROW entries — most of them — never leave the first-block region.
 	u32 pad_dense;   // 0: row-pointer layout above, 1: dense
 	u32 pad_ent_off; // dword offset of entry 0 inside a record (lcap1 for the row-pointer layout, 0 for the dense one)
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(64) pad_build_dense_kernel(StoreParams s)
 		const u32 LA = s.seq_len[A];
 		u32 *rec_out = s.pad + b * (u64)s.pad_stride;
 		for (u32 q = t; q < units; q += 64) { // every block starts as an empty one
-			rec_out[4 * q] = 0u; rec_out[4 * q + 1] = MPC_PAD_SENTINEL; rec_out[4 * q + 2] = 0u; rec_out[4 * q + 3] = MPC_PAD_SENTINEL;
+			rec_out[4 * q] = 0u; rec_out[4 * q + 1] = 0u; rec_out[4 * q + 2] = MPC_PAD_SENTINEL; rec_out[4 * q + 3] = MPC_PAD_SENTINEL;
 		}
 		if (A == Z) continue; // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
 		const bool fwd = A < Z;
@@ -292,8 +293,8 @@ __global__ void __launch_bounds__(64) pad_build_dense_kernel(StoreParams s)
 			const u32 ovf0 = s.lcap1 + s_ovf[r]; // first overflow block of this row
 			const u32 unit = j == 0 ? r : ovf0 + (j - 1);
 			const u32 delta = j + 1 < nb ? (j == 0 ? ovf0 - r : 1u) : 0u; // blocks to the row's next block
-			rec_out[4 * unit + 2 * slot] = pbits;
-			rec_out[4 * unit + 2 * slot + 1] = slot == 0 ? (c | (delta << 16)) : c;
+			rec_out[4 * unit + slot] = pbits;
+			rec_out[4 * unit + 2 + slot] = slot == 0 ? (c | (delta << 16)) : c;
 			pos[q] = (unsigned short)(unit * MPC_PAD_ROW + slot);
 		}
 		__syncthreads(); // s_start is reused by the next record
@@ -393,8 +394,13 @@ __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
 		const u32 tq = ent[3 * (u64)nnz + idx];
 		ent[2 * (u64)idx] = pb;
 		(void)tq;
-		s.pad[((u64)X * s.n + Y) * s.pad_stride + s.pad_ent_off + 2 * (u64)s.pos_f[e]] = pb;
-		s.pad[((u64)Y * s.n + X) * s.pad_stride + s.pad_ent_off + 2 * (u64)s.pos_t[e]] = pb;
+		// dword of entry `pos` inside a record: row-pointer layout: entries {P, col} back to back after the row pointers;
+		// dense layout: entry = block * 2 + slot, its P at dword block * 4 + slot
+		const u32 pf = s.pos_f[e], pt = s.pos_t[e];
+		const u64 df = s.pad_dense ? (u64)((pf >> 1) * 4u + (pf & 1u)) : s.pad_ent_off + 2 * (u64)pf;
+		const u64 dt = s.pad_dense ? (u64)((pt >> 1) * 4u + (pt & 1u)) : s.pad_ent_off + 2 * (u64)pt;
+		s.pad[((u64)X * s.n + Y) * s.pad_stride + df] = pb;
+		s.pad[((u64)Y * s.n + X) * s.pad_stride + dt] = pb;
 	}
 }
 
