@@ -430,9 +430,9 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
 	rp.k0 = k0; rp.k1 = k1;
 	size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-block reads may run past the last matrix
-	// dense records: a second staging buffer (one barrier per step instead of two) when the CU's LDS holds both
+	// dense records, MPCGPU_RELAX_DBUF=1: a second staging buffer (one barrier per step instead of two) when the CU's LDS holds both
 	rp.buf_units = 0;
-	if (dense && env_int("MPCGPU_RELAX_DBUF", 1) != 0) {
+	if (dense && env_int("MPCGPU_RELAX_DBUF", 0) != 0) { // opt-in until it has been measured (and run) on the GPU
 		const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", threads == 1024 ? 160 : 80) * 1024;
 		if (2 * (u64)(bx + by) * mat_bytes + 8 * MPC_RT_ROW <= lds_cap) {
 			rp.buf_units = (u32)((u64)(bx + by) * mat_bytes / 16);

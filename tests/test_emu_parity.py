@@ -306,11 +306,13 @@ def test_emu_dense_records_long_rows(emu):
     P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "dense records, long rows")
 
 
-def test_emu_dense_records_single_lds_buffer(emu):
-    """MPCGPU_RELAX_DBUF=0: the one-buffer, two-barrier schedule of relax_dense_kernel (the default uses two buffers when they fit)"""
+def test_emu_dense_records_two_lds_buffers(emu):
+    """MPCGPU_RELAX_DBUF=1: the two-buffer, one-barrier schedule of relax_dense_kernel (opt-in; the default is one buffer).
+    The emulator runs a workgroup's threads one after the other between barriers, so it checks the indexing of the
+    two buffers, not the absence of races — that is what the GPU test with the same knob is for."""
     seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0]]
-    got = _with_env({"MPCGPU_RELAX_DBUF": "0"}, lambda: P.run_lib(seqs, lib_path=emu))
-    P.assert_same(got, P.run_oracle(seqs), "single LDS buffer")
+    got = _with_env({"MPCGPU_RELAX_DBUF": "1"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "two LDS buffers")
 
 
 def test_emu_row_blocks_vs_reference_golden(emu):
