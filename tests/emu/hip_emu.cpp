@@ -105,9 +105,25 @@ void run_block(Worker &w, unsigned bid, dim3 block, size_t smem)
 		for (int k = 0; k < 6; ++k) *--sp = nullptr;
 		f.sp = sp;
 	}
+	// Order in which the fibers get the OS thread in each round. Between two barriers a fiber runs without interruption,
+	// so a data race inside a barrier interval shows as a result that depends on this order: EMU_SCHED=reverse and
+	// EMU_SCHED=random (a new shuffle every round, fixed seed) make the tests look at other orders than 0..n-1.
+	static const int sched_mode = [] {
+		const char *m = getenv("EMU_SCHED");
+		return (m && !strcmp(m, "reverse")) ? 1 : (m && !strcmp(m, "random")) ? 2 : 0;
+	}();
+	std::vector<unsigned> order(nthreads);
+	for (unsigned t = 0; t < nthreads; ++t) order[t] = sched_mode == 1 ? nthreads - 1 - t : t;
+	uint64_t rng = 0x9e3779b97f4a7c15ull ^ (uint64_t)bid;
 	unsigned remaining = nthreads;
 	while (remaining) {
-		for (unsigned t = 0; t < nthreads; ++t) {
+		if (sched_mode == 2)
+			for (unsigned k = nthreads - 1; k > 0; --k) { // Fisher-Yates with xorshift64
+				rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+				std::swap(order[k], order[rng % (k + 1)]);
+			}
+		for (unsigned oi = 0; oi < nthreads; ++oi) {
+			const unsigned t = order[oi];
 			Fiber &f = w.fibers[t];
 			if (f.done) continue;
 			w.cur = &f;

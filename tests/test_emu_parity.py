@@ -308,8 +308,7 @@ def test_emu_dense_records_long_rows(emu):
 
 def test_emu_dense_records_two_lds_buffers(emu):
     """MPCGPU_RELAX_DBUF=1: the two-buffer, one-barrier schedule of relax_dense_kernel (opt-in; the default is one buffer).
-    The emulator runs a workgroup's threads one after the other between barriers, so it checks the indexing of the
-    two buffers, not the absence of races — that is what the GPU test with the same knob is for."""
+    test_emu_other_thread_orders runs it under reverse and shuffled thread orders as well (race check)."""
     seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0]]
     got = _with_env({"MPCGPU_RELAX_DBUF": "1"}, lambda: P.run_lib(seqs, lib_path=emu))
     P.assert_same(got, P.run_oracle(seqs), "two LDS buffers")
@@ -347,3 +346,14 @@ def test_emu_dense_relax_prefetch_variant(emu):
     seqs = make_family(9, 18, seed=5) + make_family(3, 60, seed=8, p_sub=0.6)
     got = _with_env({"MPCGPU_RELAX_PF": "1"}, lambda: P.run_lib(seqs, lib_path=emu))
     P.assert_same(got, P.run_oracle(seqs), "prefetch variant")
+
+
+@pytest.mark.parametrize("order", ["reverse", "random"])
+def test_emu_other_thread_orders(emu, order):
+    """race check: the emulator runs the GPU threads of a block in reverse / shuffled order (tests/_emu_sched_check.py)"""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, EMU_SCHED=order, PYTHONPATH=os.path.dirname(here) + os.pathsep + here)
+    r = subprocess.run([sys.executable, "-u", os.path.join(here, "_emu_sched_check.py")], env=env, cwd=here,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert r.returncode == 0 and "OK thread order " + order in r.stdout, r.stdout[-3000:]
