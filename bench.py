@@ -70,6 +70,20 @@ def pmc_traffic(kernel, n, length):
         return None
 
 
+def parity_check(g, a):
+    """Self-check after the timed region: the store left by the last timed step (stage 2 = after both relax
+    iterations) and the EA values against the digests the compiled reference produced for this exact workload
+    (tests/golden/mpcbig_*.npz, tests/golden/make_golden.py big). -> ("match" | "MISMATCH" | None, detail)."""
+    import _bigdigest as D
+    name = D.fixture_for(a.n, a.len, a.seed)
+    if name is None:
+        return None, "no reference-generated digest fixture for this workload (fixtures: %s)" % ", ".join(sorted(D.BIG_SETS))
+    z = D.load(name)
+    err = D.compare_ea(z, g.get_ea()) or D.compare_stage(z, 2, g)
+    return ("match", "EA bits and stage-2 sparse posteriors (offsets, columns, float bits) of all pairs equal the "
+            "reference's: tests/golden/mpcbig_%s.npz" % name) if err is None else ("MISMATCH", err)
+
+
 def cpu_baseline(seqs, n_full, budget_s=20.0):
     """Reference (oracle/_ref/libmuscle_ref.so = the reference's own MPCFlat::CalcPosteriors +
     ConsIter, OpenMP over all host cores) on a bounded sample of the same family, extrapolated to
@@ -118,6 +132,7 @@ def main():
     ap.add_argument("--len", "--seqlen", dest="len", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the digest self-check after the timed region")
     a = ap.parse_args()
 
     from muscle_amd.hostinfo import pin_openmp_team
@@ -179,6 +194,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     timers = g.timers_get()
+    rc = 0
 
     if rank == 0:
         nnz = g.get_nnz()
@@ -230,12 +246,18 @@ def main():
         }
         if dry:
             out["dry_run"] = True
+        elif not a.no_parity:
+            out["parity_digest"], out["parity_detail"] = parity_check(g, a)
         if world == 1 and not a.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(seqs, a.n)
         print(json.dumps(out), flush=True)
+        if out.get("parity_digest") == "MISMATCH":
+            rc = 3  # a fast wrong answer is not a result
     g.close()
     if world > 1:
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

@@ -38,22 +38,36 @@ __device__ __forceinline__ float mpc_la2(float x, float y)
 // ---- hot-path form of LOG_ADD (kernels_fb.h): same values, fewer instructions ------------------
 // The four coefficient sets of LOGEXP1 are picked with 12 selects above. The interval bounds
 // (1, 2.5, 4.5, 7.5) are all multiples of 0.5, so ceil(2d) identifies the interval exactly
-// (2d and the ceiling are exact in float; "d <= bound" <=> ceil(2d) <= 2*bound): one 16-entry LDS
-// table indexed by ceil(2d), fetched with a single 16-byte read, replaces the selects. lo/hi use
+// ("d <= bound" <=> ceil(2d) <= 2*bound): one 16-entry LDS table indexed by ceil(2d) - 1, fetched with a
+// single 16-byte read, replaces the selects (mpc_coef_offset below). lo/hi use
 // min/max (no NaNs on this path; equal operands give d = 0 either way). The Horner chain and every
 // rounding step are unchanged, so results are bit-identical to mpc_la2.
 struct __attribute__((aligned(16))) MpcCoef { float c3, c2, c1, c0; };
 #define MPC_COEF_ENTRIES 16
 
-// entry k of the table = coefficient set of the interval that holds d with ceil(2d) == k
-__device__ __forceinline__ void mpc_coef_table_init(MpcCoef *tab, int k)
+// entry q of the table = coefficient set of the interval that holds d with ceil(2d) - 1 == q (q = 0 also for d == 0)
+__device__ __forceinline__ void mpc_coef_table_init(MpcCoef *tab, int q)
 {
 	MpcCoef c;
-	if (k <= 2) { c.c3 = -0.009350833524763f; c.c2 = 0.130659527668286f; c.c1 = 0.498799810682272f; c.c0 = 0.693203116424741f; }
-	else if (k <= 5) { c.c3 = -0.014532321752540f; c.c2 = 0.139942324101744f; c.c1 = 0.495635523139337f; c.c0 = 0.692140569840976f; }
-	else if (k <= 9) { c.c3 = -0.004605031767994f; c.c2 = 0.063427417320019f; c.c1 = 0.695956496475118f; c.c0 = 0.514272634594009f; }
+	if (q <= 1) { c.c3 = -0.009350833524763f; c.c2 = 0.130659527668286f; c.c1 = 0.498799810682272f; c.c0 = 0.693203116424741f; }
+	else if (q <= 4) { c.c3 = -0.014532321752540f; c.c2 = 0.139942324101744f; c.c1 = 0.495635523139337f; c.c0 = 0.692140569840976f; }
+	else if (q <= 8) { c.c3 = -0.004605031767994f; c.c2 = 0.063427417320019f; c.c1 = 0.695956496475118f; c.c0 = 0.514272634594009f; }
 	else { c.c3 = -0.000458661602210f; c.c2 = 0.009695946122598f; c.c1 = 0.930734667215156f; c.c0 = 0.168037164329057f; }
-	tab[k] = c;
+	tab[q] = c;
+}
+
+// Byte offset of d's coefficient set in the table: 16 * (ceil(2d) - 1), from three cheap instructions (measured on
+// MI355X, diag/pkbench: floor / min / cvt / shift issue at 0.6 of the add rate, integer add and `and` at the full rate).
+// bits(d) + (5 << 23) are the bits of 32d (d >= 0, normal), minus one: the float just below it, p = prev(32d). Then
+// trunc(p) = 16 * floor(prev(2d)) + (a fraction part < 16), and floor(prev(2d)) = ceil(2d) - 1 whenever 2d > 0 (prev()
+// only matters when 2d is an integer, which is exactly when the two differ) — so masking trunc(p) with 0xf0 leaves
+// 16 * (ceil(2d) - 1) for every d in (0, 8]. d == 0 and denormal d give a tiny p (offset 0: the first interval, as it
+// should be); d > 8 gives some in-range offset whose result the caller discards (d >= 7.5 returns hi); the conversion
+// saturates for the huge d of LOG_ZERO operands (v_cvt_u32_f32: 0xffffffff).
+__device__ __forceinline__ u32 mpc_coef_offset(float d)
+{
+	const float p = __uint_as_float(__float_as_uint(d) + 0x027fffffu);
+	return mpc_cvt_u32_sat(p) & 0xf0u;
 }
 
 __device__ __forceinline__ float mpc_la2t(float x, float y, const MpcCoef *tab)
@@ -61,9 +75,7 @@ __device__ __forceinline__ float mpc_la2t(float x, float y, const MpcCoef *tab)
 	const float lo = fminf(x, y);
 	const float hi = fmaxf(x, y);
 	const float d = hi - lo;
-	// ceil(2d), clamped in float first (d can be as large as 4e20 when an operand is LOG_ZERO)
-	const int k = (int)fminf(-floorf(-(d + d)), (float)(MPC_COEF_ENTRIES - 1));
-	const MpcCoef c = tab[k];
+	const MpcCoef c = *(const MpcCoef *)((const unsigned char *)tab + mpc_coef_offset(d));
 	const float p = ((c.c3 * d + c.c2) * d + c.c1) * d + c.c0 + lo;
 	return d >= MPC_LOG_UNDERFLOW ? hi : p;
 }

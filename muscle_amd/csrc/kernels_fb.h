@@ -48,7 +48,7 @@
 #define MPC_KEY_COL_MASK ((1u << MPC_KEY_ROW_SHIFT) - 1u)
 #define MPC_KEY_ROW_SHIFT_LONG 16 // row-block (LONG) kernels: rows and columns < 2^16 (checked by the host)
 #define MPC_KEY_COL_MASK_LONG ((1u << MPC_KEY_ROW_SHIFT_LONG) - 1u)
-#define MPC_FB_COEF_BYTES (MPC_COEF_ENTRIES * 16)
+#define MPC_FB_COEF_BYTES (MPC_COEF_ENTRIES * 16) // static LDS of fb_kernel (the host's occupancy / capacity arithmetic adds it)
 #define MPC_MEGA_FMAX 8 // features per position (one byte each in a u64)
 
 struct FbParams {
@@ -110,8 +110,10 @@ template <int H, bool MEGA, bool LONG, int MINB = 1>
 __global__ void __launch_bounds__(256, MINB) fb_kernel(FbParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
-	MpcCoef *s_coef = (MpcCoef *)smem_raw;                        // LOGEXP1 coefficient table, LDS offset 0
-	float *s_match = (float *)(smem_raw + MPC_FB_COEF_BYTES);    // A*A (MEGA: the feature tables)
+	// LOGEXP1 coefficient table: statically allocated, so its LDS address is a compile-time constant that rides in the
+	// offset field of every ds_read_b128 (no per-LOG_ADD base add); the dynamic part below follows it
+	__shared__ MpcCoef s_coef[MPC_COEF_ENTRIES];
+	float *s_match = (float *)smem_raw;                          // A*A (MEGA: the feature tables)
 	float *s_ins = s_match + p.A * p.A;                          // A   (MEGA: unused)
 	if (threadIdx.x < MPC_COEF_ENTRIES)
 		mpc_coef_table_init(s_coef, (int)threadIdx.x);

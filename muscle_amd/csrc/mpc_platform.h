@@ -40,6 +40,9 @@ __device__ __forceinline__ float mpc_read_lane(float v, unsigned l) { return __b
 // orders this wave's earlier global stores before its later global loads (other lanes' data): s_waitcnt only,
 // the waves of a workgroup share the CU's L1
 #define MPC_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+// float -> u32, truncating, saturating (negative and NaN -> 0, >= 2^32 -> 0xffffffff): what v_cvt_u32_f32 does. The C cast is
+// undefined outside the range, so the instruction is named (plain asm: schedulable, no side effects).
+__device__ __forceinline__ unsigned mpc_cvt_u32_sat(float f) { unsigned r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
 // value held by the first active lane, as a wave-uniform scalar (v_readfirstlane_b32 -> SGPR)
 __device__ __forceinline__ unsigned mpc_wave_first(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 #endif

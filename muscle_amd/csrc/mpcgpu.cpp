@@ -795,7 +795,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	const int waves_per_block = 4, block = 64 * waves_per_block;
 	const u32 cus = (u32)c->prop.multiProcessorCount;
 	const bool mega = c->have_mega;
-	const size_t fb_smem = MPC_FB_COEF_BYTES + (mega ? (size_t)c->mg_tab_floats : (size_t)c->A * c->A + c->A) * sizeof(float);
+	const size_t fb_smem = (mega ? (size_t)c->mg_tab_floats : (size_t)c->A * c->A + c->A) * sizeof(float);
 
 	u64 words_done = 0; // record words packed so far
 	u64 done = 0;

@@ -142,7 +142,9 @@ class Store:
             self.h = None
 
     def pairs(self):
-        return [(i, j) for i in range(self.n) for j in range(i + 1, self.n)]
+        if getattr(self, "_pairs", None) is None:
+            self._pairs = [(i, j) for i in range(self.n) for j in range(i + 1, self.n)]
+        return self._pairs
 
     def calc_posteriors(self, hmm, k0=0, k1=None, threads=0):
         ea = np.zeros(max(self.npairs, 1), np.float32)

@@ -106,6 +106,7 @@ static inline float mpc_wave_scan_max_nonneg(float v)
 	}
 	return v;
 }
+static inline unsigned mpc_cvt_u32_sat(float f) { return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xffffffffu : (unsigned)f); }
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
 static inline unsigned long long __ballot(int pred)
 {

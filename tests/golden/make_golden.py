@@ -151,6 +151,83 @@ def gen_mpc(only=None):
             print(pool.map(_mpc_worker, [job])[0])
 
 
+BLOCK = 1000  # pairs per block digest of the digest-only fixtures
+
+
+def _mpc_big_worker(args):
+    """Digest-only fixture of a BASELINE-size set (configs 2 and 3): nothing is kept per pair but its nnz is
+    folded into per-block sha256 digests (BLOCK pairs each, InitPairs order), so a mismatch on the GPU box
+    localises to 1000 pairs; the whole-stage digest is the same stage_digest() as the small sets'."""
+    name, n, length, seed, threads = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import time
+    import _ref as R
+    from muscle_amd.synth import make_family
+    seqs = make_family(n, length, seed=seed)
+    R.init_hmm(False, 0)
+    L = R.lib()
+    arr = (C.c_char_p * len(seqs))(*[s.encode() for s in seqs])
+    if L.ref_mpc_begin(len(seqs), arr, threads) != 0:
+        raise RuntimeError("ref_mpc_begin may only be called once per process")
+    lens = [len(s) for s in seqs]
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    u32p, u8p = R.u32p, R.u8p
+
+    def snap():
+        whole, blocks, blk, tot = hashlib.sha256(), [], hashlib.sha256(), 0
+        for k, (i, j) in enumerate(pairs):
+            nnz = L.ref_mpc_nnz(k)
+            off = np.empty(lens[i] + 1, np.uint32)
+            val = np.empty(max(nnz, 1) * 2, np.uint32)
+            L.ref_mpc_sparse(k, off.ctypes.data_as(u32p), val.ctypes.data_as(u8p))
+            b = off.tobytes() + val[:2 * nnz].tobytes()
+            whole.update(b)
+            blk.update(b)
+            tot += nnz
+            if (k + 1) % BLOCK == 0 or k + 1 == len(pairs):
+                blocks.append(blk.digest())
+                blk = hashlib.sha256()
+        return whole.hexdigest(), np.frombuffer(b"".join(blocks), np.uint8).reshape(-1, 32), tot
+
+    t0 = time.time()
+    L.ref_mpc_calc_posteriors()
+    tA = time.time() - t0
+    ea = np.array([L.ref_mpc_ea(i, j) for (i, j) in pairs], np.float32)
+    eab = [hashlib.sha256(ea[b:b + BLOCK].tobytes()).digest() for b in range(0, len(ea), BLOCK)]
+    d = {"n": np.int32(n), "length": np.int32(length), "seed": np.int32(seed), "block": np.int32(BLOCK),
+         "seqs_sha": np.array(hashlib.sha256("\n".join(seqs).encode()).hexdigest()),
+         "ea_sha": np.array(hashlib.sha256(ea.tobytes()).hexdigest()),
+         "ea_blocks": np.frombuffer(b"".join(eab), np.uint8).reshape(-1, 32)}
+    stages = [snap()]
+    tB = []
+    for it in range(2):
+        t0 = time.time()
+        L.ref_mpc_cons_iter(it)
+        tB.append(time.time() - t0)
+        stages.append(snap())
+    d["nstages"] = np.int32(len(stages))
+    for s, (dig, blocks, tot) in enumerate(stages):
+        d["digest%d" % s] = np.array(dig)
+        d["blocks%d" % s] = blocks
+        d["nnz_total%d" % s] = np.int64(tot)
+    d["ref_seconds"] = np.array([tA] + tB)
+    d["ref_threads"] = np.int32(threads)
+    np.savez_compressed(os.path.join(HERE, "mpcbig_%s.npz" % name), **d)
+    return name, n, [st[2] for st in stages], [tA] + tB
+
+
+BIG_SETS = {"n256_L300": (256, 300, 1), "n1000_L400": (1000, 400, 1)}  # BASELINE configs 2 and 3 (bench.py's families)
+
+
+def gen_mpc_big(names, threads):
+    ctx = mp.get_context("spawn")
+    for name in names:
+        n, length, seed = BIG_SETS[name]
+        with ctx.Pool(1) as pool:
+            print(pool.map(_mpc_big_worker, [(name, n, length, seed, threads)])[0], flush=True)
+
+
 def _mega_worker(name):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import tempfile
@@ -193,6 +270,9 @@ def gen_mega():
 if __name__ == "__main__":
     if sys.argv[1:] == ["mega"]:
         gen_mega()
+        sys.exit(0)
+    if sys.argv[1:2] == ["big"]:  # python make_golden.py big <threads> <name> ...: digest-only BASELINE-size sets (CPU-hours)
+        gen_mpc_big(sys.argv[3:], int(sys.argv[2]))
         sys.exit(0)
     if sys.argv[1:2] == ["mpc"]:  # python make_golden.py mpc <name> ...: only these whole-stage sets
         gen_mpc(set(sys.argv[2:]))

@@ -391,3 +391,31 @@ def test_errors_are_loud():
     with pytest.raises(MpcGpuError):
         g.calc_posteriors(2, 1)
     g.close()
+
+
+@pytest.mark.parametrize("name", ["n256_L300", "n1000_L400"])
+def test_baseline_configs_vs_reference_digests(name):
+    """BASELINE configs 2 (256 x L~300) and 3 (1000 x L~400, the benchmarked workload) in full through the default
+    kernels: EA bits and all three stage snapshots (after CalcPosteriors, after each ConsIter) against digests
+    generated by the compiled reference (tests/golden/mpcbig_*.npz; mpcflat.cpp:313,328, mysparsemx.cpp:87-113)."""
+    import _bigdigest as D
+    if D.fixture_for(*D.BIG_SETS[name]) is None:
+        pytest.skip("fixture tests/golden/mpcbig_%s.npz not generated" % name)
+    z = D.load(name)
+    n, length, seed = D.BIG_SETS[name]
+    seqs = make_family(n, length, seed=seed)
+    import hashlib
+    assert hashlib.sha256("\n".join(seqs).encode()).hexdigest() == str(z["seqs_sha"])
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    assert D.compare_ea(z, g.get_ea()) is None
+    g.build_store()
+    assert D.compare_stage(z, 0, g) is None
+    for it in range(2):
+        g.cons_iter()
+        g.cons_commit()
+        assert D.compare_stage(z, it + 1, g) is None
+    g.close()

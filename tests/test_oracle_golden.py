@@ -95,3 +95,30 @@ def test_expf_emulation_matches_libm():
         if bits(L.orc_expf_emul(float(x), use_fma)) != bits(L.orc_libm_expf(float(x))):
             bad += 1
     assert bad == 0, "%d mismatches (use_fma=%d)" % (bad, use_fma)
+
+
+def test_oracle_vs_config2_block0(hmm):
+    """BASELINE config 2 (256 x L~300) is pinned by reference-generated digests (mpcbig_n256_L300.npz). The oracle
+    reproduces the first two 1000-pair blocks of stage 0 and their EA values (sequences 0..3 against all later ones) —
+    a size the CPU suite can afford; the whole set is the GPU suite's."""
+    import hashlib
+    import _bigdigest as D
+    from muscle_amd.synth import make_family
+    name = "n256_L300"
+    if D.fixture_for(*D.BIG_SETS[name]) is None:
+        pytest.skip("fixture not generated")
+    z = D.load(name)
+    n, length, seed = D.BIG_SETS[name]
+    seqs = make_family(n, length, seed=seed)
+    assert hashlib.sha256("\n".join(seqs).encode()).hexdigest() == str(z["seqs_sha"])
+    st = O.Store(seqs)
+    ea = st.calc_posteriors(hmm, 0, 2000, threads=0)
+    block = int(z["block"])
+    for b in range(2):
+        h = hashlib.sha256()
+        for k in range(b * block, (b + 1) * block):
+            off, val = st.get(k)
+            h.update(np.ascontiguousarray(off, np.uint32).tobytes())
+            h.update(np.ascontiguousarray(val, np.uint32).tobytes())
+        assert h.digest() == z["blocks0"][b].tobytes(), "block %d" % b
+        assert hashlib.sha256(np.ascontiguousarray(ea[b * block:(b + 1) * block], np.float32).tobytes()).digest() == z["ea_blocks"][b].tobytes()
