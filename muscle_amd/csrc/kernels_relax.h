@@ -246,7 +246,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_tile_k
 // pointers, no block counts, no matrix-base arithmetic: rows of up to two entries — most rows — take one step.
 // PF (tuning variant, MPCGPU_RELAX_PF=1): the first blocks of slot q+1's two rows are requested from LDS before slot q's
 // arithmetic, so the round trip of the common one-step merge hides behind it (8 more VGPRs).
-template <int MAXSEQ, int NLD, int THREADS, bool PF = false>
+// DIAG (measurement only, MPCGPU_RELAX_DIAG, results are wrong): 1 = staging and barriers without the merges, 2 = the merges
+// without staging or barriers (every step reads the records of Z = 0) — splits the launch time into its two halves.
+template <int MAXSEQ, int NLD, int THREADS, bool PF = false, int DIAG = 0>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_kernel(RelaxTileParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_
 			if (n > 1) stage_load(1);
 		}
 		for (u32 Z = 0; Z < n; ++Z) {
-			if (!bstride) {
+			if (!bstride && (DIAG != 2 || Z == 0)) {
 				__syncthreads(); // every wave is done reading step Z-1 from LDS
 				stage_store(0);
 				__syncthreads();
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 1 : 4) relax_dense_
 			} else
 #pragma unroll
 			for (int q = 0; q < MPC_RT_SLOTS; ++q) {
-				if ((u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
+				if (DIAG != 1 && (u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
 					u32 c = ab[q];
 					MPC_OPAQUE(c); // one register per slot: the two block indices are unpacked per step
 					u32 ia = c & 0xffffu, ib = c >> 16;

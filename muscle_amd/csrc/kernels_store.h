@@ -60,6 +60,12 @@ struct StoreParams {
 	// (no row pointers), rows of up to MPC_PAD_ROW entries — most of them — never leave the first-block region.
 	u32 pad_dense;   // 0: row-pointer layout above, 1: dense
 	u32 pad_ent_off; // dword offset of entry 0 inside a record (lcap1 for the row-pointer layout, 0 for the dense one)
+	// variable-size dense records (the default; relax_var_kernel, kernels_relaxv.h): the dense block format, but record (A,Z)
+	// holds exactly len(A) first blocks + its own overflow blocks and starts at block rec_off[A*n+Z] of `pad`
+	// (rec_off: n*n+1 entries, 16-byte units); the "distance to the row's next block" of a block is kept in BYTES. No record is
+	// padded to the worst one: 8.1 KB instead of 13.3 KB on average at 1000 x L~400.
+	const u32 *rec_off;
+	u32 pad_var;
 };
 
 #define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128). 4 was tried: records grow past the 16 KiB a 1024-thread
@@ -301,6 +307,122 @@ __global__ void __launch_bounds__(64) pad_build_dense_kernel(StoreParams s)
 	}
 }
 
+// ---- variable-size dense records ---------------------------------------------------------------------------------
+// blocks of record (A,Z): len(A) + sum_a max(ceil(cnt[a]/2) - 1, 0); one 64-thread workgroup per record
+__global__ void __launch_bounds__(64) var_size_kernel(StoreParams s, u32 *sizes)
+{
+	const int t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		const u32 LA = s.seq_len[A];
+		u32 mine = 0;
+		if (A != Z) {
+			const bool fwd = A < Z;
+			const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+			const u32 *rec = s.packed + s.pbase[k];
+			const u32 *cnt = fwd ? rec : rec + s.seq_len[Z];
+			for (u32 a = t; a < LA; a += 64) {
+				const u32 nb = (cnt[a] + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
+				mine += nb > 1 ? nb - 1 : 0;
+			}
+			for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
+		}
+		if (t == 0) sizes[b] = LA + mine;
+	}
+}
+
+// One 64-thread workgroup per ordered pair (A,Z). Dynamic LDS: 2*lcap1 u32 (lcap1 >= the longest sequence).
+__global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
+{
+	MPC_DYN_SMEM(smem_raw);
+	u32 *s_start = (u32 *)smem_raw; // entries before row a in the packed (unpadded) order
+	u32 *s_ovf = s_start + s.lcap1; // overflow blocks before row a
+	const int t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		const u32 LA = s.seq_len[A];
+		u32 *rec_out = s.pad + 4 * (u64)s.rec_off[b];
+		const u32 units = s.rec_off[b + 1] - s.rec_off[b];
+		for (u32 q = t; q < units; q += 64) { // every block starts as an empty one
+			rec_out[4 * q] = 0u; rec_out[4 * q + 1] = 0u; rec_out[4 * q + 2] = MPC_PAD_SENTINEL; rec_out[4 * q + 3] = MPC_PAD_SENTINEL;
+		}
+		if (A == Z) continue; // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
+		const bool fwd = A < Z;
+		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 LX = fwd ? LA : s.seq_len[Z]; // rows of the stored (unordered) pair
+		const u32 LY = fwd ? s.seq_len[Z] : LA;
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		const u32 *cnt = fwd ? rec : rec + LX; // rowcnt or colcnt, LA entries
+		u32 carry = 0, carry_o = 0;
+		for (u32 a0 = 0; a0 < LA; a0 += 64) {
+			const u32 a = a0 + t;
+			const u32 v = (a < LA) ? cnt[a] : 0;
+			const u32 nb = (v + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
+			const u32 vo = nb > 1 ? nb - 1 : 0;
+			u32 incl = v, incl_o = vo;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d), oo = __shfl_up(incl_o, d);
+				if (t >= d) { incl += o; incl_o += oo; }
+			}
+			if (a < LA) {
+				s_start[a] = carry + incl - v;
+				s_ovf[a] = carry_o + incl_o - vo;
+			}
+			carry += __shfl(incl, 63);
+			carry_o += __shfl(incl_o, 63);
+		}
+		__syncthreads(); // empty blocks and scans are in place before the entries go in
+		const u32 *e = rec + LX + LY;
+		const u32 *rowv = e + 2 * (u64)nnz;
+		const u32 *tperm = rowv + nnz;
+		unsigned short *pos = (fwd ? s.pos_f : s.pos_t) + s.vbase[k];
+		for (u32 q = t; q < nnz; q += 64) {
+			const u32 pbits = e[2 * (u64)q];
+			const u32 col = e[2 * (u64)q + 1], row = rowv[q];
+			const u32 r = fwd ? row : col;       // row of this entry in M(A,Z)
+			const u32 rank = fwd ? q : tperm[q]; // its rank in M(A,Z)'s row-major order
+			const u32 c = fwd ? col : row;
+			const u32 within = rank - s_start[r];
+			const u32 j = within / MPC_PAD_ROW, slot = within % MPC_PAD_ROW;
+			const u32 nb = (cnt[r] + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
+			const u32 ovf0 = LA + s_ovf[r]; // first overflow block of this row
+			const u32 unit = j == 0 ? r : ovf0 + (j - 1);
+			const u32 delta = j + 1 < nb ? (j == 0 ? ovf0 - r : 1u) : 0u; // blocks to the row's next block
+			rec_out[4 * unit + slot] = pbits;
+			rec_out[4 * unit + 2 + slot] = slot == 0 ? (c | (delta << 20)) : c; // << 16 and * 16: bytes
+			pos[q] = (unsigned short)(unit * MPC_PAD_ROW + slot);
+		}
+		__syncthreads(); // s_start is reused by the next record
+	}
+}
+
+// Largest LDS footprint of a tile's records over one walk: out[t] = max over Z of the sum over the tile's resident sequences
+// (the X range, then the part of the Y range not in it) of blocks(seq, Z). One wave per tile, lanes stride over Z.
+__global__ void __launch_bounds__(64) var_tile_fit_kernel(StoreParams s, const u32 *tiles, u32 ntiles, u32 *out)
+{
+	const u32 t = threadIdx.x, n = s.n;
+	for (u32 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+		const u32 x0 = tiles[4 * tl], nx = tiles[4 * tl + 1], y0 = tiles[4 * tl + 2], ny = tiles[4 * tl + 3];
+		u32 best = 0;
+		for (u32 Z = t; Z < n; Z += 64) {
+			u32 sum = 0;
+			for (u32 i = 0; i < nx; ++i) { const u64 b = (u64)(x0 + i) * n + Z; sum += s.rec_off[b + 1] - s.rec_off[b]; }
+			for (u32 i = 0; i < ny; ++i) {
+				const u32 Y = y0 + i;
+				if (Y >= x0 && Y < x0 + nx) continue;
+				const u64 b = (u64)Y * n + Z;
+				sum += s.rec_off[b + 1] - s.rec_off[b];
+			}
+			best = sum > best ? sum : best;
+		}
+		for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_down(best, d); best = o > best ? o : best; }
+		if (t == 0) out[tl] = best;
+	}
+}
+
 __device__ __forceinline__ u64 mpc_find_pair(const u64 *vbase, u64 lo, u64 hi, u64 e)
 {
 	// largest k in [lo,hi) with vbase[k] <= e (pairs without entries are skipped naturally)
@@ -399,8 +521,10 @@ __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
 		const u32 pf = s.pos_f[e], pt = s.pos_t[e];
 		const u64 df = s.pad_dense ? (u64)((pf >> 1) * 4u + (pf & 1u)) : s.pad_ent_off + 2 * (u64)pf;
 		const u64 dt = s.pad_dense ? (u64)((pt >> 1) * 4u + (pt & 1u)) : s.pad_ent_off + 2 * (u64)pt;
-		s.pad[((u64)X * s.n + Y) * s.pad_stride + df] = pb;
-		s.pad[((u64)Y * s.n + X) * s.pad_stride + dt] = pb;
+		const u64 bf = s.pad_var ? 4 * (u64)s.rec_off[(u64)X * s.n + Y] : ((u64)X * s.n + Y) * s.pad_stride;
+		const u64 bt = s.pad_var ? 4 * (u64)s.rec_off[(u64)Y * s.n + X] : ((u64)Y * s.n + X) * s.pad_stride;
+		s.pad[bf + df] = pb;
+		s.pad[bt + dt] = pb;
 	}
 }
 

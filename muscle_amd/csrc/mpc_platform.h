@@ -43,6 +43,37 @@ __device__ __forceinline__ float mpc_read_lane(float v, unsigned l) { return __b
 // float -> u32, truncating, saturating (negative and NaN -> 0, >= 2^32 -> 0xffffffff): what v_cvt_u32_f32 does. The C cast is
 // undefined outside the range, so the instruction is named (plain asm: schedulable, no side effects).
 __device__ __forceinline__ unsigned mpc_cvt_u32_sat(float f) { unsigned r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f)); return r; }
+// lane `l` (wave-uniform) of v := sv (wave-uniform scalar). A compare and a select (v_writelane_b32 cannot take its value
+// and its lane number from two different SGPRs on gfx9-class hardware); one-dimensional workgroups of whole waves assumed.
+__device__ __forceinline__ unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { return (threadIdx.x & 63u) == l ? sv : v; }
+// LDS-DMA, 16 bytes per lane: lane L's 16 bytes at `gsrc` go to LDS address `lds_wave_base + 16 * L` without passing
+// through VGPRs (global_load_lds_dwordx4; the LDS base is wave-uniform and travels in M0). Asynchronous: the data is
+// in LDS once the ISSUING wave has waited for vmcnt(0) (mpc_dma_wait) — other waves additionally need a barrier after that.
+__device__ __forceinline__ void mpc_dma16(const void *gsrc, void *lds_wave_base)
+{
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+		(__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void mpc_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// LDS by 32-bit address: the address of a dynamic-LDS location as an integer, and an aligned 16-byte read through such an
+// address (ds_read_b128 on the register as it is: no per-access add of the dynamic-LDS base).
+struct __attribute__((aligned(16))) MpcQuad { unsigned x, y, z, w; };
+__device__ __forceinline__ unsigned mpc_lds_addr(const void *p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void *)p; }
+typedef unsigned mpc_uint4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ MpcQuad mpc_lds_load16(unsigned addr)
+{
+	const mpc_uint4v v = *(const __attribute__((address_space(3))) mpc_uint4v *)(unsigned long long)addr;
+	MpcQuad q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+	return q;
+}
+// A pointer through which wave-uniform reads of memory that this kernel never writes become scalar loads (s_load_dword*:
+// SGPR results, no VGPRs, no vmcnt): the constant address space. (Through a plain global pointer the compiler has to assume
+// the kernel's own stores may alias and issues vector loads.)
+typedef const __attribute__((address_space(4))) unsigned *mpc_const_u32p;
+#define MPC_CONST_U32(p) ((mpc_const_u32p)(unsigned long long)(p))
+// no instruction is scheduled across this point (keeps the loads of unrolled prologue / epilogue iterations from being hoisted
+// on top of each other: register pressure, not speed, decides those parts)
+#define MPC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // value held by the first active lane, as a wave-uniform scalar (v_readfirstlane_b32 -> SGPR)
 __device__ __forceinline__ unsigned mpc_wave_first(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 #endif

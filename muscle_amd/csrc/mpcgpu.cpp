@@ -11,6 +11,7 @@
 #include "kernels_post.h"
 #include "kernels_store.h"
 #include "kernels_relax.h"
+#include "kernels_relaxv.h"
 #include "kernels_aln.h"
 #include "kernels_prog.h"
 #ifndef MPC_EMU
@@ -114,7 +115,12 @@ struct mpcgpu_ctx {
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // padded layout + LDS-tiled relax (else: slabs + gather relax)
 	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0, pad_threads = MPC_RT_THREADS;
-	bool pad_dense = false;      // dense records + relax_dense_kernel (default), else row-pointer records + relax_tile_kernel (MPCGPU_PAD=rows)
+	bool pad_dense = false;      // dense records + relax_dense_kernel (MPCGPU_PAD=dense), else row-pointer records + relax_tile_kernel (MPCGPU_PAD=rows)
+	bool pad_var = false;        // variable-size dense records + relax_var_kernel (the default)
+	DevBuf d_rec_off, d_sizes, d_tilefit;
+	u32 var_max_rec_blocks = 0;  // largest record, 16-byte blocks
+	u64 var_total_blocks = 0;
+	u32 var_threads = 1024, var_nbuf = 2, var_buf_bytes = 0;
 	u32 pad_stride_dw() const { return pad_dense ? 4 * (pad_lcap1 + pad_ecap) : pad_lcap1 + 2 * pad_ecap; }
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
 	std::vector<u32> h_tiles;
@@ -325,6 +331,9 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.pad_ent_off = c->pad_dense ? 0u : c->pad_lcap1;
 	s.pos_f = c->d_pos.as<unsigned short>();
 	s.pos_t = c->d_pos.as<unsigned short>() + c->total_entries;
+	s.rec_off = c->d_rec_off.as<u32>();
+	s.pad_var = c->pad_var ? 1u : 0u;
+	if (c->pad_var) { s.pad_dense = 1u; s.pad_ent_off = 0u; }
 }
 
 // Padded-layout geometry for the LDS-tiled relax; false when a tile cannot fit the CU's LDS (or the
@@ -439,8 +448,11 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			smem = 2 * (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW;
 		}
 	}
+	const int diag = (dense && threads == 1024 && nld == 1 && !pf) ? env_int("MPCGPU_RELAX_DIAG", 0) : 0; // measurement only
 	const void *fn = nullptr;
-	if (pf) fn = (const void *)relax_dense_kernel<8, 1, 1024, true>;
+	if (diag == 1) fn = (const void *)relax_dense_kernel<8, 1, 1024, false, 1>;
+	else if (diag == 2) fn = (const void *)relax_dense_kernel<8, 1, 1024, false, 2>;
+	else if (pf) fn = (const void *)relax_dense_kernel<8, 1, 1024, true>;
 	else if (dense) {
 		if (threads == 1024) fn = nld == 1 ? (const void *)relax_dense_kernel<8, 1, 1024> : (const void *)relax_dense_kernel<8, 2, 1024>;
 		else fn = nld == 1 ? (const void *)relax_dense_kernel<6, 1, 512> : (const void *)relax_dense_kernel<6, 2, 512>;
@@ -472,7 +484,9 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
 	auto launch = [&]() {
-		if (pf) launch_relax_dense<8, 1, 1024, true>(rp, grid, smem, c->stream);
+		if (diag == 1) { auto kern = relax_dense_kernel<8, 1, 1024, false, 1>; MPC_LAUNCH(kern, grid, 1024, smem, c->stream, rp); }
+		else if (diag == 2) { auto kern = relax_dense_kernel<8, 1, 1024, false, 2>; MPC_LAUNCH(kern, grid, 1024, smem, c->stream, rp); }
+		else if (pf) launch_relax_dense<8, 1, 1024, true>(rp, grid, smem, c->stream);
 		else if (dense) {
 			if (threads == 1024) {
 				if (nld == 1) launch_relax_dense<8, 1, 1024>(rp, grid, smem, c->stream);
@@ -503,6 +517,206 @@ int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 	HIPCHK(c, le);
 	if (span_end(c, &ts)) return 1;
+	return 0;
+}
+
+// ---- variable-size records + relax_var_kernel (kernels_relaxv.h) -------------------------------------------------------
+// LDS of one workgroup: the pair table + nbuf staging buffers. 1024-thread workgroups own the CU's 160 KB, 512-thread ones
+// run two per CU.
+void var_lds_geometry(u32 geo, u32 nbuf, u32 *buf_bytes, size_t *smem)
+{
+	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", geo == 1024 ? 160 : 80) * 1024;
+	*buf_bytes = (u32)(((lds_cap - MPC_RV_TAB_BYTES) / nbuf) & ~15ull);
+	*smem = MPC_RV_TAB_BYTES + (size_t)nbuf * *buf_bytes;
+}
+
+// workgroup sizes of relax_var_kernel: 1024 (one per CU), or two per CU of 512 / 640 / 768 threads (4 / 5 / 6 waves per SIMD:
+// 128 / 96 / 80 VGPRs); slots = cells per lane a tile may need (about 12.7 k wave-aligned cells per 4x4 tile at L~400)
+// geometry id = threads per workgroup, except 2048 = two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs)
+u32 var_max_slots(u32 geo) { return geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : geo == 640 ? 21u : 26u; }
+u32 var_geo_from_env()
+{
+	// default: two 768-thread workgroups per CU (6 waves per SIMD): measured 1748 ms per two iterations at 1000 x L~400 against
+	// 1984 (512 x 2), 2017 (1024 x 2: spills in the walk), 2060 (1024 x 1, two staging buffers) — profiles/r02e
+	const int t = env_int("MPCGPU_RELAX_WG", 768);
+	return t == 512 ? 512u : t == 640 ? 640u : t == 1024 ? 1024u : t == 2048 ? 2048u : 768u;
+}
+
+template <int TH, int SL, int WGS, int DG = 0> void launch_relax_var(const RelaxVarParams &rp, u32 grid, size_t smem, hipStream_t st)
+{
+	auto kern = relax_var_kernel<TH, SL, WGS, DG>;
+	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
+}
+
+int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
+{
+	const u32 n = c->n;
+	const u32 geo = c->var_threads, nbuf = c->var_nbuf;
+	const u32 threads = geo == 2048 ? 1024u : geo;
+	u32 buf_bytes = 0;
+	size_t smem = 0;
+	var_lds_geometry(geo, nbuf, &buf_bytes, &smem);
+	const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)var_max_slots(geo)), 1), (int)var_max_slots(geo));
+	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
+	// slots a tile needs: the cells of its pairs in [k0,k1), every pair rounded up to whole waves, in chunks of `threads`
+	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
+		u64 cells = 0;
+		for (u32 X = x0; X < x0 + nx; ++X)
+			for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
+				const u64 k = pidx(X, Y);
+				if (k >= k0 && k < k1) cells += ((u64)c->all_nnz[k] + 63) & ~63ull;
+			}
+		return (u32)((cells + threads - 1) / threads);
+	};
+	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != 4 || c->tiles_by != 4) {
+		std::vector<u32> tiles;
+		bool too_big = false;
+		std::function<void(u32, u32, u32, u32)> emit = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
+			const u32 slots = tile_slots(x0, nx, y0, ny);
+			if (slots == 0) return;
+			if (slots <= max_slots) { tiles.push_back(x0); tiles.push_back(nx); tiles.push_back(y0); tiles.push_back(ny); return; }
+			if (ny > 1) { emit(x0, nx, y0, ny / 2); emit(x0, nx, y0 + ny / 2, ny - ny / 2); }
+			else if (nx > 1) { emit(x0, nx / 2, y0, ny); emit(x0 + nx / 2, nx - nx / 2, y0, ny); }
+			else too_big = true;
+		};
+		// X blocks of 4, Y blocks of 4, walked in 8x8 super-tiles (the workgroups of an XCD read the same sequences' records)
+		const u32 nbx = (n + 3) / 4, nby = (n + 3) / 4;
+		for (u32 sx = 0; sx < nbx; sx += 8)
+			for (u32 sy = 0; sy < nby; sy += 8)
+				for (u32 xb = sx; xb < std::min(sx + 8, nbx); ++xb)
+					for (u32 yb = sy; yb < std::min(sy + 8, nby); ++yb) {
+						const u32 x0 = xb * 4, nx = std::min(4u, n - x0), y0 = yb * 4, ny = std::min(4u, n - y0);
+						if (y0 + ny <= x0 + 1) continue; // no pair X < Y in this block
+						emit(x0, nx, y0, ny);
+					}
+		c->tiles_k0 = c->tiles_k1 = ~0ull;
+		if (too_big) return fail(c, "mpcgpu_cons_iter: a pair has more than %u stored cells (tile slot budget)", max_slots * threads);
+		// LDS fit: a tile's records of one step, packed back to back, must fit one staging buffer at EVERY step. The worst
+		// step of every tile is measured on the device; the few tiles over the budget are split and measured again.
+		const u32 budget_blocks = buf_bytes / 16;
+		std::vector<u32> ok;
+		for (int round = 0; round < 8 && !tiles.empty(); ++round) {
+			const u32 nt = (u32)(tiles.size() / 4);
+			if (upload(c, c->d_tiles, tiles)) return 1;
+			HIPCHK(c, c->d_tilefit.ensure((size_t)nt * 4));
+			MPC_LAUNCH(var_tile_fit_kernel, std::min<u32>(nt, (u32)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_tiles.as<u32>(), nt,
+				c->d_tilefit.as<u32>());
+			HIPCHK(c, hipGetLastError());
+			std::vector<u32> fit(nt);
+			HIPCHK(c, hipMemcpyAsync(fit.data(), c->d_tilefit.p, (size_t)nt * 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			std::vector<u32> next;
+			u32 nsplit = 0;
+			for (u32 t = 0; t < nt; ++t) {
+				const u32 x0 = tiles[4 * t], nx = tiles[4 * t + 1], y0 = tiles[4 * t + 2], ny = tiles[4 * t + 3];
+				if (fit[t] <= budget_blocks) { ok.insert(ok.end(), {x0, nx, y0, ny}); continue; }
+				++nsplit;
+				auto push = [&](u32 a, u32 b, u32 cc, u32 d) { if (tile_slots(a, b, cc, d)) next.insert(next.end(), {a, b, cc, d}); };
+				if (ny > 1) { push(x0, nx, y0, ny / 2); push(x0, nx, y0 + ny / 2, ny - ny / 2); }
+				else if (nx > 1) { push(x0, nx / 2, y0, ny); push(x0 + nx / 2, nx - nx / 2, y0, ny); }
+				else return fail(c, "mpcgpu_cons_iter: the two records of pair (%u,%u) need %u bytes of LDS at some step, one staging buffer holds %u",
+					x0, y0, fit[t] * 16, buf_bytes);
+			}
+			if (trace_on() && nsplit) { fprintf(stderr, "[mpcgpu] relax var: %u of %u tiles over the LDS budget (%u B), split\n", nsplit, nt, buf_bytes); fflush(stderr); }
+			tiles.swap(next);
+		}
+		if (!tiles.empty()) return fail(c, "mpcgpu_cons_iter: tile splitting did not converge");
+		c->h_tiles.swap(ok);
+		if (upload(c, c->d_tiles, c->h_tiles)) return 1;
+		HIPCHK(c, hipStreamSynchronize(c->stream)); // the source of the async copy lives in the context; drained before any rebuild
+		c->tiles_k0 = k0; c->tiles_k1 = k1; c->tiles_bx = 4; c->tiles_by = 4;
+	}
+	const std::vector<u32> &tiles = c->h_tiles;
+	if (tiles.empty()) return 0;
+	RelaxVarParams rp;
+	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
+	rp.k0 = k0; rp.k1 = k1; rp.nbuf = nbuf; rp.buf_bytes = buf_bytes;
+	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only
+	const void *fn = geo == 1024 ? (diag == 1 ? (const void *)relax_var_kernel<1024, 16, 1, 1> : (const void *)relax_var_kernel<1024, 16, 1>)
+	               : geo == 2048 ? (const void *)relax_var_kernel<1024, 14, 2> : geo == 768 ? (const void *)relax_var_kernel<768, 18, 2>
+	               : geo == 640 ? (const void *)relax_var_kernel<640, 21, 2> : (const void *)relax_var_kernel<512, 26, 2>;
+	HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+	int occ = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)threads, smem) != hipSuccess || occ < 1) occ = 1;
+	u32 grid = std::max(std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ), 1u);
+	if (trace_on()) {
+		fprintf(stderr, "[mpcgpu] relax var: tiles=%u wg=%u (geometry %u) nbuf=%u buf=%u B lds=%zu B occ=%d grid=%u max_nnz=%u\n", rp.ntiles, threads, geo, nbuf, buf_bytes, smem, occ, grid, c->max_nnz);
+		fflush(stderr);
+	}
+	TimedSpan ts;
+	if (span_begin(c, 3, &ts)) return 1;
+	if (geo == 1024) {
+		if (diag == 1) launch_relax_var<1024, 16, 1, 1>(rp, grid, smem, c->stream);
+		else launch_relax_var<1024, 16, 1>(rp, grid, smem, c->stream);
+	} else if (geo == 2048) launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
+	else if (geo == 768) launch_relax_var<768, 18, 2>(rp, grid, smem, c->stream);
+	else if (geo == 640) launch_relax_var<640, 21, 2>(rp, grid, smem, c->stream);
+	else launch_relax_var<512, 26, 2>(rp, grid, smem, c->stream);
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts)) return 1;
+	return 0;
+}
+
+// Builds the variable-size record store (rec_off table, records, entry positions). 0 = built (c->pad_var set), 1 = error,
+// 2 = this run does not fit the layout's limits (the caller falls back to the fixed-size records / the gather kernel).
+int build_var_store(mpcgpu_ctx *c)
+{
+	const u32 n = c->n;
+	if (c->max_len > MPC_RV_MAXLEN) return 2;
+	const u32 threads = var_geo_from_env(); // geometry id (see var_max_slots)
+	const u32 nbuf = (u32)std::min(std::max(env_int("MPCGPU_RELAX_NBUF", threads == 1024 ? 2 : 1), 1), 2);
+	if ((((u64)c->max_nnz + 63) & ~63ull) > (u64)var_max_slots(threads) * (threads == 2048 ? 1024u : threads)) return 2; // one pair must fit the slots of a tile
+	StoreParams sp0;
+	fill_store_params(c, sp0);
+	const u64 nn = (u64)n * n;
+	HIPCHK(c, c->d_sizes.ensure(nn * 4));
+	MPC_LAUNCH(var_size_kernel, (u32)std::min<u64>(nn, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp0, c->d_sizes.as<u32>());
+	HIPCHK(c, hipGetLastError());
+	std::vector<u32> off(nn + 1);
+	HIPCHK(c, hipMemcpyAsync(off.data() + 1, c->d_sizes.p, nn * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	off[0] = 0;
+	u32 max_rec = 0;
+	u64 run = 0;
+	for (u64 b = 0; b < nn; ++b) { // exclusive scan in place: off[b+1] holds size(b) on entry
+		const u32 sz = off[b + 1];
+		max_rec = std::max(max_rec, sz);
+		run += sz;
+		if (run > 0xffffffffull) return 2; // block offsets are 32-bit (64 GB of records)
+		off[b + 1] = (u32)run;
+	}
+	if (max_rec > 4095u) return 2; // a block's distance field holds 16 bits of bytes
+	u32 buf_bytes = 0;
+	size_t smem = 0;
+	var_lds_geometry(threads, nbuf, &buf_bytes, &smem);
+	if (2ull * max_rec * 16 > buf_bytes) return 2; // any single pair (two records) must fit one staging buffer
+	const u64 pad_bytes = run * 16 + 4 * std::max<u64>(c->total_entries, 1);
+	size_t freeb = 0, totb = 0;
+	HIPCHK(c, hipMemGetInfo(&freeb, &totb));
+	if (!(pad_bytes <= c->d_pad.cap + c->d_pos.cap || pad_bytes + ((u64)2 << 30) <= (u64)freeb)) return 2;
+	c->d_rp.release(); c->d_ent.release(); c->d_mbase.release(); // slabs of an earlier run are not needed
+	HIPCHK(c, c->d_pad.ensure(std::max<u64>(run, 1) * 16));
+	HIPCHK(c, c->d_pos.ensure(4 * std::max<u64>(c->total_entries, 1))); // pos_f then pos_t, u16 each
+	if (upload(c, c->d_rec_off, off)) return 1;
+	HIPCHK(c, hipStreamSynchronize(c->stream)); // `off` dies with this frame
+	c->have_pad = true; c->pad_var = true; c->pad_dense = true;
+	c->pad_lcap1 = c->max_len; c->pad_ecap = 0; c->pad_bx = 4; c->pad_by = 4;
+	c->var_threads = threads; c->var_nbuf = nbuf; c->var_buf_bytes = buf_bytes;
+	c->var_max_rec_blocks = max_rec; c->var_total_blocks = run;
+	c->tiles_k0 = c->tiles_k1 = ~0ull;
+	StoreParams sp;
+	fill_store_params(c, sp);
+	if (trace_on()) {
+		fprintf(stderr, "[mpcgpu] store: variable-size dense records, %u x %u records, %.2f GB (mean %.0f B, largest %u B), wg=%u nbuf=%u\n", n, n,
+			(double)run * 16 / 1e9, (double)run * 16 / (double)nn, max_rec * 16, threads, nbuf);
+		fflush(stderr);
+	}
+	TimedSpan ts;
+	if (span_begin(c, 2, &ts)) return 1;
+	MPC_LAUNCH(var_build_kernel, (u32)std::min<u64>(nn, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)std::max(sp.lcap1, 1u) * 8, c->stream, sp);
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts)) return 1;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return 0;
 }
 
@@ -1109,11 +1323,20 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	// records fit HBM; otherwise compact slabs + the gather kernel (MPCGPU_RELAX=gather forces it).
 	// Both are device paths with identical results.
 	c->have_pad = false;
+	c->pad_var = false;
 	{
 		const char *mode = getenv("MPCGPU_RELAX");
 		u32 lcap1 = 0, ecap = 0, bx = 0, by = 0, threads = 0;
 		const char *padmode = getenv("MPCGPU_PAD");
-		const bool dense = !(padmode && !strcmp(padmode, "rows")); // default: dense records; MPCGPU_PAD=rows: row-pointer records
+		// default: variable-size dense records (relax_var_kernel); MPCGPU_PAD=dense: fixed-size dense records
+		// (relax_dense_kernel), also the fallback when a run exceeds the variable layout's limits; MPCGPU_PAD=rows: row pointers
+		const bool dense = !(padmode && !strcmp(padmode, "rows"));
+		const bool want_var = !padmode || !strcmp(padmode, "var");
+		if (!(mode && !strcmp(mode, "gather")) && want_var) {
+			const int rc = build_var_store(c);
+			if (rc == 1) return 1;
+			if (rc == 0) { c->have_store = true; return 0; }
+		}
 		if (!(mode && !strcmp(mode, "gather")) && c->max_len <= MPC_RT_MAXLEN) {
 			// size of the largest padded record: rows occupy whole blocks of MPC_PAD_ROW entries
 			StoreParams sp0;
@@ -1275,6 +1498,7 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	if (cnt == 0) return 0;
 	StoreParams sp;
 	fill_store_params(c, sp);
+	if (c->have_pad && c->pad_var) return relax_var(c, sp, k0, k1);
 	if (c->have_pad) return relax_tiled(c, sp, k0, k1);
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;

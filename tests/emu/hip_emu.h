@@ -94,6 +94,7 @@ template <class T> static inline T __shfl_up(T v, unsigned d) { return emu_xchg(
 template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xchg(v, (int)d, false); }
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
 #define MPC_OPAQUE(v) ((void)0)
+#define MPC_SCHED_BARRIER() ((void)0)
 #define MPC_WAVE_FENCE() ((void)0) // emulated lanes meet at every shuffle
 template <class T> static inline T mpc_read_lane(T v, unsigned l) { return __shfl(v, (int)l); }
 template <class T> static inline T mpc_lane_up1(T v) { return __shfl_up(v, 1); }
@@ -107,6 +108,15 @@ static inline float mpc_wave_scan_max_nonneg(float v)
 	return v;
 }
 static inline unsigned mpc_cvt_u32_sat(float f) { return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xffffffffu : (unsigned)f); }
+struct __attribute__((aligned(16))) MpcQuad { unsigned x, y, z, w; };
+static inline unsigned mpc_lds_addr(const void *p) { return (unsigned)((const unsigned char *)p - emu::g_block->dyn_smem); }
+static inline MpcQuad mpc_lds_load16(unsigned addr) { return *(const MpcQuad *)(emu::g_block->dyn_smem + addr); }
+typedef const unsigned *mpc_const_u32p;
+#define MPC_CONST_U32(p) ((mpc_const_u32p)(p))
+static inline unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { return emu::t_lane == l ? sv : v; }
+// LDS-DMA stand-in: synchronous copy (the emulator has no asynchronous memory pipeline; what it checks is addressing)
+static inline void mpc_dma16(const void *gsrc, void *lds_wave_base) { memcpy((unsigned char *)lds_wave_base + 16 * emu::t_lane, gsrc, 16); }
+static inline void mpc_dma_wait() {}
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
 static inline unsigned long long __ballot(int pred)
 {
