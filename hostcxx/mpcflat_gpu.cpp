@@ -50,18 +50,80 @@ struct Batch
 	uint m_PairCount = 0;
 	uint m_Served = 0;	// CalcPosterior calls answered from this batch
 	bool m_Materialise = false; // host copies of the stage-A matrices are needed (no relax follows)
+	bool m_OnHost = false;	// the CURRENT device matrices have been copied into the MySparseMx objects
+	uint m_ItersDone = 0;	// ConsIter calls since the batch started
 	vector<float> m_EA;	// what calcposteriorflat.cpp:89 stores in m_DistMx
+// what the batch was computed from: a caller that re-runs InitSeqs on the same MPCFlat object (cmd_profseq does, with a
+// fresh MPCFlat at the same stack address per query) must get a new batch, not the previous one's numbers
+	vector<const byte *> m_SeqPtrs;
+	vector<uint> m_SeqLens;
+	vector<uint64_t> m_SeqEnds; // first and last 4 bytes of every sequence
 	};
+
+uint64_t SeqEnds(const byte *p, uint L)
+	{
+	uint64_t v = 0;
+	for (uint i = 0; i < 4 && i < L; ++i)
+		v = (v << 8) | p[i];
+	for (uint i = 0; i < 4 && i < L; ++i)
+		v = (v << 8) | p[L - 1 - i];
+	return v;
+	}
 
 std::mutex g_Mu;
 mpcgpu_ctx *g_Ctx = 0;
+mpcgpu_group *g_Group = 0; // MUSCLE_GPU_DEVICES: the all-pairs stage sharded over several GPUs; g_Ctx is then its rank 0
 mpcgpu_ctx *g_CtxJoin = 0; // PProg joins: their own context, so a join never disturbs the store of an MPCFlat run
 std::map<const MPCFlat *, Batch> g_Batches;
+const MPCFlat *g_StoreOwner = 0; // the MPCFlat whose all-pairs store the device currently holds
+
+// MUSCLE_GPU_DEVICES="0-7" | "0,1,2,3" (an ordinal may repeat, e.g. "0,0" on a one-GPU box): one context per listed device,
+// pair loops sharded over them (include/mpcgpu.h, mpcgpu_group_*). Without it: one context on MUSCLE_GPU_DEVICE (default 0).
+vector<int> ParseDevices(const char *s)
+	{
+	vector<int> Devs;
+	while (*s != 0)
+		{
+		char *End = 0;
+		long a = strtol(s, &End, 10);
+		if (End == s)
+			Die("MUSCLE_GPU_DEVICES: cannot parse '%s'", s);
+		long b = a;
+		s = End;
+		if (*s == '-')
+			{
+			b = strtol(s + 1, &End, 10);
+			if (End == s + 1 || b < a)
+				Die("MUSCLE_GPU_DEVICES: bad range");
+			s = End;
+			}
+		for (long d = a; d <= b; ++d)
+			Devs.push_back((int) d);
+		if (*s == ',')
+			++s;
+		else if (*s != 0)
+			Die("MUSCLE_GPU_DEVICES: unexpected '%c'", *s);
+		}
+	return Devs;
+	}
 
 mpcgpu_ctx *GetCtx()
 	{
 	if (g_Ctx != 0)
 		return g_Ctx;
+	const char *List = getenv("MUSCLE_GPU_DEVICES");
+	if (List != 0 && *List != 0)
+		{
+		vector<int> Devs = ParseDevices(List);
+		if (Devs.empty())
+			Die("MUSCLE_GPU_DEVICES is empty");
+		if (mpcgpu_group_create(&g_Group, (uint32_t) Devs.size(), Devs.data()) != 0)
+			Die("GPU posterior stage: %s", mpcgpu_group_last_error(0));
+		g_Ctx = mpcgpu_group_ctx(g_Group, 0);
+		if (getenv("MUSCLE_GPU_TIMING") != 0 || getenv("MUSCLE_GPU_DEBUG") != 0)
+			fprintf(stderr, "[muscle_gpu] %u GPU contexts, exchange by %s\n", mpcgpu_group_size(g_Group), mpcgpu_group_transport(g_Group));
+		return g_Ctx;
+		}
 	int Device = 0;
 	const char *s = getenv("MUSCLE_GPU_DEVICE");
 	if (s != 0 && *s != 0)
@@ -155,6 +217,7 @@ uint64_t Fnv(uint64_t h, const void *p, size_t n)
 	}
 
 #define GPUCHK(call)	do { if ((call) != 0) Die("GPU posterior stage: %s", mpcgpu_last_error(Ctx)); } while (0)
+#define GRPCHK(call)	do { if ((call) != 0) Die("GPU posterior stage: %s", mpcgpu_group_last_error(g_Group)); } while (0)
 
 // Copies pairs [k0,k1) of the device store into MySparseMx objects (layout of
 // mysparsemx.h:6-98; buffers through AllocLX/AllocVec so ownership stays with myalloc/myfree).
@@ -223,7 +286,7 @@ template<class GETMX> void Download(mpcgpu_ctx *Ctx, MPCFlat &M, uint PairCount,
 // calcpost.cpp:14-22: with a .mega input loaded the emissions come from the structure profiles of the
 // sequences (looked up by label, like CalcPost does), not from the PairHMM letter tables. Labels[i] is
 // the label of sequence i of the set just given to mpcgpu_set_seqs / mpcgpu_set_seqs_registry.
-void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_t> &Lens)
+void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_t> &Lens, bool AllRanks = false)
 	{
 	if (!Mega::m_Loaded)
 		return; // set_seqs already switched the context back to letter emissions
@@ -263,8 +326,12 @@ void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_
 			}
 		ProfPtrs[i] = Profs[i].data();
 		}
-	GPUCHK(mpcgpu_set_mega(Ctx, FeatureCount, AlphaSizes.data(), Weights.data(), LogProbPtrs.data(),
-	  MxPtrs.data(), ProfPtrs.data()));
+	if (AllRanks && g_Group != 0)
+		GRPCHK(mpcgpu_group_set_mega(g_Group, FeatureCount, AlphaSizes.data(), Weights.data(), LogProbPtrs.data(),
+		  MxPtrs.data(), ProfPtrs.data()));
+	else
+		GPUCHK(mpcgpu_set_mega(Ctx, FeatureCount, AlphaSizes.data(), Weights.data(), LogProbPtrs.data(),
+		  MxPtrs.data(), ProfPtrs.data()));
 	}
 
 // First CalcPosterior call of a run: the whole all-pairs stage A on the device.
@@ -277,8 +344,12 @@ void StartBatch(MPCFlat &M, Batch &B)
 	asserta(PairCount == (SeqCount*(SeqCount - 1))/2);
 
 // The PairHMM tables are process globals that can change between replicates (align.cpp:35-40)
-	GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
-	  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
+	if (g_Group != 0)
+		GRPCHK(mpcgpu_group_set_hmm(g_Group, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
+		  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
+	else
+		GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
+		  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
 
 	vector<const uint8_t *> Ptrs(SeqCount);
 	vector<uint32_t> Lens(SeqCount);
@@ -290,14 +361,32 @@ void StartBatch(MPCFlat &M, Batch &B)
 		Labels[i] = string(M.GetLabel(i)); // calcposteriorflat.cpp:63-64
 		}
 // (the "HMM overflow" length check of calcposteriorflat.cpp:54-61 is made by the library)
-	GPUCHK(mpcgpu_set_seqs(Ctx, SeqCount, Ptrs.data(), Lens.data()));
-	SetMega(Ctx, Labels, Lens);
-	GPUCHK(mpcgpu_calc_posteriors(Ctx, 0, PairCount));
-	GPUCHK(mpcgpu_build_store(Ctx));
+	if (g_Group != 0)
+		{
+// mpcflat.cpp:239-251 sharded over the devices + the all-gather of the sparse posteriors (mpcgpu_group.cpp)
+		GRPCHK(mpcgpu_group_set_seqs(g_Group, SeqCount, Ptrs.data(), Lens.data()));
+		SetMega(Ctx, Labels, Lens, true);
+		GRPCHK(mpcgpu_group_calc_posteriors(g_Group));
+		}
+	else
+		{
+		GPUCHK(mpcgpu_set_seqs(Ctx, SeqCount, Ptrs.data(), Lens.data()));
+		SetMega(Ctx, Labels, Lens);
+		GPUCHK(mpcgpu_calc_posteriors(Ctx, 0, PairCount));
+		GPUCHK(mpcgpu_build_store(Ctx));
+		}
 
 	B.m_Seqs = M.m_MyInputSeqs;
 	B.m_PairCount = PairCount;
 	B.m_Served = 0;
+	B.m_OnHost = false;
+	B.m_ItersDone = 0;
+	B.m_SeqPtrs.assign(Ptrs.begin(), Ptrs.end());
+	B.m_SeqLens.assign(Lens.begin(), Lens.end());
+	B.m_SeqEnds.resize(SeqCount);
+	for (uint i = 0; i < SeqCount; ++i)
+		B.m_SeqEnds[i] = SeqEnds(Ptrs[i], Lens[i]);
+	g_StoreOwner = &M;
 	B.m_EA.resize(PairCount);
 	GPUCHK(mpcgpu_get_ea(Ctx, 0, PairCount, B.m_EA.data()));
 // MPCFlat::Consistency (mpcflat.cpp:173-181) is skipped for < 3 sequences or 0 iterations: then the
@@ -328,11 +417,28 @@ void MPCFlat::CalcPosterior(uint PairIndex)
 		{
 		std::lock_guard<std::mutex> Guard(g_Mu);
 		Batch &B = g_Batches[this];
-		if (B.m_Seqs != m_MyInputSeqs || B.m_PairCount != SIZE(m_Pairs) || B.m_Served >= B.m_PairCount)
+		bool Fresh = (B.m_Seqs == m_MyInputSeqs && B.m_PairCount == SIZE(m_Pairs) && B.m_Served < B.m_PairCount &&
+		  g_StoreOwner == this && SIZE(B.m_SeqPtrs) == GetSeqCount());
+		if (Fresh)
+			{
+// the two sequences of this pair are still the ones the batch was computed from
+			const uint Idx[2] = { SeqIndexX, SeqIndexY };
+			for (int q = 0; q < 2; ++q)
+				{
+				const uint i = Idx[q];
+				if (B.m_SeqPtrs[i] != GetBytePtr(i) || B.m_SeqLens[i] != GetSeqLength(i) ||
+				  B.m_SeqEnds[i] != SeqEnds(GetBytePtr(i), GetSeqLength(i)))
+					Fresh = false;
+				}
+			}
+		if (!Fresh)
 			{
 			StartBatch(*this, B);
 			if (B.m_Materialise && DownloadOn())
+				{
 				Download(g_Ctx, *this, B.m_PairCount, [this](uint k) -> MySparseMx & { return GetSparsePost(k); });
+				B.m_OnHost = true;
+				}
 			}
 		asserta(PairIndex < B.m_PairCount);
 		EA = B.m_EA[PairIndex];
@@ -351,14 +457,50 @@ void MPCFlat::ConsIter(uint Iter)
 		{
 		std::lock_guard<std::mutex> Guard(g_Mu);
 		mpcgpu_ctx *Ctx = GetCtx();
-		GPUCHK(mpcgpu_cons_iter(Ctx, 0, PairCount));
-		GPUCHK(mpcgpu_cons_commit(Ctx));
+		if (g_StoreOwner != this)
+			Die("GPU posterior stage: ConsIter on an MPCFlat whose posteriors are not the ones on the device");
+		Batch &B = g_Batches[this];
+		++B.m_ItersDone;
+		B.m_OnHost = false;
+		if (g_Group != 0)
+			GRPCHK(mpcgpu_group_cons_iter(g_Group)); // consflat.cpp:5-23 sharded + the all-gather of the new values
+		else
+			{
+			GPUCHK(mpcgpu_cons_iter(Ctx, 0, PairCount));
+			GPUCHK(mpcgpu_cons_commit(Ctx));
+			}
 // Nothing on the host reads the matrices any more (ProgressiveAlign/Refine -> AlignAlns below);
 // they are downloaded after the last iteration only on request.
 		if (Iter + 1 == m_ConsistencyIterCount && DownloadOn())
+			{
 			Download(Ctx, *this, PairCount, [this](uint k) -> MySparseMx & { return GetUpdatedSparsePost(k); });
+			B.m_OnHost = true; // (they become GetSparsePost after the swap below)
+			}
 		}
 	swap(m_ptrSparsePosts, m_ptrUpdatedSparsePosts); // consflat.cpp:22
+	}
+
+// MPCFlat::BuildPost (buildpostflat.cpp:18-106) stays the reference's: its definition is renamed at link time
+// (hostcxx/build_muscle_gpu.sh: objcopy --redefine-sym) and called from here after the sparse matrices it reads
+// (GetSparsePost, mpcflat.h) have been copied back from the device. MPCFlat::AlignAlns above never takes this road (it builds
+// the matrix on the device); the callers that do are outside MPCFlat::Run — cmd_profseq (profseq.cpp:49) computes a
+// few posteriors and goes straight to BuildPost.
+void MPCFlat_BuildPost_ref(MPCFlat *This, const MultiSequence &MSA1, const MultiSequence &MSA2, float *Post) asm("MPCFlat_BuildPost_ref");
+
+void MPCFlat::BuildPost(const MultiSequence &MSA1, const MultiSequence &MSA2, float *Post)
+	{
+		{
+		std::lock_guard<std::mutex> Guard(g_Mu);
+		std::map<const MPCFlat *, Batch>::iterator p = g_Batches.find(this);
+		if (p != g_Batches.end() && g_StoreOwner == this && !p->second.m_OnHost)
+			{
+			Batch &B = p->second;
+			mpcgpu_ctx *Ctx = GetCtx();
+			Download(Ctx, *this, B.m_PairCount, [this](uint k) -> MySparseMx & { return GetSparsePost(k); });
+			B.m_OnHost = true;
+			}
+		}
+	MPCFlat_BuildPost_ref(this, MSA1, MSA2, Post);
 	}
 
 MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
@@ -379,6 +521,8 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 		if (m_Weights[i] != 1.0f)
 			Die("GPU posterior stage: sequence weights other than 1 are not supported");
 
+	if (g_StoreOwner != this)
+		Die("GPU posterior stage: AlignAlns on an MPCFlat whose posteriors are not the ones on the device");
 	Stopwatch SW(T_ALN_PREP);
 	vector<uint32_t> Seqs1(SeqCount1), Seqs2(SeqCount2);
 	vector<uint32_t> Map1, Map2;

@@ -98,9 +98,11 @@ int mpcgpu_shard_info(mpcgpu_ctx *ctx, uint64_t *bytes, void **dev_ptr);
 int mpcgpu_shard_export(mpcgpu_ctx *ctx, void *dev_dst);
 /* Build the all-pairs store from nshards packed shards laid out back to back in device memory
  * (dev_all; shard s occupies bytes[s] bytes, covers pairs [k0[s],k1[s]), ascending, contiguous,
- * covering [0,pair_count)). dev_all must stay valid until the next set_seqs/destroy. */
+ * covering [0,pair_count)). The library ADOPTS dev_all as the packed half of its store: it must stay
+ * valid and otherwise untouched until the next set_seqs/destroy, and mpcgpu_cons_commit writes the
+ * new probabilities into it (the swap of consflat.cpp:22) — hence not const. */
 int mpcgpu_store_import(mpcgpu_ctx *ctx, uint32_t nshards, const uint64_t *k0, const uint64_t *k1,
-                        const uint64_t *bytes, const void *dev_all);
+                        const uint64_t *bytes, void *dev_all);
 /* Device address + element count of the float array holding the next-iteration probabilities of
  * ALL pairs in canonical order (pair ascending, entries row-major), and the [first, first+count)
  * slice that cons_iter(k0,k1) writes. The caller all-gathers the slices in place, then commits. */
@@ -164,6 +166,33 @@ int mpcgpu_set_seqs_registry(mpcgpu_ctx *ctx, uint32_t n, const uint8_t *const *
 int mpcgpu_align_msas(mpcgpu_ctx *ctx, uint32_t npairs, const uint32_t *seq1, const uint32_t *seq2, uint32_t C1,
                       uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, char *path, uint32_t *pathlen,
                       float *score, float *ea_out);
+
+/* ---- several GPUs of one node inside ONE process (muscle_amd/csrc/mpcgpu_group.cpp) --------------------------
+ * The drop-in binary is one process; it consumes the multi-GPU path through these calls. A group owns one context per
+ * listed device (an ordinal may repeat: two contexts on one device is how the tests run this on a one-GPU box), shards
+ * the pair loops of MPCFlat::CalcPosteriors (mpcflat.cpp:239-251) and MPCFlat::ConsIter (consflat.cpp:5-23) over them
+ * (contiguous pair ranges balanced by DP cells) and performs the two exchanges itself: the all-gather of the packed
+ * sparse posteriors before relax and the all-gather of the new probabilities after each iteration — RCCL point-to-point
+ * sends/receives over xGMI with exact sizes when the devices are distinct and librccl loads (transport "rccl"), peer
+ * copies otherwise ("peer"; MPCGPU_GROUP_TRANSPORT=peer|rccl forces one). After group_calc_posteriors every context
+ * holds the full store, so the host reads results (EA, matrices, mpcgpu_align_alns ...) from mpcgpu_group_ctx(g, 0). */
+typedef struct mpcgpu_group mpcgpu_group;
+int mpcgpu_group_create(mpcgpu_group **out, uint32_t ndev, const int *device_ordinals);
+void mpcgpu_group_destroy(mpcgpu_group *g);
+const char *mpcgpu_group_last_error(const mpcgpu_group *g); /* g may be NULL: last create() error */
+uint32_t mpcgpu_group_size(const mpcgpu_group *g);
+mpcgpu_ctx *mpcgpu_group_ctx(mpcgpu_group *g, uint32_t rank);
+const char *mpcgpu_group_transport(const mpcgpu_group *g); /* "rccl" or "peer" */
+/* mpcgpu_set_hmm / mpcgpu_set_seqs / mpcgpu_set_mega on every context */
+int mpcgpu_group_set_hmm(mpcgpu_group *g, const float start[5], const float trans[25], const float match[256 * 256],
+                         const float ins[256], float min_sparse_score, int expf_variant);
+int mpcgpu_group_set_seqs(mpcgpu_group *g, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens);
+int mpcgpu_group_set_mega(mpcgpu_group *g, uint32_t nfeat, const uint32_t *alpha, const float *weight,
+                          const float *const *logprobs, const float *const *logprob_mx, const uint8_t *const *profiles);
+/* MPCFlat::CalcPosteriors for all pairs: stage A sharded, all-gather, store built on every device. */
+int mpcgpu_group_calc_posteriors(mpcgpu_group *g);
+/* One MPCFlat::ConsIter: relax sharded, all-gather of the values, commit on every device. */
+int mpcgpu_group_cons_iter(mpcgpu_group *g);
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------------- */
 /* Kernel time in ms measured with hipEvents on the library's own stream, accumulated since the

@@ -21,6 +21,9 @@ SYMBOLS = [
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
     "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize",
+    "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
+    "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
+    "mpcgpu_group_calc_posteriors", "mpcgpu_group_cons_iter",
 ]
 
 
@@ -74,8 +77,87 @@ def load(lib_path=None):
     L.mpcgpu_timers_get.argtypes = [vp, vp, vp]
     L.mpcgpu_work_get.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mpcgpu_synchronize.argtypes = [vp]
+    L.mpcgpu_group_create.argtypes = [C.POINTER(vp), u32, vp]
+    L.mpcgpu_group_destroy.argtypes = [vp]
+    L.mpcgpu_group_destroy.restype = None
+    L.mpcgpu_group_last_error.argtypes = [vp]
+    L.mpcgpu_group_last_error.restype = C.c_char_p
+    L.mpcgpu_group_size.argtypes = [vp]
+    L.mpcgpu_group_size.restype = u32
+    L.mpcgpu_group_ctx.argtypes = [vp, u32]
+    L.mpcgpu_group_ctx.restype = vp
+    L.mpcgpu_group_transport.argtypes = [vp]
+    L.mpcgpu_group_transport.restype = C.c_char_p
+    L.mpcgpu_group_set_hmm.argtypes = [vp, vp, vp, vp, vp, C.c_float, i32]
+    L.mpcgpu_group_set_seqs.argtypes = [vp, u32, vp, vp]
+    L.mpcgpu_group_set_mega.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+    L.mpcgpu_group_calc_posteriors.argtypes = [vp]
+    L.mpcgpu_group_cons_iter.argtypes = [vp]
     _libs[path] = L
     return L
+
+
+class MpcGroup:
+    """Several GPUs of one node inside one process (include/mpcgpu.h, mpcgpu_group_*): what the drop-in binary uses with
+    MUSCLE_GPU_DEVICES. `devices` may repeat an ordinal (tests on a one-GPU box). ctx(r) is a non-owning MpcGpu view of
+    rank r's context; rank 0 is the one a host reads results from."""
+
+    def __init__(self, devices, lib_path=None):
+        self.L = load(lib_path)
+        self.lib_path = lib_path
+        devs = np.asarray(devices, np.int32)
+        h = C.c_void_p()
+        if self.L.mpcgpu_group_create(C.byref(h), len(devs), devs.ctypes.data) != 0:
+            raise MpcGpuError(self.L.mpcgpu_group_last_error(None).decode())
+        self.h = h
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mpcgpu_group_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MpcGpuError(self.L.mpcgpu_group_last_error(self.h).decode())
+
+    @property
+    def size(self):
+        return int(self.L.mpcgpu_group_size(self.h))
+
+    def transport(self):
+        return self.L.mpcgpu_group_transport(self.h).decode()
+
+    def set_hmm(self, start, trans, match, ins, min_sparse_score, expf_variant=-1):
+        a = [np.ascontiguousarray(x, np.float32) for x in (start, trans, match, ins)]
+        self._ck(self.L.mpcgpu_group_set_hmm(self.h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                                              float(min_sparse_score), expf_variant))
+
+    def set_seqs(self, seqs):
+        bufs = [np.frombuffer(s.encode() if isinstance(s, str) else bytes(s), np.uint8).copy() for s in seqs]
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        lens = np.array([len(b) for b in bufs], np.uint32)
+        self._ck(self.L.mpcgpu_group_set_seqs(self.h, len(bufs), ptrs, lens.ctypes.data))
+        self.n = len(bufs)
+        self.lens = lens
+
+    def calc_posteriors(self):
+        self._ck(self.L.mpcgpu_group_calc_posteriors(self.h))
+
+    def cons_iter(self):
+        self._ck(self.L.mpcgpu_group_cons_iter(self.h))
+
+    def ctx(self, rank):
+        g = MpcGpu.__new__(MpcGpu)
+        g.L = self.L
+        g._owned = False  # close()/__del__ of the view must not destroy the group's context
+        g.h = C.c_void_p(self.L.mpcgpu_group_ctx(self.h, rank))
+        g.n = self.n
+        g.lens = self.lens
+        g.pairs = [(i, j) for i in range(self.n) for j in range(i + 1, self.n)] if self.n <= 4096 else None
+        return g
 
 
 class MpcGpu:
@@ -93,7 +175,8 @@ class MpcGpu:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.mpcgpu_destroy(self.h)
+            if getattr(self, "_owned", True):
+                self.L.mpcgpu_destroy(self.h)
             self.h = None
 
     __del__ = close

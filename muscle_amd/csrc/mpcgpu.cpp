@@ -1268,7 +1268,7 @@ int mpcgpu_shard_export(mpcgpu_ctx *c, void *dev_dst)
 }
 
 int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, const uint64_t *k1,
-	const uint64_t *bytes, const void *dev_all)
+	const uint64_t *bytes, void *dev_all)
 {
 	if (!c) return 1;
 	if (c->n == 0) return fail(c, "mpcgpu_store_import: call mpcgpu_set_seqs first");

@@ -36,8 +36,9 @@ def shard_bounds(lens, world):
 
 class TorchExchange:
     """The two collectives of the sharded stage, over torch.distributed (backend nccl == RCCL on
-    ROCm; gloo in the CPU tests). Uneven shard sizes are padded to the maximum so the collective is
-    one all_gather_into_tensor."""
+    ROCm; gloo in the CPU tests). Shards differ in size, so the all-gather is `world` broadcasts,
+    each of one rank's exact segment straight into its final place in ONE preallocated buffer
+    (queued together, waited for once): no padding to the largest shard and no concatenation copy."""
 
     def __init__(self, dist, device):
         self.dist = dist
@@ -52,15 +53,20 @@ class TorchExchange:
         self.dist.all_gather_into_tensor(out, t)
         return [int(x) for x in out.cpu()]
 
-    def all_gather_padded(self, mine, sizes, dtype):
-        """mine: 1-D tensor of sizes[rank] elements. Returns 1-D tensor = concatenation over ranks."""
+    def all_gather_var(self, mine, sizes, dtype):
+        """mine: 1-D tensor of sizes[rank] elements. Returns a 1-D tensor = concatenation over ranks."""
         import torch
-        mx = max(max(sizes), 1)
-        pad = torch.zeros(mx, dtype=dtype, device=self.device)
-        pad[:sizes[self.rank]] = mine
-        out = torch.empty(mx * self.world, dtype=dtype, device=self.device)
-        self.dist.all_gather_into_tensor(out, pad)
-        return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(self.world)])
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + int(sz))
+        full = torch.empty(max(offs[-1], 1), dtype=dtype, device=self.device)
+        if sizes[self.rank]:
+            full[offs[self.rank]:offs[self.rank + 1]].copy_(mine)
+        works = [self.dist.broadcast(full[offs[r]:offs[r + 1]], src=r, async_op=True) for r in range(self.world) if sizes[r]]
+        for w in works:
+            if w is not None:
+                w.wait()
+        return full[:offs[-1]]
 
 
 def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=None):
@@ -86,7 +92,7 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
     sizes = exchange.all_sizes(nbytes)
     mine = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=exchange.device)
     engine.shard_export(mine.data_ptr())
-    full = exchange.all_gather_padded(mine[:nbytes], sizes, torch.uint8)
+    full = exchange.all_gather_var(mine[:nbytes], sizes, torch.uint8)
     _sync(torch, exchange.device)
     engine.store_import(cuts[:-1], cuts[1:], sizes, full.data_ptr())
     engine._keepalive = full  # dev_all must outlive the store
@@ -98,7 +104,7 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
             engine.cons_iter(k0, k1)
             v = torch.empty(max(count, 1), dtype=torch.float32, device=exchange.device)
             engine.values_export(first, count, v.data_ptr())
-            allv = exchange.all_gather_padded(v[:count], counts, torch.float32)
+            allv = exchange.all_gather_var(v[:count], counts, torch.float32)
             _sync(torch, exchange.device)
             engine.values_import(0, int(allv.numel()), allv.data_ptr())
             engine.cons_commit()

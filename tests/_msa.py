@@ -83,7 +83,7 @@ def mega_input(name):
     return _mega.mega_text(base), extra
 
 
-def run_muscle(binary, name, threads=4, timeout=900):
+def run_muscle(binary, name, threads=4, timeout=900, env=None):
     mega = name.startswith("mega_")
     if mega:
         text, extra = mega_input(name)
@@ -105,7 +105,8 @@ def run_muscle(binary, name, threads=4, timeout=900):
             with open(os.path.join(d, fn), "w") as f:
                 f.write(text)
         subprocess.run([binary, cmd, fa, "-output", out, "-threads", str(threads), "-quiet"] + cmd_extra + extra,
-                       check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                       check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       env=None if env is None else dict(os.environ, **env))
         with open(out, "rb") as f:
             data = f.read()
     return hashlib.md5(data).hexdigest(), data

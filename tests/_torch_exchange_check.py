@@ -48,6 +48,18 @@ class ThreadDist:
         self.bar.wait()
 
 
+    def broadcast(self, t, src, async_op=False):
+        _sync()
+        if self.tl.rank == src:
+            self.slots[src] = t
+        self.bar.wait()
+        if self.tl.rank != src:
+            t.copy_(self.slots[src])
+        _sync()
+        self.bar.wait()
+        return None
+
+
 def _sync():
     if DEVICE.startswith("cuda"):
         torch.cuda.synchronize()

@@ -41,3 +41,12 @@ def emu_muscle():
 def test_final_msa_identical(emu_muscle, name):
     md5, _ = _msa.run_muscle(emu_muscle, name, threads=3)
     assert md5 == _msa.golden_md5()[name]
+
+
+@pytest.mark.parametrize("name,devices", [("synth_6x40_s2+r2", "0,0"), ("n8_L60", "0,0,0"), ("mega_synth_6x40_s2+r2", "0,0")])
+def test_final_msa_identical_sharded_over_contexts(emu_muscle, name, devices):
+    """MUSCLE_GPU_DEVICES: the drop-in shards CalcPosteriors / ConsIter over several contexts (mpcgpu_group_*: pair shards,
+    all-gather of the packed posteriors, all-gather of the values) — here contexts of the one emulated device — and the
+    final MSA stays the reference's."""
+    md5, _ = _msa.run_muscle(emu_muscle, name, threads=3, env={"MUSCLE_GPU_DEVICES": devices})
+    assert md5 == _msa.golden_md5()[name]

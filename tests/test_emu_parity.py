@@ -357,3 +357,27 @@ def test_emu_other_thread_orders(emu, order):
     r = subprocess.run([sys.executable, "-u", os.path.join(here, "_emu_sched_check.py")], env=env, cwd=here,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
     assert r.returncode == 0 and "OK thread order " + order in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("nctx", [2, 3])
+def test_emu_group_of_contexts(nctx):
+    """mpcgpu_group_* on the emulator: pairs sharded over nctx contexts, all-gather of the packed shards, sharded relax,
+    all-gather of the values — every rank's store equals the oracle's after every stage."""
+    from muscle_amd._lib import MpcGroup
+    seqs = make_family(9, 110, seed=3) + make_family(2, 200, seed=4)
+    want = P.run_oracle(seqs)
+    grp = MpcGroup([0] * nctx, EMU_LIB)
+    grp.set_hmm(*G.hmm_tables())
+    grp.set_seqs(seqs)
+    grp.calc_posteriors()
+    views = [grp.ctx(r) for r in range(nctx)]
+    st = [[v.get_sparse_range()] for v in views]
+    ea = [v.get_ea().copy() for v in views]
+    for _ in range(2):
+        grp.cons_iter()
+        for r, v in enumerate(views):
+            st[r].append(v.get_sparse_range())
+    for r in range(nctx):
+        P.assert_same((st[r], ea[r]), want, "group of %d, rank %d" % (nctx, r))
+    del views
+    grp.close()

@@ -42,3 +42,13 @@ def test_final_msa_identical_to_reference(gpu_muscle, name):
             pytest.xfail("the unmodified reference itself writes a different MSA on this host than in the build "
                          "container (%s vs %s); muscle_gpu follows the live reference" % (md5_ref, golden))
     assert md5_gpu == golden, "final MSA differs from the reference's committed MD5 for %s" % name
+
+
+@pytest.mark.parametrize("name,devices", [("n32_L150", "0,0"), ("synth_64x200_s1", "0,0,0"), ("bb11001", "0,0"), ("mega_bb11001", "0,0")])
+def test_final_msa_identical_sharded_over_contexts(gpu_muscle, name, devices):
+    """The multi-GPU path of the product (MUSCLE_GPU_DEVICES -> mpcgpu_group_*: pairs sharded over contexts, all-gather of
+    the sparse posteriors before relax, all-gather of the values after each iteration) with several contexts on the one
+    device of this box (peer-copy transport): same final MSA as the reference."""
+    from muscle_amd.hostinfo import usable_cores
+    md5, _ = _msa.run_muscle(gpu_muscle, name, threads=usable_cores(), env={"MUSCLE_GPU_DEVICES": devices})
+    assert md5 == _msa.golden_md5()[name]

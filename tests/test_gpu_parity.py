@@ -419,3 +419,50 @@ def test_baseline_configs_vs_reference_digests(name):
         g.cons_commit()
         assert D.compare_stage(z, it + 1, g) is None
     g.close()
+
+
+@pytest.mark.parametrize("nctx", [2, 3])
+def test_group_of_contexts_equals_reference(nctx):
+    """mpcgpu_group_* (several GPUs inside one process; here nctx contexts on device 0, peer-copy transport): after the
+    sharded stage A + all-gather and after each sharded relax iteration + value all-gather, EVERY rank's store equals the
+    reference's digests."""
+    from muscle_amd._lib import MpcGroup
+    g = G.mpc("n48_L260")
+    grp = MpcGroup([0] * nctx)
+    assert grp.transport() == "peer"
+    grp.set_hmm(*G.hmm_tables())
+    grp.set_seqs(g["seqs"])
+    grp.calc_posteriors()
+    views = [grp.ctx(r) for r in range(nctx)]
+    for v in views:
+        assert np.array_equal(P.bits(v.get_ea()), P.bits(g["ea"]))
+        assert G.stage_digest(v.get_sparse_range()) == g["digest"][0]
+    for it in range(2):
+        grp.cons_iter()
+        for v in views:
+            assert G.stage_digest(v.get_sparse_range()) == g["digest"][it + 1]
+    del views
+    grp.close()
+
+
+def test_group_rccl_loader_one_device():
+    """librccl is dlopen()ed by the group layer on first use; a one-device communicator on request checks that the library is
+    found and ncclCommInitAll / ncclCommDestroy work on this box (the N > 1 exchange itself needs N GPUs)."""
+    import os
+    from muscle_amd._lib import MpcGroup
+    os.environ["MPCGPU_GROUP_TRANSPORT"] = "rccl"
+    try:
+        grp = MpcGroup([0])
+        assert grp.transport() == "rccl"
+        seqs = make_family(5, 60, seed=8)
+        grp.set_hmm(*G.hmm_tables())
+        grp.set_seqs(seqs)
+        grp.calc_posteriors()
+        grp.cons_iter()
+        got = grp.ctx(0).get_sparse_range()
+        grp.close()
+    finally:
+        del os.environ["MPCGPU_GROUP_TRANSPORT"]
+    want, _ = P.run_oracle(seqs, iters=1)
+    for (o1, v1), (o2, v2) in zip(got, want[1]):
+        assert np.array_equal(o1, o2) and np.array_equal(v1, v2)
