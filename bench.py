@@ -56,17 +56,14 @@ def stage_b_bytes(lens, nnz):
     return float(np.sum(ent + ptr + 4 * nnz))
 
 
-def pmc_traffic(kernel, n, length):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json,
-    written by scripts/pmc_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
-    runs of this same command); None when no pass exists for this workload."""
+def pmc_entry(kernel, n, length):
+    """Committed PMC figures of `kernel` for this workload (profiles/pmc_traffic.json, written by scripts/pmc_summary.py from separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / SQ passes of this same command); None when no pass exists for it."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            d = json.load(f)
-        e = d.get("%s@%dx%d" % (kernel, n, length))
-        return None if e is None else float(e["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
+            return json.load(f).get("%s@%dx%d" % (kernel, n, length))
+    except (OSError, ValueError):
         return None
 
 
@@ -75,7 +72,7 @@ def parity_check(g, a):
     iterations) and the EA values against the digests the compiled reference produced for this exact workload
     (tests/golden/mpcbig_*.npz, tests/golden/make_golden.py big). -> ("match" | "MISMATCH" | None, detail)."""
     import _bigdigest as D
-    name = D.fixture_for(a.n, a.len, a.seed)
+    name = None if a.fasta else D.fixture_for(a.n, a.len, a.seed)
     if name is None:
         return None, "no reference-generated digest fixture for this workload (fixtures: %s)" % ", ".join(sorted(D.BIG_SETS))
     z = D.load(name)
@@ -119,8 +116,12 @@ def cpu_baseline(seqs, n_full, budget_s=20.0):
     per_triple = tB / (2.0 * np_s * (n_s - 2))
     per_pair_full = per_pair_a + 2.0 * (n_full - 2) * per_triple
     return {"value": 1.0 / per_pair_full, "unit": "pairs/s", "cores": cores, "kind": kind,
-            "sample": "first %d sequences of the same family (%d pairs): stage A %.2f s, 2 relax iterations %.2f s; "
-                      "extrapolated to N=%d as t_pair = tA/pairs + 2*(N-2)*t_triple" % (n_s, np_s, tA, tB, n_full)}
+            "extrapolated": n_s < n_full,
+            "sample": "%s on the first %d sequences of the same family (%d pairs) on this box: stage A %.2f s, 2 relax iterations %.2f s; "
+                      "EXTRAPOLATED to N=%d as t_pair = tA/pairs + 2*(N-2)*t_triple (stage A scales per pair, relax per (pair,Z) triple) — "
+                      "not a timed N=%d run (the one full reference run of 1000 x L~400, 81 min on 6 threads, was made in the build "
+                      "container: profiles/r01i_ref1000.log)" % ("compiled reference (MPCFlat::CalcPosteriors + ConsIter, OpenMP)" if kind == "reference"
+                                                                  else "C restatement (oracle/, reference binary not shipped)", n_s, np_s, tA, tB, n_full, n_full)}
 
 
 def main():
@@ -131,6 +132,8 @@ def main():
     ap.add_argument("--n", "--nseqs", dest="n", type=int, default=1000)  # --nseqs/--seqlen: spellings torchrun's parser does not trip over
     ap.add_argument("--len", "--seqlen", dest="len", type=int, default=400)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--fasta", default=None, help="real sequences instead of the synthetic family: first --n records of this FASTA "
+                    "(.gz accepted), e.g. tests/golden/rdrp_first1000.fa.gz (first 1000 records of the reference's test_data/rdrp/rdrp.fa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the digest self-check after the timed region")
     a = ap.parse_args()
@@ -165,7 +168,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(device))
         exchange = TorchExchange(dist, device)
 
-    seqs = make_family(a.n, a.len, seed=a.seed)
+    if a.fasta:
+        from muscle_amd.synth import read_fasta
+        seqs = read_fasta(a.fasta)[:a.n]
+        if len(seqs) < a.n:
+            raise SystemExit("bench.py: %s holds only %d records" % (a.fasta, len(seqs)))
+        family = "first %d records of %s (real data)" % (a.n, os.path.basename(a.fasta))
+    else:
+        seqs = make_family(a.n, a.len, seed=a.seed)
+        family = "%d synthetic protein seqs L~%d (seed %d)" % (a.n, a.len, a.seed)
     lens = [len(s) for s in seqs]
     npairs = a.n * (a.n - 1) // 2
     g = MpcGpu(0 if dry else local, dry)
@@ -200,49 +211,73 @@ def main():
         nnz = g.get_nnz()
         ms_step = 1000.0 * el / a.steps
         # dominant kernel family of THIS rank over the timed steps (hipEvents on the library's stream)
-        fam = max(("fb", "relax"), key=lambda k: timers[k][0])
-        ms, launches = timers[fam]
         my_frac = 1.0 / world  # this rank's share of the pair-sharded work
-        avg_s = ms * 1e-3 / max(launches, 1)  # average launch duration of the dominant kernel
-        if fam == "fb":
-            # all pairs of this rank per step, spread over `launches / steps` batch launches
-            per_launch = stage_a_flops(lens) * my_frac * a.steps / max(launches, 1)
-            achieved = per_launch / avg_s / 1e12
-            roof = {"kernel": "fb_kernel<H> (pair-HMM fwd+bwd+posterior, one wave per pair)", "bound": "valu",
-                    "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                    "traffic": pmc_traffic("fb_kernel", a.n, a.len),
-                    "note": "FP32 vector-ALU bound recurrence (no contraction, no MFMA: SURVEY.md 8d); peak = 157.3 TFLOP/s "
-                            "FP32 vector = FP32 dense MFMA peak; algorithmic flops per launch = sum over the launch's pairs of "
-                            "164(LX+1)(LY+1)+5LXLY"}
-        else:
-            # one launch = one relax iteration over this rank's pairs
-            per_launch = stage_b_bytes(lens, nnz) * my_frac
+        geo, _fallback = g.relax_info()
+        kname = ("relax_var_kernel" if "relax_var_kernel" in geo else "relax_dense_kernel" if "relax_dense_kernel" in geo
+                 else "relax_tile_kernel" if "relax_tile_kernel" in geo else "relax_kernel")
+        fixture_shape = (a.n, a.len) if not a.fasta else (a.n, 0)
+
+        def issue_fraction(pmc, avg_s, units_per_inst):
+            """VALU issue time / launch time from the committed SQ pass: wave-instructions x issue cost (diag/pkbench: a full-rate
+            VALU op = 2 cycles per wave on a SIMD; units_per_inst = the mix's mean cost in such ops from scripts/isa_cost.py)
+            over 1024 SIMDs at the 2.1 GHz the chip sustains under this load."""
+            if not pmc or "sq_per_launch" not in pmc or "SQ_INSTS_VALU" not in pmc["sq_per_launch"]:
+                return None
+            return pmc["sq_per_launch"]["SQ_INSTS_VALU"] * units_per_inst * 2.0 / (1024 * 2.1e9) / avg_s
+
+        def relax_roof():
+            ms, launches = timers["relax"]
+            avg_s = ms * 1e-3 / max(launches, 1)
+            per_launch = stage_b_bytes(lens, nnz) * my_frac  # one launch = one relax iteration over this rank's pairs
             achieved = per_launch / avg_s / 1e9
-            # the library's default is the dense record layout (relax_dense_kernel); MPCGPU_PAD=rows selects the older one
-            kname = "relax_tile_kernel" if os.environ.get("MPCGPU_PAD") == "rows" else "relax_dense_kernel"
-            roof = {"kernel": kname + " (consistency relax: sampled sparse product over the all-pairs store, LDS-tiled)",
-                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic(kname, a.n, a.len),
-                    "algorithmic_bytes_per_launch": per_launch,
-                    "note": "algorithmic bytes per launch (= one relax iteration) = operands of every (pair,Z) read once: sum "
-                            "over pairs and Z of 8*(nnz_XZ+nnz_YZ)+4*(LX+LY+2), + 4*nnz written (SURVEY.md 8d stage B), divided "
-                            "by the average launch time from hipEvents on the library stream; traffic = HBM bytes per launch "
-                            "from separate rocprofv3 --pmc passes of this command (2*FETCH_SIZE + WRITE_SIZE, KiB, per "
-                            "MI355X_MICROARCH.md HBM section), null when none is committed for this workload. The LDS tiling "
-                            "serves 16 pairs from 8 records, so real traffic is below the algorithmic figure; the kernel is "
-                            "instruction-bound (DESIGN.md 4.3)"}
-        roof["launches"] = launches
-        roof["avg_launch_ms"] = ms / max(launches, 1)
+            pmc = pmc_entry(kname, *fixture_shape)
+            traffic = None if pmc is None else float(pmc["hbm_bytes_per_launch"])
+            r = {"kernel": kname + " (consistency relax: sampled sparse product over the all-pairs store, LDS-tiled)",
+                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                 "traffic": traffic, "algorithmic_bytes_per_launch": per_launch, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+                 "measured_hbm_frac": None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
+                 "valu_issue_frac": issue_fraction(pmc, avg_s, 1.30),
+                 "note": "achieved = ALGORITHMIC bytes per launch (SURVEY.md 8d stage B: every (pair,Z) reads both operand matrices once = "
+                         "sum of 8*(nnz_XZ+nnz_YZ)+4*(LX+LY+2), + 4*nnz written) / average launch time (hipEvents on the library stream; "
+                         "profiles/*kernel_stats*.csv agrees). The LDS tiling serves 16 pairs from 8 records, so the bytes that really cross "
+                         "the fabric are FEWER than the algorithmic ones and `frac` can exceed 1: it is a progress figure. The real roofs: "
+                         "`traffic` = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                         "(2*FETCH_SIZE + WRITE_SIZE, KiB; MI355X_MICROARCH.md HBM section) -> measured_hbm_frac of the 8 TB/s spec; "
+                         "valu_issue_frac = VALU issue time / launch time from the SQ pass (the kernel is bound by instruction issue and LDS "
+                         "latency, DESIGN.md 4.3). null = no committed PMC pass for this workload."}
+            return r
+
+        def fb_roof():
+            ms, launches = timers["fb"]
+            avg_s = ms * 1e-3 / max(launches, 1)
+            per_launch = stage_a_flops(lens) * my_frac * a.steps / max(launches, 1)  # all pairs of this rank per step, over launches/steps batches
+            achieved = per_launch / avg_s / 1e12
+            pmc = pmc_entry("fb_kernel", *fixture_shape)
+            return {"kernel": "fb_kernel<H> (pair-HMM fwd+bwd+posterior threshold, one wave per pair)", "bound": "valu",
+                    "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+                    "traffic": None if pmc is None else float(pmc["hbm_bytes_per_launch"]), "launches": launches,
+                    "avg_launch_ms": ms / max(launches, 1), "valu_issue_frac": issue_fraction(pmc, avg_s, 1.27),
+                    "no_fma_add_mul_peak_TFLOPs": 63.0,
+                    "note": "FP32 vector-ALU bound log-space recurrence: no contraction (parity), no MFMA shape. peak = 157.3 TFLOP/s FP32 vector = "
+                            "FP32 dense MFMA peak, which counts v_pk_fma_f32; measured on this chip (diag/pkbench, profiles/r02b_pkbench.log) plain "
+                            "add/mul issue at 63 Tlane-op/s and min/max/cvt/select at 0.6 of that, so 63 TFLOP/s is the ceiling of an FMA-free "
+                            "stream. Algorithmic flops per launch = sum over its pairs of 164(LX+1)(LY+1)+5LXLY (SURVEY.md 8d). valu_issue_frac "
+                            "(SQ pass) says how much of the launch the VALU is issuing."}
+
+        roof = relax_roof() if timers["relax"][0] >= timers["fb"][0] else fb_roof()
+        roof_other = fb_roof() if timers["relax"][0] >= timers["fb"][0] else relax_roof()
         out = {
             "metric": "sequence-pairs/sec (fwd+bwd+posterior+relax)", "value": npairs * a.steps / el, "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MPCFlat posterior stage: %d synthetic protein seqs L~%d (seed %d), %d pairs, "
-                                   "fwd+bwd+posterior+sparsify+EA + 2 relax iterations" % (a.n, a.len, a.seed, npairs),
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "real (rdrp)" if a.fasta else "synthetic",
+            "config": {"workload": "MPCFlat posterior stage: %s, %d pairs, "
+                                   "fwd+bwd+posterior+sparsify+EA + 2 relax iterations" % (family, npairs),
                        "n_seqs": a.n, "mean_len": float(np.mean(lens)), "pairs": npairs,
                        "stored_posteriors": int(nnz.sum()), "parallelism": "pair-shard x%d" % world},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in timers.items()},
+            "relax_geometry": dict(zip(("layout", "fallback"), g.relax_info())),
             "roofline": roof,
+            "roofline_stage_a" if roof["kernel"].startswith("relax") else "roofline_relax": roof_other,
         }
         if dry:
             out["dry_run"] = True

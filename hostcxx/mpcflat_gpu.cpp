@@ -389,6 +389,13 @@ void StartBatch(MPCFlat &M, Batch &B)
 	g_StoreOwner = &M;
 	B.m_EA.resize(PairCount);
 	GPUCHK(mpcgpu_get_ea(Ctx, 0, PairCount, B.m_EA.data()));
+		{
+// a run outside the default layout's limits takes a slower relax path: say so once instead of just being slow
+		char Info[1024];
+		int Fallback = 0;
+		if (mpcgpu_relax_info(Ctx, Info, sizeof(Info), &Fallback) == 0 && (Fallback != 0 || TimingOn()))
+			fprintf(stderr, "[muscle_gpu] %sconsistency store: %s\n", Fallback ? "NOTE (slower path) " : "", Info);
+		}
 // MPCFlat::Consistency (mpcflat.cpp:173-181) is skipped for < 3 sequences or 0 iterations: then the
 // progressive stage reads the stage-A matrices, so they must exist on the host.
 	B.m_Materialise = (SeqCount < 3 || M.m_ConsistencyIterCount == 0);

@@ -205,6 +205,10 @@ int mpcgpu_timers_get(mpcgpu_ctx *ctx, float ms[MPCGPU_NKERNELS], uint64_t launc
  * (sum (LX+1)(LY+1)) and of the last cons_iter: (pair,Z) triples and stored entries. */
 int mpcgpu_work_get(mpcgpu_ctx *ctx, uint64_t *dp_cells, uint64_t *relax_entry_z, uint64_t *store_entries);
 int mpcgpu_synchronize(mpcgpu_ctx *ctx);
+/* Which store layout and relax kernel the current store uses, in words (record sizes, workgroup geometry, the tile shapes
+ * once a relax iteration has built them), and whether that is a FALLBACK this build chose because the run exceeds the default
+ * layout's limits (sequences longer than 4095, records beyond the CU's LDS ...): bench.py prints it, the drop-in warns. */
+int mpcgpu_relax_info(mpcgpu_ctx *ctx, char *buf, uint32_t buflen, int *is_fallback);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
     "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_get",
-    "mpcgpu_work_get", "mpcgpu_synchronize",
+    "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
     "mpcgpu_group_calc_posteriors", "mpcgpu_group_cons_iter",
@@ -77,6 +77,7 @@ def load(lib_path=None):
     L.mpcgpu_timers_get.argtypes = [vp, vp, vp]
     L.mpcgpu_work_get.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mpcgpu_synchronize.argtypes = [vp]
+    L.mpcgpu_relax_info.argtypes = [vp, C.c_char_p, u32, C.POINTER(i32)]
     L.mpcgpu_group_create.argtypes = [C.POINTER(vp), u32, vp]
     L.mpcgpu_group_destroy.argtypes = [vp]
     L.mpcgpu_group_destroy.restype = None
@@ -354,6 +355,13 @@ class MpcGpu:
         self._ck(self.L.mpcgpu_align_alns(self.h, len(s1), s1.ctypes.data, len(s2), s2.ctypes.data, C1, C2,
                                            m1.ctypes.data, m2.ctypes.data, path.ctypes.data, C.byref(n), C.byref(sc)))
         return path[:n.value].tobytes().decode(), float(np.float32(sc.value))
+
+    def relax_info(self):
+        """-> (description of the store layout / relax geometry in use, is_fallback)"""
+        buf = C.create_string_buffer(1024)
+        fb = C.c_int(0)
+        self._ck(self.L.mpcgpu_relax_info(self.h, buf, 1024, C.byref(fb)))
+        return buf.value.decode(), bool(fb.value)
 
     def timers_reset(self):
         self._ck(self.L.mpcgpu_timers_reset(self.h))

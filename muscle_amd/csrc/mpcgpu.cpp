@@ -44,9 +44,8 @@ struct DevBuf {
 		if (e != hipSuccess) return e;
 		if (keep && p && cap) {
 			e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st);
-			if (e != hipSuccess) return e;
-			e = hipStreamSynchronize(st);
-			if (e != hipSuccess) return e;
+			if (e == hipSuccess) e = hipStreamSynchronize(st);
+			if (e != hipSuccess) { (void)hipFree(np); return e; }
 		}
 		if (p) (void)hipFree(p);
 		p = np;
@@ -121,6 +120,8 @@ struct mpcgpu_ctx {
 	u32 var_max_rec_blocks = 0;  // largest record, 16-byte blocks
 	u64 var_total_blocks = 0;
 	u32 var_threads = 1024, var_nbuf = 2, var_buf_bytes = 0;
+	std::string store_desc, tiles_desc; // mpcgpu_relax_info
+	bool relax_fallback = false;
 	u32 pad_stride_dw() const { return pad_dense ? 4 * (pad_lcap1 + pad_ecap) : pad_lcap1 + 2 * pad_ecap; }
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
 	std::vector<u32> h_tiles;
@@ -182,6 +183,22 @@ int span_end(mpcgpu_ctx *c, TimedSpan *sp)
 	HIPCHK(c, hipEventRecord(sp->b, c->stream));
 	c->spans.push_back(*sp);
 	c->launches[sp->fam] += 1;
+	// a caller that never reads the timers (the drop-in: thousands of joins) must not accumulate events: fold the
+	// finished spans into the totals now and then, without waiting for the running ones
+	if (c->spans.size() >= 64) {
+		size_t keep = 0;
+		for (size_t q = 0; q < c->spans.size(); ++q) {
+			TimedSpan &t = c->spans[q];
+			float ms = 0;
+			if (hipEventQuery(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+				c->ms[t.fam] += ms;
+				(void)hipEventDestroy(t.a);
+				(void)hipEventDestroy(t.b);
+			} else c->spans[keep++] = t;
+		}
+		(void)hipGetLastError(); // hipErrorNotReady of the queries is not an error
+		c->spans.resize(keep);
+	}
 	if (trace_on()) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		float t = 0;
@@ -621,6 +638,16 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			tiles.swap(next);
 		}
 		if (!tiles.empty()) return fail(c, "mpcgpu_cons_iter: tile splitting did not converge");
+		{
+			u32 hist[5][5] = {{0}};
+			for (size_t t = 0; t + 3 < ok.size(); t += 4) hist[std::min(ok[t + 1], 4u)][std::min(ok[t + 3], 4u)]++;
+			char b[256];
+			int o = snprintf(b, sizeof(b), "%zu tiles:", ok.size() / 4);
+			for (u32 a = 4; a >= 1; --a)
+				for (u32 bb = 4; bb >= 1; --bb)
+					if (hist[a][bb] && o < (int)sizeof(b) - 24) o += snprintf(b + o, sizeof(b) - o, " %ux%u x %u", a, bb, hist[a][bb]);
+			c->tiles_desc = b;
+		}
 		c->h_tiles.swap(ok);
 		if (upload(c, c->d_tiles, c->h_tiles)) return 1;
 		HIPCHK(c, hipStreamSynchronize(c->stream)); // the source of the async copy lives in the context; drained before any rebuild
@@ -663,9 +690,12 @@ int build_var_store(mpcgpu_ctx *c)
 {
 	const u32 n = c->n;
 	if (c->max_len > MPC_RV_MAXLEN) return 2;
-	const u32 threads = var_geo_from_env(); // geometry id (see var_max_slots)
-	const u32 nbuf = (u32)std::min(std::max(env_int("MPCGPU_RELAX_NBUF", threads == 1024 ? 2 : 1), 1), 2);
-	if ((((u64)c->max_nnz + 63) & ~63ull) > (u64)var_max_slots(threads) * (threads == 2048 ? 1024u : threads)) return 2; // one pair must fit the slots of a tile
+	// geometry: the configured one (default two 768-thread workgroups per CU, 80 KB of LDS each); when the largest pair does not
+	// fit it — long or poorly aligned sequences: wide posterior rows, records of tens of KB — one 1024-thread workgroup per CU
+	// with the whole 160 KB as ONE staging buffer, before giving the run to the fallback layouts
+	u32 threads = var_geo_from_env(); // geometry id (see var_max_slots)
+	u32 nbuf = (u32)std::min(std::max(env_int("MPCGPU_RELAX_NBUF", threads == 1024 ? 2 : 1), 1), 2);
+	auto slots_ok = [&](u32 geo) { return (((u64)c->max_nnz + 63) & ~63ull) <= (u64)var_max_slots(geo) * (geo == 2048 ? 1024u : geo); };
 	StoreParams sp0;
 	fill_store_params(c, sp0);
 	const u64 nn = (u64)n * n;
@@ -689,7 +719,11 @@ int build_var_store(mpcgpu_ctx *c)
 	u32 buf_bytes = 0;
 	size_t smem = 0;
 	var_lds_geometry(threads, nbuf, &buf_bytes, &smem);
-	if (2ull * max_rec * 16 > buf_bytes) return 2; // any single pair (two records) must fit one staging buffer
+	if (2ull * max_rec * 16 > buf_bytes || !slots_ok(threads)) { // any single pair (two records, its cells) must fit a tile
+		threads = 1024; nbuf = 1;
+		var_lds_geometry(threads, nbuf, &buf_bytes, &smem);
+		if (2ull * max_rec * 16 > buf_bytes || !slots_ok(threads)) return 2;
+	}
 	const u64 pad_bytes = run * 16 + 4 * std::max<u64>(c->total_entries, 1);
 	size_t freeb = 0, totb = 0;
 	HIPCHK(c, hipMemGetInfo(&freeb, &totb));
@@ -704,6 +738,15 @@ int build_var_store(mpcgpu_ctx *c)
 	c->var_threads = threads; c->var_nbuf = nbuf; c->var_buf_bytes = buf_bytes;
 	c->var_max_rec_blocks = max_rec; c->var_total_blocks = run;
 	c->tiles_k0 = c->tiles_k1 = ~0ull;
+	{
+		char b[512];
+		snprintf(b, sizeof(b), "variable-size dense records: %u x %u records, %.2f GB, mean %.0f B, largest %u B; relax_var_kernel, %s, %u staging buffer%s of %u B",
+			n, n, (double)run * 16 / 1e9, (double)run * 16 / (double)nn, max_rec * 16,
+			threads == 2048 ? "2 x 1024-thread workgroups per CU" : threads == 1024 ? "1 x 1024-thread workgroup per CU" :
+			threads == 768 ? "2 x 768-thread workgroups per CU" : threads == 640 ? "2 x 640-thread workgroups per CU" : "2 x 512-thread workgroups per CU",
+			nbuf, nbuf == 1 ? "" : "s", buf_bytes);
+		c->store_desc = b; c->tiles_desc.clear(); c->relax_fallback = false;
+	}
 	StoreParams sp;
 	fill_store_params(c, sp);
 	if (trace_on()) {
@@ -1019,7 +1062,9 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		const u64 per_pair = (u64)capc * 8 + res_stride * 4 + 64;
 		size_t freeb = 0, totb = 0;
 		HIPCHK(c, hipMemGetInfo(&freeb, &totb));
-		u64 budget = std::min<u64>((u64)env_int("MPCGPU_SCRATCH_GB", 16) << 30, (u64)(freeb * 0.4));
+		// the scratch of the previous batch (or of an overflow retry) is already owned and gets reused: count it as available
+		const u64 owned = (u64)c->d_cand.cap + c->d_res.cap + c->d_fm.cap;
+		u64 budget = std::min<u64>((u64)env_int("MPCGPU_SCRATCH_GB", 16) << 30, (u64)((freeb + owned) * 0.4));
 		u64 B = std::max<u64>(1, std::min<u64>(np - done, budget / per_pair));
 		B = std::min<u64>(B, 1u << 22);
 		const u64 b0 = done;
@@ -1379,6 +1424,14 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 				c->pad_dense ? "dense" : "row pointers", n, n, sp.pad_stride * 4, (double)n * n * sp.pad_stride * 4 / 1e9, c->pad_bx, c->pad_by);
 			fflush(stderr);
 		}
+		{
+			char b[256];
+			snprintf(b, sizeof(b), "fixed-size %s records: %u x %u records of %u B (%.2f GB); %s, tile block %ux%u", c->pad_dense ? "dense" : "row-pointer", n, n,
+				sp.pad_stride * 4, (double)n * n * sp.pad_stride * 4 / 1e9, c->pad_dense ? "relax_dense_kernel" : "relax_tile_kernel", c->pad_bx, c->pad_by);
+			c->store_desc = b; c->tiles_desc.clear();
+			const char *pm = getenv("MPCGPU_PAD");
+			c->relax_fallback = !(pm && *pm); // reached without being asked for: the variable-size layout refused this run
+		}
 		if (span_begin(c, 2, &ts)) return 1;
 		const u64 blocks = (u64)n * n;
 		if (c->pad_dense)
@@ -1393,6 +1446,12 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	}
 	c->d_pad.release();
 	c->d_pos.release();
+	{
+		const char *rm = getenv("MPCGPU_RELAX");
+		c->store_desc = "CSR slabs per sequence; relax_kernel (one thread per stored cell gathers its rows from HBM: the slow path, ~5x the LDS-tiled kernels)";
+		c->tiles_desc.clear();
+		c->relax_fallback = !(rm && !strcmp(rm, "gather"));
+	}
 	// ---- slab geometry: per ordered pair entry counts -> mbase (within slab), slab bases
 	std::vector<u32> mbase((size_t)n * (n + 1), 0);
 	std::vector<u64> ent_base(n + 1, 0), rp_base(n + 1, 0);
@@ -1780,6 +1839,19 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 		c->stream, keys_sorted, vals_sorted, (u64)M, bq, c->d_aln_post.as<float>(), (u64)cells);
 	HIPCHK(c, hipGetLastError());
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // syncs before the vectors above die
+}
+
+int mpcgpu_relax_info(mpcgpu_ctx *c, char *buf, uint32_t buflen, int *is_fallback)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_relax_info: no store");
+	if (buf && buflen) {
+		std::string d = c->store_desc;
+		if (!c->tiles_desc.empty()) d += "; " + c->tiles_desc;
+		snprintf(buf, buflen, "%s", d.c_str());
+	}
+	if (is_fallback) *is_fallback = c->relax_fallback ? 1 : 0;
+	return 0;
 }
 
 int mpcgpu_timers_reset(mpcgpu_ctx *c)

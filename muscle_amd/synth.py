@@ -34,3 +34,21 @@ def write_fasta(path, seqs, labels=None):
     with open(path, "w") as f:
         for i, s in enumerate(seqs):
             f.write(">%s\n%s\n" % (labels[i] if labels else "s%d" % i, s))
+
+
+def read_fasta(path):
+    """Sequences of a FASTA file (.gz accepted), upper-cased like the reference's loader (sequence.cpp:87-88)."""
+    import gzip
+    seqs, cur = [], []
+    with (gzip.open(path, "rt") if path.endswith(".gz") else open(path)) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith(">"):
+                if cur:
+                    seqs.append("".join(cur))
+                cur = []
+            elif line:
+                cur.append(line.upper())
+    if cur:
+        seqs.append("".join(cur))
+    return seqs

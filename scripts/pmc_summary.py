@@ -45,6 +45,19 @@ def main():
             "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0,
             "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}
         print(short, d["%s@%dx%d" % (short, n, length)])
+    # SQ passes next to the FETCH/WRITE directories (prof_sq, prof_sq2), when present: instruction counts per launch
+    base = os.path.dirname(os.path.normpath(fdir))
+    sq = defaultdict(lambda: defaultdict(list))
+    for sub in ("prof_sq", "prof_sq2"):
+        for fn in glob.glob(os.path.join(base, sub, "**", "*counter_collection.csv"), recursive=True):
+            with open(fn) as f:
+                for row in csv.DictReader(f):
+                    sq[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for kname, counters in sq.items():
+        short = kname.split("(")[0].replace("void ", "").split("<")[0]
+        key = "%s@%dx%d" % (short, n, length)
+        if key in d:
+            d[key]["sq_per_launch"] = {c: sum(v) / len(v) for c, v in sorted(counters.items())}
     with open(out, "w") as f:
         json.dump(d, f, indent=1, sort_keys=True)
 

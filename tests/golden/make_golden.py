@@ -95,8 +95,9 @@ def gen_pairs_small():
 
 
 def read_fasta(path):
+    import gzip
     seqs, cur = [], []
-    for line in open(path):
+    for line in (gzip.open(path, "rt") if path.endswith(".gz") else open(path)):
         line = line.strip()
         if line.startswith(">"):
             if cur:
@@ -143,6 +144,11 @@ def gen_mpc(only=None):
     bb5 = "/root/reference/test_data/fa/BB11005"
     if os.path.exists(bb5):
         jobs.append(("bb11005", read_fasta(bb5), False))
+    # real data with wide posterior rows (r ~ 6 stored cells per row against ~2 on the synthetic family): the first 128 records of
+    # the reference's test_data/rdrp/rdrp.fa (its first 1000 records are committed as rdrp_first1000.fa.gz for bench.py --fasta)
+    rd = os.path.join(HERE, "rdrp_first1000.fa.gz")
+    if os.path.exists(rd):
+        jobs.append(("rdrp128", read_fasta(rd)[:128], False))
     ctx = mp.get_context("spawn")
     if only:
         jobs = [j for j in jobs if j[0] in only]
