@@ -179,6 +179,14 @@ bool TimingOn()
 				  "AlignAlns: library", "AlignAlns: result MSA", "AlignMSAsFlat: pairs+maps", "AlignMSAsFlat: library" };
 				for (int i = 0; i < T_COUNT; ++i)
 					fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  %8llu calls\n", Names[i], g_Seconds[i], g_Calls[i]);
+// device time per kernel family of the library (hipEvents on its stream): where the library seconds above go
+				static const char *Fam[MPCGPU_NKERNELS] = { "fwd/bwd", "posterior finish", "store build", "relax", "commit",
+				  "BuildPost: records", "BuildPost: sort", "BuildPost: reduce", "CalcAlnFlat+traceback" };
+				float Ms[MPCGPU_NKERNELS];
+				uint64_t Launches[MPCGPU_NKERNELS];
+				if (g_Ctx != 0 && mpcgpu_timers_get(g_Ctx, Ms, Launches) == 0)
+					for (int i = 0; i < MPCGPU_NKERNELS; ++i)
+						fprintf(stderr, "[muscle_gpu]   device: %-24s %10.3f s  %8llu launches\n", Fam[i], Ms[i]*1e-3, (unsigned long long) Launches[i]);
 				});
 		}
 	return On == 1;

@@ -198,7 +198,8 @@ int mpcgpu_group_cons_iter(mpcgpu_group *g);
 /* Kernel time in ms measured with hipEvents on the library's own stream, accumulated since the
  * last reset, per kernel family: 0 = fwd/bwd (fb), 1 = posterior finish (sort/EA/pack),
  * 2 = store build, 3 = relax, 4 = commit/scatter; and launches counted per family. */
-#define MPCGPU_NKERNELS 5
+#define MPCGPU_NKERNELS 9 /* ... 5 = BuildPost record generation, 6 = BuildPost grouping (sort), 7 = BuildPost in-order reduction,
+                             8 = CalcAlnFlat + traceback (families 5-8: mpcgpu_align_alns / mpcgpu_align_msas / mpcgpu_calc_aln) */
 int mpcgpu_timers_reset(mpcgpu_ctx *ctx);
 int mpcgpu_timers_get(mpcgpu_ctx *ctx, float ms[MPCGPU_NKERNELS], uint64_t launches[MPCGPU_NKERNELS]);
 /* Algorithmic work of the last calc_posteriors call: DP cells summed over pairs

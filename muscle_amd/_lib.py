@@ -11,8 +11,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "csrc", "libmpcgpu.so")
-NKERNELS = 5
-KERNEL_FAMILIES = ["fb", "post", "store_build", "relax", "commit"]
+NKERNELS = 9
+KERNEL_FAMILIES = ["fb", "post", "store_build", "relax", "commit", "buildpost_gen", "buildpost_sort", "buildpost_reduce", "calc_aln"]
 
 SYMBOLS = [
     "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_version", "mpcgpu_set_hmm",

@@ -10,10 +10,10 @@
 // output cell must receive its contributions in the reference's order: s ascending (position in
 // MSA1), then t ascending (position in MSA2); one pair contributes at most once to a cell. The
 // device form: (1) every stored entry of every (s,t) pair becomes a (key, P) record with
-// key = cell << (ba+bb) | rank(s) << bb | rank(t); (2) one radix sort of the records (rocPRIM via
-// hipCUB — bulk data movement, not arithmetic); (3) one thread per output cell finds its run by
-// binary search and adds it up front to back, starting from 0.0f like the reference's zeroed
-// matrix. The probabilities are the current ones of the packed records (after the last commit).
+// key = cell << (ba+bb) | rank(s) << bb | rank(t); (2) one radix sort of the records (rocprim::radix_sort_pairs —
+// bulk data movement, not arithmetic); (3) one WAVE per output cell finds its run by binary search and
+// adds it up front to back through its lanes (build_post_reduce_kernel), starting from 0.0f like the
+// reference's zeroed matrix. The probabilities are the current ones of the packed records (after the last commit).
 #pragma once
 #include "kernels_store.h"
 
@@ -59,19 +59,41 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 	}
 }
 
-// one thread per output cell: in-order sum of its run in the sorted records
+// In-order sum of every output cell's run in the sorted records, ONE WAVE PER CELL. The sum of a cell is a chain
+//     (((0 + v0) + v1) + v2) ...                      (buildpostflat.cpp:27-30 zeroes Post, :74 / :96 add, w1*w2 == 1.0f)
+// whose order is fixed (float addition is not associative and CalcAlnFlat breaks ties on exact values), and the cells on the
+// alignment path receive a contribution from almost every (s,t) pair — 250 000 terms at the root of a 1000-sequence tree — so
+// the work cannot be one thread per cell (round 1: a serial load -> add chain per thread, 7.7 of the 11.8 s of the
+// progressive + refinement tail at 1000 x L~400, profiles/r02g_e2e_timing.log). Here the wave loads 64 consecutive terms at
+// once (coalesced) and runs the chain through its lanes (mpc_wave_chain_add, mpc_platform.h: one wave instruction per term,
+// every term added exactly once in sequence; lanes past the end of the run add +0.0f, exact for these non-negative sums). The run of a cell is found with two binary
+// searches made of scalar loads (the sorted keys are not written by this kernel).
 __global__ void __launch_bounds__(256) build_post_reduce_kernel(const u64 *keys, const float *vals, u64 count, u32 shift,
 	float *post, u64 cells)
 {
-	for (u64 cell = (u64)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (u64)gridDim.x * blockDim.x) {
-		u64 lo = 0, hi = count; // first record with key >> shift >= cell
-		while (lo < hi) {
-			const u64 mid = (lo + hi) >> 1;
-			if ((keys[mid] >> shift) < cell) lo = mid + 1; else hi = mid;
+	const u32 lane = threadIdx.x & 63u;
+	const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + mpc_wave_first(threadIdx.x >> 6);
+	const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
+	mpc_const_u32p k32 = MPC_CONST_U32(keys); // key q = k32[2q] | k32[2q+1] << 32, read with scalar loads
+	for (u64 cell = wave; cell < cells; cell += nwaves) {
+		auto lower = [&](u64 want) { // first record whose cell is >= want
+			u64 lo = 0, hi = count;
+			while (lo < hi) {
+				const u64 mid = (lo + hi) >> 1;
+				const u64 key = (u64)k32[2 * mid] | ((u64)k32[2 * mid + 1] << 32);
+				if ((key >> shift) < want) lo = mid + 1; else hi = mid;
+			}
+			return lo;
+		};
+		const u64 lo = lower(cell), hi = lower(cell + 1);
+		float total = 0.0f; // wave-uniform
+		float v = (lo + lane < hi) ? vals[lo + lane] : 0.0f;
+		for (u64 q0 = lo; q0 < hi; q0 += 64) {
+			const float vn = (q0 + 64 + lane < hi) ? vals[q0 + 64 + lane] : 0.0f; // the next chunk is in flight while this one is added
+			total = mpc_wave_chain_add(total, v);
+			v = vn;
 		}
-		float acc = 0.0f; // the reference zeroes Post first (buildpostflat.cpp:27-30)
-		while (lo < count && (keys[lo] >> shift) == cell) { acc += vals[lo]; ++lo; } // buildpostflat.cpp:74 / :96 (w1*w2 == 1.0f)
-		post[cell] = acc;
+		if (lane == 0) post[cell] = total;
 	}
 }
 

@@ -4,7 +4,7 @@
 // kernels_relax.h (LDS-tiled relax), kernels_aln.h (posterior-DP alignment + traceback) and
 // kernels_prog.h (MSA x MSA posterior build). Built by hipcc (-x hip) for gfx950. There is no CPU
 // implementation behind this API: without a HIP device mpcgpu_create() fails. rocPRIM's radix sort
-// (through hipCUB) is used for one bulk data-movement step (kernels_prog.h); everything else is
+// (rocprim::radix_sort_pairs, called directly) is used for one bulk data-movement step (kernels_prog.h); everything else is
 // hand-written.
 #include "../../include/mpcgpu.h"
 #include "kernels_fb.h"
@@ -14,9 +14,6 @@
 #include "kernels_relaxv.h"
 #include "kernels_aln.h"
 #include "kernels_prog.h"
-#ifndef MPC_EMU
-#include <hipcub/hipcub.hpp>
-#endif
 
 #include <algorithm>
 #include <climits>
@@ -27,6 +24,9 @@
 #include <functional>
 #include <string>
 #include <vector>
+#ifndef MPC_EMU
+#include <rocprim/device/device_radix_sort.hpp>
+#endif
 
 namespace {
 
@@ -135,8 +135,8 @@ struct mpcgpu_ctx {
 
 	// measurement
 	std::vector<TimedSpan> spans;
-	float ms[MPCGPU_NKERNELS] = {0, 0, 0, 0, 0};
-	u64 launches[MPCGPU_NKERNELS] = {0, 0, 0, 0, 0};
+	float ms[MPCGPU_NKERNELS] = {0};
+	u64 launches[MPCGPU_NKERNELS] = {0};
 	u64 work_cells = 0, work_entry_z = 0;
 };
 
@@ -1653,8 +1653,11 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	ap.tb = c->d_aln_tb.as<char>(); ap.rev = c->d_aln_rev.as<char>(); ap.path = c->d_aln_path.as<char>();
 	ap.pathlen = c->d_aln_out.as<u32>(); ap.score = c->d_aln_out.as<float>() + 1;
 	(void)hipFuncSetAttribute((const void *)calc_aln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	TimedSpan ts_aln;
+	if (span_begin(c, 8, &ts_aln)) return 1;
 	MPC_LAUNCH(calc_aln_kernel, 1, MPC_ALN_THREADS, smem, c->stream, ap);
 	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts_aln)) return 1;
 	u32 out[2] = {0, 0};
 	HIPCHK(c, hipMemcpyAsync(out, c->d_aln_out.p, 8, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1714,7 +1717,7 @@ int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t
 	const u64 cells = (u64)C1 * C2;
 	const u32 ba = bits_for(n1 - 1), bb = bits_for(n2 - 1), bc = bits_for(cells - 1);
 	if (ba + bb + bc > 64) return fail(c, "mpcgpu_align_alns: key does not fit 64 bits (%u x %u rows, %llu cells)", n1, n2, (u64)cells);
-	if (M > 0x7fffffffull) return fail(c, "mpcgpu_align_alns: %llu contributions exceed this build's sort size", (u64)M);
+	if (M > 0xffffffffull) return fail(c, "mpcgpu_align_alns: %llu contributions exceed this build's record count", (u64)M);
 	if (upload(c, c->d_bp_seq, seqs) || upload(c, c->d_bp_off, off) || upload(c, c->d_bp_map, maps) || upload(c, c->d_bp_coff, coff))
 		return 1;
 	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 8 * 2));
@@ -1729,10 +1732,14 @@ int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t
 	bp.p2c1_off = c->d_bp_off.as<u64>(); bp.p2c2_off = bp.p2c1_off + n1;
 	bp.C2 = C2; bp.coff = c->d_bp_coff.as<u64>(); bp.keys = keys_in; bp.vals = vals_in; bp.bits_a = ba; bp.bits_b = bb;
 	const u64 npairs12 = (u64)n1 * n2;
+	TimedSpan ts_bp;
+	if (span_begin(c, 5, &ts_bp)) return 1;
 	MPC_LAUNCH(build_post_gen_kernel, (u32)std::min<u64>(npairs12, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, bp);
 	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts_bp)) return 1;
 	const u64 *keys_sorted = keys_in;
 	const float *vals_sorted = vals_in;
+	if (span_begin(c, 6, &ts_bp)) return 1;
 	if (M > 1) {
 #ifdef MPC_EMU
 		{ // emulator build (tests only): "device" memory is host memory
@@ -1743,18 +1750,19 @@ int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t
 		}
 #else
 		size_t tmp_bytes = 0;
-		HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)M, 0,
-			(int)(ba + bb + bc), c->stream));
+		HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)M, 0u, ba + bb + bc, c->stream));
 		HIPCHK(c, c->d_bp_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
-		HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->d_bp_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)M, 0,
-			(int)(ba + bb + bc), c->stream));
+		HIPCHK(c, rocprim::radix_sort_pairs(c->d_bp_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)M, 0u, ba + bb + bc, c->stream));
 #endif
 		keys_sorted = keys_out;
 		vals_sorted = vals_out;
 	}
-	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((cells + 255) / 256, (u64)c->prop.multiProcessorCount * 64), 256, 0,
+	if (span_end(c, &ts_bp)) return 1;
+	if (span_begin(c, 7, &ts_bp)) return 1;
+	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((cells + 3) / 4, (u64)c->prop.multiProcessorCount * 8), 256, 0, // one wave per cell
 		c->stream, keys_sorted, vals_sorted, (u64)M, (u32)(ba + bb), c->d_aln_post.as<float>(), (u64)cells);
 	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts_bp)) return 1;
 	// the uploads above came from vectors that die with this call: drain before returning (run_calc_aln syncs)
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score);
 }
@@ -1786,7 +1794,7 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	const u64 cells = (u64)C1 * C2;
 	const u32 bq = bits_for(npairs - 1), bc = bits_for(cells - 1);
 	if (bq + bc > 64) return fail(c, "mpcgpu_align_msas: key does not fit 64 bits");
-	if (M > 0x7fffffffull) return fail(c, "mpcgpu_align_msas: %llu contributions exceed this build's sort size", (u64)M);
+	if (M > 0xffffffffull) return fail(c, "mpcgpu_align_msas: %llu contributions exceed this build's record count", (u64)M);
 	std::vector<u32> maps(off1[npairs] + off2[npairs]);
 	memcpy(maps.data(), pos2col1, off1[npairs] * 4);
 	memcpy(maps.data() + off1[npairs], pos2col2, off2[npairs] * 4);
@@ -1826,16 +1834,14 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 		}
 #else
 		size_t tmp_bytes = 0;
-		HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)M, 0, (int)(bq + bc),
-			c->stream));
+		HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)M, 0u, bq + bc, c->stream));
 		HIPCHK(c, c->d_bp_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
-		HIPCHK(c, hipcub::DeviceRadixSort::SortPairs(c->d_bp_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)M, 0,
-			(int)(bq + bc), c->stream));
+		HIPCHK(c, rocprim::radix_sort_pairs(c->d_bp_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)M, 0u, bq + bc, c->stream));
 #endif
 		keys_sorted = keys_out;
 		vals_sorted = vals_out;
 	}
-	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((cells + 255) / 256, (u64)c->prop.multiProcessorCount * 64), 256, 0,
+	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((cells + 3) / 4, (u64)c->prop.multiProcessorCount * 8), 256, 0, // one wave per cell
 		c->stream, keys_sorted, vals_sorted, (u64)M, bq, c->d_aln_post.as<float>(), (u64)cells);
 	HIPCHK(c, hipGetLastError());
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // syncs before the vectors above die

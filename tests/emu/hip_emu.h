@@ -99,6 +99,20 @@ template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src
 template <class T> static inline T mpc_read_lane(T v, unsigned l) { return __shfl(v, (int)l); }
 template <class T> static inline T mpc_lane_up1(T v) { return __shfl_up(v, 1); }
 template <class T> static inline T mpc_lane_down1(T v) { return __shfl_down(v, 1); }
+static inline float mpc_lane_up1_fill(float v, float fill) { const float r = __shfl_up(v, 1); return emu::t_lane == 0 ? fill : r; }
+// the same left-to-right chain as the device's 64 DPP steps, from one exchange (every lane adds the 64 values in lane order)
+static inline float mpc_wave_chain_add(float total, float v)
+{
+	emu::WaveState *w = emu::t_wave;
+	uint64_t raw = 0;
+	memcpy(&raw, &v, 4);
+	w->xbuf[emu::t_lane] = raw;
+	emu::barrier_wait(w->bar);
+	volatile float acc = total; // volatile: no reassociation, no extended precision
+	for (int i = 0; i < 64; ++i) { float x = 0.0f; if (i < w->nthreads) memcpy(&x, &w->xbuf[i], 4); acc = acc + x; }
+	emu::barrier_wait(w->bar);
+	return acc;
+}
 static inline float mpc_wave_scan_max_nonneg(float v)
 {
 	for (int d = 1; d < 64; d <<= 1) {
