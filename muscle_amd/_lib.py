@@ -35,7 +35,7 @@ _libs = {}
 
 
 def load(lib_path=None):
-    path = lib_path or DEFAULT_LIB
+    path = lib_path or os.environ.get("MPCGPU_LIB") or DEFAULT_LIB  # MPCGPU_LIB: another build of the same library (A/B runs)
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):

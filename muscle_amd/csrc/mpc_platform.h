@@ -15,23 +15,25 @@
 __device__ __forceinline__ int mpc_lane_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int mpc_lane_down1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ float mpc_lane_up1(float v) { return __builtin_bit_cast(float, mpc_lane_up1(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float mpc_lane_down1(float v) { return __builtin_bit_cast(float, mpc_lane_down1(__builtin_bit_cast(int, v))); }
 // the same shift with lane 0 receiving `fill` (the DPP move keeps the old destination value in lanes without a source)
 __device__ __forceinline__ float mpc_lane_up1_fill(float v, float fill)
 {
 	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
 }
-// ((((total + v[0]) + v[1]) + ...) + v[63]) over the wave's 64 lane values, strictly left to right, as a wave-uniform result:
-// 64 steps of p = shift_up(p) + v with lane 0 taking `total` — after step j lane k holds ((v[k-j+1] + ...) + v[k]) added in
-// order (onto `total` once the chain reaches lane 0), so after 64 steps lane 63 holds the whole chain. One wave instruction
-// (v_add_f32 with a DPP operand) per term; every term is added exactly once, in sequence, each add rounded on its own.
+// ((((total + v[0]) + v[1]) + ...) + v[63]) over the wave's 64 lane values, strictly left to right, as a wave-uniform result.
+// Lane 0's term is replaced by w[0] = total + v[0]; then 64 steps of p = shift_up(p) + w, a lane without a source (lane 0)
+// reading 0.0f (0 + w[0] == w[0] exactly: the sums here are non-negative): after step j lane k holds
+// ((w[k-j+1] + ...) + w[k]) added in order, so after 64 steps lane 63 holds the whole chain. ONE instruction per term
+// (v_add_f32 with a DPP source; the two wait states a DPP read of a just-written register needs are spelled out because the
+// hazard recognizer does not look into inline asm); every term is added exactly once, in sequence, each add rounded on its own.
 __device__ __forceinline__ float mpc_wave_chain_add(float total, float v)
 {
+	const float w = (threadIdx.x & 63u) == 0u ? total + v : v;
 	float p = 0.0f;
-#pragma unroll
-	for (int j = 0; j < 64; ++j) p = mpc_lane_up1_fill(p, total) + v;
+	asm volatile(".rept 64\n\ts_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t.endr" : "+v"(p) : "v"(w));
 	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 63));
 }
-__device__ __forceinline__ float mpc_lane_down1(float v) { return __builtin_bit_cast(float, mpc_lane_down1(__builtin_bit_cast(int, v))); }
 // Inclusive prefix maximum over the wave for values >= 0 (identity 0.0f): DPP row shifts inside the
 // rows of 16 lanes, then row_bcast:15 / row_bcast:31 across rows. max is exact and associative, so
 // the order of combination does not matter.

@@ -550,13 +550,14 @@ void var_lds_geometry(u32 geo, u32 nbuf, u32 *buf_bytes, size_t *smem)
 // workgroup sizes of relax_var_kernel: 1024 (one per CU), or two per CU of 512 / 640 / 768 threads (4 / 5 / 6 waves per SIMD:
 // 128 / 96 / 80 VGPRs); slots = cells per lane a tile may need (about 12.7 k wave-aligned cells per 4x4 tile at L~400)
 // geometry id = threads per workgroup, except 2048 = two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs)
-u32 var_max_slots(u32 geo) { return geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : geo == 640 ? 21u : 26u; }
+u32 var_max_slots(u32 geo) { return geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : 26u; }
 u32 var_geo_from_env()
 {
 	// default: two 768-thread workgroups per CU (6 waves per SIMD): measured 1748 ms per two iterations at 1000 x L~400 against
-	// 1984 (512 x 2), 2017 (1024 x 2: spills in the walk), 2060 (1024 x 1, two staging buffers) — profiles/r02e
+	// 1984 (512 x 2), 2017 (1024 x 2: spills in the walk), 2060 (1024 x 1, two staging buffers), 2759 (640 x 2) and 2932 (896 x 2:
+	// both spill inside the walk; not kept) — profiles/r02e, r02h
 	const int t = env_int("MPCGPU_RELAX_WG", 768);
-	return t == 512 ? 512u : t == 640 ? 640u : t == 1024 ? 1024u : t == 2048 ? 2048u : 768u;
+	return t == 512 ? 512u : t == 1024 ? 1024u : t == 2048 ? 2048u : 768u;
 }
 
 template <int TH, int SL, int WGS, int DG = 0> void launch_relax_var(const RelaxVarParams &rp, u32 grid, size_t smem, hipStream_t st)
@@ -661,7 +662,7 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only
 	const void *fn = geo == 1024 ? (diag == 1 ? (const void *)relax_var_kernel<1024, 16, 1, 1> : (const void *)relax_var_kernel<1024, 16, 1>)
 	               : geo == 2048 ? (const void *)relax_var_kernel<1024, 14, 2> : geo == 768 ? (const void *)relax_var_kernel<768, 18, 2>
-	               : geo == 640 ? (const void *)relax_var_kernel<640, 21, 2> : (const void *)relax_var_kernel<512, 26, 2>;
+	               : (const void *)relax_var_kernel<512, 26, 2>;
 	HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 	int occ = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)threads, smem) != hipSuccess || occ < 1) occ = 1;
@@ -677,7 +678,6 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		else launch_relax_var<1024, 16, 1>(rp, grid, smem, c->stream);
 	} else if (geo == 2048) launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
 	else if (geo == 768) launch_relax_var<768, 18, 2>(rp, grid, smem, c->stream);
-	else if (geo == 640) launch_relax_var<640, 21, 2>(rp, grid, smem, c->stream);
 	else launch_relax_var<512, 26, 2>(rp, grid, smem, c->stream);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
@@ -743,7 +743,7 @@ int build_var_store(mpcgpu_ctx *c)
 		snprintf(b, sizeof(b), "variable-size dense records: %u x %u records, %.2f GB, mean %.0f B, largest %u B; relax_var_kernel, %s, %u staging buffer%s of %u B",
 			n, n, (double)run * 16 / 1e9, (double)run * 16 / (double)nn, max_rec * 16,
 			threads == 2048 ? "2 x 1024-thread workgroups per CU" : threads == 1024 ? "1 x 1024-thread workgroup per CU" :
-			threads == 768 ? "2 x 768-thread workgroups per CU" : threads == 640 ? "2 x 640-thread workgroups per CU" : "2 x 512-thread workgroups per CU",
+			threads == 768 ? "2 x 768-thread workgroups per CU" : "2 x 512-thread workgroups per CU",
 			nbuf, nbuf == 1 ? "" : "s", buf_bytes);
 		c->store_desc = b; c->tiles_desc.clear(); c->relax_fallback = false;
 	}
