@@ -12,7 +12,7 @@ from muscle_amd.synth import make_family
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", G.MPC_SETS)
+@pytest.mark.parametrize("name", G.MPC_SETS_GPU)
 def test_golden_sets(name):
     g = G.mpc(name)
     stages, ea = P.run_lib(g["seqs"])
