@@ -30,7 +30,9 @@ objcopy --weaken-symbol=_ZN7MPCFlat13CalcPosteriorEj "$REFOBJ/calcposteriorflat.
 # MPCFlat::BuildPost: the reference's definition stays in use under another name; hostcxx/mpcflat_gpu.cpp defines the member
 # (copies the device matrices to the host first, then calls it) for the callers outside MPCFlat::Run, e.g. -profseq
 objcopy --redefine-sym _ZN7MPCFlat9BuildPostERK13MultiSequenceS2_Pf=MPCFlat_BuildPost_ref "$REFOBJ/buildpostflat.o" "$OUT/buildpostflat_ref.o"
-OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$')
+# Super7::IntraAlignShrubs: ours (parallel over device contexts); the rest of super7.o stays
+objcopy --weaken-symbol=_ZN6Super716IntraAlignShrubsEv "$REFOBJ/super7.o" "$OUT/super7_weak.o"
+OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$')
 # The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
 # MPCGPU_LIBDIR/MPCGPU_LIBNAME pointing at the SIMT-emulator build of the same library sources
 # (tests/emu, test infrastructure) to check the host-side plumbing of this file without a GPU.
@@ -39,6 +41,6 @@ LIBNAME="${MPCGPU_LIBNAME:-mpcgpu}"
 BIN="${MPCGPU_BIN:-muscle_gpu}"
 # --wrap=rand: the reference's rand() (refineflat.cpp:14) gets a private copy of glibc's default
 # stream; the HIP runtime in the same process otherwise consumes it (hostcxx/rand_isolate.cpp)
-g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/buildpostflat_ref.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
+g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/buildpostflat_ref.o" "$OUT/super7_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
   -L"$LIBDIR" -l"$LIBNAME" -Wl,-rpath,"$LIBDIR" -Wl,-rpath,'$ORIGIN/../../muscle_amd/csrc' -Wl,-rpath,/opt/rocm/lib -o "$OUT/$BIN"
 echo "built: $OUT/$BIN"

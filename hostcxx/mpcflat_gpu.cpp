@@ -36,11 +36,19 @@
 #include "pairhmm.h"
 #include "pprog.h"
 #include "mega.h"
+#include "super7.h"
 #include "mpcgpu.h"
 
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <thread>
+
+// hostcxx/rand_isolate.cpp
+extern "C" void MuscleGpuRandThreadSeek(unsigned long long Offset);
+extern "C" void MuscleGpuRandThreadEnd(void);
+extern "C" void MuscleGpuRandSharedSkip(unsigned long long Count);
 
 namespace
 {
@@ -70,12 +78,37 @@ uint64_t SeqEnds(const byte *p, uint L)
 	return v;
 	}
 
-std::mutex g_Mu;
-mpcgpu_ctx *g_Ctx = 0;
-mpcgpu_group *g_Group = 0; // MUSCLE_GPU_DEVICES: the all-pairs stage sharded over several GPUs; g_Ctx is then its rank 0
-mpcgpu_ctx *g_CtxJoin = 0; // PProg joins: their own context, so a join never disturbs the store of an MPCFlat run
+// One Slot = one device context (or one group of contexts) with the state of the MPCFlat run it is serving. Slot 0 serves every
+// MPCFlat that was not given a slot of its own (-align, -super5, the sequential shrub loop); slots 1.. belong to the worker
+// threads of the parallel shrub loop of -super7 (Super7::IntraAlignShrubs below), each with its own context so that the small
+// launches of different shrubs overlap on the device(s).
+struct Slot
+	{
+	std::mutex m_Mu;
+	mpcgpu_ctx *m_Ctx = 0;
+	mpcgpu_group *m_Group = 0;	// MUSCLE_GPU_DEVICES (slot 0 only): the all-pairs stage sharded over several GPUs; m_Ctx is its rank 0
+	const MPCFlat *m_StoreOwner = 0; // the MPCFlat whose all-pairs store the context currently holds
+	};
+enum { MAX_SLOTS = 65 };
+Slot g_Slots[MAX_SLOTS];
+std::mutex g_MapMu;	// guards the two maps (not the batches themselves: a batch is used under its slot's mutex)
 std::map<const MPCFlat *, Batch> g_Batches;
-const MPCFlat *g_StoreOwner = 0; // the MPCFlat whose all-pairs store the device currently holds
+std::map<const MPCFlat *, int> g_SlotOf;
+std::mutex g_JoinMu;
+mpcgpu_ctx *g_CtxJoin = 0; // PProg joins: their own context, so a join never disturbs the store of an MPCFlat run
+
+int SlotIndexOf(const MPCFlat *M)
+	{
+	std::lock_guard<std::mutex> Guard(g_MapMu);
+	std::map<const MPCFlat *, int>::const_iterator p = g_SlotOf.find(M);
+	return p == g_SlotOf.end() ? 0 : p->second;
+	}
+
+Batch &BatchOf(const MPCFlat *M)
+	{
+	std::lock_guard<std::mutex> Guard(g_MapMu);
+	return g_Batches[M]; // std::map: references stay valid when other keys are inserted
+	}
 
 // MUSCLE_GPU_DEVICES="0-7" | "0,1,2,3" (an ordinal may repeat, e.g. "0,0" on a one-GPU box): one context per listed device,
 // pair loops sharded over them (include/mpcgpu.h, mpcgpu_group_*). Without it: one context on MUSCLE_GPU_DEVICE (default 0).
@@ -107,30 +140,44 @@ vector<int> ParseDevices(const char *s)
 	return Devs;
 	}
 
-mpcgpu_ctx *GetCtx()
+vector<int> DeviceList()
 	{
-	if (g_Ctx != 0)
-		return g_Ctx;
 	const char *List = getenv("MUSCLE_GPU_DEVICES");
 	if (List != 0 && *List != 0)
 		{
 		vector<int> Devs = ParseDevices(List);
 		if (Devs.empty())
 			Die("MUSCLE_GPU_DEVICES is empty");
-		if (mpcgpu_group_create(&g_Group, (uint32_t) Devs.size(), Devs.data()) != 0)
-			Die("GPU posterior stage: %s", mpcgpu_group_last_error(0));
-		g_Ctx = mpcgpu_group_ctx(g_Group, 0);
-		if (getenv("MUSCLE_GPU_TIMING") != 0 || getenv("MUSCLE_GPU_DEBUG") != 0)
-			fprintf(stderr, "[muscle_gpu] %u GPU contexts, exchange by %s\n", mpcgpu_group_size(g_Group), mpcgpu_group_transport(g_Group));
-		return g_Ctx;
+		return Devs;
 		}
 	int Device = 0;
 	const char *s = getenv("MUSCLE_GPU_DEVICE");
 	if (s != 0 && *s != 0)
 		Device = atoi(s);
-	if (mpcgpu_create(&g_Ctx, Device) != 0)
+	return vector<int>(1, Device);
+	}
+
+// Context of a slot, created on first use (call with the slot's mutex held). Slot 0: a group when MUSCLE_GPU_DEVICES lists
+// several devices, else one context. Worker slots: one context each, dealt round-robin over the listed devices.
+mpcgpu_ctx *GetCtx(int SlotIndex)
+	{
+	Slot &S = g_Slots[SlotIndex];
+	if (S.m_Ctx != 0)
+		return S.m_Ctx;
+	vector<int> Devs = DeviceList();
+	if (SlotIndex == 0 && getenv("MUSCLE_GPU_DEVICES") != 0 && *getenv("MUSCLE_GPU_DEVICES") != 0)
+		{
+		if (mpcgpu_group_create(&S.m_Group, (uint32_t) Devs.size(), Devs.data()) != 0)
+			Die("GPU posterior stage: %s", mpcgpu_group_last_error(0));
+		S.m_Ctx = mpcgpu_group_ctx(S.m_Group, 0);
+		if (getenv("MUSCLE_GPU_TIMING") != 0 || getenv("MUSCLE_GPU_DEBUG") != 0)
+			fprintf(stderr, "[muscle_gpu] %u GPU contexts, exchange by %s\n", mpcgpu_group_size(S.m_Group), mpcgpu_group_transport(S.m_Group));
+		return S.m_Ctx;
+		}
+	const int Device = Devs[SlotIndex == 0 ? 0 : (SlotIndex - 1) % SIZE(Devs)];
+	if (mpcgpu_create(&S.m_Ctx, Device) != 0)
 		Die("GPU posterior stage: %s", mpcgpu_last_error(0));
-	return g_Ctx;
+	return S.m_Ctx;
 	}
 
 // MUSCLE_GPU_DEBUG=1: FNV-1a digests of what crosses the boundary, on stderr (diagnostics)
@@ -184,7 +231,7 @@ bool TimingOn()
 				  "BuildPost: records", "BuildPost: sort", "BuildPost: reduce", "CalcAlnFlat+traceback" };
 				float Ms[MPCGPU_NKERNELS];
 				uint64_t Launches[MPCGPU_NKERNELS];
-				if (g_Ctx != 0 && mpcgpu_timers_get(g_Ctx, Ms, Launches) == 0)
+				if (g_Slots[0].m_Ctx != 0 && mpcgpu_timers_get(g_Slots[0].m_Ctx, Ms, Launches) == 0)
 					for (int i = 0; i < MPCGPU_NKERNELS; ++i)
 						fprintf(stderr, "[muscle_gpu]   device: %-24s %10.3f s  %8llu launches\n", Fam[i], Ms[i]*1e-3, (unsigned long long) Launches[i]);
 				});
@@ -225,7 +272,7 @@ uint64_t Fnv(uint64_t h, const void *p, size_t n)
 	}
 
 #define GPUCHK(call)	do { if ((call) != 0) Die("GPU posterior stage: %s", mpcgpu_last_error(Ctx)); } while (0)
-#define GRPCHK(call)	do { if ((call) != 0) Die("GPU posterior stage: %s", mpcgpu_group_last_error(g_Group)); } while (0)
+#define GRPCHK(call)	do { if ((call) != 0) Die("GPU posterior stage: %s", mpcgpu_group_last_error(Group)); } while (0)
 
 // Copies pairs [k0,k1) of the device store into MySparseMx objects (layout of
 // mysparsemx.h:6-98; buffers through AllocLX/AllocVec so ownership stays with myalloc/myfree).
@@ -294,7 +341,7 @@ template<class GETMX> void Download(mpcgpu_ctx *Ctx, MPCFlat &M, uint PairCount,
 // calcpost.cpp:14-22: with a .mega input loaded the emissions come from the structure profiles of the
 // sequences (looked up by label, like CalcPost does), not from the PairHMM letter tables. Labels[i] is
 // the label of sequence i of the set just given to mpcgpu_set_seqs / mpcgpu_set_seqs_registry.
-void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_t> &Lens, bool AllRanks = false)
+void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_t> &Lens, mpcgpu_group *Group = 0)
 	{
 	if (!Mega::m_Loaded)
 		return; // set_seqs already switched the context back to letter emissions
@@ -334,8 +381,8 @@ void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_
 			}
 		ProfPtrs[i] = Profs[i].data();
 		}
-	if (AllRanks && g_Group != 0)
-		GRPCHK(mpcgpu_group_set_mega(g_Group, FeatureCount, AlphaSizes.data(), Weights.data(), LogProbPtrs.data(),
+	if (Group != 0)
+		GRPCHK(mpcgpu_group_set_mega(Group, FeatureCount, AlphaSizes.data(), Weights.data(), LogProbPtrs.data(),
 		  MxPtrs.data(), ProfPtrs.data()));
 	else
 		GPUCHK(mpcgpu_set_mega(Ctx, FeatureCount, AlphaSizes.data(), Weights.data(), LogProbPtrs.data(),
@@ -343,17 +390,18 @@ void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_
 	}
 
 // First CalcPosterior call of a run: the whole all-pairs stage A on the device.
-void StartBatch(MPCFlat &M, Batch &B)
+void StartBatch(MPCFlat &M, Batch &B, int SlotIndex)
 	{
 	Stopwatch SW(T_STAGE_A);
-	mpcgpu_ctx *Ctx = GetCtx();
+	mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
+	mpcgpu_group *Group = g_Slots[SlotIndex].m_Group;
 	const uint SeqCount = M.GetSeqCount();
 	const uint PairCount = SIZE(M.m_Pairs);
 	asserta(PairCount == (SeqCount*(SeqCount - 1))/2);
 
 // The PairHMM tables are process globals that can change between replicates (align.cpp:35-40)
-	if (g_Group != 0)
-		GRPCHK(mpcgpu_group_set_hmm(g_Group, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
+	if (Group != 0)
+		GRPCHK(mpcgpu_group_set_hmm(Group, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
 		  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
 	else
 		GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
@@ -369,12 +417,12 @@ void StartBatch(MPCFlat &M, Batch &B)
 		Labels[i] = string(M.GetLabel(i)); // calcposteriorflat.cpp:63-64
 		}
 // (the "HMM overflow" length check of calcposteriorflat.cpp:54-61 is made by the library)
-	if (g_Group != 0)
+	if (Group != 0)
 		{
 // mpcflat.cpp:239-251 sharded over the devices + the all-gather of the sparse posteriors (mpcgpu_group.cpp)
-		GRPCHK(mpcgpu_group_set_seqs(g_Group, SeqCount, Ptrs.data(), Lens.data()));
-		SetMega(Ctx, Labels, Lens, true);
-		GRPCHK(mpcgpu_group_calc_posteriors(g_Group));
+		GRPCHK(mpcgpu_group_set_seqs(Group, SeqCount, Ptrs.data(), Lens.data()));
+		SetMega(Ctx, Labels, Lens, Group);
+		GRPCHK(mpcgpu_group_calc_posteriors(Group));
 		}
 	else
 		{
@@ -394,7 +442,7 @@ void StartBatch(MPCFlat &M, Batch &B)
 	B.m_SeqEnds.resize(SeqCount);
 	for (uint i = 0; i < SeqCount; ++i)
 		B.m_SeqEnds[i] = SeqEnds(Ptrs[i], Lens[i]);
-	g_StoreOwner = &M;
+	g_Slots[SlotIndex].m_StoreOwner = &M;
 	B.m_EA.resize(PairCount);
 	GPUCHK(mpcgpu_get_ea(Ctx, 0, PairCount, B.m_EA.data()));
 		{
@@ -430,10 +478,12 @@ void MPCFlat::CalcPosterior(uint PairIndex)
 	const uint SeqIndexY = Pair.second;
 	float EA;
 		{
-		std::lock_guard<std::mutex> Guard(g_Mu);
-		Batch &B = g_Batches[this];
+		const int SlotIndex = SlotIndexOf(this);
+		Slot &S = g_Slots[SlotIndex];
+		std::lock_guard<std::mutex> Guard(S.m_Mu);
+		Batch &B = BatchOf(this);
 		bool Fresh = (B.m_Seqs == m_MyInputSeqs && B.m_PairCount == SIZE(m_Pairs) && B.m_Served < B.m_PairCount &&
-		  g_StoreOwner == this && SIZE(B.m_SeqPtrs) == GetSeqCount());
+		  S.m_StoreOwner == this && SIZE(B.m_SeqPtrs) == GetSeqCount());
 		if (Fresh)
 			{
 // the two sequences of this pair are still the ones the batch was computed from
@@ -448,10 +498,10 @@ void MPCFlat::CalcPosterior(uint PairIndex)
 			}
 		if (!Fresh)
 			{
-			StartBatch(*this, B);
+			StartBatch(*this, B, SlotIndex);
 			if (B.m_Materialise && DownloadOn())
 				{
-				Download(g_Ctx, *this, B.m_PairCount, [this](uint k) -> MySparseMx & { return GetSparsePost(k); });
+				Download(S.m_Ctx, *this, B.m_PairCount, [this](uint k) -> MySparseMx & { return GetSparsePost(k); });
 				B.m_OnHost = true;
 				}
 			}
@@ -470,15 +520,18 @@ void MPCFlat::ConsIter(uint Iter)
 	ProgressStep(0, 1, "Consistency (%u/%u)", Iter+1, m_ConsistencyIterCount);
 	Stopwatch SW(T_CONS_ITER);
 		{
-		std::lock_guard<std::mutex> Guard(g_Mu);
-		mpcgpu_ctx *Ctx = GetCtx();
-		if (g_StoreOwner != this)
+		const int SlotIndex = SlotIndexOf(this);
+		Slot &S = g_Slots[SlotIndex];
+		std::lock_guard<std::mutex> Guard(S.m_Mu);
+		mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
+		mpcgpu_group *Group = S.m_Group;
+		if (S.m_StoreOwner != this)
 			Die("GPU posterior stage: ConsIter on an MPCFlat whose posteriors are not the ones on the device");
-		Batch &B = g_Batches[this];
+		Batch &B = BatchOf(this);
 		++B.m_ItersDone;
 		B.m_OnHost = false;
-		if (g_Group != 0)
-			GRPCHK(mpcgpu_group_cons_iter(g_Group)); // consflat.cpp:5-23 sharded + the all-gather of the new values
+		if (Group != 0)
+			GRPCHK(mpcgpu_group_cons_iter(Group)); // consflat.cpp:5-23 sharded + the all-gather of the new values
 		else
 			{
 			GPUCHK(mpcgpu_cons_iter(Ctx, 0, PairCount));
@@ -505,12 +558,13 @@ void MPCFlat_BuildPost_ref(MPCFlat *This, const MultiSequence &MSA1, const Multi
 void MPCFlat::BuildPost(const MultiSequence &MSA1, const MultiSequence &MSA2, float *Post)
 	{
 		{
-		std::lock_guard<std::mutex> Guard(g_Mu);
-		std::map<const MPCFlat *, Batch>::iterator p = g_Batches.find(this);
-		if (p != g_Batches.end() && g_StoreOwner == this && !p->second.m_OnHost)
+		const int SlotIndex = SlotIndexOf(this);
+		Slot &S = g_Slots[SlotIndex];
+		std::lock_guard<std::mutex> Guard(S.m_Mu);
+		Batch &B = BatchOf(this);
+		if (B.m_PairCount != 0 && S.m_StoreOwner == this && !B.m_OnHost)
 			{
-			Batch &B = p->second;
-			mpcgpu_ctx *Ctx = GetCtx();
+			mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
 			Download(Ctx, *this, B.m_PairCount, [this](uint k) -> MySparseMx & { return GetSparsePost(k); });
 			B.m_OnHost = true;
 			}
@@ -536,7 +590,9 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 		if (m_Weights[i] != 1.0f)
 			Die("GPU posterior stage: sequence weights other than 1 are not supported");
 
-	if (g_StoreOwner != this)
+	const int SlotIndex = SlotIndexOf(this);
+	Slot &S = g_Slots[SlotIndex];
+	if (S.m_StoreOwner != this)
 		Die("GPU posterior stage: AlignAlns on an MPCFlat whose posteriors are not the ones on the device");
 	Stopwatch SW(T_ALN_PREP);
 	vector<uint32_t> Seqs1(SeqCount1), Seqs2(SeqCount2);
@@ -568,8 +624,8 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 	float Score = 0;
 	SW.Next(T_ALN_LIB);
 		{
-		std::lock_guard<std::mutex> Guard(g_Mu);
-		mpcgpu_ctx *Ctx = GetCtx();
+		std::lock_guard<std::mutex> Guard(S.m_Mu);
+		mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
 		GPUCHK(mpcgpu_align_alns(Ctx, SeqCount1, Seqs1.data(), SeqCount2, Seqs2.data(), ColCount1, ColCount2,
 		  Map1.data(), Map2.data(), &Path[0], &PathLen, &Score));
 		}
@@ -670,13 +726,10 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 	vector<float> EA(PairCount);
 	SW.Next(T_JOIN_LIB);
 		{
-		std::lock_guard<std::mutex> Guard(g_Mu);
+		std::lock_guard<std::mutex> Guard(g_JoinMu);
 		if (g_CtxJoin == 0)
 			{
-			int Device = 0;
-			const char *s = getenv("MUSCLE_GPU_DEVICE");
-			if (s != 0 && *s != 0)
-				Device = atoi(s);
+			const int Device = DeviceList()[0];
 			if (mpcgpu_create(&g_CtxJoin, Device) != 0)
 				Die("GPU posterior stage: %s", mpcgpu_last_error(0));
 			}
@@ -695,4 +748,87 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 	for (uint PairIndex = 0; PairIndex < PairCount; ++PairIndex)
 		SumEA += EA[PairIndex];
 	return SumEA/PairCount;
+	}
+
+// Super7::IntraAlignShrubs (super7.cpp:127-137): one MPCFlat::Run per shrub of <= shrub_size sequences. The reference runs
+// them one after the other; a shrub is far too small to fill a GPU (496 pairs, then 131 small alignments-of-alignments whose
+// cost is launch and synchronisation latency), and the shrubs are independent. Here MUSCLE_GPU_SHRUB_CONTEXTS worker threads
+// (default 8; 1 = the reference's loop) take shrubs from a counter, each with its own MPCFlat object and its own device
+// context (dealt round-robin over MUSCLE_GPU_DEVICES), so the small launches of different shrubs overlap and several GPUs
+// share the shrubs. Results land in m_ShrubMSAs by shrub index; the one process-wide input of MPCFlat::Run that depends on
+// the order of the shrubs, the rand() stream of RefineIter (refineflat.cpp:14: one draw per sequence per refinement round,
+// Derep is off in -super7: super7.cpp:11), is positioned per shrub where the sequential loop would have had it.
+// (.mega inputs: Super7_mega::IntraAlignShrub hands per-shrub profile tables to its MPCFlat — kept sequential.)
+void Super7::IntraAlignShrubs()
+	{
+	asserta(m_ShrubMSAs.empty());
+	const uint ShrubCount = GetShrubCount();
+	uint Workers = 8;
+	const char *EnvWorkers = getenv("MUSCLE_GPU_SHRUB_CONTEXTS");
+	if (EnvWorkers != 0 && *EnvWorkers != 0)
+		Workers = (uint) atoi(EnvWorkers);
+	if (Workers > MAX_SLOTS - 1)
+		Workers = MAX_SLOTS - 1;
+	if (Workers > ShrubCount)
+		Workers = ShrubCount;
+	if (Workers <= 1 || dynamic_cast<Super7_mega *>(this) != 0)
+		{
+		for (uint ShrubIndex = 0; ShrubIndex < ShrubCount; ++ShrubIndex)
+			{
+			ProgressLog("Aligning shrub %u / %u\n", ShrubIndex+1, ShrubCount);
+			IntraAlignShrub(ShrubIndex);
+			}
+		return;
+		}
+
+// where the sequential loop's rand() stream stands when shrub k starts
+	vector<unsigned long long> RandOffset(ShrubCount + 1, 0);
+	for (uint ShrubIndex = 0; ShrubIndex < ShrubCount; ++ShrubIndex)
+		{
+		vector<uint> LeafNodes;
+		m_GuideTree->GetSubtreeLeafNodes(m_ShrubLCAs[ShrubIndex], LeafNodes);
+		const unsigned long long n = SIZE(LeafNodes);
+		const unsigned long long Draws = (n >= 3) ? n*m_MPC->m_RefineIterCount : 0; // mpcflat.cpp:254-264
+		RandOffset[ShrubIndex + 1] = RandOffset[ShrubIndex] + Draws;
+		}
+
+	m_ShrubMSAs.assign(ShrubCount, (const MultiSequence *) 0);
+	std::atomic<uint> Next(0);
+	vector<std::thread> Threads;
+	for (uint w = 0; w < Workers; ++w)
+		Threads.emplace_back([&, w]()
+			{
+			MPCFlat Local;
+			Local.m_ConsistencyIterCount = m_MPC->m_ConsistencyIterCount;
+			Local.m_RefineIterCount = m_MPC->m_RefineIterCount;
+			Local.m_D.m_Disable = m_MPC->m_D.m_Disable; // super7.cpp:11
+				{
+				std::lock_guard<std::mutex> Guard(g_MapMu);
+				g_SlotOf[&Local] = 1 + (int) w;
+				}
+			for (;;)
+				{
+				const uint ShrubIndex = Next.fetch_add(1);
+				if (ShrubIndex >= ShrubCount)
+					break;
+				MuscleGpuRandThreadSeek(RandOffset[ShrubIndex]);
+				MultiSequence ShrubInput;
+				MakeShrubInput(m_ShrubLCAs[ShrubIndex], ShrubInput); // super7.cpp:116-126
+				Local.m_TreePerm = TP_None;
+				Local.Run(&ShrubInput);
+				MultiSequence *ShrubMSA = new MultiSequence;
+				ShrubMSA->Copy(*Local.m_MSA);
+				m_ShrubMSAs[ShrubIndex] = ShrubMSA;
+				}
+			MuscleGpuRandThreadEnd();
+				{
+				std::lock_guard<std::mutex> Guard(g_MapMu);
+				g_SlotOf.erase(&Local);
+				g_Batches.erase(&Local);
+				}
+			g_Slots[1 + w].m_StoreOwner = 0; // Local dies with this thread
+			});
+	for (size_t t = 0; t < Threads.size(); ++t)
+		Threads[t].join();
+	MuscleGpuRandSharedSkip(RandOffset[ShrubCount]);
 	}

@@ -21,10 +21,55 @@ struct random_data g_Data;
 char g_State[128];
 bool g_Init = false;
 std::mutex g_Mu;
+
+// Parallel shrub loop of -super7 (hostcxx/mpcflat_gpu.cpp, Super7::IntraAlignShrubs): the reference aligns the shrubs one after
+// the other, so shrub k's refinement sees the stream from position sum_{j<k} calls_j on. A worker thread that runs shrub k
+// positions a PRIVATE copy of the same generator there (same seed, that many values discarded) and draws from it until it
+// says otherwise; the shared stream is advanced past all shrubs at the end, as the sequential loop would have left it.
+struct ThreadStream
+	{
+	bool m_On = false;
+	struct random_data m_Data;
+	char m_State[128];
+	};
+thread_local ThreadStream t_Stream;
+}
+
+extern "C" void MuscleGpuRandThreadSeek(unsigned long long Offset)
+	{
+	ThreadStream &T = t_Stream;
+	T.m_Data.state = 0;
+	initstate_r(1, T.m_State, sizeof(T.m_State), &T.m_Data);
+	int32_t r = 0;
+	for (unsigned long long i = 0; i < Offset; ++i)
+		random_r(&T.m_Data, &r);
+	T.m_On = true;
+	}
+
+extern "C" void MuscleGpuRandThreadEnd(void)
+	{
+	t_Stream.m_On = false;
+	}
+
+extern "C" int __wrap_rand(void);
+extern "C" void MuscleGpuRandSharedSkip(unsigned long long Count)
+	{
+	for (unsigned long long i = 0; i < Count; ++i)
+		(void) __wrap_rand();
+	}
+
+namespace
+{
 }
 
 extern "C" int __wrap_rand(void)
 	{
+	if (t_Stream.m_On)
+		{
+		int32_t r = 0;
+		random_r(&t_Stream.m_Data, &r);
+		return (int) r;
+		}
 	std::lock_guard<std::mutex> Guard(g_Mu);
 	if (!g_Init)
 		{

@@ -25,6 +25,17 @@ def _balanced_newick(lo, hi):
     return "(%s,%s):0.1" % (_balanced_newick(lo, mid), _balanced_newick(mid, hi))
 
 
+def reseek_distmx(n, band=24):
+    """A deterministic sparse similarity matrix in the reseek format -distmxin reads (upgma5.cpp:436-503: "distmx<TAB>N", N lines
+    "index<TAB>label", then "i<TAB>j<TAB>similarity"; absent pairs are 0): every sequence is similar to its next `band` neighbours,
+    less with distance, plus a little hash noise so that UPGMA has no ties."""
+    out = ["distmx\t%d" % n] + ["%d\ts%d" % (i, i) for i in range(n)]
+    for i in range(n):
+        for j in range(i + 1, min(i + 1 + band, n)):
+            out.append("%d\t%d\t%.6f" % (i, j, 1.0 / (1 + j - i) + 0.001 * ((i * 7919 + j * 104729) % 97) / 97.0))
+    return "\n".join(out) + "\n"
+
+
 def command(name):
     """The muscle command of a set: -align (MPCFlat::Run on everything), or for super7_* the
     BASELINE config-5 path (super7.cpp:9-137: guide tree -> shrubs -> MPCFlat::Run per shrub ->
@@ -36,6 +47,10 @@ def command(name):
         n = int(name[7:].split("x")[0])
         shrub = name.split("_b")[1]
         return "-super7", ["-guidetreein", "tree.nwk", "-shrub_size", shrub], {"tree.nwk": _balanced_newick(0, n) + ";\n"}
+    if name.startswith("super7dm_"):  # super7dm_<n>x<L>_b<shrub size>: BASELINE config 5 as stated — guide tree from a precomputed distance matrix
+        n = int(name[9:].split("x")[0])
+        shrub = name.split("_b")[1]
+        return "-super7", ["-distmxin", "dm.tsv", "-shrub_size", shrub], {"dm.tsv": reseek_distmx(n)}
     if name.startswith("super5_"):  # super5_<n>x<L>: UCLUST split + MPCFlat per cluster + PProg joins (super5.cpp)
         return "-super5", [], {}
     return "-align", [], {}
@@ -50,6 +65,9 @@ def input_set(name):
         return seqs, labels, extra + ["-refineiters", k]
     if name.startswith("super7_"):
         n, L = name[7:].split("_b")[0].split("x")
+        return make_family(int(n), int(L), seed=13), None, []
+    if name.startswith("super7dm_"):
+        n, L = name[9:].split("_b")[0].split("x")
         return make_family(int(n), int(L), seed=13), None, []
     if name.startswith("super5_"):
         n, L = name[7:].split("x")

@@ -50,3 +50,12 @@ def test_final_msa_identical_sharded_over_contexts(emu_muscle, name, devices):
     final MSA stays the reference's."""
     md5, _ = _msa.run_muscle(emu_muscle, name, threads=3, env={"MUSCLE_GPU_DEVICES": devices})
     assert md5 == _msa.golden_md5()[name]
+
+
+@pytest.mark.parametrize("name,workers", [("super7_8x18_b4", "1"), ("super7_8x18_b4", "2"), ("super7_8x18_b4", "5")])
+def test_super7_shrubs_over_worker_contexts(emu_muscle, name, workers):
+    """-super7: the shrub loop (super7.cpp:127-137) run by MUSCLE_GPU_SHRUB_CONTEXTS worker threads, each with its own MPCFlat and
+    device context and its own position in the rand() stream of the refinement (hostcxx/mpcflat_gpu.cpp, rand_isolate.cpp):
+    the final MSA is the reference's whatever the number of workers (1 = the reference's sequential loop)."""
+    md5, _ = _msa.run_muscle(emu_muscle, name, threads=2, env={"MUSCLE_GPU_SHRUB_CONTEXTS": workers})
+    assert md5 == _msa.golden_md5()[name]

@@ -52,3 +52,15 @@ def test_final_msa_identical_sharded_over_contexts(gpu_muscle, name, devices):
     from muscle_amd.hostinfo import usable_cores
     md5, _ = _msa.run_muscle(gpu_muscle, name, threads=usable_cores(), env={"MUSCLE_GPU_DEVICES": devices})
     assert md5 == _msa.golden_md5()[name]
+
+
+@pytest.mark.parametrize("name,workers", [("super7dm_300x100_b16", "1"), ("super7dm_300x100_b16", "4"), ("super7dm_2000x250_b32", "8"),
+                                          ("super7_200x120_b32", "3")])
+def test_super7_with_distmx_and_parallel_shrubs(gpu_muscle, name, workers):
+    """BASELINE config 5 as stated: -super7 with the guide tree from a precomputed distance matrix (-distmxin, reseek format),
+    MPCFlat on the shrubs — run by MUSCLE_GPU_SHRUB_CONTEXTS worker threads with a device context each (the reference's loop is
+    sequential: super7.cpp:127-137) — then the PProg joins. Final MSA = the reference's (MD5s from the compiled reference:
+    2000 x L~250 took it 231 s on 7 threads; muscle_gpu 3.5 s)."""
+    from muscle_amd.hostinfo import usable_cores
+    md5, _ = _msa.run_muscle(gpu_muscle, name, threads=usable_cores(), env={"MUSCLE_GPU_SHRUB_CONTEXTS": workers})
+    assert md5 == _msa.golden_md5()[name]
