@@ -103,11 +103,8 @@ __device__ __forceinline__ float mpc_mega_match(const float *s_tab, const u32 *a
 	return m;
 }
 
-// MINB: minimum workgroups per CU the register allocation has to allow (1 = no constraint, the default kernels;
-// 4 = 4 waves per SIMD, i.e. at most 128 VGPRs — a tuning variant for H = 5..7, MPCGPU_FB_OCC4=1, which spills a few
-// registers at H = 6 and 7).
-template <int H, bool MEGA, bool LONG, int MINB = 1>
-__global__ void __launch_bounds__(256, MINB) fb_kernel(FbParams p)
+template <int H, bool MEGA, bool LONG>
+__global__ void __launch_bounds__(256) fb_kernel(FbParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
 	// LOGEXP1 coefficient table: statically allocated, so its LDS address is a compile-time constant that rides in the
@@ -382,7 +379,6 @@ __global__ void __launch_bounds__(256, MINB) fb_kernel(FbParams p)
 			const float *fmrow = fmb + ((u64)(sf < 0 ? 0 : sf) * H) * 64 + t;
 			float dgM = gM;                           // M(i+1, j+1)
 			float dnIX = nIX, dnJX = nJX;             // (i+1, j)
-			float newfirstM = LZ;
 			bool anyhit = false;
 			float sc[H];
 #pragma unroll
@@ -418,9 +414,7 @@ __global__ void __launch_bounds__(256, MINB) fb_kernel(FbParams p)
 				dgM = oM; // becomes M(i, j+1) = diagonal of row i-1
 				cM[r] = vM; cIX[r] = vIX; cJX[r] = vJX; cIY[r] = vIY; cJY[r] = vJY;
 				dnIX = vIX; dnJX = vJX;
-				if (r == 0) newfirstM = vM;
 			}
-			(void)newfirstM;
 			gM = nM;
 			ynext_prev = yc;
 			ylo_prev = ylo; yhi_prev = yhi; insy_prev = insy;

@@ -38,38 +38,22 @@ struct StoreParams {
 	const u32 *mbase;    // n*(n+1): entry offset of M(A,Z) inside slab A at [A*(n+1)+Z]; [..+n] = slab size
 	// values of the next iteration, canonical order
 	float *vnext;
-	// padded layout for the LDS-tiled relax (kernels_relax.h), used INSTEAD of the slabs when it fits:
-	// one fixed-size record per ordered pair (A,Z) at pad + (A*n+Z)*pad_stride dwords =
-	//   [row pointers: lcap1 dwords, in BLOCKS of MPC_PAD_ROW entries][entries: ecap x {P bits, col}]
-	// Every row occupies whole 16-byte blocks of MPC_PAD_ROW = 2 entries; the tail of its last block
-	// is filled with sentinel entries {P = 0.0f, col = MPC_PAD_SENTINEL}. The merge in the kernel then
-	// needs no validity masks (a sentinel can only meet a sentinel, and 0*0 adds +0.0f) and reads each
-	// block with one aligned 16-byte LDS load. A record is a straight 16-byte-aligned copy of what
-	// the kernel wants in LDS: no per-matrix metadata, no dependent address loads, one
-	// global_load_dwordx4 per thread per matrix. pos_f / pos_t give, per canonical entry, its entry
-	// index inside the record of (X,Y) and of (Y,X) (written by pad_build, used by commit).
+	// Records for the LDS-tiled relax (relax_var_kernel, kernels_relaxv.h), used INSTEAD of the slabs when a run fits their
+	// limits: one record per ORDERED pair (A,Z), a 16-byte-aligned verbatim copy of what the kernel wants in LDS:
+	//   [first block of every row: len(A) blocks, row a at block a][its overflow blocks]
+	// block = 16 bytes = {P0 bits, P1 bits, col0 | dist << 16, col1}: 2 entries (the two probabilities adjacent), dist = bytes to the
+	// next block of the same row (0 in its last); unused entries are sentinels {0.0f, MPC_PAD_SENTINEL}. A row is reached by its
+	// index alone (no row pointers); rows of up to 2 entries — most of them — never leave the first-block region. Record (A,Z)
+	// starts at block rec_off[A*n+Z] of `pad` (rec_off: n*n+1 entries, 16-byte units) and is exactly as long as it needs to be:
+	// 8.1 KB on average at 1000 x L~400 (padding every record to the worst one cost 13.3 KB). pos_f / pos_t give, per canonical
+	// entry, its entry index (block * 2 + slot) inside the record of (X,Y) and of (Y,X): written by var_build, used by commit.
 	u32 *pad;
-	u32 pad_stride; // dwords per record = lcap1 + 2*ecap (multiple of 4)
-	u32 lcap1, ecap;
+	u32 lcap1; // >= the longest sequence: LDS scratch of var_build_kernel
 	unsigned short *pos_f, *pos_t;
-	// dense variant of the padded layout (the default; relax_dense_kernel. MPCGPU_PAD=rows selects the one above): a record is
-	//   [first block of every row: lcap1 blocks, row a at block a][overflow blocks: ecap blocks]
-	// block = 16 bytes = {P0 bits, P1 bits, col0 | delta << 16, col1} (the two probabilities adjacent: one packed
-	// multiply in the kernel): delta = distance in blocks to the next block of the same row, 0 in its last block;
-	// unused entries are sentinels as above. A row is reached by its index alone
-	// (no row pointers), rows of up to MPC_PAD_ROW entries — most of them — never leave the first-block region.
-	u32 pad_dense;   // 0: row-pointer layout above, 1: dense
-	u32 pad_ent_off; // dword offset of entry 0 inside a record (lcap1 for the row-pointer layout, 0 for the dense one)
-	// variable-size dense records (the default; relax_var_kernel, kernels_relaxv.h): the dense block format, but record (A,Z)
-	// holds exactly len(A) first blocks + its own overflow blocks and starts at block rec_off[A*n+Z] of `pad`
-	// (rec_off: n*n+1 entries, 16-byte units); the "distance to the row's next block" of a block is kept in BYTES. No record is
-	// padded to the worst one: 8.1 KB instead of 13.3 KB on average at 1000 x L~400.
 	const u32 *rec_off;
-	u32 pad_var;
 };
 
-#define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128). 4 was tried: records grow past the 16 KiB a 1024-thread
-                      // workgroup stages with one load per thread (+45 % HBM traffic, spills in the two-load variant): slower.
+#define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128)
 #define MPC_PAD_SENTINEL 0x1fffu // larger than any column: sequences in the padded layout are <= 8191 long
 
 __device__ __forceinline__ u64 mpc_pair_index(u32 n, u32 i, u32 j) // i<j, mpcflat.cpp:145-155 order
@@ -121,189 +105,6 @@ __global__ void __launch_bounds__(64) slab_build_kernel(StoreParams s)
 			if (fwd) { v.c = e[2 * (u64)q + 1]; dst[q] = v; }
 			else { v.c = rowv[q]; dst[tperm[q]] = v; }
 		}
-	}
-}
-
-// Blocks of MPC_PAD_ROW entries the largest record needs: max over (A,Z) of sum_a ceil(cnt[a]/4).
-__global__ void __launch_bounds__(64) pad_size_kernel(StoreParams s, u32 *max_blocks)
-{
-	const int t = threadIdx.x;
-	const u64 total = (u64)s.n * s.n;
-	u32 best = 0;
-	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
-		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
-		if (A == Z) continue;
-		const u32 LA = s.seq_len[A];
-		const bool fwd = A < Z;
-		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
-		const u32 *rec = s.packed + s.pbase[k];
-		const u32 *cnt = fwd ? rec : rec + s.seq_len[Z];
-		u32 mine = 0;
-		for (u32 a = t; a < LA; a += 64) mine += (cnt[a] + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
-		for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
-		mine = __shfl(mine, 0);
-		best = mine > best ? mine : best;
-	}
-	if (t == 0 && best) atomicMax(max_blocks, best);
-}
-
-// Padded layout: one 64-thread workgroup per ordered pair (A,Z), same sources as slab_build_kernel.
-// Dynamic LDS: 2*lcap1 u32 (exclusive scans of the per-row entry counts and block counts).
-__global__ void __launch_bounds__(64) pad_build_kernel(StoreParams s)
-{
-	MPC_DYN_SMEM(smem_raw);
-	u32 *s_start = (u32 *)smem_raw; // entries before row a in the packed (unpadded) order
-	u32 *s_blk = s_start + s.lcap1; // blocks before row a in the padded record (copy of its row pointers)
-	const int t = threadIdx.x;
-	const u64 total = (u64)s.n * s.n;
-	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
-		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
-		const u32 LA = s.seq_len[A];
-		u32 *rec_out = s.pad + b * (u64)s.pad_stride;
-		MpcEnt *dst = (MpcEnt *)(rec_out + s.lcap1);
-		MpcEnt sentinel; sentinel.p = 0u; sentinel.c = MPC_PAD_SENTINEL;
-		if (A == Z) { // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
-			for (u32 q = t; q < s.lcap1; q += 64) rec_out[q] = 0;
-			for (u32 q = t; q < s.ecap; q += 64) dst[q] = sentinel;
-			continue;
-		}
-		const bool fwd = A < Z;
-		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
-		const u32 *rec = s.packed + s.pbase[k];
-		const u32 LX = fwd ? LA : s.seq_len[Z]; // rows of the stored (unordered) pair
-		const u32 LY = fwd ? s.seq_len[Z] : LA;
-		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
-		const u32 *cnt = fwd ? rec : rec + LX; // rowcnt or colcnt, LA entries
-		u32 carry = 0, carry_b = 0;
-		for (u32 a0 = 0; a0 < s.lcap1; a0 += 64) {
-			const u32 a = a0 + t;
-			const u32 v = (a < LA) ? cnt[a] : 0;
-			const u32 vb = (v + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
-			u32 incl = v, incl_b = vb;
-			for (int d = 1; d < 64; d <<= 1) {
-				const u32 o = __shfl_up(incl, d), ob = __shfl_up(incl_b, d);
-				if (t >= d) { incl += o; incl_b += ob; }
-			}
-			if (a < s.lcap1) { // rows past LA repeat the total
-				s_start[a] = carry + incl - v;
-				s_blk[a] = carry_b + incl_b - vb;
-				rec_out[a] = carry_b + incl_b - vb;
-			}
-			carry += __shfl(incl, 63);
-			carry_b += __shfl(incl_b, 63);
-		}
-		for (u32 q = t; q < s.ecap; q += 64) dst[q] = sentinel;
-		__syncthreads(); // sentinels and row pointers are in place (and visible to this workgroup) before the entries go in
-		const u32 *e = rec + LX + LY;
-		const u32 *rowv = e + 2 * (u64)nnz;
-		const u32 *tperm = rowv + nnz;
-		unsigned short *pos = (fwd ? s.pos_f : s.pos_t) + s.vbase[k];
-		for (u32 q = t; q < nnz; q += 64) {
-			MpcEnt v;
-			v.p = e[2 * (u64)q];
-			const u32 col = e[2 * (u64)q + 1], row = rowv[q];
-			const u32 r = fwd ? row : col;          // row of this entry in M(A,Z)
-			const u32 rank = fwd ? q : tperm[q];    // its rank in M(A,Z)'s row-major order
-			v.c = fwd ? col : row;
-			const u32 at = s_blk[r] * MPC_PAD_ROW + (rank - s_start[r]);
-			dst[at] = v;
-			pos[q] = (unsigned short)at;
-		}
-		__syncthreads(); // s_start is reused by the next record
-	}
-}
-
-// ---- dense variant ----------------------------------------------------------------------------------------------
-// Overflow blocks the largest record needs: max over (A,Z) of sum_a max(ceil(cnt[a]/MPC_PAD_ROW) - 1, 0).
-__global__ void __launch_bounds__(64) pad_size_dense_kernel(StoreParams s, u32 *max_blocks)
-{
-	const int t = threadIdx.x;
-	const u64 total = (u64)s.n * s.n;
-	u32 best = 0;
-	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
-		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
-		if (A == Z) continue;
-		const u32 LA = s.seq_len[A];
-		const bool fwd = A < Z;
-		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
-		const u32 *rec = s.packed + s.pbase[k];
-		const u32 *cnt = fwd ? rec : rec + s.seq_len[Z];
-		u32 mine = 0;
-		for (u32 a = t; a < LA; a += 64) {
-			const u32 nb = (cnt[a] + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
-			mine += nb > 1 ? nb - 1 : 0;
-		}
-		for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
-		mine = __shfl(mine, 0);
-		best = mine > best ? mine : best;
-	}
-	if (t == 0 && best) atomicMax(max_blocks, best);
-}
-
-// One 64-thread workgroup per ordered pair (A,Z). Dynamic LDS: 2*lcap1 u32.
-__global__ void __launch_bounds__(64) pad_build_dense_kernel(StoreParams s)
-{
-	MPC_DYN_SMEM(smem_raw);
-	u32 *s_start = (u32 *)smem_raw; // entries before row a in the packed (unpadded) order
-	u32 *s_ovf = s_start + s.lcap1; // overflow blocks before row a
-	const int t = threadIdx.x;
-	const u64 total = (u64)s.n * s.n;
-	const u32 units = s.lcap1 + s.ecap; // blocks per record
-	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
-		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
-		const u32 LA = s.seq_len[A];
-		u32 *rec_out = s.pad + b * (u64)s.pad_stride;
-		for (u32 q = t; q < units; q += 64) { // every block starts as an empty one
-			rec_out[4 * q] = 0u; rec_out[4 * q + 1] = 0u; rec_out[4 * q + 2] = MPC_PAD_SENTINEL; rec_out[4 * q + 3] = MPC_PAD_SENTINEL;
-		}
-		if (A == Z) continue; // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
-		const bool fwd = A < Z;
-		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
-		const u32 *rec = s.packed + s.pbase[k];
-		const u32 LX = fwd ? LA : s.seq_len[Z]; // rows of the stored (unordered) pair
-		const u32 LY = fwd ? s.seq_len[Z] : LA;
-		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
-		const u32 *cnt = fwd ? rec : rec + LX; // rowcnt or colcnt, LA entries
-		u32 carry = 0, carry_o = 0;
-		for (u32 a0 = 0; a0 < s.lcap1; a0 += 64) {
-			const u32 a = a0 + t;
-			const u32 v = (a < LA) ? cnt[a] : 0;
-			const u32 nb = (v + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
-			const u32 vo = nb > 1 ? nb - 1 : 0;
-			u32 incl = v, incl_o = vo;
-			for (int d = 1; d < 64; d <<= 1) {
-				const u32 o = __shfl_up(incl, d), oo = __shfl_up(incl_o, d);
-				if (t >= d) { incl += o; incl_o += oo; }
-			}
-			if (a < s.lcap1) {
-				s_start[a] = carry + incl - v;
-				s_ovf[a] = carry_o + incl_o - vo;
-			}
-			carry += __shfl(incl, 63);
-			carry_o += __shfl(incl_o, 63);
-		}
-		__syncthreads(); // empty blocks and scans are in place before the entries go in
-		const u32 *e = rec + LX + LY;
-		const u32 *rowv = e + 2 * (u64)nnz;
-		const u32 *tperm = rowv + nnz;
-		unsigned short *pos = (fwd ? s.pos_f : s.pos_t) + s.vbase[k];
-		for (u32 q = t; q < nnz; q += 64) {
-			const u32 pbits = e[2 * (u64)q];
-			const u32 col = e[2 * (u64)q + 1], row = rowv[q];
-			const u32 r = fwd ? row : col;       // row of this entry in M(A,Z)
-			const u32 rank = fwd ? q : tperm[q]; // its rank in M(A,Z)'s row-major order
-			const u32 c = fwd ? col : row;
-			const u32 within = rank - s_start[r];
-			const u32 j = within / MPC_PAD_ROW, slot = within % MPC_PAD_ROW;
-			const u32 nb = (cnt[r] + MPC_PAD_ROW - 1) / MPC_PAD_ROW;
-			const u32 ovf0 = s.lcap1 + s_ovf[r]; // first overflow block of this row
-			const u32 unit = j == 0 ? r : ovf0 + (j - 1);
-			const u32 delta = j + 1 < nb ? (j == 0 ? ovf0 - r : 1u) : 0u; // blocks to the row's next block
-			rec_out[4 * unit + slot] = pbits;
-			rec_out[4 * unit + 2 + slot] = slot == 0 ? (c | (delta << 16)) : c;
-			pos[q] = (unsigned short)(unit * MPC_PAD_ROW + slot);
-		}
-		__syncthreads(); // s_start is reused by the next record
 	}
 }
 
@@ -500,7 +301,7 @@ __global__ void __launch_bounds__(256) commit_kernel(StoreParams s)
 	}
 }
 
-// commit for the padded layout
+// commit for the record layout: the packed record of the pair and both orientations' records
 __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
 {
 	const u64 last = s.vbase[s.npairs];
@@ -509,22 +310,14 @@ __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
 		const u32 X = s.pair_x[k], Y = s.pair_y[k];
 		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];
 		u32 *rec = s.packed + s.pbase[k];
-		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
 		const u32 idx = (u32)(e - s.vbase[k]);
 		u32 *ent = rec + LX + LY;
 		const u32 pb = __float_as_uint(s.vnext[e]);
-		const u32 tq = ent[3 * (u64)nnz + idx];
 		ent[2 * (u64)idx] = pb;
-		(void)tq;
-		// dword of entry `pos` inside a record: row-pointer layout: entries {P, col} back to back after the row pointers;
-		// dense layout: entry = block * 2 + slot, its P at dword block * 4 + slot
+		// entry `pos` of a record = block pos / 2, slot pos % 2: its probability is dword block * 4 + slot
 		const u32 pf = s.pos_f[e], pt = s.pos_t[e];
-		const u64 df = s.pad_dense ? (u64)((pf >> 1) * 4u + (pf & 1u)) : s.pad_ent_off + 2 * (u64)pf;
-		const u64 dt = s.pad_dense ? (u64)((pt >> 1) * 4u + (pt & 1u)) : s.pad_ent_off + 2 * (u64)pt;
-		const u64 bf = s.pad_var ? 4 * (u64)s.rec_off[(u64)X * s.n + Y] : ((u64)X * s.n + Y) * s.pad_stride;
-		const u64 bt = s.pad_var ? 4 * (u64)s.rec_off[(u64)Y * s.n + X] : ((u64)Y * s.n + X) * s.pad_stride;
-		s.pad[bf + df] = pb;
-		s.pad[bt + dt] = pb;
+		s.pad[4 * (u64)s.rec_off[(u64)X * s.n + Y] + (pf >> 1) * 4u + (pf & 1u)] = pb;
+		s.pad[4 * (u64)s.rec_off[(u64)Y * s.n + X] + (pt >> 1) * 4u + (pt & 1u)] = pb;
 	}
 }
 

@@ -1,7 +1,7 @@
 // mpcgpu.cpp — host side of libmpcgpu.so: the C ABI of include/mpcgpu.h over the HIP kernels in
 // kernels_fb.h (pair-HMM forward/backward, letter and structure-profile emissions), kernels_post.h (probabilities, sparsify, EA),
 // kernels_store.h (packed records, padded / slab stores, gather relax, commit, export),
-// kernels_relax.h (LDS-tiled relax), kernels_aln.h (posterior-DP alignment + traceback) and
+// kernels_relaxv.h (LDS-tiled relax over variable-size records), kernels_aln.h (posterior-DP alignment + traceback) and
 // kernels_prog.h (MSA x MSA posterior build). Built by hipcc (-x hip) for gfx950. There is no CPU
 // implementation behind this API: without a HIP device mpcgpu_create() fails. rocPRIM's radix sort
 // (rocprim::radix_sort_pairs, called directly) is used for one bulk data-movement step (kernels_prog.h); everything else is
@@ -10,7 +10,6 @@
 #include "kernels_fb.h"
 #include "kernels_post.h"
 #include "kernels_store.h"
-#include "kernels_relax.h"
 #include "kernels_relaxv.h"
 #include "kernels_aln.h"
 #include "kernels_prog.h"
@@ -112,17 +111,14 @@ struct mpcgpu_ctx {
 	u32 max_nnz = 0, max_len = 0;
 	DevBuf d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp;
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
-	bool have_pad = false;       // padded layout + LDS-tiled relax (else: slabs + gather relax)
-	u32 pad_lcap1 = 0, pad_ecap = 0, pad_bx = 0, pad_by = 0, pad_threads = MPC_RT_THREADS;
-	bool pad_dense = false;      // dense records + relax_dense_kernel (MPCGPU_PAD=dense), else row-pointer records + relax_tile_kernel (MPCGPU_PAD=rows)
-	bool pad_var = false;        // variable-size dense records + relax_var_kernel (the default)
+	bool have_pad = false;       // variable-size dense records + relax_var_kernel (else: slabs + gather relax)
+	u32 pad_lcap1 = 0;           // longest sequence (LDS scratch of var_build_kernel)
 	DevBuf d_rec_off, d_sizes, d_tilefit;
 	u32 var_max_rec_blocks = 0;  // largest record, 16-byte blocks
 	u64 var_total_blocks = 0;
 	u32 var_threads = 1024, var_nbuf = 2, var_buf_bytes = 0;
 	std::string store_desc, tiles_desc; // mpcgpu_relax_info
 	bool relax_fallback = false;
-	u32 pad_stride_dw() const { return pad_dense ? 4 * (pad_lcap1 + pad_ecap) : pad_lcap1 + 2 * pad_ecap; }
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
 	std::vector<u32> h_tiles;
 	u64 tiles_k0 = ~0ull, tiles_k1 = ~0ull;
@@ -273,27 +269,8 @@ void launch_fb_long(int H, bool mega, const FbParams &p, u32 grid, u32 block, si
 	else launch_fb<MPC_LONG_H, false, true>(p, grid, block, smem, st);
 }
 
-// MPCGPU_FB_OCC4=1: letter-emission pairs with H = 5..7 rows per lane run the 128-VGPR variants (4 waves per SIMD
-// instead of 3, a few spills at H = 6 and 7) — a tuning knob, off by default.
-bool fb_occ4(int H, bool mega) { return !mega && H >= 5 && H <= 7 && env_int("MPCGPU_FB_OCC4", 0) != 0; }
-
-template <int H> void launch_fb_occ4(const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
-{
-	auto kern = fb_kernel<H, false, false, 4>;
-	MPC_LAUNCH(kern, grid, block, smem, st, p);
-}
-
-template <int H> int occ_fb_occ4(u32 block, size_t smem)
-{
-	int nb = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_kernel<H, false, false, 4>, (int)block, smem) != hipSuccess || nb < 1)
-		nb = 1;
-	return nb;
-}
-
 int occ_fb_h(int H, bool mega, u32 block, size_t smem)
 {
-	if (fb_occ4(H, mega)) return H == 5 ? occ_fb_occ4<5>(block, smem) : H == 6 ? occ_fb_occ4<6>(block, smem) : occ_fb_occ4<7>(block, smem);
 	switch (H) {
 #define MPC_CASE(h) case h: return mega ? occ_fb<h, true>(block, smem) : occ_fb<h, false>(block, smem);
 	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
@@ -305,12 +282,6 @@ int occ_fb_h(int H, bool mega, u32 block, size_t smem)
 
 void launch_fb_h(int H, bool mega, const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
-	if (fb_occ4(H, mega)) {
-		if (H == 5) launch_fb_occ4<5>(p, grid, block, smem, st);
-		else if (H == 6) launch_fb_occ4<6>(p, grid, block, smem, st);
-		else launch_fb_occ4<7>(p, grid, block, smem, st);
-		return;
-	}
 	switch (H) {
 #define MPC_CASE(h) case h: if (mega) launch_fb<h, true>(p, grid, block, smem, st); else launch_fb<h, false>(p, grid, block, smem, st); break;
 	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
@@ -342,199 +313,9 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.vnext = c->d_vnext.as<float>();
 	s.pad = c->d_pad.as<u32>();
 	s.lcap1 = c->pad_lcap1;
-	s.ecap = c->pad_ecap;
-	s.pad_stride = c->pad_stride_dw();
-	s.pad_dense = c->pad_dense ? 1u : 0u;
-	s.pad_ent_off = c->pad_dense ? 0u : c->pad_lcap1;
 	s.pos_f = c->d_pos.as<unsigned short>();
 	s.pos_t = c->d_pos.as<unsigned short>() + c->total_entries;
 	s.rec_off = c->d_rec_off.as<u32>();
-	s.pad_var = c->pad_var ? 1u : 0u;
-	if (c->pad_var) { s.pad_dense = 1u; s.pad_ent_off = 0u; }
-}
-
-// Padded-layout geometry for the LDS-tiled relax; false when a tile cannot fit the CU's LDS (or the
-// cell coordinates do not pack into 16:16): the caller then builds the slabs for the gather kernel.
-bool pad_geometry(const mpcgpu_ctx *c, bool dense, u32 max_blocks, u32 *lcap1, u32 *ecap, u32 *bx, u32 *by, u32 *threads)
-{
-	*threads = env_int("MPCGPU_RELAX_WG", MPC_RT_THREADS) == 512 ? 512u : 1024u;
-	if (c->max_len > MPC_RT_MAXLEN) return false; // cell descriptors pack x and y into 13 bits each
-	if ((u64)c->max_nnz > (u64)MPC_RT_SLOTS * *threads) return false; // one pair must fit the slots of a tile
-	u64 rec_bytes;
-	if (dense) {
-		*lcap1 = c->max_len;  // one first block per row
-		*ecap = max_blocks;   // overflow blocks of the largest record
-		const u64 units = (u64)*lcap1 + *ecap;
-		if (8 * units > 65535u) return false; // a cell keeps two block indices over <= 8 resident records in 16 bits each
-		rec_bytes = units * 16;
-	} else {
-		*lcap1 = (c->max_len + 1 + 3) & ~3u;                 // >= Lmax+1, multiple of 4 dwords
-		*ecap = std::max<u32>(max_blocks, 1) * MPC_PAD_ROW;   // whole 32-byte blocks (kernels_store.h)
-		if (*ecap > 65535u) return false;                    // pos_f / pos_t are 16-bit
-		rec_bytes = ((u64)*lcap1 + 2 * (u64)*ecap) * 4;
-	}
-	if (rec_bytes > 2 * 16 * (u64)*threads) return false; // at most two 16-byte loads per thread per matrix
-	// 1024-thread workgroups own the whole LDS of a CU; 512-thread ones share it two per CU
-	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", *threads == 1024 ? 160 : 80) * 1024;
-	static const u32 shapes[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
-	for (auto &sh : shapes) {
-		if (*threads == 512 && sh[0] + sh[1] > 6) continue; // the 512-thread kernel keeps at most 6 matrices resident
-		if ((sh[0] + sh[1]) * rec_bytes + 8 * MPC_RT_ROW <= lds_cap) { *bx = sh[0]; *by = sh[1]; return true; }
-	}
-	return false;
-}
-
-template <int MS, int NLD, int TH> void launch_relax_tile(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
-{
-	auto kern = relax_tile_kernel<MS, NLD, TH>;
-	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
-}
-
-template <int MS, int NLD, int TH, bool PF = false> void launch_relax_dense(const RelaxTileParams &rp, u32 grid, size_t smem, hipStream_t st)
-{
-	auto kern = relax_dense_kernel<MS, NLD, TH, PF>;
-	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
-}
-
-// LDS-tiled relax (kernels_relax.h) over the padded layout; 0 = launched, 1 = error.
-int relax_tiled(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
-{
-	const u32 n = c->n;
-	const u32 bx = c->pad_bx, by = c->pad_by;
-	const u64 mat_bytes = (u64)c->pad_stride_dw() * 4;
-	const u32 threads = c->pad_threads;
-	const int nld = mat_bytes <= (u64)threads * 16 ? 1 : 2;
-	const bool dense = c->pad_dense;
-	// tuning variant of the dense kernel (next slot's first blocks prefetched); only the main shape has it
-	const bool pf = dense && threads == 1024 && nld == 1 && env_int("MPCGPU_RELAX_PF", 0) != 0;
-	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
-	// slots a tile needs: its cells (all pairs in [k0,k1), laid end to end) in chunks of 1024
-	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
-		u64 cells = 0;
-		for (u32 X = x0; X < x0 + nx; ++X)
-			for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
-				const u64 k = pidx(X, Y);
-				if (k >= k0 && k < k1) cells += c->all_nnz[k];
-			}
-		return (u32)((cells + threads - 1) / threads);
-	};
-	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != bx || c->tiles_by != by) {
-		std::vector<u32> &tiles = c->h_tiles;
-		tiles.clear();
-		bool too_big = false;
-		const u32 slot_budget = (u32)std::min(std::max(env_int("MPCGPU_RELAX_SLOTS", MPC_RT_SLOTS), 1), MPC_RT_SLOTS);
-		// a tile over the slot budget is split (Y range first, then X range) until it fits
-		std::function<void(u32, u32, u32, u32)> emit = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
-			const u32 slots = tile_slots(x0, nx, y0, ny);
-			if (slots == 0) return;
-			if (slots <= slot_budget) { tiles.push_back(x0); tiles.push_back(nx); tiles.push_back(y0); tiles.push_back(ny); return; }
-			if (ny > 1) { emit(x0, nx, y0, ny / 2); emit(x0, nx, y0 + ny / 2, ny - ny / 2); }
-			else if (nx > 1) { emit(x0, nx / 2, y0, ny); emit(x0 + nx / 2, nx - nx / 2, y0, ny); }
-			else too_big = true; // a single pair with more than 16*1024 cells
-		};
-		// X blocks of bx, Y blocks of by, walked in 8x8 super-tiles (L2 sharing between the workgroups of an XCD)
-		const u32 nbx = (n + bx - 1) / bx, nby = (n + by - 1) / by;
-		for (u32 sx = 0; sx < nbx; sx += 8)
-			for (u32 sy = 0; sy < nby; sy += 8)
-				for (u32 xb = sx; xb < std::min(sx + 8, nbx); ++xb)
-					for (u32 yb = sy; yb < std::min(sy + 8, nby); ++yb) {
-						const u32 x0 = xb * bx, nx = std::min(bx, n - x0), y0 = yb * by, ny = std::min(by, n - y0);
-						if (y0 + ny <= x0 + 1) continue; // no pair X < Y in this block
-						emit(x0, nx, y0, ny);
-					}
-		c->tiles_k0 = c->tiles_k1 = ~0ull;
-		if (too_big) { tiles.clear(); return fail(c, "mpcgpu_cons_iter: a pair has more than %u stored cells (tile slot budget)", MPC_RT_SLOTS * threads); }
-		// the source of an async H2D copy must outlive it: the list lives in the context AND the
-		// stream is drained before it can be rebuilt
-		if (upload(c, c->d_tiles, tiles)) return 1;
-		HIPCHK(c, hipStreamSynchronize(c->stream));
-		c->tiles_k0 = k0; c->tiles_k1 = k1; c->tiles_bx = bx; c->tiles_by = by;
-	}
-	const std::vector<u32> &tiles = c->h_tiles;
-	if (tiles.empty()) return 0;
-	RelaxTileParams rp;
-	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
-	rp.k0 = k0; rp.k1 = k1;
-	size_t smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW; // pad: whole-block reads may run past the last matrix
-	// dense records, MPCGPU_RELAX_DBUF=1: a second staging buffer (one barrier per step instead of two) when the CU's LDS holds both
-	rp.buf_units = 0;
-	if (dense && env_int("MPCGPU_RELAX_DBUF", 0) != 0) { // opt-in until it has been measured (and run) on the GPU
-		const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", threads == 1024 ? 160 : 80) * 1024;
-		if (2 * (u64)(bx + by) * mat_bytes + 8 * MPC_RT_ROW <= lds_cap) {
-			rp.buf_units = (u32)((u64)(bx + by) * mat_bytes / 16);
-			smem = 2 * (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW;
-		}
-	}
-	const int diag = (dense && threads == 1024 && nld == 1 && !pf) ? env_int("MPCGPU_RELAX_DIAG", 0) : 0; // measurement only
-	const void *fn = nullptr;
-	if (diag == 1) fn = (const void *)relax_dense_kernel<8, 1, 1024, false, 1>;
-	else if (diag == 2) fn = (const void *)relax_dense_kernel<8, 1, 1024, false, 2>;
-	else if (pf) fn = (const void *)relax_dense_kernel<8, 1, 1024, true>;
-	else if (dense) {
-		if (threads == 1024) fn = nld == 1 ? (const void *)relax_dense_kernel<8, 1, 1024> : (const void *)relax_dense_kernel<8, 2, 1024>;
-		else fn = nld == 1 ? (const void *)relax_dense_kernel<6, 1, 512> : (const void *)relax_dense_kernel<6, 2, 512>;
-	} else
-	if (threads == 1024) fn = nld == 1 ? (const void *)relax_tile_kernel<8, 1, 1024> : (const void *)relax_tile_kernel<8, 2, 1024>;
-	else fn = nld == 1 ? (const void *)relax_tile_kernel<6, 1, 512> : (const void *)relax_tile_kernel<6, 2, 512>;
-	int occ = 0;
-	if (rp.buf_units) {
-		// the doubled allocation is an optimisation: if the runtime refuses it (or reports that no workgroup fits),
-		// go back to one buffer instead of failing the launch
-		const bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess &&
-			hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)threads, smem) == hipSuccess && occ >= 1;
-		if (!ok) {
-			(void)hipGetLastError(); // not an error of this call: clear it
-			rp.buf_units = 0;
-			smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW;
-		}
-	}
-	(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-	occ = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)threads, smem) != hipSuccess || occ < 1) occ = 1;
-	u32 grid = std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ);
-	grid = std::max(grid, 1u);
-	if (trace_on()) {
-		fprintf(stderr, "[mpcgpu] relax tiled (%s records%s): tiles=%u block=%ux%u wg=%u nld=%d max_nnz=%u lds=%zu B occ=%d grid=%u\n",
-			dense ? "dense" : "row-pointer", rp.buf_units ? ", 2 LDS buffers" : "", rp.ntiles, bx, by, threads, nld, c->max_nnz, smem, occ, grid);
-		fflush(stderr);
-	}
-	TimedSpan ts;
-	if (span_begin(c, 3, &ts)) return 1;
-	auto launch = [&]() {
-		if (diag == 1) { auto kern = relax_dense_kernel<8, 1, 1024, false, 1>; MPC_LAUNCH(kern, grid, 1024, smem, c->stream, rp); }
-		else if (diag == 2) { auto kern = relax_dense_kernel<8, 1, 1024, false, 2>; MPC_LAUNCH(kern, grid, 1024, smem, c->stream, rp); }
-		else if (pf) launch_relax_dense<8, 1, 1024, true>(rp, grid, smem, c->stream);
-		else if (dense) {
-			if (threads == 1024) {
-				if (nld == 1) launch_relax_dense<8, 1, 1024>(rp, grid, smem, c->stream);
-				else launch_relax_dense<8, 2, 1024>(rp, grid, smem, c->stream);
-			} else {
-				if (nld == 1) launch_relax_dense<6, 1, 512>(rp, grid, smem, c->stream);
-				else launch_relax_dense<6, 2, 512>(rp, grid, smem, c->stream);
-			}
-		} else
-		if (threads == 1024) {
-			if (nld == 1) launch_relax_tile<8, 1, 1024>(rp, grid, smem, c->stream);
-			else launch_relax_tile<8, 2, 1024>(rp, grid, smem, c->stream);
-		} else {
-			if (nld == 1) launch_relax_tile<6, 1, 512>(rp, grid, smem, c->stream);
-			else launch_relax_tile<6, 2, 512>(rp, grid, smem, c->stream);
-		}
-	};
-	launch();
-	hipError_t le = hipGetLastError();
-	if (le != hipSuccess && rp.buf_units) {
-		// launch refused with the doubled LDS allocation (an optimisation): once more with one staging buffer
-		if (trace_on()) { fprintf(stderr, "[mpcgpu] relax launch with 2 LDS buffers failed (%s): retrying with one\n", hipGetErrorString(le)); fflush(stderr); }
-		rp.buf_units = 0;
-		smem = (size_t)(bx + by) * mat_bytes + 8 * MPC_RT_ROW;
-		(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-		launch();
-		le = hipGetLastError();
-	}
-	HIPCHK(c, le);
-	if (span_end(c, &ts)) return 1;
-	return 0;
 }
 
 // ---- variable-size records + relax_var_kernel (kernels_relaxv.h) -------------------------------------------------------
@@ -733,8 +514,8 @@ int build_var_store(mpcgpu_ctx *c)
 	HIPCHK(c, c->d_pos.ensure(4 * std::max<u64>(c->total_entries, 1))); // pos_f then pos_t, u16 each
 	if (upload(c, c->d_rec_off, off)) return 1;
 	HIPCHK(c, hipStreamSynchronize(c->stream)); // `off` dies with this frame
-	c->have_pad = true; c->pad_var = true; c->pad_dense = true;
-	c->pad_lcap1 = c->max_len; c->pad_ecap = 0; c->pad_bx = 4; c->pad_by = 4;
+	c->have_pad = true;
+	c->pad_lcap1 = c->max_len;
 	c->var_threads = threads; c->var_nbuf = nbuf; c->var_buf_bytes = buf_bytes;
 	c->var_max_rec_blocks = max_rec; c->var_total_blocks = run;
 	c->tiles_k0 = c->tiles_k1 = ~0ull;
@@ -1368,82 +1149,18 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	// records fit HBM; otherwise compact slabs + the gather kernel (MPCGPU_RELAX=gather forces it).
 	// Both are device paths with identical results.
 	c->have_pad = false;
-	c->pad_var = false;
 	{
+		// variable-size dense records + the LDS-tiled relax_var_kernel; a run beyond that layout's limits (sequences longer
+		// than 4095, records that do not fit the CU's LDS two at a time, ...) gets compact CSR slabs + the gather kernel
+		// (MPCGPU_RELAX=gather forces it). Both are device paths with identical results.
 		const char *mode = getenv("MPCGPU_RELAX");
-		u32 lcap1 = 0, ecap = 0, bx = 0, by = 0, threads = 0;
-		const char *padmode = getenv("MPCGPU_PAD");
-		// default: variable-size dense records (relax_var_kernel); MPCGPU_PAD=dense: fixed-size dense records
-		// (relax_dense_kernel), also the fallback when a run exceeds the variable layout's limits; MPCGPU_PAD=rows: row pointers
-		const bool dense = !(padmode && !strcmp(padmode, "rows"));
-		const bool want_var = !padmode || !strcmp(padmode, "var");
-		if (!(mode && !strcmp(mode, "gather")) && want_var) {
+		if (!(mode && !strcmp(mode, "gather"))) {
 			const int rc = build_var_store(c);
 			if (rc == 1) return 1;
 			if (rc == 0) { c->have_store = true; return 0; }
 		}
-		if (!(mode && !strcmp(mode, "gather")) && c->max_len <= MPC_RT_MAXLEN) {
-			// size of the largest padded record: rows occupy whole blocks of MPC_PAD_ROW entries
-			StoreParams sp0;
-			fill_store_params(c, sp0);
-			HIPCHK(c, c->d_aln_out.ensure(8));
-			HIPCHK(c, hipMemsetAsync(c->d_aln_out.p, 0, 4, c->stream));
-			if (dense)
-				MPC_LAUNCH(pad_size_dense_kernel, (u32)std::min<u64>((u64)n * n, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp0,
-					c->d_aln_out.as<u32>());
-			else
-			MPC_LAUNCH(pad_size_kernel, (u32)std::min<u64>((u64)n * n, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp0,
-				c->d_aln_out.as<u32>());
-			HIPCHK(c, hipGetLastError());
-			u32 max_blocks = 0;
-			HIPCHK(c, hipMemcpyAsync(&max_blocks, c->d_aln_out.p, 4, hipMemcpyDeviceToHost, c->stream));
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			if (pad_geometry(c, dense, max_blocks, &lcap1, &ecap, &bx, &by, &threads)) {
-				const u64 rec_dw = dense ? 4 * ((u64)lcap1 + ecap) : (u64)lcap1 + 2 * (u64)ecap;
-				const u64 pad_bytes = (u64)n * n * rec_dw * 4 + 4 * std::max<u64>(c->total_entries, 1);
-				size_t freeb = 0, totb = 0;
-				HIPCHK(c, hipMemGetInfo(&freeb, &totb));
-				if (pad_bytes <= c->d_pad.cap + c->d_pos.cap || pad_bytes + ((u64)2 << 30) <= (u64)freeb) {
-					c->have_pad = true;
-					c->pad_lcap1 = lcap1; c->pad_ecap = ecap; c->pad_bx = bx; c->pad_by = by; c->pad_threads = threads;
-					c->pad_dense = dense;
-					c->tiles_k0 = c->tiles_k1 = ~0ull; // the tile list depends on the block shape
-					c->d_rp.release(); c->d_ent.release(); c->d_mbase.release(); // slabs of an earlier run are not needed
-					HIPCHK(c, c->d_pad.ensure((u64)n * n * rec_dw * 4));
-					HIPCHK(c, c->d_pos.ensure(4 * std::max<u64>(c->total_entries, 1))); // pos_f then pos_t, u16 each
-				}
-			}
-		}
 	}
 	TimedSpan ts;
-	if (c->have_pad) {
-		StoreParams sp;
-		fill_store_params(c, sp);
-		if (trace_on()) {
-			fprintf(stderr, "[mpcgpu] store: padded layout (%s), %u x %u records of %u B (%.2f GB), tile block %ux%u\n",
-				c->pad_dense ? "dense" : "row pointers", n, n, sp.pad_stride * 4, (double)n * n * sp.pad_stride * 4 / 1e9, c->pad_bx, c->pad_by);
-			fflush(stderr);
-		}
-		{
-			char b[256];
-			snprintf(b, sizeof(b), "fixed-size %s records: %u x %u records of %u B (%.2f GB); %s, tile block %ux%u", c->pad_dense ? "dense" : "row-pointer", n, n,
-				sp.pad_stride * 4, (double)n * n * sp.pad_stride * 4 / 1e9, c->pad_dense ? "relax_dense_kernel" : "relax_tile_kernel", c->pad_bx, c->pad_by);
-			c->store_desc = b; c->tiles_desc.clear();
-			const char *pm = getenv("MPCGPU_PAD");
-			c->relax_fallback = !(pm && *pm); // reached without being asked for: the variable-size layout refused this run
-		}
-		if (span_begin(c, 2, &ts)) return 1;
-		const u64 blocks = (u64)n * n;
-		if (c->pad_dense)
-			MPC_LAUNCH(pad_build_dense_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)sp.lcap1 * 8, c->stream, sp);
-		else
-		MPC_LAUNCH(pad_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)sp.lcap1 * 8, c->stream, sp);
-		HIPCHK(c, hipGetLastError());
-		if (span_end(c, &ts)) return 1;
-		HIPCHK(c, hipStreamSynchronize(c->stream));
-		c->have_store = true;
-		return 0;
-	}
 	c->d_pad.release();
 	c->d_pos.release();
 	{
@@ -1557,8 +1274,7 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	if (cnt == 0) return 0;
 	StoreParams sp;
 	fill_store_params(c, sp);
-	if (c->have_pad && c->pad_var) return relax_var(c, sp, k0, k1);
-	if (c->have_pad) return relax_tiled(c, sp, k0, k1);
+	if (c->have_pad) return relax_var(c, sp, k0, k1);
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
 	const u32 block = 256;

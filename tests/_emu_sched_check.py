@@ -31,8 +31,8 @@ def with_env(env, fn):
 def main():
     seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0], "MKV"]
     want = P.run_oracle(seqs)
-    for env in ({}, {"MPCGPU_RELAX_DBUF": "1"}, {"MPCGPU_PAD": "rows"}, {"MPCGPU_RELAX": "gather"}, {"MPCGPU_POST": "sort"},
-                {"MPCGPU_RELAX_PF": "1"}, {"MPCGPU_RELAX_WG": "512"}):
+    for env in ({}, {"MPCGPU_RELAX_WG": "1024"}, {"MPCGPU_RELAX_WG": "1024", "MPCGPU_RELAX_NBUF": "1"}, {"MPCGPU_RELAX": "gather"},
+                {"MPCGPU_POST": "sort"}, {"MPCGPU_RELAX_WG": "512"}):
         P.assert_same(with_env(env, lambda: P.run_lib(seqs, lib_path=EMU)), want, "order %s %s" % (os.environ.get("EMU_SCHED"), env))
     seqs = [make_family(1, 131, seed=21)[0], make_family(1, 66, seed=22)[0], "MKV"]
     got = with_env({"MPCGPU_FB_LONG_H": "1", "MPCGPU_FB_LONG_MIN": "2"}, lambda: P.run_lib(seqs, lib_path=EMU))

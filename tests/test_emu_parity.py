@@ -292,26 +292,22 @@ def test_emu_relax_512_thread_workgroups(emu):
     P.assert_same(got, P.run_oracle(seqs), "512-thread relax workgroups")
 
 
-@pytest.mark.parametrize("env", [{}, {"MPCGPU_RELAX_SLOTS": "3"}, {"MPCGPU_RELAX_LDS_KB": "2"}, {"MPCGPU_RELAX_WG": "512"}])
-def test_emu_relax_row_pointer_records(emu, env):
-    """MPCGPU_PAD=rows: the row-pointer record layout + relax_tile_kernel (the default is the dense layout)"""
+@pytest.mark.parametrize("env", [{"MPCGPU_RELAX_WG": "1024"}, {"MPCGPU_RELAX_WG": "1024", "MPCGPU_RELAX_NBUF": "1"}, {"MPCGPU_RELAX_WG": "2048"},
+                                 {"MPCGPU_RELAX_WG": "512", "MPCGPU_RELAX_NBUF": "2"}, {"MPCGPU_RELAX_SLOTS": "3"}, {"MPCGPU_RELAX_LDS_KB": "6"},
+                                 {"MPCGPU_RELAX_WG": "1024", "MPCGPU_RELAX_LDS_KB": "12"}])
+def test_emu_relax_var_geometries(emu, env):
+    """relax_var_kernel in its other shapes: one 1024-thread workgroup per CU with two staging buffers (DMA of step Z+1 under the
+    merges of step Z) or one, two 1024- or 512-thread workgroups per CU, a small slot budget and a small LDS (tiles split by
+    the host's per-tile fit check) — all the default's arithmetic, all bit-identical to the oracle."""
     seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0], "MKV"]
-    got = _with_env(dict(env, MPCGPU_PAD="rows"), lambda: P.run_lib(seqs, lib_path=emu))
-    P.assert_same(got, P.run_oracle(seqs), "row-pointer records %s" % env)
+    got = _with_env(env, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "relax_var_kernel %s" % env)
 
 
 def test_emu_dense_records_long_rows(emu):
     """rows with many entries (weakly related sequences: several blocks per row chained through the overflow region)"""
     seqs = make_family(6, 60, seed=8, p_sub=0.7) + make_family(2, 50, seed=9, p_sub=0.6)
     P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "dense records, long rows")
-
-
-def test_emu_dense_records_two_lds_buffers(emu):
-    """MPCGPU_RELAX_DBUF=1: the two-buffer, one-barrier schedule of relax_dense_kernel (opt-in; the default is one buffer).
-    test_emu_other_thread_orders runs it under reverse and shuffled thread orders as well (race check)."""
-    seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0]]
-    got = _with_env({"MPCGPU_RELAX_DBUF": "1"}, lambda: P.run_lib(seqs, lib_path=emu))
-    P.assert_same(got, P.run_oracle(seqs), "two LDS buffers")
 
 
 def test_emu_row_blocks_vs_reference_golden(emu):
@@ -326,26 +322,12 @@ def test_emu_row_blocks_vs_reference_golden(emu):
 
 def test_emu_very_long_row_sequence(emu):
     """a 9048-residue row sequence against short ones: 21 row blocks in the fb kernel, 16-bit-column candidate keys,
-    and (longer than 8191) the gather relax instead of the LDS tiles"""
+    and (longer than 4095) the gather relax instead of the LDS tiles"""
     fam = make_family(2, 50, seed=3)
     big = make_family(1, 9000, seed=4)[0]
     big = big[:4000] + fam[0] + big[4000:]  # related to the short ones somewhere in the middle
     seqs = [big, fam[0], fam[1]]
     P.assert_same(P.run_lib(seqs, lib_path=emu), P.run_oracle(seqs), "9048-long row sequence")
-
-
-def test_emu_fb_occ4_dispatch(emu):
-    """MPCGPU_FB_OCC4=1 routes H = 5..7 pairs to the 128-VGPR instantiations (same source; the emulator checks the dispatch)"""
-    seqs = make_family(3, 400, seed=71) + make_family(2, 330, seed=72)
-    got = _with_env({"MPCGPU_FB_OCC4": "1"}, lambda: P.run_lib(seqs, iters=0, lib_path=emu))
-    P.assert_same(got, P.run_oracle(seqs, iters=0), "occ4 dispatch")
-
-
-def test_emu_dense_relax_prefetch_variant(emu):
-    """MPCGPU_RELAX_PF=1: relax_dense_kernel<8,1,1024,PF=true> (next slot's first blocks requested early)"""
-    seqs = make_family(9, 18, seed=5) + make_family(3, 60, seed=8, p_sub=0.6)
-    got = _with_env({"MPCGPU_RELAX_PF": "1"}, lambda: P.run_lib(seqs, lib_path=emu))
-    P.assert_same(got, P.run_oracle(seqs), "prefetch variant")
 
 
 @pytest.mark.parametrize("order", ["reverse", "random"])

@@ -242,8 +242,8 @@ def test_back_to_back_iterations_without_sync():
 
 
 def test_relax_gather_equals_tiled():
-    """All relax kernels (LDS-tiled over dense records = default, LDS-tiled over row-pointer records, one-cell-per-thread
-    gather fallback) are device code with the reference's accumulation order: identical bits."""
+    """Both relax kernels (LDS-tiled over variable-size records = default in its geometries, one-cell-per-thread gather
+    fallback) are device code with the reference's accumulation order: identical bits."""
     import os
     seqs = make_family(21, 120, seed=41)
     a = P.run_lib(seqs)
@@ -254,31 +254,14 @@ def test_relax_gather_equals_tiled():
         del os.environ["MPCGPU_RELAX"]
     P.assert_same(a, b, "gather vs tiled")
     P.assert_same(a, P.run_oracle(seqs), "tiled vs oracle")
-    # the row-pointer record layout + relax_tile_kernel (the default is the dense layout + relax_dense_kernel)
-    os.environ["MPCGPU_PAD"] = "rows"
-    try:
-        r = P.run_lib(seqs)
-    finally:
-        del os.environ["MPCGPU_PAD"]
-    P.assert_same(a, r, "row-pointer records vs dense records")
-
-
-@pytest.mark.parametrize("knob", ["MPCGPU_RELAX_DBUF", "MPCGPU_RELAX_PF", "MPCGPU_FB_OCC4"])
-def test_opt_in_variants(knob):
-    """The tuning variants that were finished without GPU time (two LDS staging buffers, first-block prefetch, 128-VGPR fb
-    kernels) against the default path. They are off by default and this test only runs on request
-    (MPCGPU_TEST_OPT_IN=1, scripts/gpu_next.sh) until each has been seen green on a GPU."""
-    import os
-    if os.environ.get("MPCGPU_TEST_OPT_IN") != "1":
-        pytest.skip("opt-in variants: set MPCGPU_TEST_OPT_IN=1")
-    seqs = make_family(21, 120, seed=41) + make_family(3, 400, seed=42)
-    a = P.run_lib(seqs)
-    os.environ[knob] = "1"
-    try:
-        b = P.run_lib(seqs)
-    finally:
-        del os.environ[knob]
-    P.assert_same(a, b, knob)
+    # the other workgroup geometries of relax_var_kernel (default: two 768-thread workgroups per CU)
+    for geo, nbuf in (("1024", "2"), ("1024", "1"), ("512", "1"), ("2048", "1")):
+        os.environ["MPCGPU_RELAX_WG"], os.environ["MPCGPU_RELAX_NBUF"] = geo, nbuf
+        try:
+            r = P.run_lib(seqs)
+        finally:
+            del os.environ["MPCGPU_RELAX_WG"], os.environ["MPCGPU_RELAX_NBUF"]
+        P.assert_same(a, r, "relax geometry %s, %s staging buffers" % (geo, nbuf))
 
 
 def test_calc_aln_paths():
