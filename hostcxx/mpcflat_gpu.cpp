@@ -584,11 +584,19 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 	const uint SeqCount = GetSeqCount();
 	if (SIZE(m_Weights) != SeqCount)
 		m_Weights.assign(SeqCount, 1.0f);
-// BuildPost multiplies by w1*w2 (buildpostflat.cpp:41,52,74); MPCFlat::Run overwrites every weight
-// with 1.0f (mpcflat.cpp:324). The device path implements exactly that case.
-	for (uint i = 0; i < SeqCount; ++i)
-		if (m_Weights[i] != 1.0f)
-			Die("GPU posterior stage: sequence weights other than 1 are not supported");
+// BuildPost multiplies by w1*w2, the weights looked up by the ROW index in MSA1 / MSA2 (buildpostflat.cpp:41,52,74);
+// MPCFlat::Run overwrites every weight with 1.0f (mpcflat.cpp:324), other callers may not: the weights go along.
+	vector<float> W1(SeqCount1), W2(SeqCount2);
+	for (uint i = 0; i < SeqCount1; ++i)
+		{
+		asserta(i < SIZE(m_Weights));
+		W1[i] = m_Weights[i];
+		}
+	for (uint i = 0; i < SeqCount2; ++i)
+		{
+		asserta(i < SIZE(m_Weights));
+		W2[i] = m_Weights[i];
+		}
 
 	const int SlotIndex = SlotIndexOf(this);
 	Slot &S = g_Slots[SlotIndex];
@@ -626,8 +634,8 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 		{
 		std::lock_guard<std::mutex> Guard(S.m_Mu);
 		mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
-		GPUCHK(mpcgpu_align_alns(Ctx, SeqCount1, Seqs1.data(), SeqCount2, Seqs2.data(), ColCount1, ColCount2,
-		  Map1.data(), Map2.data(), &Path[0], &PathLen, &Score));
+		GPUCHK(mpcgpu_align_alns_w(Ctx, SeqCount1, Seqs1.data(), SeqCount2, Seqs2.data(), ColCount1, ColCount2,
+		  Map1.data(), Map2.data(), W1.data(), W2.data(), &Path[0], &PathLen, &Score));
 		}
 	Path.resize(PathLen);
 	if (ptrScore != 0)

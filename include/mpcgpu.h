@@ -151,6 +151,12 @@ int mpcgpu_calc_aln(mpcgpu_ctx *ctx, const float *post, uint32_t LX, uint32_t LY
 int mpcgpu_align_alns(mpcgpu_ctx *ctx, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2,
                       uint32_t C1, uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2,
                       char *path, uint32_t *pathlen, float *score);
+/* The same with sequence weights: every contribution is (w1[a] * w2[b]) * P, the product of the two weights rounded first,
+ * as at buildpostflat.cpp:41,52,74,96 (w1[a] / w2[b] = the reference's m_Weights[SeqIndex1] / m_Weights[SeqIndex2] of row a of
+ * MSA1 / row b of MSA2; NULL = all 1.0f, which is what MPCFlat::Run sets at mpcflat.cpp:324). */
+int mpcgpu_align_alns_w(mpcgpu_ctx *ctx, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2,
+                        uint32_t C1, uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2,
+                        const float *w1, const float *w2, char *path, uint32_t *pathlen, float *score);
 
 /* The MSA x MSA join of PProg (pprog2.cpp:7-56 -> PProg::AlignMSAsFlat, alnmsasflat.cpp:4-50) for an
  * explicit list of cross pairs (getpairs.cpp:33-69 samples at most 2000): per pair

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mpcgpu_set_seqs", "mpcgpu_set_mega", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
-    "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_get",
+    "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
@@ -71,6 +71,7 @@ def load(lib_path=None):
     L.mpcgpu_get_sparse_range.argtypes = [vp, u64, u64, vp, vp]
     L.mpcgpu_calc_aln.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.mpcgpu_align_alns.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float)]
+    L.mpcgpu_align_alns_w.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.mpcgpu_set_seqs_registry.argtypes = [vp, u32, vp, vp]
     L.mpcgpu_align_msas.argtypes = [vp, u32, vp, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float), vp]
     L.mpcgpu_timers_reset.argtypes = [vp]
@@ -344,14 +345,20 @@ class MpcGpu:
         self._ck(self.L.mpcgpu_calc_aln(self.h, post.ctypes.data, LX, LY, path.ctypes.data, C.byref(n), C.byref(sc)))
         return path[:n.value].tobytes().decode(), float(np.float32(sc.value))
 
-    def align_alns(self, seq1, seq2, p2c1, p2c2, C1, C2):
+    def align_alns(self, seq1, seq2, p2c1, p2c2, C1, C2, w1=None, w2=None):
         """seq1/seq2: sequence indices of the rows of the two alignments; p2c1/p2c2: list of per-row
-        position->column arrays -> (path, score) of BuildPost + CalcAlnFlat on the device store"""
+        position->column arrays; w1/w2: optional sequence weights of the rows -> (path, score) of BuildPost + CalcAlnFlat
+        on the device store"""
         s1, s2 = np.asarray(seq1, np.uint32), np.asarray(seq2, np.uint32)
         m1 = np.concatenate([np.asarray(x, np.uint32) for x in p2c1]).astype(np.uint32)
         m2 = np.concatenate([np.asarray(x, np.uint32) for x in p2c2]).astype(np.uint32)
         path = np.empty(C1 + C2, np.uint8)
         n, sc = C.c_uint32(), C.c_float()
+        if w1 is not None:
+            a1, a2 = np.ascontiguousarray(w1, np.float32), np.ascontiguousarray(w2, np.float32)
+            self._ck(self.L.mpcgpu_align_alns_w(self.h, len(s1), s1.ctypes.data, len(s2), s2.ctypes.data, C1, C2, m1.ctypes.data,
+                                                 m2.ctypes.data, a1.ctypes.data, a2.ctypes.data, path.ctypes.data, C.byref(n), C.byref(sc)))
+            return path[:n.value].tobytes().decode(), float(np.float32(sc.value))
         self._ck(self.L.mpcgpu_align_alns(self.h, len(s1), s1.ctypes.data, len(s2), s2.ctypes.data, C1, C2,
                                            m1.ctypes.data, m2.ctypes.data, path.ctypes.data, C.byref(n), C.byref(sc)))
         return path[:n.value].tobytes().decode(), float(np.float32(sc.value))

@@ -28,6 +28,7 @@ struct BuildPostParams {
 	u64 *keys;
 	float *vals;
 	u32 bits_a, bits_b; // key = cell << (bits_a+bits_b) | a << bits_b | b
+	const float *w1, *w2; // sequence weights of the rows of MSA1 / MSA2 (buildpostflat.cpp:41,52), nullptr = 1.0f
 };
 
 // one 64-thread workgroup per (a,b)
@@ -47,6 +48,8 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 		const u32 *m1 = p.p2c1 + p.p2c1_off[a], *m2 = p.p2c2 + p.p2c2_off[b];
 		u64 *keys = p.keys + p.coff[ab];
 		float *vals = p.vals + p.coff[ab];
+		const bool weighted = p.w1 != nullptr;
+		const float w12 = weighted ? p.w1[a] * p.w2[b] : 1.0f; // w1*w2 rounded first: buildpostflat.cpp:74 / :96
 		for (u32 q = threadIdx.x; q < nnz; q += 64) {
 			const u32 row = rowv[q], col = ent[2 * (u64)q + 1];
 			// stored (S,T): rows are positions of S (MSA1); stored (T,S): rows are positions of T (MSA2)
@@ -54,7 +57,8 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 			const u32 c2 = fwd ? m2[col] : m2[row];
 			const u64 cell = (u64)c1 * p.C2 + c2;
 			keys[q] = (cell << (p.bits_a + p.bits_b)) | ((u64)a << p.bits_b) | (u64)b;
-			vals[q] = __uint_as_float(ent[2 * (u64)q]);
+			const float P = __uint_as_float(ent[2 * (u64)q]);
+			vals[q] = weighted ? w12 * P : P;
 		}
 	}
 }

@@ -109,7 +109,7 @@ struct mpcgpu_ctx {
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
-	DevBuf d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp;
+	DevBuf d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_w;
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // variable-size dense records + relax_var_kernel (else: slabs + gather relax)
 	u32 pad_lcap1 = 0;           // longest sequence (LDS scratch of var_build_kernel)
@@ -1401,6 +1401,13 @@ static u32 bits_for(u64 v) { u32 b = 1; while ((v >> b) != 0) ++b; return b; } /
 int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
 	uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, char *path, uint32_t *pathlen, float *score)
 {
+	return mpcgpu_align_alns_w(c, n1, seq1, n2, seq2, C1, C2, pos2col1, pos2col2, nullptr, nullptr, path, pathlen, score);
+}
+
+int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
+	uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, const float *w1, const float *w2, char *path,
+	uint32_t *pathlen, float *score)
+{
 	if (!c) return 1;
 	if (!c->have_store) return fail(c, "mpcgpu_align_alns: no store (call mpcgpu_build_store / mpcgpu_store_import)");
 	if (!seq1 || !seq2 || !pos2col1 || !pos2col2 || !path || !pathlen) return fail(c, "mpcgpu_align_alns: NULL argument");
@@ -1447,6 +1454,20 @@ int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t
 	bp.p2c1 = c->d_bp_map.as<u32>(); bp.p2c2 = bp.p2c1; // offsets below are into the one concatenated array
 	bp.p2c1_off = c->d_bp_off.as<u64>(); bp.p2c2_off = bp.p2c1_off + n1;
 	bp.C2 = C2; bp.coff = c->d_bp_coff.as<u64>(); bp.keys = keys_in; bp.vals = vals_in; bp.bits_a = ba; bp.bits_b = bb;
+	bp.w1 = bp.w2 = nullptr;
+	if ((w1 != nullptr) != (w2 != nullptr)) return fail(c, "mpcgpu_align_alns_w: give both weight arrays or neither");
+	if (w1) {
+		bool all_one = true; // all 1.0f (what MPCFlat::Run sets): (1*1)*P == P, skip the multiply
+		for (u32 a = 0; a < n1; ++a) all_one = all_one && w1[a] == 1.0f;
+		for (u32 b = 0; b < n2; ++b) all_one = all_one && w2[b] == 1.0f;
+		if (!all_one) {
+			std::vector<float> w(w1, w1 + n1);
+			w.insert(w.end(), w2, w2 + n2);
+			if (upload(c, c->d_bp_w, w)) return 1;
+			HIPCHK(c, hipStreamSynchronize(c->stream)); // `w` dies with this scope
+			bp.w1 = c->d_bp_w.as<float>(); bp.w2 = bp.w1 + n1;
+		}
+	}
 	const u64 npairs12 = (u64)n1 * n2;
 	TimedSpan ts_bp;
 	if (span_begin(c, 5, &ts_bp)) return 1;

@@ -316,6 +316,12 @@ def test_align_alns_vs_restatement():
         sc0, path0 = O.calc_aln(post)
         path, sc = g.align_alns(grp1, grp2, m1, m2, C1, C2)
         assert path == path0 and P.bits(sc) == P.bits(sc0), cut
+        # sequence weights (buildpostflat.cpp:41,52,74: every contribution is (w1*w2)*P)
+        w1 = rng.uniform(0.2, 1.8, len(grp1)).astype(np.float32)
+        w2 = rng.uniform(0.2, 1.8, len(grp2)).astype(np.float32)
+        sc0w, path0w = O.calc_aln(BP.build_post(stage, pidx, grp1, grp2, m1, m2, C1, C2, w1, w2))
+        pathw, scw = g.align_alns(grp1, grp2, m1, m2, C1, C2, w1, w2)
+        assert pathw == path0w and P.bits(scw) == P.bits(sc0w), ("weighted", cut)
     g.close()
 
 
