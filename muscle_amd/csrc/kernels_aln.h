@@ -17,11 +17,6 @@
 #pragma once
 #include "device_math.h"
 
-#ifdef MPC_EMU
-#define MPC_ALN_THREADS 128 // emulator build (tests): fewer OS threads per workgroup; the kernel is written for any multiple of 64
-#else
-#define MPC_ALN_THREADS 1024
-#endif
 
 struct AlnParams {
 	const float *post; // LX*LY, row-major

@@ -6,6 +6,35 @@
 #include "hip_emu.h"
 #else
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <dlfcn.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#define MPC_VERSION_STRING "mpcgpu 0.2 (HIP gfx950)"
+#define MPC_ALN_THREADS 1024 // workgroup of calc_aln_kernel (kernels_aln.h)
+// Stable grouping of n (key, value) records by key bits [0, end_bit): rocprim::radix_sort_pairs, called directly (bulk data
+// movement, kernels_prog.h). ensure_tmp(bytes) must return device scratch of at least that size (or nullptr on failure).
+template <class EnsureTmp>
+inline hipError_t mpc_sort_pairs(EnsureTmp ensure_tmp, const unsigned long long *keys_in, unsigned long long *keys_out, const float *vals_in,
+	float *vals_out, size_t n, unsigned end_bit, hipStream_t stream)
+{
+	size_t tmp_bytes = 0;
+	hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
+	if (e != hipSuccess) return e;
+	void *tmp = ensure_tmp(tmp_bytes < 16 ? (size_t)16 : tmp_bytes);
+	if (!tmp) return hipErrorOutOfMemory;
+	return rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, stream);
+}
+// shared library by name / symbol by name (librccl is loaded on first use: mpcgpu_group.cpp)
+inline void *mpc_dl_open(const char *name) { return dlopen(name, RTLD_NOW | RTLD_GLOBAL); }
+inline void *mpc_dl_sym(void *lib, const char *name) { return dlsym(lib, name); }
+inline const char *mpc_dl_error() { const char *e = dlerror(); return e ? e : "unknown error"; }
+// direct access from device `dev` to device `peer` when the hardware offers it (xGMI); "already enabled" is not an error
+inline void mpc_enable_peer(int dev, int peer)
+{
+	(void)hipSetDevice(dev);
+	int can = 0;
+	if (hipDeviceCanAccessPeer(&can, dev, peer) == hipSuccess && can && hipDeviceEnablePeerAccess(peer, 0) != hipSuccess) (void)hipGetLastError();
+}
 #define MPC_LAUNCH(kern, grid, block, smem, stream, ...) \
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (smem), (stream), __VA_ARGS__)
 #define MPC_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]

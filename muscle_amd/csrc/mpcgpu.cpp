@@ -23,9 +23,6 @@
 #include <functional>
 #include <string>
 #include <vector>
-#ifndef MPC_EMU
-#include <rocprim/device/device_radix_sort.hpp>
-#endif
 
 namespace {
 
@@ -548,14 +545,7 @@ int build_var_store(mpcgpu_ctx *c)
 
 extern "C" {
 
-const char *mpcgpu_version(void)
-{
-#ifdef MPC_EMU
-	return "mpcgpu 0.1 (SIMT emulator build: tests only)";
-#else
-	return "mpcgpu 0.1 (HIP gfx950)";
-#endif
-}
+const char *mpcgpu_version(void) { return MPC_VERSION_STRING; }
 
 const char *mpcgpu_last_error(const mpcgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -1478,19 +1468,8 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 	const float *vals_sorted = vals_in;
 	if (span_begin(c, 6, &ts_bp)) return 1;
 	if (M > 1) {
-#ifdef MPC_EMU
-		{ // emulator build (tests only): "device" memory is host memory
-			std::vector<u64> idx(M);
-			for (u64 q = 0; q < M; ++q) idx[q] = q;
-			std::sort(idx.begin(), idx.end(), [&](u64 x, u64 y) { return keys_in[x] < keys_in[y]; });
-			for (u64 q = 0; q < M; ++q) { keys_out[q] = keys_in[idx[q]]; vals_out[q] = vals_in[idx[q]]; }
-		}
-#else
-		size_t tmp_bytes = 0;
-		HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)M, 0u, ba + bb + bc, c->stream));
-		HIPCHK(c, c->d_bp_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
-		HIPCHK(c, rocprim::radix_sort_pairs(c->d_bp_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)M, 0u, ba + bb + bc, c->stream));
-#endif
+		HIPCHK(c, mpc_sort_pairs([&](size_t bytes) -> void * { return c->d_bp_tmp.ensure(bytes) == hipSuccess ? c->d_bp_tmp.p : nullptr; },
+			keys_in, keys_out, vals_in, vals_out, (size_t)M, ba + bb + bc, c->stream));
 		keys_sorted = keys_out;
 		vals_sorted = vals_out;
 	}
@@ -1562,19 +1541,8 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	const u64 *keys_sorted = keys_in;
 	const float *vals_sorted = vals_in;
 	if (M > 1) {
-#ifdef MPC_EMU
-		{
-			std::vector<u64> idx(M);
-			for (u64 q = 0; q < M; ++q) idx[q] = q;
-			std::sort(idx.begin(), idx.end(), [&](u64 x, u64 y) { return keys_in[x] < keys_in[y]; });
-			for (u64 q = 0; q < M; ++q) { keys_out[q] = keys_in[idx[q]]; vals_out[q] = vals_in[idx[q]]; }
-		}
-#else
-		size_t tmp_bytes = 0;
-		HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)M, 0u, bq + bc, c->stream));
-		HIPCHK(c, c->d_bp_tmp.ensure(std::max<size_t>(tmp_bytes, 16)));
-		HIPCHK(c, rocprim::radix_sort_pairs(c->d_bp_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)M, 0u, bq + bc, c->stream));
-#endif
+		HIPCHK(c, mpc_sort_pairs([&](size_t bytes) -> void * { return c->d_bp_tmp.ensure(bytes) == hipSuccess ? c->d_bp_tmp.p : nullptr; },
+			keys_in, keys_out, vals_in, vals_out, (size_t)M, bq + bc, c->stream));
 		keys_sorted = keys_out;
 		vals_sorted = vals_out;
 	}

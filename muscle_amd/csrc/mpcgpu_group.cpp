@@ -23,9 +23,6 @@
 #include <string>
 #include <thread>
 #include <vector>
-#ifndef MPC_EMU
-#include <dlfcn.h>
-#endif
 
 namespace {
 
@@ -42,14 +39,10 @@ struct Rccl {
 	const char *(*GetErrorString)(int) = nullptr;
 	bool load(std::string &why)
 	{
-#ifdef MPC_EMU
-		why = "emulator build";
-		return false;
-#else
 		const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-		for (const char *nm : names) { lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
-		if (!lib) { why = std::string("dlopen librccl: ") + dlerror(); return false; }
-		auto sym = [&](const char *s) { void *p = dlsym(lib, s); if (!p) why = std::string("librccl lacks ") + s; return p; };
+		for (const char *nm : names) { lib = mpc_dl_open(nm); if (lib) break; }
+		if (!lib) { why = std::string("librccl: ") + mpc_dl_error(); return false; }
+		auto sym = [&](const char *s) { void *p = mpc_dl_sym(lib, s); if (!p) why = std::string("librccl lacks ") + s; return p; };
 		*(void **)&CommInitAll = sym("ncclCommInitAll");
 		*(void **)&CommDestroy = sym("ncclCommDestroy");
 		*(void **)&Send = sym("ncclSend");
@@ -58,7 +51,6 @@ struct Rccl {
 		*(void **)&GroupEnd = sym("ncclGroupEnd");
 		*(void **)&GetErrorString = sym("ncclGetErrorString");
 		return CommInitAll && CommDestroy && Send && Recv && GroupStart && GroupEnd && GetErrorString;
-#endif
 	}
 };
 
@@ -222,19 +214,9 @@ int mpcgpu_group_create(mpcgpu_group **out, uint32_t ndev, const int *devices)
 	bool distinct = true;
 	for (uint32_t a = 0; a < ndev; ++a)
 		for (uint32_t b = a + 1; b < ndev; ++b) if (devices[a] == devices[b]) distinct = false;
-#ifndef MPC_EMU
-	// direct access between every pair of distinct devices (xGMI); "already enabled" is not an error
-	for (uint32_t a = 0; a < ndev; ++a)
-		for (uint32_t b = 0; b < ndev; ++b) {
-			if (devices[a] == devices[b]) continue;
-			(void)hipSetDevice(devices[a]);
-			int can = 0;
-			if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
-				const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-				if (e != hipSuccess) (void)hipGetLastError();
-			}
-		}
-#endif
+	for (uint32_t a = 0; a < ndev; ++a) // direct access between every pair of distinct devices (xGMI)
+		for (uint32_t b = 0; b < ndev; ++b)
+			if (devices[a] != devices[b]) mpc_enable_peer(devices[a], devices[b]);
 	const char *want = getenv("MPCGPU_GROUP_TRANSPORT");
 	const bool want_peer = want && !strcmp(want, "peer"), want_rccl = want && !strcmp(want, "rccl");
 	if ((ndev > 1 || want_rccl) && distinct && !want_peer) { // (a one-device group only makes a communicator on request: the loader's test)

@@ -164,6 +164,9 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 static inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
 static inline double __longlong_as_double(long long u) { double d; memcpy(&d, &u, 8); return d; }
 
+#define MPC_VERSION_STRING "mpcgpu 0.2 (SIMT emulator build: tests only)"
+#define MPC_ALN_THREADS 128 // fewer OS threads per workgroup; calc_aln_kernel is written for any multiple of 64
+
 // ---- host runtime subset -----------------------------------------------------------------
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
@@ -211,3 +214,20 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 	*ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
 	return hipSuccess;
 }
+
+// stand-in for the product's rocprim::radix_sort_pairs ("device" memory is host memory here): stable order by key bits [0, end_bit)
+template <class EnsureTmp>
+static inline hipError_t mpc_sort_pairs(EnsureTmp, const unsigned long long *keys_in, unsigned long long *keys_out, const float *vals_in,
+	float *vals_out, size_t n, unsigned end_bit, hipStream_t)
+{
+	const unsigned long long mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
+	std::vector<size_t> idx(n);
+	for (size_t q = 0; q < n; ++q) idx[q] = q;
+	std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return (keys_in[x] & mask) < (keys_in[y] & mask); });
+	for (size_t q = 0; q < n; ++q) { keys_out[q] = keys_in[idx[q]]; vals_out[q] = vals_in[idx[q]]; }
+	return hipSuccess;
+}
+static inline void *mpc_dl_open(const char *) { return nullptr; } // no RCCL on the emulator: groups exchange by "peer" copies
+static inline void *mpc_dl_sym(void *, const char *) { return nullptr; }
+static inline const char *mpc_dl_error() { return "emulator build"; }
+static inline void mpc_enable_peer(int, int) {}
