@@ -93,3 +93,109 @@ __global__ void __launch_bounds__(MPC_ALN_THREADS) calc_aln_kernel(AlnParams p)
 	const u32 n = *s_n;
 	for (u32 k = tid; k < n; k += MPC_ALN_THREADS) p.path[k] = p.rev[n - 1 - k];
 }
+
+// ---- one wavefront per alignment (the common size: both alignments <= 512 columns, <= 600 rows) -----------------------
+// The progressive joins and the 100 refinement rounds of a typical run align matrices of ~450 x 450: with one column per
+// thread of a 1024-thread workgroup a row costs two workgroup barriers and a cross-wave scan through LDS, and the walk back
+// chases ~900 dependent bytes through HBM (round 1: 0.72 ms per call, 0.79 s of a 7.3 s run). Here ONE wave keeps the
+// previous DP row in registers, C = 8 consecutive columns per lane: the left neighbour of a lane's first column is a DPP
+// shift, the prefix maximum of the row is the same wave scan (exact: max is associative), and there is no barrier at all.
+// The traceback letters are 4-bit codes in LDS (two columns per byte, a lane's 8 columns = 4 whole bytes), so the one-lane
+// walk back reads LDS, not HBM. Same cells, same comparisons, same tie order as calc_aln_kernel above.
+#define MPC_ALNW_C 8                       // columns per lane
+#define MPC_ALNW_MAXW (64 * MPC_ALNW_C)    // W = LY + 1 <= 512
+#define MPC_ALNW_ROWBYTES (MPC_ALNW_MAXW / 2)
+
+__global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
+{
+	MPC_DYN_SMEM(smem_raw); // (LX+1) rows of MPC_ALNW_ROWBYTES traceback nibbles
+	const u32 LX = p.LX, LY = p.LY, W = LY + 1;
+	const u32 lane = threadIdx.x & 63u;
+	const u32 j0 = lane * MPC_ALNW_C; // my columns [j0, j0 + C)
+	float oldr[MPC_ALNW_C];
+	u32 code0 = 0; // row 0: 'Y' everywhere (calcalnflat.cpp:15-19); codes: 0 = 'B', 1 = 'X', 2 = 'Y'
+#pragma unroll
+	for (int c = 0; c < MPC_ALNW_C; ++c) { oldr[c] = 0.0f; code0 |= 2u << (4 * c); }
+	((u32 *)smem_raw)[lane] = code0;
+	// Post(i-1, j-1) of my columns, one row ahead: the row loop is a dependent chain and must not wait for HBM every row
+	float pvn[MPC_ALNW_C];
+	auto load_row = [&](u32 i) {
+		const float *prow = p.post + (u64)(i - 1) * LY;
+#pragma unroll
+		for (int c = 0; c < MPC_ALNW_C; ++c) {
+			const u32 j = j0 + c;
+			pvn[c] = (i <= LX && j >= 1 && j <= LY) ? prow[j - 1] : 0.0f;
+		}
+	};
+	load_row(1);
+	for (u32 i = 1; i <= LX; ++i) {
+		float pvc[MPC_ALNW_C];
+#pragma unroll
+		for (int c = 0; c < MPC_ALNW_C; ++c) pvc[c] = pvn[c];
+		load_row(i + 1);
+		// S(i-1, j0-1): the previous lane's last column of the previous row
+		float left_old = mpc_lane_up1(oldr[MPC_ALNW_C - 1]);
+		if (lane == 0) left_old = 0.0f; // unused (column 0 has no B)
+		float T[MPC_ALNW_C];
+		bool bx[MPC_ALNW_C];
+		float run = 0.0f; // T_j >= 0 always (X >= 0), and S(i,0) = 0
+#pragma unroll
+		for (int c = 0; c < MPC_ALNW_C; ++c) {
+			const u32 j = j0 + c;
+			const float diag = c == 0 ? left_old : oldr[c - 1];
+			const float B = diag + pvc[c];
+			const float X = oldr[c];
+			bx[c] = B >= X; // best3.h:9
+			T[c] = bx[c] ? B : X;
+			if (j >= 1 && j <= LY) run = T[c] >= run ? T[c] : run;
+		}
+		// exclusive prefix maximum over the lanes = S(i, j0-1)
+		const float incl = mpc_wave_scan_max_nonneg(run);
+		float Y = mpc_lane_up1(incl);
+		if (lane == 0) Y = 0.0f;
+		u32 codes = 0;
+#pragma unroll
+		for (int c = 0; c < MPC_ALNW_C; ++c) {
+			const u32 j = j0 + c;
+			float S;
+			u32 code;
+			if (j == 0) { S = 0.0f; code = 1u; } // calcalnflat.cpp:23-25: column 0 = 'X'
+			else {
+				const bool ty = T[c] >= Y; // best3.h:11 / :21
+				S = ty ? T[c] : Y;
+				code = ty ? (bx[c] ? 0u : 1u) : 2u;
+			}
+			if (j > LY) { S = 0.0f; code = 2u; } // beyond the matrix: never read
+			oldr[c] = S;
+			codes |= code << (4 * c);
+			Y = S;
+		}
+		*(u32 *)(smem_raw + (u64)i * MPC_ALNW_ROWBYTES + 4 * lane) = codes;
+	}
+	// score = S(LX, LY): lane LY / C, register LY % C
+	float sc = 0.0f;
+#pragma unroll
+	for (int c = 0; c < MPC_ALNW_C; ++c) if ((u32)c == (LY % MPC_ALNW_C)) sc = oldr[c];
+	sc = mpc_read_lane(sc, LY / MPC_ALNW_C);
+	__syncthreads(); // one wave: orders the LDS writes above before the walk below
+	// TraceBackFlat (tracebackflat.cpp:3-37) out of LDS
+	u32 *s_n = (u32 *)(smem_raw + (u64)(LX + 1) * MPC_ALNW_ROWBYTES);
+	if (lane == 0) {
+		*p.score = sc;
+		int i = (int)LX, j = (int)LY;
+		u32 n = 0;
+		while (i != 0 || j != 0) {
+			const u32 byte = smem_raw[(u64)i * MPC_ALNW_ROWBYTES + (j >> 1)];
+			const u32 code = (byte >> (4 * (j & 1))) & 0xfu;
+			const char ch = code == 0u ? 'B' : (code == 1u ? 'X' : 'Y');
+			p.rev[n++] = ch;
+			if (code == 0u) { --i; --j; } else if (code == 1u) --i; else --j;
+		}
+		*s_n = n;
+		*p.pathlen = n;
+	}
+	__syncthreads();
+	const u32 n = *s_n;
+	for (u32 k = lane; k < n; k += 64) p.path[k] = p.rev[n - 1 - k];
+	(void)W;
+}

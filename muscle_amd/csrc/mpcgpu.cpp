@@ -1347,7 +1347,11 @@ int mpcgpu_get_sparse(mpcgpu_ctx *c, uint64_t k, uint32_t *offsets, void *values
 static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_t LY, char *path, uint32_t *pathlen, float *score)
 {
 	const u64 W = (u64)LY + 1;
-	const size_t smem = (size_t)(2 * W + MPC_ALN_THREADS / 64 + 4) * 4;
+	// one wavefront with the previous row in registers and the traceback codes in LDS when the matrix is small enough
+	// (the progressive joins and refinement rounds of L~400 families are), else the workgroup kernel
+	const size_t smem_wave = (size_t)(LX + 1) * MPC_ALNW_ROWBYTES + 16;
+	const bool wave = W <= MPC_ALNW_MAXW && smem_wave <= 160u * 1024u && env_int("MPCGPU_ALN_WAVE", 1) != 0;
+	const size_t smem = wave ? smem_wave : (size_t)(2 * W + MPC_ALN_THREADS / 64 + 4) * 4;
 	if (smem > 160u * 1024u)
 		return fail(c, "mpcgpu_calc_aln: %u columns exceed the LDS-resident DP rows of this build", LY);
 	HIPCHK(c, c->d_aln_tb.ensure(((u64)LX + 1) * W));
@@ -1358,10 +1362,11 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	ap.post = d_post; ap.LX = LX; ap.LY = LY;
 	ap.tb = c->d_aln_tb.as<char>(); ap.rev = c->d_aln_rev.as<char>(); ap.path = c->d_aln_path.as<char>();
 	ap.pathlen = c->d_aln_out.as<u32>(); ap.score = c->d_aln_out.as<float>() + 1;
-	(void)hipFuncSetAttribute((const void *)calc_aln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	(void)hipFuncSetAttribute(wave ? (const void *)calc_aln_wave_kernel : (const void *)calc_aln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
 	TimedSpan ts_aln;
 	if (span_begin(c, 8, &ts_aln)) return 1;
-	MPC_LAUNCH(calc_aln_kernel, 1, MPC_ALN_THREADS, smem, c->stream, ap);
+	if (wave) MPC_LAUNCH(calc_aln_wave_kernel, 1, 64, smem, c->stream, ap);
+	else MPC_LAUNCH(calc_aln_kernel, 1, MPC_ALN_THREADS, smem, c->stream, ap);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts_aln)) return 1;
 	u32 out[2] = {0, 0};

@@ -87,9 +87,11 @@ def test_emu_relax_two_slots_per_pair(emu):
     P.assert_same((stages, ea), P.run_oracle(seqs), "nent=2")
 
 
-def test_emu_calc_aln(emu):
+@pytest.mark.parametrize("kernel", ["wave", "workgroup"])
+def test_emu_calc_aln(emu, kernel, monkeypatch):
     """CalcAlnFlat + TraceBackFlat on the device (kernels_aln.h) vs the oracle: same path string,
     same score bits, including tie cases (equal B/X/Y candidates) and general non-posterior input."""
+    monkeypatch.setenv("MPCGPU_ALN_WAVE", "1" if kernel == "wave" else "0")  # calc_aln_wave_kernel (small matrices) / calc_aln_kernel
     import _oracle as O
     from muscle_amd._lib import MpcGpu
     rng = np.random.default_rng(5)

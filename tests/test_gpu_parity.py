@@ -264,10 +264,12 @@ def test_relax_gather_equals_tiled():
         P.assert_same(a, r, "relax geometry %s, %s staging buffers" % (geo, nbuf))
 
 
-def test_calc_aln_paths():
+@pytest.mark.parametrize("kernel", ["wave", "workgroup"])
+def test_calc_aln_paths(kernel, monkeypatch):
     """CalcAlnFlat + TraceBackFlat on the device: integer traceback bit-for-bit (path string) and
     score bits, vs the golden paths of the compiled reference (pairs_small) and vs the oracle on
     dense MSA-sized matrices with many exact ties."""
+    monkeypatch.setenv("MPCGPU_ALN_WAVE", "1" if kernel == "wave" else "0")  # calc_aln_wave_kernel (small matrices) / calc_aln_kernel
     import _oracle as O
     g = MpcGpu(0)
     z = G.load("pairs_small")
