@@ -371,3 +371,27 @@ def test_emu_group_of_contexts(nctx):
         P.assert_same((st[r], ea[r]), want, "group of %d, rank %d" % (nctx, r))
     del views
     grp.close()
+
+
+@pytest.mark.parametrize("n,nctx", [(3, 4), (2, 2), (4, 3)])
+def test_emu_group_more_contexts_than_work(n, nctx):
+    """mpcgpu_group_* when shards are empty or tiny (more contexts than pairs; two sequences: no consistency stage)"""
+    from muscle_amd._lib import MpcGroup
+    seqs = make_family(n, 40, seed=3)
+    want = P.run_oracle(seqs)
+    grp = MpcGroup([0] * nctx, EMU_LIB)
+    grp.set_hmm(*G.hmm_tables())
+    grp.set_seqs(seqs)
+    grp.calc_posteriors()
+    views = [grp.ctx(r) for r in range(nctx)]
+    st = [[v.get_sparse_range()] for v in views]
+    ea = [v.get_ea().copy() for v in views]
+    if n >= 3:  # mpcflat.cpp:176
+        for _ in range(2):
+            grp.cons_iter()
+            for r, v in enumerate(views):
+                st[r].append(v.get_sparse_range())
+    for r in range(nctx):
+        P.assert_same((st[r], ea[r]), want, "n=%d, %d contexts, rank %d" % (n, nctx, r))
+    del views
+    grp.close()
