@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -75,6 +76,7 @@ struct mpcgpu_group {
 namespace {
 
 std::string g_group_create_err;
+std::mutex g_err_mu; // the per-rank host threads of a sharded step may fail at the same time
 
 int gfail(mpcgpu_group *g, const char *fmt, ...)
 {
@@ -83,6 +85,7 @@ int gfail(mpcgpu_group *g, const char *fmt, ...)
 	va_start(ap, fmt);
 	vsnprintf(buf, sizeof(buf), fmt, ap);
 	va_end(ap);
+	std::lock_guard<std::mutex> guard(g_err_mu);
 	if (g) g->err = buf; else g_group_create_err = buf;
 	return 1;
 }
