@@ -9,11 +9,12 @@
 // Float addition is not associative and the alignment DP breaks ties on exact values, so every
 // output cell must receive its contributions in the reference's order: s ascending (position in
 // MSA1), then t ascending (position in MSA2); one pair contributes at most once to a cell. The
-// device form: (1) every stored entry of every (s,t) pair becomes a (key, P) record with
-// key = cell << (ba+bb) | rank(s) << bb | rank(t); (2) one radix sort of the records (rocprim::radix_sort_pairs —
-// bulk data movement, not arithmetic); (3) one WAVE per output cell finds its run by binary search and
-// adds it up front to back through its lanes (build_post_reduce_kernel), starting from 0.0f like the
-// reference's zeroed matrix. The probabilities are the current ones of the packed records (after the last commit).
+// device form: (1) every stored entry of every (s,t) pair becomes a (cell, P) record, written pair after pair in the
+// reference's loop order (s-major), so the records of any one cell already stand in the order they must be added in; (2) one
+// STABLE radix sort of the records by cell alone (rocprim::radix_sort_pairs on 32-bit keys, bits [0, bits(cells)) — bulk
+// data movement, not arithmetic; stability is what carries the (s,t) order into each run); (3) the runs of equal cells are
+// listed (build_post_heads_kernel) and one WAVE per run adds it up front to back through its lanes
+// (build_post_reduce_kernel), starting from 0.0f like the reference's zeroed matrix. The probabilities are the current ones of the packed records (after the last commit).
 #pragma once
 #include "kernels_store.h"
 
@@ -25,9 +26,8 @@ struct BuildPostParams {
 	const u64 *p2c1_off, *p2c2_off; // start of each row's map
 	u32 C2;
 	const u64 *coff; // n1*n2+1: first record of pair (a,b)
-	u64 *keys;
+	u32 *keys; // cell of every record
 	float *vals;
-	u32 bits_a, bits_b; // key = cell << (bits_a+bits_b) | a << bits_b | b
 	const float *w1, *w2; // sequence weights of the rows of MSA1 / MSA2 (buildpostflat.cpp:41,52), nullptr = 1.0f
 };
 
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 		const u32 *ent = rec + LX + LY;
 		const u32 *rowv = ent + 2 * (u64)nnz;
 		const u32 *m1 = p.p2c1 + p.p2c1_off[a], *m2 = p.p2c2 + p.p2c2_off[b];
-		u64 *keys = p.keys + p.coff[ab];
+		u32 *keys = p.keys + p.coff[ab];
 		float *vals = p.vals + p.coff[ab];
 		const bool weighted = p.w1 != nullptr;
 		const float w12 = weighted ? p.w1[a] * p.w2[b] : 1.0f; // w1*w2 rounded first: buildpostflat.cpp:74 / :96
@@ -55,8 +55,7 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 			// stored (S,T): rows are positions of S (MSA1); stored (T,S): rows are positions of T (MSA2)
 			const u32 c1 = fwd ? m1[row] : m1[col];
 			const u32 c2 = fwd ? m2[col] : m2[row];
-			const u64 cell = (u64)c1 * p.C2 + c2;
-			keys[q] = (cell << (p.bits_a + p.bits_b)) | ((u64)a << p.bits_b) | (u64)b;
+			keys[q] = c1 * p.C2 + c2;
 			const float P = __uint_as_float(ent[2 * (u64)q]);
 			vals[q] = weighted ? w12 * P : P;
 		}
@@ -72,30 +71,73 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 // once (coalesced) and runs the chain through its lanes (mpc_wave_chain_add, mpc_platform.h: one wave instruction per term,
 // every term added exactly once in sequence; lanes past the end of the run add +0.0f, exact for these non-negative sums). The run of a cell is found with two binary
 // searches made of scalar loads (the sorted keys are not written by this kernel).
-__global__ void __launch_bounds__(256) build_post_reduce_kernel(const u64 *keys, const float *vals, u64 count, u32 shift,
-	float *post, u64 cells)
+// Run boundaries of the sorted records: record q opens a run when its cell differs from record q-1's. The opener appends
+// {cell, q} to the list of runs (one atomic per wave: the lanes that open a run are counted by a ballot) and closes the
+// previous run (run_end[previous cell] = q); the last record closes its own. Cells without records never appear: the matrix
+// is zeroed beforehand (buildpostflat.cpp:27-30) and only the ~10^4..10^5 cells near the alignment path of the ~10^6 of a
+// 1000-column join get a wave in the reduction below.
+__global__ void __launch_bounds__(256) build_post_heads_kernel(const u32 *keys, u64 count, u32 *run_end, u32 *heads, u32 *nheads)
 {
 	const u32 lane = threadIdx.x & 63u;
-	const u64 wave = (u64)blockIdx.x * (blockDim.x >> 6) + mpc_wave_first(threadIdx.x >> 6);
-	const u64 nwaves = (u64)gridDim.x * (blockDim.x >> 6);
-	mpc_const_u32p k32 = MPC_CONST_U32(keys); // key q = k32[2q] | k32[2q+1] << 32, read with scalar loads
-	for (u64 cell = wave; cell < cells; cell += nwaves) {
-		auto lower = [&](u64 want) { // first record whose cell is >= want
-			u64 lo = 0, hi = count;
-			while (lo < hi) {
-				const u64 mid = (lo + hi) >> 1;
-				const u64 key = (u64)k32[2 * mid] | ((u64)k32[2 * mid + 1] << 32);
-				if ((key >> shift) < want) lo = mid + 1; else hi = mid;
+	const u64 stride = (u64)gridDim.x * blockDim.x;
+	for (u64 q0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); q0 < count; q0 += stride) { // whole waves enter together
+		const u64 q = q0 + lane;
+		bool head = false;
+		u32 cell = 0;
+		if (q < count) {
+			cell = keys[q];
+			const u32 prev = q ? keys[q - 1] : 0u;
+			head = q == 0 || cell != prev;
+			if (head && q) run_end[prev] = (u32)q;
+			if (q + 1 == count) run_end[cell] = (u32)count;
+		}
+		const u64 bal = __ballot(head);
+		if (bal) {
+			u32 base = 0;
+			if (lane == 0) base = atomicAdd(nheads, (u32)__popcll(bal));
+			base = mpc_wave_first(base);
+			if (head) {
+				const u32 at = base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+				heads[2 * (u64)at] = cell;
+				heads[2 * (u64)at + 1] = (u32)q;
 			}
-			return lo;
-		};
-		const u64 lo = lower(cell), hi = lower(cell + 1);
+		}
+	}
+}
+
+#define MPC_BP_GROUP 8
+__global__ void __launch_bounds__(256) build_post_reduce_kernel(const float *vals, const u32 *run_end, const u32 *heads, const u32 *nheads,
+	float *post)
+{
+	const u32 lane = threadIdx.x & 63u;
+	const u32 wave = blockIdx.x * (blockDim.x >> 6) + mpc_wave_first(threadIdx.x >> 6);
+	const u32 nwaves = gridDim.x * (blockDim.x >> 6);
+	const u32 nh = mpc_wave_first(*nheads);
+	for (u32 h = wave; h < nh; h += nwaves) {
+		const u32 cell = mpc_wave_first(heads[2 * (u64)h]);
+		const u64 lo = mpc_wave_first(heads[2 * (u64)h + 1]), hi = mpc_wave_first(run_end[cell]);
+		// The chain is serial — ~6 cycles per term, 250 000 terms on the heaviest cells — and the heaviest run is the critical
+		// path of the launch, so its loads must never be waited for: groups of MPC_BP_GROUP chunks of 64 terms, the next
+		// group in flight while this one is added (chunks past the end are neither loaded nor added).
 		float total = 0.0f; // wave-uniform
-		float v = (lo + lane < hi) ? vals[lo + lane] : 0.0f;
-		for (u64 q0 = lo; q0 < hi; q0 += 64) {
-			const float vn = (q0 + 64 + lane < hi) ? vals[q0 + 64 + lane] : 0.0f; // the next chunk is in flight while this one is added
-			total = mpc_wave_chain_add(total, v);
-			v = vn;
+		float cur[MPC_BP_GROUP], nxt[MPC_BP_GROUP];
+#pragma unroll
+		for (int g = 0; g < MPC_BP_GROUP; ++g) {
+			cur[g] = 0.0f;
+			if (lo + 64u * g < hi) cur[g] = (lo + 64u * g + lane < hi) ? vals[lo + 64u * g + lane] : 0.0f;
+		}
+		for (u64 q0 = lo; q0 < hi; q0 += 64u * MPC_BP_GROUP) {
+			const u64 q1 = q0 + 64u * MPC_BP_GROUP;
+#pragma unroll
+			for (int g = 0; g < MPC_BP_GROUP; ++g) {
+				nxt[g] = 0.0f;
+				if (q1 + 64u * g < hi) nxt[g] = (q1 + 64u * g + lane < hi) ? vals[q1 + 64u * g + lane] : 0.0f;
+			}
+#pragma unroll
+			for (int g = 0; g < MPC_BP_GROUP; ++g)
+				if (q0 + 64u * g < hi) total = mpc_wave_chain_add(total, cur[g]);
+#pragma unroll
+			for (int g = 0; g < MPC_BP_GROUP; ++g) cur[g] = nxt[g];
 		}
 		if (lane == 0) post[cell] = total;
 	}
@@ -103,7 +145,8 @@ __global__ void __launch_bounds__(256) build_post_reduce_kernel(const u64 *keys,
 
 // ---- list form: CalcPosteriorFlat3 (buildposterior3flat.cpp:19-85) over an explicit pair list whose
 // packed records (kernels_post.h) lie back to back in one shard, X = the MSA1 sequence of the pair.
-// Contributions are added in pair-list order (buildposterior3flat.cpp:41, :81): key = cell << bits_q | q.
+// Contributions are added in pair-list order (buildposterior3flat.cpp:41, :81): the records are written in that order and the
+// sort by cell is stable.
 struct BuildPostListParams {
 	const u32 *seq_len;
 	const u32 *packed;
@@ -115,9 +158,8 @@ struct BuildPostListParams {
 	const u64 *rbase;       // word offset of each pair's packed record
 	const u32 *nnz;
 	u32 C2;
-	u64 *keys;
+	u32 *keys; // cell of every record
 	float *vals;
-	u32 bits_q;
 };
 
 __global__ void __launch_bounds__(64) build_post_list_gen_kernel(BuildPostListParams p)
@@ -128,11 +170,10 @@ __global__ void __launch_bounds__(64) build_post_list_gen_kernel(BuildPostListPa
 		const u32 *ent = p.packed + p.rbase[q] + LX + LY;
 		const u32 *rowv = ent + 2 * (u64)nnz;
 		const u32 *m1 = p.p2c1 + p.off1[q], *m2 = p.p2c2 + p.off2[q];
-		u64 *keys = p.keys + p.coff[q];
+		u32 *keys = p.keys + p.coff[q];
 		float *vals = p.vals + p.coff[q];
 		for (u32 e = threadIdx.x; e < nnz; e += 64) {
-			const u64 cell = (u64)m1[rowv[e]] * p.C2 + m2[ent[2 * (u64)e + 1]];
-			keys[e] = (cell << p.bits_q) | (u64)q;
+			keys[e] = m1[rowv[e]] * p.C2 + m2[ent[2 * (u64)e + 1]];
 			vals[e] = __uint_as_float(ent[2 * (u64)e]);
 		}
 	}

@@ -11,10 +11,10 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #define MPC_VERSION_STRING "mpcgpu 0.2 (HIP gfx950)"
 #define MPC_ALN_THREADS 1024 // workgroup of calc_aln_kernel (kernels_aln.h)
-// Stable grouping of n (key, value) records by key bits [0, end_bit): rocprim::radix_sort_pairs, called directly (bulk data
-// movement, kernels_prog.h). ensure_tmp(bytes) must return device scratch of at least that size (or nullptr on failure).
+// STABLE sort of n (key, value) records by key bits [0, end_bit) — records with equal keys keep their input order, which
+// kernels_prog.h relies on: rocprim::radix_sort_pairs, called directly (bulk data movement). ensure_tmp(bytes) must return device scratch of at least that size (or nullptr on failure).
 template <class EnsureTmp>
-inline hipError_t mpc_sort_pairs(EnsureTmp ensure_tmp, const unsigned long long *keys_in, unsigned long long *keys_out, const float *vals_in,
+inline hipError_t mpc_sort_pairs(EnsureTmp ensure_tmp, const unsigned *keys_in, unsigned *keys_out, const float *vals_in,
 	float *vals_out, size_t n, unsigned end_bit, hipStream_t stream)
 {
 	size_t tmp_bytes = 0;

@@ -15,6 +15,7 @@
 #include "kernels_prog.h"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -106,7 +107,7 @@ struct mpcgpu_ctx {
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
-	DevBuf d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_w;
+	DevBuf d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_runs, d_bp_w;
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // variable-size dense records + relax_var_kernel (else: slabs + gather relax)
 	u32 pad_lcap1 = 0;           // longest sequence (LDS scratch of var_build_kernel)
@@ -584,7 +585,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
 		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_pos, &c->d_bp_seq, &c->d_bp_map, &c->d_bp_off, &c->d_bp_coff,
-		&c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
+		&c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
 		&c->d_aln_out};
 	for (DevBuf *b : all) b->release();
 	(void)hipStreamDestroy(c->stream);
@@ -1399,6 +1400,27 @@ int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t
 	return mpcgpu_align_alns_w(c, n1, seq1, n2, seq2, C1, C2, pos2col1, pos2col2, nullptr, nullptr, path, pathlen, score);
 }
 
+// post[cell] = the cell's records added in key order, 0 where there are none (kernels_prog.h): zero the matrix, list the runs
+// of the sorted records, one wave per run. d_aln_post holds `cells` floats already.
+static int reduce_runs(mpcgpu_ctx *c, const u32 *keys_sorted, const float *vals_sorted, u64 M, u64 cells)
+{
+	if (cells > 0xffffffffull) return fail(c, "mpcgpu_align_alns: %llu cells exceed this build's cell index", (u64)cells);
+	HIPCHK(c, hipMemsetAsync(c->d_aln_post.p, 0, cells * 4, c->stream));
+	if (!M) return 0;
+	const u64 maxruns = std::min<u64>(M, cells);
+	HIPCHK(c, c->d_bp_runs.ensure((cells + 2 * maxruns + 1) * 4));
+	u32 *run_end = c->d_bp_runs.as<u32>(), *heads = run_end + cells, *nheads = heads + 2 * maxruns;
+	HIPCHK(c, hipMemsetAsync(nheads, 0, 4, c->stream));
+	const u32 grid_cap = (u32)c->prop.multiProcessorCount * 8;
+	MPC_LAUNCH(build_post_heads_kernel, (u32)std::min<u64>((M + 255) / 256, grid_cap), 256, 0, c->stream, keys_sorted, (u64)M, run_end, heads,
+		nheads);
+	HIPCHK(c, hipGetLastError());
+	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((maxruns + 3) / 4, grid_cap), 256, 0, c->stream, vals_sorted, (const u32 *)run_end,
+		(const u32 *)heads, (const u32 *)nheads, c->d_aln_post.as<float>());
+	HIPCHK(c, hipGetLastError());
+	return 0;
+}
+
 int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
 	uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, const float *w1, const float *w2, char *path,
 	uint32_t *pathlen, float *score)
@@ -1409,6 +1431,12 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 	if (n1 == 0 || n2 == 0 || C1 == 0 || C2 == 0) return fail(c, "mpcgpu_align_alns: empty alignment");
 	HIPCHK(c, hipSetDevice(c->device));
 	const u32 n = c->n;
+	static const bool host_trace = env_int("MPCGPU_TRACE_HOST", 0) != 0; // diagnostics: host wall time of this call's phases, summed
+	static double acc_t[5] = {0, 0, 0, 0, 0};
+	static u64 acc_n = 0;
+	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double t_prev = host_trace ? now() : 0.0;
+	auto lap = [&](int k) { if (host_trace) { const double t = now(); acc_t[k] += t - t_prev; t_prev = t; } };
 	// ---- host: maps, pair record offsets
 	std::vector<u32> seqs(seq1, seq1 + n1);
 	seqs.insert(seqs.end(), seq2, seq2 + n2);
@@ -1433,22 +1461,24 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 		}
 	const u64 M = coff[(u64)n1 * n2];
 	const u64 cells = (u64)C1 * C2;
-	const u32 ba = bits_for(n1 - 1), bb = bits_for(n2 - 1), bc = bits_for(cells - 1);
-	if (ba + bb + bc > 64) return fail(c, "mpcgpu_align_alns: key does not fit 64 bits (%u x %u rows, %llu cells)", n1, n2, (u64)cells);
+	if (cells > 0xffffffffull) return fail(c, "mpcgpu_align_alns: %llu cells exceed this build's cell index", (u64)cells);
+	const u32 bc = bits_for(cells - 1);
 	if (M > 0xffffffffull) return fail(c, "mpcgpu_align_alns: %llu contributions exceed this build's record count", (u64)M);
+	lap(0);
 	if (upload(c, c->d_bp_seq, seqs) || upload(c, c->d_bp_off, off) || upload(c, c->d_bp_map, maps) || upload(c, c->d_bp_coff, coff))
 		return 1;
-	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 8 * 2));
+	lap(1);
+	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 4 * 2));
 	HIPCHK(c, c->d_bp_vals.ensure(std::max<u64>(M, 1) * 4 * 2));
 	HIPCHK(c, c->d_aln_post.ensure(cells * 4));
-	u64 *keys_in = c->d_bp_keys.as<u64>(), *keys_out = keys_in + std::max<u64>(M, 1);
+	u32 *keys_in = c->d_bp_keys.as<u32>(), *keys_out = keys_in + std::max<u64>(M, 1);
 	float *vals_in = c->d_bp_vals.as<float>(), *vals_out = vals_in + std::max<u64>(M, 1);
 	BuildPostParams bp;
 	fill_store_params(c, bp.s);
 	bp.seq1 = c->d_bp_seq.as<u32>(); bp.seq2 = bp.seq1 + n1; bp.n1 = n1; bp.n2 = n2;
 	bp.p2c1 = c->d_bp_map.as<u32>(); bp.p2c2 = bp.p2c1; // offsets below are into the one concatenated array
 	bp.p2c1_off = c->d_bp_off.as<u64>(); bp.p2c2_off = bp.p2c1_off + n1;
-	bp.C2 = C2; bp.coff = c->d_bp_coff.as<u64>(); bp.keys = keys_in; bp.vals = vals_in; bp.bits_a = ba; bp.bits_b = bb;
+	bp.C2 = C2; bp.coff = c->d_bp_coff.as<u64>(); bp.keys = keys_in; bp.vals = vals_in;
 	bp.w1 = bp.w2 = nullptr;
 	if ((w1 != nullptr) != (w2 != nullptr)) return fail(c, "mpcgpu_align_alns_w: give both weight arrays or neither");
 	if (w1) {
@@ -1469,23 +1499,27 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 	MPC_LAUNCH(build_post_gen_kernel, (u32)std::min<u64>(npairs12, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, bp);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts_bp)) return 1;
-	const u64 *keys_sorted = keys_in;
+	const u32 *keys_sorted = keys_in;
 	const float *vals_sorted = vals_in;
 	if (span_begin(c, 6, &ts_bp)) return 1;
 	if (M > 1) {
 		HIPCHK(c, mpc_sort_pairs([&](size_t bytes) -> void * { return c->d_bp_tmp.ensure(bytes) == hipSuccess ? c->d_bp_tmp.p : nullptr; },
-			keys_in, keys_out, vals_in, vals_out, (size_t)M, ba + bb + bc, c->stream));
+			keys_in, keys_out, vals_in, vals_out, (size_t)M, bc, c->stream));
 		keys_sorted = keys_out;
 		vals_sorted = vals_out;
 	}
 	if (span_end(c, &ts_bp)) return 1;
 	if (span_begin(c, 7, &ts_bp)) return 1;
-	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((cells + 3) / 4, (u64)c->prop.multiProcessorCount * 8), 256, 0, // one wave per cell
-		c->stream, keys_sorted, vals_sorted, (u64)M, (u32)(ba + bb), c->d_aln_post.as<float>(), (u64)cells);
-	HIPCHK(c, hipGetLastError());
+	if (reduce_runs(c, keys_sorted, vals_sorted, M, cells)) return 1;
 	if (span_end(c, &ts_bp)) return 1;
+	lap(2);
 	// the uploads above came from vectors that die with this call: drain before returning (run_calc_aln syncs)
-	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score);
+	const int rc_aln = run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score);
+	lap(3);
+	if (host_trace && (++acc_n % 100) == 0)
+		fprintf(stderr, "[mpcgpu] align_alns host seconds after %llu calls: vectors %.3f, uploads %.3f, launches %.3f, calc_aln+syncs %.3f\n",
+			(unsigned long long)acc_n, acc_t[0], acc_t[1], acc_t[2], acc_t[3]);
+	return rc_aln;
 }
 
 int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, const uint32_t *seq2, uint32_t C1, uint32_t C2,
@@ -1513,8 +1547,8 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	for (u64 x = 0; x < off2[npairs]; ++x) if (pos2col2[x] >= C2) return fail(c, "mpcgpu_align_msas: column map of MSA2 out of range");
 	const u64 M = coff[npairs];
 	const u64 cells = (u64)C1 * C2;
-	const u32 bq = bits_for(npairs - 1), bc = bits_for(cells - 1);
-	if (bq + bc > 64) return fail(c, "mpcgpu_align_msas: key does not fit 64 bits");
+	if (cells > 0xffffffffull) return fail(c, "mpcgpu_align_msas: %llu cells exceed this build's cell index", (u64)cells);
+	const u32 bc = bits_for(cells - 1);
 	if (M > 0xffffffffull) return fail(c, "mpcgpu_align_msas: %llu contributions exceed this build's record count", (u64)M);
 	std::vector<u32> maps(off1[npairs] + off2[npairs]);
 	memcpy(maps.data(), pos2col1, off1[npairs] * 4);
@@ -1527,10 +1561,10 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	bases.insert(bases.end(), rbase.begin(), rbase.end());
 	if (upload(c, c->d_bp_seq, seqs) || upload(c, c->d_bp_off, offs) || upload(c, c->d_bp_map, maps) || upload(c, c->d_bp_coff, bases))
 		return 1;
-	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 8 * 2));
+	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 4 * 2));
 	HIPCHK(c, c->d_bp_vals.ensure(std::max<u64>(M, 1) * 4 * 2));
 	HIPCHK(c, c->d_aln_post.ensure(cells * 4));
-	u64 *keys_in = c->d_bp_keys.as<u64>(), *keys_out = keys_in + std::max<u64>(M, 1);
+	u32 *keys_in = c->d_bp_keys.as<u32>(), *keys_out = keys_in + std::max<u64>(M, 1);
 	float *vals_in = c->d_bp_vals.as<float>(), *vals_out = vals_in + std::max<u64>(M, 1);
 	BuildPostListParams lp;
 	lp.seq_len = c->d_seq_len.as<u32>();
@@ -1540,20 +1574,18 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	lp.off1 = c->d_bp_off.as<u64>(); lp.off2 = lp.off1 + (npairs + 1);
 	lp.coff = c->d_bp_coff.as<u64>(); lp.rbase = lp.coff + (npairs + 1);
 	lp.nnz = nullptr; // counts come from coff
-	lp.C2 = C2; lp.keys = keys_in; lp.vals = vals_in; lp.bits_q = bq;
+	lp.C2 = C2; lp.keys = keys_in; lp.vals = vals_in;
 	MPC_LAUNCH(build_post_list_gen_kernel, (u32)std::min<u64>(npairs, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, lp);
 	HIPCHK(c, hipGetLastError());
-	const u64 *keys_sorted = keys_in;
+	const u32 *keys_sorted = keys_in;
 	const float *vals_sorted = vals_in;
 	if (M > 1) {
 		HIPCHK(c, mpc_sort_pairs([&](size_t bytes) -> void * { return c->d_bp_tmp.ensure(bytes) == hipSuccess ? c->d_bp_tmp.p : nullptr; },
-			keys_in, keys_out, vals_in, vals_out, (size_t)M, bq + bc, c->stream));
+			keys_in, keys_out, vals_in, vals_out, (size_t)M, bc, c->stream));
 		keys_sorted = keys_out;
 		vals_sorted = vals_out;
 	}
-	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((cells + 3) / 4, (u64)c->prop.multiProcessorCount * 8), 256, 0, // one wave per cell
-		c->stream, keys_sorted, vals_sorted, (u64)M, bq, c->d_aln_post.as<float>(), (u64)cells);
-	HIPCHK(c, hipGetLastError());
+	if (reduce_runs(c, keys_sorted, vals_sorted, M, cells)) return 1;
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // syncs before the vectors above die
 }
 

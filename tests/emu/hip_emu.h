@@ -217,10 +217,10 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 
 // stand-in for the product's rocprim::radix_sort_pairs ("device" memory is host memory here): stable order by key bits [0, end_bit)
 template <class EnsureTmp>
-static inline hipError_t mpc_sort_pairs(EnsureTmp, const unsigned long long *keys_in, unsigned long long *keys_out, const float *vals_in,
+static inline hipError_t mpc_sort_pairs(EnsureTmp, const unsigned *keys_in, unsigned *keys_out, const float *vals_in,
 	float *vals_out, size_t n, unsigned end_bit, hipStream_t)
 {
-	const unsigned long long mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
+	const unsigned mask = end_bit >= 32 ? ~0u : ((1u << end_bit) - 1u);
 	std::vector<size_t> idx(n);
 	for (size_t q = 0; q < n; ++q) idx[q] = q;
 	std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return (keys_in[x] & mask) < (keys_in[y] & mask); });
