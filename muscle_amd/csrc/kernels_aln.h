@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(MPC_ALN_THREADS) calc_aln_kernel(AlnParams p)
 #define MPC_ALNW_C 8                       // columns per lane
 #define MPC_ALNW_MAXW (64 * MPC_ALNW_C)    // W = LY + 1 <= 512
 #define MPC_ALNW_ROWBYTES (MPC_ALNW_MAXW / 2)
+#define MPC_ALNW_PF 4                      // rows of Post in flight
 
 __global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
 {
@@ -117,22 +118,28 @@ __global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
 #pragma unroll
 	for (int c = 0; c < MPC_ALNW_C; ++c) { oldr[c] = 0.0f; code0 |= 2u << (4 * c); }
 	((u32 *)smem_raw)[lane] = code0;
-	// Post(i-1, j-1) of my columns, one row ahead: the row loop is a dependent chain and must not wait for HBM every row
-	float pvn[MPC_ALNW_C];
-	auto load_row = [&](u32 i) {
+	// Post(i-1, j-1) of my columns, MPC_ALNW_PF rows ahead: the row loop is a dependent chain of ~0.2 us per row and a load from
+	// HBM/L2 takes ~1-2 us, so one row of lookahead leaves the chain waiting on memory every row (measured: 1.5 us per row).
+	float ring[MPC_ALNW_PF][MPC_ALNW_C];
+	auto load_row = [&](float *dst, u32 i) {
 		const float *prow = p.post + (u64)(i - 1) * LY;
 #pragma unroll
 		for (int c = 0; c < MPC_ALNW_C; ++c) {
 			const u32 j = j0 + c;
-			pvn[c] = (i <= LX && j >= 1 && j <= LY) ? prow[j - 1] : 0.0f;
+			dst[c] = (i <= LX && j >= 1 && j <= LY) ? prow[j - 1] : 0.0f;
 		}
 	};
-	load_row(1);
-	for (u32 i = 1; i <= LX; ++i) {
+#pragma unroll
+	for (int r = 0; r < MPC_ALNW_PF; ++r) load_row(ring[r], 1u + r);
+	for (u32 ib = 1; ib <= LX; ib += MPC_ALNW_PF) {
+#pragma unroll
+	for (int r = 0; r < MPC_ALNW_PF; ++r) {
+		const u32 i = ib + r;
+		if (i > LX) break; // wave-uniform
 		float pvc[MPC_ALNW_C];
 #pragma unroll
-		for (int c = 0; c < MPC_ALNW_C; ++c) pvc[c] = pvn[c];
-		load_row(i + 1);
+		for (int c = 0; c < MPC_ALNW_C; ++c) pvc[c] = ring[r][c];
+		load_row(ring[r], i + MPC_ALNW_PF);
 		// S(i-1, j0-1): the previous lane's last column of the previous row
 		float left_old = mpc_lane_up1(oldr[MPC_ALNW_C - 1]);
 		if (lane == 0) left_old = 0.0f; // unused (column 0 has no B)
@@ -172,6 +179,7 @@ __global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
 		}
 		*(u32 *)(smem_raw + (u64)i * MPC_ALNW_ROWBYTES + 4 * lane) = codes;
 	}
+	}
 	// score = S(LX, LY): lane LY / C, register LY % C
 	float sc = 0.0f;
 #pragma unroll
@@ -198,4 +206,132 @@ __global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
 	const u32 n = *s_n;
 	for (u32 k = lane; k < n; k += 64) p.path[k] = p.rev[n - 1 - k];
 	(void)W;
+}
+
+// ---- several wavefronts, previous row in registers (matrices wider than one wave holds: the joins near the root) ---------
+// Gap-rich families reach ~1000 x 1000 at the root and in every refinement round (793 of the 1099 joins of the 1000 x L~400
+// run, ~1 ms each with calc_aln_kernel: the rows ping-pong through LDS with two barriers a row and the walk back chases
+// ~2000 dependent bytes through L2). Here thread t keeps S(i-1, .) of its 4 columns [4t, 4t+4) in registers, NW = blockDim/64
+// waves cover the row. The only values that cross waves are the per-wave maxima of T (one float per wave and row, LDS slots
+// double-buffered by row parity: ONE barrier per row); S(i-1, 4t-1), the diagonal input of a thread's first column, is the
+// exclusive prefix maximum the thread itself used one row earlier (S(i,j) is the prefix maximum of T), so the previous row
+// never travels. Traceback letters are 2-bit codes, 4 columns = one byte per thread and row, written to HBM as the rows
+// complete; the walk back stages them through LDS in blocks of `block_rows` rows (bulk copies by the whole workgroup), so
+// every dependent step of the walk reads LDS. Same cells, same comparisons, same tie order as calc_aln_kernel.
+#define MPC_ALNQ_C 4
+#define MPC_ALNQ_PF 4          // rows of Post in flight
+#define MPC_ALNQ_HDR 256       // bytes of LDS before the staged block: wave maxima [2][16], walk state
+
+__global__ void __launch_bounds__(1024) calc_aln_quad_kernel(AlnParams p, u32 block_rows)
+{
+	MPC_DYN_SMEM(smem_raw);
+	const u32 LX = p.LX, LY = p.LY;
+	const u32 tid = threadIdx.x, lane = tid & 63u, wave = mpc_wave_first(tid >> 6);
+	const u32 rowbytes = blockDim.x; // one byte per thread and row
+	float *s_tot = (float *)smem_raw;                   // [2][16]
+	u32 *s_state = (u32 *)(smem_raw + 128);             // i, j, n, done
+	unsigned char *s_blk = smem_raw + MPC_ALNQ_HDR;     // block_rows * rowbytes
+	unsigned char *tb = (unsigned char *)p.tb;
+	const u32 j0 = tid * MPC_ALNQ_C;
+	float oldr[MPC_ALNQ_C];
+#pragma unroll
+	for (int c = 0; c < MPC_ALNQ_C; ++c) oldr[c] = 0.0f;
+	tb[tid] = 0xaau; // row 0: 'Y' everywhere (calcalnflat.cpp:15-19); codes: 0 = 'B', 1 = 'X', 2 = 'Y'
+	float left_old = 0.0f; // S(i-1, j0-1)
+	float ring[MPC_ALNQ_PF][MPC_ALNQ_C];
+	auto load_row = [&](float *dst, u32 i) {
+		const float *prow = p.post + (u64)(i - 1) * LY;
+#pragma unroll
+		for (int c = 0; c < MPC_ALNQ_C; ++c) {
+			const u32 j = j0 + c;
+			dst[c] = (i <= LX && j >= 1 && j <= LY) ? prow[j - 1] : 0.0f;
+		}
+	};
+#pragma unroll
+	for (int r = 0; r < MPC_ALNQ_PF; ++r) load_row(ring[r], 1u + r);
+	for (u32 ib = 1; ib <= LX; ib += MPC_ALNQ_PF) {
+#pragma unroll
+	for (int r = 0; r < MPC_ALNQ_PF; ++r) {
+		const u32 i = ib + r;
+		if (i > LX) break; // uniform
+		float pvc[MPC_ALNQ_C];
+#pragma unroll
+		for (int c = 0; c < MPC_ALNQ_C; ++c) pvc[c] = ring[r][c];
+		load_row(ring[r], i + MPC_ALNQ_PF);
+		float T[MPC_ALNQ_C];
+		bool bx[MPC_ALNQ_C];
+		float run = 0.0f; // T_j >= 0 always (X >= 0), and S(i,0) = 0
+#pragma unroll
+		for (int c = 0; c < MPC_ALNQ_C; ++c) {
+			const u32 j = j0 + c;
+			const float diag = c == 0 ? left_old : oldr[c - 1];
+			const float B = diag + pvc[c];
+			const float X = oldr[c];
+			bx[c] = B >= X; // best3.h:9
+			T[c] = bx[c] ? B : X;
+			if (j >= 1 && j <= LY) run = T[c] >= run ? T[c] : run;
+		}
+		const float incl = mpc_wave_scan_max_nonneg(run);
+		float *tot = s_tot + 16u * (i & 1u);
+		if (lane == 63) tot[wave] = incl;
+		__syncthreads();
+		float Y = mpc_lane_up1(incl);
+		if (lane == 0) Y = 0.0f;
+		for (u32 w = 0; w < wave; ++w) { const float o = tot[w]; Y = o >= Y ? o : Y; }
+		left_old = Y; // S(i, j0-1): next row's diagonal input
+		u32 codes = 0;
+#pragma unroll
+		for (int c = 0; c < MPC_ALNQ_C; ++c) {
+			const u32 j = j0 + c;
+			float S;
+			u32 code;
+			if (j == 0) { S = 0.0f; code = 1u; } // calcalnflat.cpp:23-25: column 0 = 'X'
+			else {
+				const bool ty = T[c] >= Y; // best3.h:11 / :21
+				S = ty ? T[c] : Y;
+				code = ty ? (bx[c] ? 0u : 1u) : 2u;
+			}
+			if (j > LY) { S = 0.0f; code = 2u; } // beyond the matrix: never read
+			oldr[c] = S;
+			codes |= code << (2 * c);
+			Y = S;
+		}
+		tb[(u64)i * rowbytes + tid] = (unsigned char)codes;
+	}
+	}
+	// score = S(LX, LY)
+	if (tid == LY / MPC_ALNQ_C) {
+		float sc = 0.0f;
+#pragma unroll
+		for (int c = 0; c < MPC_ALNQ_C; ++c) if ((u32)c == (LY % MPC_ALNQ_C)) sc = oldr[c];
+		*p.score = sc;
+	}
+	if (tid == 0) { s_state[0] = LX; s_state[1] = LY; s_state[2] = 0; s_state[3] = 0; }
+	__syncthreads(); // also orders the traceback bytes above before the copies below
+	// TraceBackFlat (tracebackflat.cpp:3-37), block after block of rows out of LDS
+	for (;;) {
+		const u32 hi = s_state[0];
+		const u32 lo = hi + 1 >= block_rows ? hi + 1 - block_rows : 0u;
+		const u32 nwords = (hi - lo + 1) * (rowbytes / 4);
+		const u32 *src = (const u32 *)(tb + (u64)lo * rowbytes);
+		for (u32 k = tid; k < nwords; k += blockDim.x) ((u32 *)s_blk)[k] = src[k];
+		__syncthreads();
+		if (tid == 0) {
+			int i = (int)hi, j = (int)s_state[1];
+			u32 n = s_state[2];
+			while ((i != 0 || j != 0) && i >= (int)lo) {
+				const u32 byte = s_blk[(u64)(i - (int)lo) * rowbytes + (j >> 2)];
+				const u32 code = (byte >> (2 * (j & 3))) & 3u;
+				p.rev[n++] = code == 0u ? 'B' : (code == 1u ? 'X' : 'Y');
+				if (code == 0u) { --i; --j; } else if (code == 1u) --i; else --j;
+			}
+			s_state[0] = (u32)(i < 0 ? 0 : i); s_state[1] = (u32)j; s_state[2] = n;
+			s_state[3] = (i == 0 && j == 0) ? 1u : 0u;
+		}
+		__syncthreads();
+		if (s_state[3]) break;
+	}
+	const u32 n = s_state[2];
+	if (tid == 0) *p.pathlen = n;
+	for (u32 k = tid; k < n; k += blockDim.x) p.path[k] = p.rev[n - 1 - k];
 }

@@ -175,6 +175,13 @@ int span_begin(mpcgpu_ctx *c, int fam, TimedSpan *sp)
 int span_end(mpcgpu_ctx *c, TimedSpan *sp)
 {
 	HIPCHK(c, hipEventRecord(sp->b, c->stream));
+	if (trace_on()) { // before the events can be folded away below
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		float t = 0;
+		HIPCHK(c, hipEventElapsedTime(&t, sp->a, sp->b));
+		fprintf(stderr, "[mpcgpu] family %d done: %.3f ms\n", sp->fam, t);
+		fflush(stderr);
+	}
 	c->spans.push_back(*sp);
 	c->launches[sp->fam] += 1;
 	// a caller that never reads the timers (the drop-in: thousands of joins) must not accumulate events: fold the
@@ -192,13 +199,6 @@ int span_end(mpcgpu_ctx *c, TimedSpan *sp)
 		}
 		(void)hipGetLastError(); // hipErrorNotReady of the queries is not an error
 		c->spans.resize(keep);
-	}
-	if (trace_on()) {
-		HIPCHK(c, hipStreamSynchronize(c->stream));
-		float t = 0;
-		HIPCHK(c, hipEventElapsedTime(&t, sp->a, sp->b));
-		fprintf(stderr, "[mpcgpu] family %d done: %.3f ms\n", sp->fam, t);
-		fflush(stderr);
 	}
 	return 0;
 }
@@ -1351,11 +1351,16 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	// one wavefront with the previous row in registers and the traceback codes in LDS when the matrix is small enough
 	// (the progressive joins and refinement rounds of L~400 families are), else the workgroup kernel
 	const size_t smem_wave = (size_t)(LX + 1) * MPC_ALNW_ROWBYTES + 16;
-	const bool wave = W <= MPC_ALNW_MAXW && smem_wave <= 160u * 1024u && env_int("MPCGPU_ALN_WAVE", 1) != 0;
-	const size_t smem = wave ? smem_wave : (size_t)(2 * W + MPC_ALN_THREADS / 64 + 4) * 4;
+	const int pick = env_int("MPCGPU_ALN_KERNEL", 0); // 0 = by size, 1 = one wave, 2 = several waves, 3 = LDS rows
+	const bool wave = W <= MPC_ALNW_MAXW && smem_wave <= 160u * 1024u && (pick == 0 || pick == 1);
+	// several waves, 4 columns per thread, previous row in registers: up to 4096 columns
+	const u32 qthreads = (u32)((W + 4 * 64 - 1) / (4 * 64)) * 64;
+	const bool quad = !wave && qthreads <= 1024 && (pick == 0 || pick == 2);
+	const u32 qrows = quad ? (u32)std::min<u64>((u64)LX + 1, (150u * 1024u) / qthreads) : 0;
+	const size_t smem = wave ? smem_wave : quad ? (size_t)MPC_ALNQ_HDR + (size_t)qrows * qthreads : (size_t)(2 * W + MPC_ALN_THREADS / 64 + 4) * 4;
 	if (smem > 160u * 1024u)
 		return fail(c, "mpcgpu_calc_aln: %u columns exceed the LDS-resident DP rows of this build", LY);
-	HIPCHK(c, c->d_aln_tb.ensure(((u64)LX + 1) * W));
+	HIPCHK(c, c->d_aln_tb.ensure(((u64)LX + 1) * (quad ? (u64)qthreads : W))); // letters per cell, or one byte per thread and row
 	HIPCHK(c, c->d_aln_rev.ensure((u64)LX + LY));
 	HIPCHK(c, c->d_aln_path.ensure((u64)LX + LY));
 	HIPCHK(c, c->d_aln_out.ensure(8));
@@ -1363,10 +1368,13 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	ap.post = d_post; ap.LX = LX; ap.LY = LY;
 	ap.tb = c->d_aln_tb.as<char>(); ap.rev = c->d_aln_rev.as<char>(); ap.path = c->d_aln_path.as<char>();
 	ap.pathlen = c->d_aln_out.as<u32>(); ap.score = c->d_aln_out.as<float>() + 1;
-	(void)hipFuncSetAttribute(wave ? (const void *)calc_aln_wave_kernel : (const void *)calc_aln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	(void)hipFuncSetAttribute(wave ? (const void *)calc_aln_wave_kernel : quad ? (const void *)calc_aln_quad_kernel : (const void *)calc_aln_kernel,
+		hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	if (trace_on()) { fprintf(stderr, "[mpcgpu] calc_aln %u x %u: %s\n", LX, LY, wave ? "one wave" : quad ? "waves, rows in registers" : "rows in LDS"); fflush(stderr); }
 	TimedSpan ts_aln;
 	if (span_begin(c, 8, &ts_aln)) return 1;
 	if (wave) MPC_LAUNCH(calc_aln_wave_kernel, 1, 64, smem, c->stream, ap);
+	else if (quad) MPC_LAUNCH(calc_aln_quad_kernel, 1, qthreads, smem, c->stream, ap, qrows);
 	else MPC_LAUNCH(calc_aln_kernel, 1, MPC_ALN_THREADS, smem, c->stream, ap);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts_aln)) return 1;

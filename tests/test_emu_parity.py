@@ -87,11 +87,13 @@ def test_emu_relax_two_slots_per_pair(emu):
     P.assert_same((stages, ea), P.run_oracle(seqs), "nent=2")
 
 
-@pytest.mark.parametrize("kernel", ["wave", "workgroup"])
+@pytest.mark.parametrize("kernel", ["by size", "one wave", "waves", "lds rows"])
 def test_emu_calc_aln(emu, kernel, monkeypatch):
     """CalcAlnFlat + TraceBackFlat on the device (kernels_aln.h) vs the oracle: same path string,
     same score bits, including tie cases (equal B/X/Y candidates) and general non-posterior input."""
-    monkeypatch.setenv("MPCGPU_ALN_WAVE", "1" if kernel == "wave" else "0")  # calc_aln_wave_kernel (small matrices) / calc_aln_kernel
+    # calc_aln_wave_kernel (<= 512 columns) / calc_aln_quad_kernel (<= 4096 columns) / calc_aln_kernel; a kernel that cannot take
+    # a matrix leaves it to the next one
+    monkeypatch.setenv("MPCGPU_ALN_KERNEL", str(["by size", "one wave", "waves", "lds rows"].index(kernel)))
     import _oracle as O
     from muscle_amd._lib import MpcGpu
     rng = np.random.default_rng(5)
@@ -103,6 +105,8 @@ def test_emu_calc_aln(emu, kernel, monkeypatch):
         mats.append(np.round(P0 * 4).astype(np.float32) / 4)  # many exact ties
     mats.append(np.zeros((5, 6), np.float32))                 # all ties: every cell equal
     mats.append((rng.random((30, 1100)) * 3).astype(np.float32))  # more columns than threads
+    if kernel == "waves":  # more rows than one staged traceback block holds (150 KB / 320 bytes per row)
+        mats.append(((rng.random((520, 1100)) < 0.01) * np.round(rng.random((520, 1100)) * 4) / 4).astype(np.float32))
     for M in mats:
         path, sc = g.calc_aln(M)
         sc0, path0 = O.calc_aln(M)

@@ -264,12 +264,14 @@ def test_relax_gather_equals_tiled():
         P.assert_same(a, r, "relax geometry %s, %s staging buffers" % (geo, nbuf))
 
 
-@pytest.mark.parametrize("kernel", ["wave", "workgroup"])
+@pytest.mark.parametrize("kernel", ["by size", "one wave", "waves", "lds rows"])
 def test_calc_aln_paths(kernel, monkeypatch):
     """CalcAlnFlat + TraceBackFlat on the device: integer traceback bit-for-bit (path string) and
     score bits, vs the golden paths of the compiled reference (pairs_small) and vs the oracle on
     dense MSA-sized matrices with many exact ties."""
-    monkeypatch.setenv("MPCGPU_ALN_WAVE", "1" if kernel == "wave" else "0")  # calc_aln_wave_kernel (small matrices) / calc_aln_kernel
+    # calc_aln_wave_kernel (<= 512 columns) / calc_aln_quad_kernel (<= 4096 columns) / calc_aln_kernel; a kernel that cannot take
+    # a matrix leaves it to the next one
+    monkeypatch.setenv("MPCGPU_ALN_KERNEL", str(["by size", "one wave", "waves", "lds rows"].index(kernel)))
     import _oracle as O
     g = MpcGpu(0)
     z = G.load("pairs_small")
@@ -278,7 +280,7 @@ def test_calc_aln_paths(kernel, monkeypatch):
         assert path == str(z["path%d" % k])
         assert P.bits(sc) == P.bits(z["calcaln_score%d" % k])
     rng = np.random.default_rng(11)
-    for LX, LY in ((1, 1), (1, 9), (7, 1), (150, 170), (620, 580), (300, 2500)):
+    for LX, LY in ((1, 1), (1, 9), (7, 1), (150, 170), (620, 580), (300, 2500), (1010, 990), (2000, 4000), (40, 4500)):
         M = ((rng.random((LX, LY)) < 0.02) * rng.random((LX, LY)) * 3).astype(np.float32)
         for Q in (M, np.round(M * 2) / 2):
             path, sc = g.calc_aln(Q.astype(np.float32))
