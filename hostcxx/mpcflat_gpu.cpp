@@ -159,11 +159,19 @@ vector<int> DeviceList()
 
 // Context of a slot, created on first use (call with the slot's mutex held). Slot 0: a group when MUSCLE_GPU_DEVICES lists
 // several devices, else one context. Worker slots: one context each, dealt round-robin over the listed devices.
+const std::chrono::steady_clock::time_point g_ProcessStart = std::chrono::steady_clock::now(); // static initialisation of this object file
+double g_CtxSeconds = 0; // MUSCLE_GPU_TIMING: creating contexts (the first one pays for the HIP runtime's start-up)
+struct CtxClock
+	{
+	std::chrono::steady_clock::time_point m_T0 = std::chrono::steady_clock::now();
+	~CtxClock() { g_CtxSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - m_T0).count(); }
+	};
 mpcgpu_ctx *GetCtx(int SlotIndex)
 	{
 	Slot &S = g_Slots[SlotIndex];
 	if (S.m_Ctx != 0)
 		return S.m_Ctx;
+	CtxClock Clock;
 	vector<int> Devs = DeviceList();
 	if (SlotIndex == 0 && getenv("MUSCLE_GPU_DEVICES") != 0 && *getenv("MUSCLE_GPU_DEVICES") != 0)
 		{
@@ -224,6 +232,9 @@ bool TimingOn()
 				{
 				static const char *Names[T_COUNT] = { "stage A (all pairs)", "ConsIter", "AlignAlns: maps",
 				  "AlignAlns: library", "AlignAlns: result MSA", "AlignMSAsFlat: pairs+maps", "AlignMSAsFlat: library" };
+				fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  (static initialisation to exit handlers; the rows below are parts of it)\n",
+				  "process", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count());
+				fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  (inside the first call below that needed it)\n", "context creation, HIP init", g_CtxSeconds);
 				for (int i = 0; i < T_COUNT; ++i)
 					fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  %8llu calls\n", Names[i], g_Seconds[i], g_Calls[i]);
 // device time per kernel family of the library (hipEvents on its stream): where the library seconds above go

@@ -120,17 +120,23 @@ __global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
 	((u32 *)smem_raw)[lane] = code0;
 	// Post(i-1, j-1) of my columns, MPC_ALNW_PF rows ahead: the row loop is a dependent chain of ~0.2 us per row and a load from
 	// HBM/L2 takes ~1-2 us, so one row of lookahead leaves the chain waiting on memory every row (measured: 1.5 us per row).
+	// The loads are unconditional (a branch around a load makes the compiler wait for ALL loads in flight, vmcnt(0), at the
+	// next use): rows past LX and columns outside 1..LY read a clamped in-range address instead, and what they read is never
+	// used (column 0 and the columns past LY get their S and letter without it and stay out of the row maximum).
 	float ring[MPC_ALNW_PF][MPC_ALNW_C];
-	auto load_row = [&](float *dst, u32 i) {
-		const float *prow = p.post + (u64)(i - 1) * LY;
+	u32 coff[MPC_ALNW_C]; // clamped column offsets: the same for every row
 #pragma unroll
-		for (int c = 0; c < MPC_ALNW_C; ++c) {
-			const u32 j = j0 + c;
-			dst[c] = (i <= LX && j >= 1 && j <= LY) ? prow[j - 1] : 0.0f;
-		}
+	for (int c = 0; c < MPC_ALNW_C; ++c) {
+		const u32 j = j0 + c;
+		coff[c] = (j < 1u ? 1u : (j > LY ? LY : j)) - 1u;
+	}
+	auto load_row = [&](float *dst, u32 i) {
+		const float *prow = p.post + (u64)((i <= LX ? i : LX) - 1u) * LY;
+#pragma unroll
+		for (int c = 0; c < MPC_ALNW_C; ++c) dst[c] = prow[coff[c]];
 	};
 #pragma unroll
-	for (int r = 0; r < MPC_ALNW_PF; ++r) load_row(ring[r], 1u + r);
+	for (int r = 0; r < MPC_ALNW_PF; ++r) { load_row(ring[r], 1u + r); MPC_SCHED_BARRIER(); } // issued oldest row first: the waits count loads in order
 	for (u32 ib = 1; ib <= LX; ib += MPC_ALNW_PF) {
 #pragma unroll
 	for (int r = 0; r < MPC_ALNW_PF; ++r) {
@@ -140,6 +146,7 @@ __global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
 #pragma unroll
 		for (int c = 0; c < MPC_ALNW_C; ++c) pvc[c] = ring[r][c];
 		load_row(ring[r], i + MPC_ALNW_PF);
+		MPC_SCHED_BARRIER();
 		// S(i-1, j0-1): the previous lane's last column of the previous row
 		float left_old = mpc_lane_up1(oldr[MPC_ALNW_C - 1]);
 		if (lane == 0) left_old = 0.0f; // unused (column 0 has no B)
@@ -239,16 +246,19 @@ __global__ void __launch_bounds__(1024) calc_aln_quad_kernel(AlnParams p, u32 bl
 	tb[tid] = 0xaau; // row 0: 'Y' everywhere (calcalnflat.cpp:15-19); codes: 0 = 'B', 1 = 'X', 2 = 'Y'
 	float left_old = 0.0f; // S(i-1, j0-1)
 	float ring[MPC_ALNQ_PF][MPC_ALNQ_C];
-	auto load_row = [&](float *dst, u32 i) {
-		const float *prow = p.post + (u64)(i - 1) * LY;
+	u32 coff[MPC_ALNQ_C]; // clamped column offsets, unconditional loads: see calc_aln_wave_kernel
 #pragma unroll
-		for (int c = 0; c < MPC_ALNQ_C; ++c) {
-			const u32 j = j0 + c;
-			dst[c] = (i <= LX && j >= 1 && j <= LY) ? prow[j - 1] : 0.0f;
-		}
+	for (int c = 0; c < MPC_ALNQ_C; ++c) {
+		const u32 j = j0 + c;
+		coff[c] = (j < 1u ? 1u : (j > LY ? LY : j)) - 1u;
+	}
+	auto load_row = [&](float *dst, u32 i) {
+		const float *prow = p.post + (u64)((i <= LX ? i : LX) - 1u) * LY;
+#pragma unroll
+		for (int c = 0; c < MPC_ALNQ_C; ++c) dst[c] = prow[coff[c]];
 	};
 #pragma unroll
-	for (int r = 0; r < MPC_ALNQ_PF; ++r) load_row(ring[r], 1u + r);
+	for (int r = 0; r < MPC_ALNQ_PF; ++r) { load_row(ring[r], 1u + r); MPC_SCHED_BARRIER(); } // issued oldest row first: the waits count loads in order
 	for (u32 ib = 1; ib <= LX; ib += MPC_ALNQ_PF) {
 #pragma unroll
 	for (int r = 0; r < MPC_ALNQ_PF; ++r) {
@@ -258,6 +268,7 @@ __global__ void __launch_bounds__(1024) calc_aln_quad_kernel(AlnParams p, u32 bl
 #pragma unroll
 		for (int c = 0; c < MPC_ALNQ_C; ++c) pvc[c] = ring[r][c];
 		load_row(ring[r], i + MPC_ALNQ_PF);
+		MPC_SCHED_BARRIER();
 		float T[MPC_ALNQ_C];
 		bool bx[MPC_ALNQ_C];
 		float run = 0.0f; // T_j >= 0 always (X >= 0), and S(i,0) = 0

@@ -106,18 +106,23 @@ __global__ void __launch_bounds__(256) build_post_heads_kernel(const u32 *keys, 
 }
 
 #define MPC_BP_GROUP 8
+// The launch is as long as its slowest SIMD: nearly all records of a join near the root sit in the ~1000-2000 cells along the
+// alignment path (~10^5 terms each), a lone wave adds a term every ~13 cycles (two wait states + the dependent add; two waves
+// on a SIMD overlap perfectly, four already share its issue: diag/chain_time.hip), and runs dealt out statically pile several
+// heavy ones onto one SIMD (measured: 4.6 ms for a 1.4 ms critical path). So: few resident waves (the host launches two per
+// SIMD) that PULL runs from a queue — whichever wave finishes takes the next run.
 __global__ void __launch_bounds__(256) build_post_reduce_kernel(const float *vals, const u32 *run_end, const u32 *heads, const u32 *nheads,
-	float *post)
+	u32 *next_run, float *post)
 {
 	const u32 lane = threadIdx.x & 63u;
-	const u32 wave = blockIdx.x * (blockDim.x >> 6) + mpc_wave_first(threadIdx.x >> 6);
-	const u32 nwaves = gridDim.x * (blockDim.x >> 6);
 	const u32 nh = mpc_wave_first(*nheads);
-	for (u32 h = wave; h < nh; h += nwaves) {
+	for (;;) {
+		const u32 h = mpc_wave_first(atomicAdd(next_run, lane == 0 ? 1u : 0u)); // lane 0 adds 1, the others 0: one atomic per wave (kernels_fb.h)
+		if (h >= nh) break;
 		const u32 cell = mpc_wave_first(heads[2 * (u64)h]);
 		const u64 lo = mpc_wave_first(heads[2 * (u64)h + 1]), hi = mpc_wave_first(run_end[cell]);
-		// The chain is serial — ~6 cycles per term, 250 000 terms on the heaviest cells — and the heaviest run is the critical
-		// path of the launch, so its loads must never be waited for: groups of MPC_BP_GROUP chunks of 64 terms, the next
+		// The chain is serial and the heaviest run (250 000 terms at the root of a 1000-sequence tree) is the critical path of
+		// the launch, so its loads must never be waited for: groups of MPC_BP_GROUP chunks of 64 terms, the next
 		// group in flight while this one is added (chunks past the end are neither loaded nor added).
 		float total = 0.0f; // wave-uniform
 		float cur[MPC_BP_GROUP], nxt[MPC_BP_GROUP];

@@ -824,7 +824,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	const int waves_per_block = 4, block = 64 * waves_per_block;
 	const u32 cus = (u32)c->prop.multiProcessorCount;
 	const bool mega = c->have_mega;
-	const size_t fb_smem = (mega ? (size_t)c->mg_tab_floats : (size_t)c->A * c->A + c->A) * sizeof(float);
+	const size_t fb_smem = (mega ? (size_t)c->mg_tab_floats : (size_t)c->A * c->A + c->A) * sizeof(float) +
+		(size_t)env_int("MPCGPU_FB_LDS_PAD_KB", 0) * 1024; // the pad (measurement only) lowers the resident workgroups per CU
 
 	u64 words_done = 0; // record words packed so far
 	u64 done = 0;
@@ -1416,15 +1417,17 @@ static int reduce_runs(mpcgpu_ctx *c, const u32 *keys_sorted, const float *vals_
 	HIPCHK(c, hipMemsetAsync(c->d_aln_post.p, 0, cells * 4, c->stream));
 	if (!M) return 0;
 	const u64 maxruns = std::min<u64>(M, cells);
-	HIPCHK(c, c->d_bp_runs.ensure((cells + 2 * maxruns + 1) * 4));
-	u32 *run_end = c->d_bp_runs.as<u32>(), *heads = run_end + cells, *nheads = heads + 2 * maxruns;
-	HIPCHK(c, hipMemsetAsync(nheads, 0, 4, c->stream));
+	HIPCHK(c, c->d_bp_runs.ensure((cells + 2 * maxruns + 2) * 4));
+	u32 *run_end = c->d_bp_runs.as<u32>(), *heads = run_end + cells, *nheads = heads + 2 * maxruns, *next_run = nheads + 1;
+	HIPCHK(c, hipMemsetAsync(nheads, 0, 8, c->stream));
 	const u32 grid_cap = (u32)c->prop.multiProcessorCount * 8;
 	MPC_LAUNCH(build_post_heads_kernel, (u32)std::min<u64>((M + 255) / 256, grid_cap), 256, 0, c->stream, keys_sorted, (u64)M, run_end, heads,
 		nheads);
 	HIPCHK(c, hipGetLastError());
-	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((maxruns + 3) / 4, grid_cap), 256, 0, c->stream, vals_sorted, (const u32 *)run_end,
-		(const u32 *)heads, (const u32 *)nheads, c->d_aln_post.as<float>());
+	// two waves per SIMD pulling runs from a queue (kernels_prog.h); MPCGPU_BP_WAVES: resident waves per SIMD
+	const u32 red_grid = (u32)c->prop.multiProcessorCount * (u32)std::min(std::max(env_int("MPCGPU_BP_WAVES", 2), 1), 8);
+	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((maxruns + 3) / 4, red_grid), 256, 0, c->stream, vals_sorted, (const u32 *)run_end,
+		(const u32 *)heads, (const u32 *)nheads, next_run, c->d_aln_post.as<float>());
 	HIPCHK(c, hipGetLastError());
 	return 0;
 }
