@@ -220,8 +220,9 @@ __global__ void __launch_bounds__(64) post_kernel(PostParams p)
 //    c <= j, of S(i-1,c-1) + P(i,c)); cells with P == 0 change nothing because S(i-1,.) is
 //    non-decreasing. So a row needs: one LDS read of PM[c-1] per stored cell (all cells of the row at
 //    once, from the previous row's values), one add each, a running maximum over the cells in column
-//    order, and one pass "PM[j] = max(PM[j], V(j))" over the columns right of the first cell. The
-//    only rounding is the one add per stored cell, max is exact: bit-identical to the sequential DP.
+//    order, and one pass "PM[j] = max(PM[j], V(j))" over the columns right of the first cell — as far as
+//    the right-most column any row has reached so far: beyond it S(i,.) is flat and is kept as that one value.
+//    The only rounding is the one add per stored cell, max is exact: bit-identical to the sequential DP.
 struct PostRowsParams {
 	const u32 *pair_x, *pair_y;
 	const u32 *seq_len;
@@ -310,7 +311,10 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			}
 		}
 		__syncthreads();
-		// ---- EA score
+		// ---- EA score. PM is kept explicitly only up to column cmax, the right-most column any row has updated so far; right of
+		// it S(i,.) is flat (nothing stored there has been reached yet), PM[j] == PM[cmax]. Stored cells hug the alignment
+		// path, so a row updates the few columns between its first cell and that frontier instead of all LY of them.
+		u32 cmax = 0; // wave-uniform
 		for (u32 i = 0; i < LX; ++i) {
 			const u32 b = i ? s_rend[i - 1] : 0u, e = s_rend[i]; // wave-uniform
 			if (e == b) continue;
@@ -318,7 +322,8 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			if (wide) {
 				for (u32 x = b + (u32)t; x < e; x += 64) {
 					const u64 key = sorted[x];
-					s_cend[x - b] = __float_as_uint(s_pm[(u32)(key >> 32)] + __uint_as_float((u32)key)); // s_cend is free until the sparsify step
+					const u32 cc = (u32)(key >> 32);
+					s_cend[x - b] = __float_as_uint(s_pm[cc < cmax ? cc : cmax] + __uint_as_float((u32)key)); // s_cend is free until the sparsify step
 				}
 				__syncthreads();
 			}
@@ -329,10 +334,13 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 				const u64 key = have ? sorted[me] : 0ull;
 				const u32 col = (u32)(key >> 32);
 				float val = 0.0f; // B = S(i-1,j-1) + P with j = col+1 (calcalnscoreflat.cpp:20)
-				if (have) val = wide ? __uint_as_float(s_cend[me - b]) : s_pm[col] + __uint_as_float((u32)key);
+				if (have) val = wide ? __uint_as_float(s_cend[me - b]) : s_pm[col < cmax ? col : cmax] + __uint_as_float((u32)key);
+				const float suffix = s_pm[cmax]; // S(i-1, j) for every j >= cmax, read before this batch writes
 				const float V = fmaxf(mpc_wave_scan_max_nonneg(val), vprev); // running maximum in column order
 				const u32 k = (e - c0 < p.batch) ? (e - c0) : p.batch;
-				for (u32 j0 = mpc_wave_first(col) + 1u; j0 <= LY; j0 += 64) {
+				const u32 last = mpc_read_lane(col, k - 1) + 1u; // right-most column this batch's cells start at
+				const u32 hi = last > cmax ? last : cmax;        // explicit range after this batch
+				for (u32 j0 = mpc_wave_first(col) + 1u; j0 <= hi; j0 += 64) {
 					const u32 j = j0 + (u32)t;
 					float cur = 0.0f;
 					for (u32 l = 0; l < k; ++l) { // cells ascend in column: the last one with col+1 <= j wins
@@ -340,8 +348,9 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 						const float vj = mpc_read_lane(V, l);
 						cur = (j >= cj) ? vj : cur;
 					}
-					if (j <= LY) s_pm[j] = fmaxf(s_pm[j], cur); // max(X, Y-chain) of the recurrence
+					if (j <= hi) s_pm[j] = fmaxf(j <= cmax ? s_pm[j] : suffix, cur); // max(X, Y-chain) of the recurrence
 				}
+				cmax = hi;
 				vprev = mpc_read_lane(V, k - 1);
 				__syncthreads();
 			}
@@ -350,7 +359,7 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 				__syncthreads();
 			}
 		}
-		const float score = s_pm[LY];
+		const float score = s_pm[LY < cmax ? LY : cmax];
 		const u32 mn = LX < LY ? LX : LY;
 		const float ea = score / (float)mn; // calcposteriorflat.cpp:89 (uint -> float, IEEE divide)
 		__syncthreads();
