@@ -242,7 +242,18 @@ struct PostRowsParams {
 	u32 *flags;
 	u32 count;
 	u32 long_min; // as in PostParams
+	u64 *prof;    // measurement only (MPCGPU_POST_PROFILE=1), else nullptr: clock ticks of workgroup 0 per phase, 8 slots
 };
+
+// phase clock of post_rows_kernel (workgroup 0, lane 0 only)
+#define MPC_POST_TICK(slot)                                                          \
+	do {                                                                             \
+		if (p.prof && blockIdx.x == 0 && t == 0) {                                   \
+			const u64 now_ = mpc_clock();                                            \
+			p.prof[slot] += now_ - tick_;                                            \
+			tick_ = now_;                                                            \
+		}                                                                            \
+	} while (0)
 
 __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 {
@@ -263,6 +274,7 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			continue;
 		}
 		if (t == 0) p.flags[pid] = 0u;
+		u64 tick_ = p.prof ? mpc_clock() : 0ull;
 		u64 *cand = p.cand + (u64)pid * p.capc;
 		u64 *sorted = (c <= p.sort_cap) ? s_sorted : (p.sort_scratch + (u64)blockIdx.x * p.sort_stride);
 		for (u32 q = t; q <= LX; q += 64) s_rend[q] = 0;
@@ -277,6 +289,7 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			atomicAdd(&s_rend[(u32)(v >> (32 + kshift))], 1u);
 		}
 		__syncthreads();
+		MPC_POST_TICK(0); // zeroing, probabilities, row histogram
 		// exclusive scan of the row counts (in place: s_rend[i] = first slot of row i)
 		{
 			u32 carry = 0;
@@ -300,6 +313,7 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			sorted[at] = ((v >> 32) & (u64)((1u << kshift) - 1u)) << 32 | (v & 0xffffffffull);
 		}
 		__syncthreads();
+		MPC_POST_TICK(1); // scan + scatter
 		// columns ascending inside each row (a lane per row; rows hold a handful of cells)
 		for (u32 i = t; i < LX; i += 64) {
 			const u32 b = i ? s_rend[i - 1] : 0u, e = s_rend[i];
@@ -311,58 +325,99 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			}
 		}
 		__syncthreads();
+		MPC_POST_TICK(2); // sort inside rows
 		// ---- EA score. PM is kept explicitly only up to column cmax, the right-most column any row has updated so far; right of
 		// it S(i,.) is flat (nothing stored there has been reached yet), PM[j] == PM[cmax]. Stored cells hug the alignment
 		// path, so a row updates the few columns between its first cell and that frontier instead of all LY of them.
+		// The rows are a dependent chain (row i reads what row i-1 wrote), so what a row costs is the latency of what it has to
+		// wait for. Off the chain: the row ends (64 rows per LDS read, then v_readlane) and the row's cells (the next non-empty
+		// row's cells start where this row's end, so they are loaded one row ahead). On it: PM[col-1] of the cells -> add ->
+		// wave scan -> the update of the few columns up to the frontier. One wavefront is the whole workgroup and LDS executes a
+		// wave's accesses in order, so a row's writes need no barrier before the next row's reads.
 		u32 cmax = 0; // wave-uniform
-		for (u32 i = 0; i < LX; ++i) {
-			const u32 b = i ? s_rend[i - 1] : 0u, e = s_rend[i]; // wave-uniform
-			if (e == b) continue;
-			const bool wide = e - b > p.batch; // more than one batch of cells: every B must still come from the previous row's PM
-			if (wide) {
-				for (u32 x = b + (u32)t; x < e; x += 64) {
-					const u64 key = sorted[x];
-					const u32 cc = (u32)(key >> 32);
-					s_cend[x - b] = __float_as_uint(s_pm[cc < cmax ? cc : cmax] + __uint_as_float((u32)key)); // s_cend is free until the sparsify step
+		u64 nkey = c ? sorted[(u32)t < c ? (u32)t : c - 1u] : 0ull; // cells [b, b+64) of the next non-empty row
+		for (u32 i0 = 0; i0 < LX; i0 += 64) {
+			const u32 ri = i0 + (u32)t;
+			const u32 rend_v = s_rend[ri < LX ? ri : LX - 1u]; // lane l: end of row i0+l
+			u32 b = mpc_wave_first(i0 ? s_rend[i0 - 1u] : 0u);
+			const u32 nl = LX - i0 < 64u ? LX - i0 : 64u;
+			for (u32 rl = 0; rl < nl; ++rl) {
+				const u32 e = mpc_read_lane(rend_v, rl);
+				if (e == b) continue;
+				if (e - b > p.batch) {
+					// more than one batch of cells (rare): every B must still come from the previous row's PM, so they are
+					// formed first (s_cend is free until the sparsify step), then the batches update PM one after the other
+					for (u32 x = b + (u32)t; x < e; x += 64) {
+						const u64 key = sorted[x];
+						const u32 cc = (u32)(key >> 32);
+						s_cend[x - b] = __float_as_uint(s_pm[cc < cmax ? cc : cmax] + __uint_as_float((u32)key));
+					}
+					__syncthreads();
+					float vprev = 0.0f; // maximum over the cells of this row handled so far
+					for (u32 c0 = b; c0 < e; c0 += p.batch) {
+						const u32 me = c0 + (u32)t;
+						const bool have = me < e && (u32)t < p.batch;
+						const u64 key = have ? sorted[me] : 0ull;
+						const u32 col = (u32)(key >> 32);
+						const float val = have ? __uint_as_float(s_cend[me - b]) : 0.0f;
+						const float suffix = s_pm[cmax];
+						const float V = fmaxf(mpc_wave_scan_max_nonneg(val), vprev);
+						const u32 k = (e - c0 < p.batch) ? (e - c0) : p.batch;
+						const u32 last = mpc_read_lane(col, k - 1) + 1u;
+						const u32 hi = last > cmax ? last : cmax;
+						for (u32 j0 = mpc_wave_first(col) + 1u; j0 <= hi; j0 += 64) {
+							const u32 j = j0 + (u32)t;
+							float cur = 0.0f;
+							for (u32 l = 0; l < k; ++l) {
+								const u32 cj = mpc_read_lane(col, l) + 1u;
+								const float vj = mpc_read_lane(V, l);
+								cur = (j >= cj) ? vj : cur;
+							}
+							if (j <= hi) s_pm[j] = fmaxf(j <= cmax ? s_pm[j] : suffix, cur);
+						}
+						cmax = hi;
+						vprev = mpc_read_lane(V, k - 1);
+						__syncthreads();
+					}
+					for (u32 x = b + (u32)t; x < e; x += 64) s_cend[x - b] = 0;
+					__syncthreads();
+					nkey = sorted[e + (u32)t < c ? e + (u32)t : c - 1u];
+					b = e;
+					continue;
 				}
-				__syncthreads();
-			}
-			float vprev = 0.0f; // maximum over the cells of this row handled so far
-			for (u32 c0 = b; c0 < e; c0 += p.batch) {
-				const u32 me = c0 + (u32)t;
-				const bool have = me < e && (u32)t < p.batch;
-				const u64 key = have ? sorted[me] : 0ull;
-				const u32 col = (u32)(key >> 32);
-				float val = 0.0f; // B = S(i-1,j-1) + P with j = col+1 (calcalnscoreflat.cpp:20)
-				if (have) val = wide ? __uint_as_float(s_cend[me - b]) : s_pm[col < cmax ? col : cmax] + __uint_as_float((u32)key);
-				const float suffix = s_pm[cmax]; // S(i-1, j) for every j >= cmax, read before this batch writes
-				const float V = fmaxf(mpc_wave_scan_max_nonneg(val), vprev); // running maximum in column order
-				const u32 k = (e - c0 < p.batch) ? (e - c0) : p.batch;
-				const u32 last = mpc_read_lane(col, k - 1) + 1u; // right-most column this batch's cells start at
-				const u32 hi = last > cmax ? last : cmax;        // explicit range after this batch
-				for (u32 j0 = mpc_wave_first(col) + 1u; j0 <= hi; j0 += 64) {
+				const u32 k = e - b; // 1..64 cells, lane l holds cell l (columns ascending)
+				const bool have = (u32)t < k;
+				const u64 key = nkey;
+				nkey = sorted[e + (u32)t < c ? e + (u32)t : c - 1u]; // in flight while this row is computed
+				const u32 col = have ? (u32)(key >> 32) : 0u;
+				const u32 jfirst = mpc_wave_first(col) + 1u;
+				// B = S(i-1,j-1) + P with j = col+1 (calcalnscoreflat.cpp:20)
+				const float val = have ? s_pm[col < cmax ? col : cmax] + __uint_as_float((u32)key) : 0.0f;
+				const float suffix = s_pm[cmax]; // S(i-1, j) for every j >= cmax
+				const float V = mpc_wave_scan_max_nonneg(val); // running maximum in column order
+				const u32 last = mpc_read_lane(col, k - 1) + 1u; // right-most column the row's cells start at
+				const u32 hi = last > cmax ? last : cmax;        // explicit range after this row
+				for (u32 j0 = jfirst; j0 <= hi; j0 += 64) {
 					const u32 j = j0 + (u32)t;
+					const float old = s_pm[j <= cmax ? j : cmax];
 					float cur = 0.0f;
 					for (u32 l = 0; l < k; ++l) { // cells ascend in column: the last one with col+1 <= j wins
 						const u32 cj = mpc_read_lane(col, l) + 1u;
 						const float vj = mpc_read_lane(V, l);
 						cur = (j >= cj) ? vj : cur;
 					}
-					if (j <= hi) s_pm[j] = fmaxf(j <= cmax ? s_pm[j] : suffix, cur); // max(X, Y-chain) of the recurrence
+					if (j <= hi) s_pm[j] = fmaxf(j <= cmax ? old : suffix, cur); // max(X, Y-chain) of the recurrence
 				}
 				cmax = hi;
-				vprev = mpc_read_lane(V, k - 1);
-				__syncthreads();
-			}
-			if (wide) {
-				for (u32 x = b + (u32)t; x < e; x += 64) s_cend[x - b] = 0;
-				__syncthreads();
+				b = e;
+				MPC_WAVE_LDS_ORDER();
 			}
 		}
 		const float score = s_pm[LY < cmax ? LY : cmax];
 		const u32 mn = LX < LY ? LX : LY;
 		const float ea = score / (float)mn; // calcposteriorflat.cpp:89 (uint -> float, IEEE divide)
 		__syncthreads();
+		MPC_POST_TICK(3); // EA rows
 		// ---- sparsify (mysparsemx.cpp:115-152): keep P >= 0.01f, row-major rank among the kept
 		u32 kept = 0;
 		for (u32 q0 = 0; q0 < c; q0 += 64) {
@@ -408,6 +463,7 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			base += __shfl(incl, 63);
 		}
 		__syncthreads();
+		MPC_POST_TICK(4); // kept entries out, row-major
 		// ---- column-major rank of every kept entry: counting sort on the column, rows ascending inside
 		for (u32 q = t; q < LY; q += 64) colcnt[q] = s_cend[q];
 		{
@@ -445,5 +501,6 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 		for (u32 q = t; q < nnz; q += 64) tperm[csorted[q]] = q;
 		if (t == 0) { p.nnz[pid] = nnz; p.ea[pid] = ea; }
 		__syncthreads();
+		MPC_POST_TICK(5); // column-major ranks
 	}
 }

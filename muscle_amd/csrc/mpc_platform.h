@@ -121,6 +121,12 @@ typedef const __attribute__((address_space(4))) unsigned *mpc_const_u32p;
 // no instruction is scheduled across this point (keeps the loads of unrolled prologue / epilogue iterations from being hoisted
 // on top of each other: register pressure, not speed, decides those parts)
 #define MPC_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// Between LDS writes of one wavefront and its own later LDS reads of what other lanes wrote, in a workgroup that IS one
+// wavefront: the hardware executes a wave's LDS instructions in order, so no barrier and no wait is needed — only the compiler
+// must not move accesses across this point.
+#define MPC_WAVE_LDS_ORDER() __builtin_amdgcn_wave_barrier()
+// free-running clock for the phase timers of the diagnostics (s_memrealtime: 100 MHz on gfx950)
+__device__ __forceinline__ unsigned long long mpc_clock() { return wall_clock64(); }
 // value held by the first active lane, as a wave-uniform scalar (v_readfirstlane_b32 -> SGPR)
 __device__ __forceinline__ unsigned mpc_wave_first(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
 #endif

@@ -107,7 +107,7 @@ struct mpcgpu_ctx {
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
-	DevBuf d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_runs, d_bp_w;
+	DevBuf d_post_prof, d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_runs, d_bp_w;
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
 	bool have_pad = false;       // variable-size dense records + relax_var_kernel (else: slabs + gather relax)
 	u32 pad_lcap1 = 0;           // longest sequence (LDS scratch of var_build_kernel)
@@ -585,7 +585,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
 		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_pos, &c->d_bp_seq, &c->d_bp_map, &c->d_bp_off, &c->d_bp_coff,
-		&c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
+		&c->d_post_prof, &c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
 		&c->d_aln_out};
 	for (DevBuf *b : all) b->release();
 	(void)hipStreamDestroy(c->stream);
@@ -971,11 +971,27 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			pr.nnz = c->d_nnz.as<u32>(); pr.ea = c->d_ea.as<float>(); pr.flags = c->d_flags.as<u32>();
 			pr.count = (u32)B;
 			pr.long_min = long_min;
+			pr.prof = nullptr;
+			const bool post_prof = env_int("MPCGPU_POST_PROFILE", 0) != 0; // measurement only: phase clocks of workgroup 0
+			if (post_prof) {
+				HIPCHK(c, c->d_post_prof.ensure(8 * 8));
+				HIPCHK(c, hipMemsetAsync(c->d_post_prof.p, 0, 64, c->stream));
+				pr.prof = c->d_post_prof.as<u64>();
+			}
 			if (trace_on()) { fprintf(stderr, "[mpcgpu] post rows: lds=%zu B blocks/CU=%d grid=%u\n", smem, pocc, pgrid); fflush(stderr); }
 			if (span_begin(c, 1, &sp)) return 1;
 			MPC_LAUNCH(post_rows_kernel, pgrid, 64, smem, c->stream, pr);
 			HIPCHK(c, hipGetLastError());
 			if (span_end(c, &sp)) return 1;
+			if (post_prof) {
+				u64 ticks[8];
+				HIPCHK(c, hipMemcpyAsync(ticks, pr.prof, 64, hipMemcpyDeviceToHost, c->stream));
+				HIPCHK(c, hipStreamSynchronize(c->stream));
+				const u64 npairs0 = (B + pgrid - 1) / pgrid; // pairs workgroup 0 handled
+				fprintf(stderr, "[mpcgpu] post_rows_kernel, workgroup 0, %llu pairs, us per pair (100 MHz clock): prob+histogram %.1f, scan+scatter %.1f, "
+					"row sort %.1f, EA %.1f, kept entries %.1f, column ranks %.1f\n", (u64)npairs0, ticks[0] / 100.0 / npairs0, ticks[1] / 100.0 / npairs0,
+					ticks[2] / 100.0 / npairs0, ticks[3] / 100.0 / npairs0, ticks[4] / 100.0 / npairs0, ticks[5] / 100.0 / npairs0);
+			}
 		} else {
 		PostParams pp;
 		pp.pair_x = c->d_bx.as<u32>(); pp.pair_y = c->d_by.as<u32>(); pp.seq_len = c->d_seq_len.as<u32>();

@@ -95,6 +95,7 @@ template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xch
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
 #define MPC_OPAQUE(v) ((void)0)
 #define MPC_SCHED_BARRIER() ((void)0)
+#define MPC_WAVE_LDS_ORDER() __syncthreads() // the emulator runs lanes one after the other between synchronisation points
 #define MPC_WAVE_FENCE() ((void)0) // emulated lanes meet at every shuffle
 template <class T> static inline T mpc_read_lane(T v, unsigned l) { return __shfl(v, (int)l); }
 template <class T> static inline T mpc_lane_up1(T v) { return __shfl_up(v, 1); }
@@ -132,6 +133,7 @@ static inline unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { ret
 static inline void mpc_dma16(const void *gsrc, void *lds_wave_base) { memcpy((unsigned char *)lds_wave_base + 16 * emu::t_lane, gsrc, 16); }
 static inline void mpc_dma_wait() {}
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
+static inline unsigned long long mpc_clock() { return 0ull; }
 static inline unsigned long long __ballot(int pred)
 {
 	emu::WaveState *w = emu::t_wave;
