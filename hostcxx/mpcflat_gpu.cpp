@@ -159,6 +159,11 @@ vector<int> DeviceList()
 
 // Context of a slot, created on first use (call with the slot's mutex held). Slot 0: a group when MUSCLE_GPU_DEVICES lists
 // several devices, else one context. Worker slots: one context each, dealt round-robin over the listed devices.
+bool TimingEnv()
+	{
+	const char *s = getenv("MUSCLE_GPU_TIMING");
+	return s != 0 && *s != 0 && *s != '0';
+	}
 const std::chrono::steady_clock::time_point g_ProcessStart = std::chrono::steady_clock::now(); // static initialisation of this object file
 double g_CtxSeconds = 0; // MUSCLE_GPU_TIMING: creating contexts (the first one pays for the HIP runtime's start-up)
 struct CtxClock
@@ -178,6 +183,8 @@ mpcgpu_ctx *GetCtx(int SlotIndex)
 		if (mpcgpu_group_create(&S.m_Group, (uint32_t) Devs.size(), Devs.data()) != 0)
 			Die("GPU posterior stage: %s", mpcgpu_group_last_error(0));
 		S.m_Ctx = mpcgpu_group_ctx(S.m_Group, 0);
+		for (uint32_t r = 0; r < mpcgpu_group_size(S.m_Group); ++r)
+			mpcgpu_timers_enable(mpcgpu_group_ctx(S.m_Group, r), TimingEnv() ? 1 : 0);
 		if (getenv("MUSCLE_GPU_TIMING") != 0 || getenv("MUSCLE_GPU_DEBUG") != 0)
 			fprintf(stderr, "[muscle_gpu] %u GPU contexts, exchange by %s\n", mpcgpu_group_size(S.m_Group), mpcgpu_group_transport(S.m_Group));
 		return S.m_Ctx;
@@ -185,6 +192,7 @@ mpcgpu_ctx *GetCtx(int SlotIndex)
 	const int Device = Devs[SlotIndex == 0 ? 0 : (SlotIndex - 1) % SIZE(Devs)];
 	if (mpcgpu_create(&S.m_Ctx, Device) != 0)
 		Die("GPU posterior stage: %s", mpcgpu_last_error(0));
+	mpcgpu_timers_enable(S.m_Ctx, TimingEnv() ? 1 : 0); // hipEvents around every launch only when the report is asked for
 	return S.m_Ctx;
 	}
 
@@ -811,6 +819,7 @@ void Super7::IntraAlignShrubs()
 		RandOffset[ShrubIndex + 1] = RandOffset[ShrubIndex] + Draws;
 		}
 
+	const double ShrubsBegin = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count();
 	m_ShrubMSAs.assign(ShrubCount, (const MultiSequence *) 0);
 	std::atomic<uint> Next(0);
 	vector<std::thread> Threads;
@@ -849,5 +858,8 @@ void Super7::IntraAlignShrubs()
 			});
 	for (size_t t = 0; t < Threads.size(); ++t)
 		Threads[t].join();
+	if (TimingOn())
+		fprintf(stderr, "[muscle_gpu] %u shrubs on %u worker contexts: entered %.3f s after process start, took %.3f s\n", ShrubCount, Workers,
+		  ShrubsBegin, std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count() - ShrubsBegin);
 	MuscleGpuRandSharedSkip(RandOffset[ShrubCount]);
 	}

@@ -207,6 +207,10 @@ int mpcgpu_group_cons_iter(mpcgpu_group *g);
 #define MPCGPU_NKERNELS 9 /* ... 5 = BuildPost record generation, 6 = BuildPost grouping (sort), 7 = BuildPost in-order reduction,
                              8 = CalcAlnFlat + traceback (families 5-8: mpcgpu_align_alns / mpcgpu_align_msas / mpcgpu_calc_aln) */
 int mpcgpu_timers_reset(mpcgpu_ctx *ctx);
+/* Timing on (default) / off. Off: no hipEvents around the launches (two events per launch family and call are a measurable share
+ * of a small join: the drop-in switches them off unless MUSCLE_GPU_TIMING asks for the report); mpcgpu_timers_get then reports
+ * what was measured while it was on. */
+int mpcgpu_timers_enable(mpcgpu_ctx *ctx, int on);
 int mpcgpu_timers_get(mpcgpu_ctx *ctx, float ms[MPCGPU_NKERNELS], uint64_t launches[MPCGPU_NKERNELS]);
 /* Algorithmic work of the last calc_posteriors call: DP cells summed over pairs
  * (sum (LX+1)(LY+1)) and of the last cons_iter: (pair,Z) triples and stored entries. */

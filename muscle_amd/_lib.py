@@ -19,7 +19,7 @@ SYMBOLS = [
     "mpcgpu_set_seqs", "mpcgpu_set_mega", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
-    "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_get",
+    "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
@@ -75,6 +75,7 @@ def load(lib_path=None):
     L.mpcgpu_set_seqs_registry.argtypes = [vp, u32, vp, vp]
     L.mpcgpu_align_msas.argtypes = [vp, u32, vp, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float), vp]
     L.mpcgpu_timers_reset.argtypes = [vp]
+    L.mpcgpu_timers_enable.argtypes = [vp, C.c_int]
     L.mpcgpu_timers_get.argtypes = [vp, vp, vp]
     L.mpcgpu_work_get.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mpcgpu_synchronize.argtypes = [vp]

@@ -29,12 +29,24 @@ struct BuildPostParams {
 	u32 *keys; // cell of every record
 	float *vals;
 	const float *w1, *w2; // sequence weights of the rows of MSA1 / MSA2 (buildpostflat.cpp:41,52), nullptr = 1.0f
+	float *post;          // C1*C2 output matrix, zeroed here (buildpostflat.cpp:27-30) — this launch precedes the sort and the reduction
+	u64 cells;
+	u32 *counters;        // {runs, next run} of the reduction, zeroed here
 };
+
+// zeroes what the reduction adds into / counts with: a slice per workgroup of the generating launch (saves two memset launches
+// per join; the joins inside a shrub of 32 sequences are launch-bound)
+__device__ __forceinline__ void build_post_zero(float *post, u64 cells, u32 *counters)
+{
+	for (u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x; q < cells; q += (u64)gridDim.x * blockDim.x) post[q] = 0.0f;
+	if (blockIdx.x == 0 && threadIdx.x < 2u) counters[threadIdx.x] = 0u;
+}
 
 // one 64-thread workgroup per (a,b)
 __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 {
 	const u64 total = (u64)p.n1 * p.n2;
+	build_post_zero(p.post, p.cells, p.counters);
 	for (u64 ab = blockIdx.x; ab < total; ab += gridDim.x) {
 		const u32 a = (u32)(ab / p.n2), b = (u32)(ab % p.n2);
 		const u32 S = p.seq1[a], T = p.seq2[b];
@@ -165,10 +177,14 @@ struct BuildPostListParams {
 	u32 C2;
 	u32 *keys; // cell of every record
 	float *vals;
+	float *post; // as in BuildPostParams
+	u64 cells;
+	u32 *counters;
 };
 
 __global__ void __launch_bounds__(64) build_post_list_gen_kernel(BuildPostListParams p)
 {
+	build_post_zero(p.post, p.cells, p.counters);
 	for (u32 q = blockIdx.x; q < p.npairs; q += gridDim.x) {
 		const u32 LX = p.seq_len[p.seq1[q]], LY = p.seq_len[p.seq2[q]];
 		const u32 nnz = (u32)(p.coff[q + 1] - p.coff[q]);

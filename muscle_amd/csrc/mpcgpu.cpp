@@ -55,6 +55,34 @@ struct DevBuf {
 		p = nullptr;
 		cap = 0;
 	}
+	// scratch whose size changes from call to call (the joins of a progressive alignment grow): room to spare, so that most calls
+	// find it large enough (hipMalloc / hipFree synchronise the device)
+	hipError_t ensure_grow(size_t bytes) { return bytes <= cap ? hipSuccess : ensure(std::max(bytes, cap + cap / 2)); }
+	template <class T> T *as() const { return (T *)p; }
+};
+
+// page-locked host staging: copies to and from it are asynchronous, and it outlives the call that filled it
+struct HostBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	hipError_t ensure(size_t bytes)
+	{
+		if (bytes <= cap) return hipSuccess;
+		const size_t ncap = std::max(bytes, cap + cap / 2);
+		void *np = nullptr;
+		hipError_t e = hipHostMalloc(&np, ncap ? ncap : 1);
+		if (e != hipSuccess) return e;
+		if (p) (void)hipHostFree(p);
+		p = np;
+		cap = ncap;
+		return hipSuccess;
+	}
+	void release()
+	{
+		if (p) (void)hipHostFree(p);
+		p = nullptr;
+		cap = 0;
+	}
 	template <class T> T *as() const { return (T *)p; }
 };
 
@@ -107,8 +135,10 @@ struct mpcgpu_ctx {
 	DevBuf d_pbase, d_vbase, d_rp, d_rp_base, d_ent, d_ent_base, d_mbase, d_vnext, d_own_packed;
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
-	DevBuf d_post_prof, d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_runs, d_bp_w;
-	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev, d_aln_path, d_aln_out;
+	HostBuf h_bp_in, h_aln_res;
+	size_t aln_smem_set[3] = {0, 0, 0}; // largest dynamic LDS each CalcAlnFlat kernel has been allowed so far
+	DevBuf d_bp_in, d_aln_res, d_post_prof, d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_runs;
+	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev;
 	bool have_pad = false;       // variable-size dense records + relax_var_kernel (else: slabs + gather relax)
 	u32 pad_lcap1 = 0;           // longest sequence (LDS scratch of var_build_kernel)
 	DevBuf d_rec_off, d_sizes, d_tilefit;
@@ -129,6 +159,7 @@ struct mpcgpu_ctx {
 
 	// measurement
 	std::vector<TimedSpan> spans;
+	bool timing = true; // mpcgpu_timers_enable
 	float ms[MPCGPU_NKERNELS] = {0};
 	u64 launches[MPCGPU_NKERNELS] = {0};
 	u64 work_cells = 0, work_entry_z = 0;
@@ -165,7 +196,8 @@ bool trace_on()
 
 int span_begin(mpcgpu_ctx *c, int fam, TimedSpan *sp)
 {
-	sp->fam = fam;
+	sp->fam = (c->timing || trace_on()) ? fam : -1;
+	if (sp->fam < 0) return 0;
 	if (trace_on()) { fprintf(stderr, "[mpcgpu] launch family %d ...\n", fam); fflush(stderr); }
 	HIPCHK(c, hipEventCreate(&sp->a));
 	HIPCHK(c, hipEventCreate(&sp->b));
@@ -174,6 +206,7 @@ int span_begin(mpcgpu_ctx *c, int fam, TimedSpan *sp)
 }
 int span_end(mpcgpu_ctx *c, TimedSpan *sp)
 {
+	if (sp->fam < 0) return 0;
 	HIPCHK(c, hipEventRecord(sp->b, c->stream));
 	if (trace_on()) { // before the events can be folded away below
 		HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -585,9 +618,10 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
 		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_pos, &c->d_bp_seq, &c->d_bp_map, &c->d_bp_off, &c->d_bp_coff,
-		&c->d_post_prof, &c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev, &c->d_aln_path,
-		&c->d_aln_out};
+		&c->d_bp_in, &c->d_aln_res, &c->d_post_prof, &c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev};
 	for (DevBuf *b : all) b->release();
+	c->h_bp_in.release();
+	c->h_aln_res.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1410,16 +1444,22 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	const size_t smem = wave ? smem_wave : quad ? (size_t)MPC_ALNQ_HDR + (size_t)qrows * qthreads : (size_t)(2 * W + MPC_ALN_THREADS / 64 + 4) * 4;
 	if (smem > 160u * 1024u)
 		return fail(c, "mpcgpu_calc_aln: %u columns exceed the LDS-resident DP rows of this build", LY);
-	HIPCHK(c, c->d_aln_tb.ensure(((u64)LX + 1) * (quad ? (u64)qthreads : W))); // letters per cell, or one byte per thread and row
-	HIPCHK(c, c->d_aln_rev.ensure((u64)LX + LY));
-	HIPCHK(c, c->d_aln_path.ensure((u64)LX + LY));
-	HIPCHK(c, c->d_aln_out.ensure(8));
+	HIPCHK(c, c->d_aln_tb.ensure_grow(((u64)LX + 1) * (quad ? (u64)qthreads : W))); // letters per cell, or one byte per thread and row
+	HIPCHK(c, c->d_aln_rev.ensure_grow((u64)LX + LY));
+	// one result record {path length, score, path}: one copy back, one wait
+	const u64 res_bytes = 8 + (u64)LX + LY;
+	HIPCHK(c, c->d_aln_res.ensure_grow(res_bytes));
+	HIPCHK(c, c->h_aln_res.ensure(res_bytes));
 	AlnParams ap;
 	ap.post = d_post; ap.LX = LX; ap.LY = LY;
-	ap.tb = c->d_aln_tb.as<char>(); ap.rev = c->d_aln_rev.as<char>(); ap.path = c->d_aln_path.as<char>();
-	ap.pathlen = c->d_aln_out.as<u32>(); ap.score = c->d_aln_out.as<float>() + 1;
-	(void)hipFuncSetAttribute(wave ? (const void *)calc_aln_wave_kernel : quad ? (const void *)calc_aln_quad_kernel : (const void *)calc_aln_kernel,
-		hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+	ap.tb = c->d_aln_tb.as<char>(); ap.rev = c->d_aln_rev.as<char>();
+	ap.pathlen = c->d_aln_res.as<u32>(); ap.score = c->d_aln_res.as<float>() + 1; ap.path = c->d_aln_res.as<char>() + 8;
+	const int which = wave ? 0 : quad ? 1 : 2;
+	if (smem > c->aln_smem_set[which]) { // raise the kernel's dynamic-LDS limit only when this call needs more than any before
+		(void)hipFuncSetAttribute(wave ? (const void *)calc_aln_wave_kernel : quad ? (const void *)calc_aln_quad_kernel : (const void *)calc_aln_kernel,
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+		c->aln_smem_set[which] = smem;
+	}
 	if (trace_on()) { fprintf(stderr, "[mpcgpu] calc_aln %u x %u: %s\n", LX, LY, wave ? "one wave" : quad ? "waves, rows in registers" : "rows in LDS"); fflush(stderr); }
 	TimedSpan ts_aln;
 	if (span_begin(c, 8, &ts_aln)) return 1;
@@ -1428,14 +1468,13 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	else MPC_LAUNCH(calc_aln_kernel, 1, MPC_ALN_THREADS, smem, c->stream, ap);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts_aln)) return 1;
-	u32 out[2] = {0, 0};
-	HIPCHK(c, hipMemcpyAsync(out, c->d_aln_out.p, 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->h_aln_res.p, c->d_aln_res.p, res_bytes, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
-	if (out[0] > LX + LY) return fail(c, "mpcgpu_calc_aln: path length %u out of range (internal error)", out[0]);
-	*pathlen = out[0];
-	if (score) memcpy(score, &out[1], 4);
-	if (out[0]) HIPCHK(c, hipMemcpyAsync(path, c->d_aln_path.p, out[0], hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const u32 n_path = c->h_aln_res.as<u32>()[0];
+	if (n_path > LX + LY) return fail(c, "mpcgpu_calc_aln: path length %u out of range (internal error)", n_path);
+	*pathlen = n_path;
+	if (score) memcpy(score, c->h_aln_res.as<char>() + 4, 4);
+	memcpy(path, c->h_aln_res.as<char>() + 8, n_path);
 	return 0;
 }
 
@@ -1458,25 +1497,31 @@ int mpcgpu_align_alns(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t
 	return mpcgpu_align_alns_w(c, n1, seq1, n2, seq2, C1, C2, pos2col1, pos2col2, nullptr, nullptr, path, pathlen, score);
 }
 
-// post[cell] = the cell's records added in key order, 0 where there are none (kernels_prog.h): zero the matrix, list the runs
-// of the sorted records, one wave per run. d_aln_post holds `cells` floats already.
-static int reduce_runs(mpcgpu_ctx *c, const u32 *keys_sorted, const float *vals_sorted, u64 M, u64 cells)
+// Buffers of the in-order reduction (kernels_prog.h): end of every cell's run, the list of runs, {runs, next run}. The
+// generating kernel zeroes the output matrix and the two counters.
+struct RunBufs { u32 *run_end, *heads, *counters; };
+static int prepare_runs(mpcgpu_ctx *c, u64 M, u64 cells, RunBufs *rb)
 {
 	if (cells > 0xffffffffull) return fail(c, "mpcgpu_align_alns: %llu cells exceed this build's cell index", (u64)cells);
-	HIPCHK(c, hipMemsetAsync(c->d_aln_post.p, 0, cells * 4, c->stream));
+	const u64 maxruns = std::min<u64>(M, cells);
+	HIPCHK(c, c->d_bp_runs.ensure_grow((cells + 2 * maxruns + 2) * 4));
+	rb->run_end = c->d_bp_runs.as<u32>(); rb->heads = rb->run_end + cells; rb->counters = rb->heads + 2 * maxruns;
+	return 0;
+}
+// post[cell] = the cell's records added in key order, 0 where there are none: list the runs of the sorted records, one wave per run.
+static int reduce_runs(mpcgpu_ctx *c, const RunBufs &rb, const u32 *keys_sorted, const float *vals_sorted, u64 M, u64 cells)
+{
 	if (!M) return 0;
 	const u64 maxruns = std::min<u64>(M, cells);
-	HIPCHK(c, c->d_bp_runs.ensure((cells + 2 * maxruns + 2) * 4));
-	u32 *run_end = c->d_bp_runs.as<u32>(), *heads = run_end + cells, *nheads = heads + 2 * maxruns, *next_run = nheads + 1;
-	HIPCHK(c, hipMemsetAsync(nheads, 0, 8, c->stream));
 	const u32 grid_cap = (u32)c->prop.multiProcessorCount * 8;
-	MPC_LAUNCH(build_post_heads_kernel, (u32)std::min<u64>((M + 255) / 256, grid_cap), 256, 0, c->stream, keys_sorted, (u64)M, run_end, heads,
-		nheads);
+	MPC_LAUNCH(build_post_heads_kernel, (u32)std::min<u64>((M + 255) / 256, grid_cap), 256, 0, c->stream, keys_sorted, (u64)M, rb.run_end, rb.heads,
+		rb.counters);
 	HIPCHK(c, hipGetLastError());
 	// two waves per SIMD pulling runs from a queue (kernels_prog.h); MPCGPU_BP_WAVES: resident waves per SIMD
-	const u32 red_grid = (u32)c->prop.multiProcessorCount * (u32)std::min(std::max(env_int("MPCGPU_BP_WAVES", 2), 1), 8);
-	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((maxruns + 3) / 4, red_grid), 256, 0, c->stream, vals_sorted, (const u32 *)run_end,
-		(const u32 *)heads, (const u32 *)nheads, next_run, c->d_aln_post.as<float>());
+	const int bp_waves = std::min(std::max(env_int("MPCGPU_BP_WAVES", 2), 1), 8);
+	const u32 red_grid = (u32)c->prop.multiProcessorCount * (u32)bp_waves;
+	MPC_LAUNCH(build_post_reduce_kernel, (u32)std::min<u64>((maxruns + 3) / 4, red_grid), 256, 0, c->stream, vals_sorted, (const u32 *)rb.run_end,
+		(const u32 *)rb.heads, (const u32 *)rb.counters, rb.counters + 1, c->d_aln_post.as<float>());
 	HIPCHK(c, hipGetLastError());
 	return 0;
 }
@@ -1497,21 +1542,39 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double t_prev = host_trace ? now() : 0.0;
 	auto lap = [&](int k) { if (host_trace) { const double t = now(); acc_t[k] += t - t_prev; t_prev = t; } };
-	// ---- host: maps, pair record offsets
-	std::vector<u32> seqs(seq1, seq1 + n1);
-	seqs.insert(seqs.end(), seq2, seq2 + n2);
-	std::vector<u64> off(n1 + n2 + 1, 0);
-	for (u32 a = 0; a < n1 + n2; ++a) {
-		if (seqs[a] >= n) return fail(c, "mpcgpu_align_alns: sequence index %u out of range", seqs[a]);
-		off[a + 1] = off[a] + c->len[seqs[a]];
+	// ---- host: everything the kernels need from this call in ONE page-locked record, one copy:
+	// [off: n1+n2+1 u64][coff: n1*n2+1 u64][seqs: n1+n2 u32][maps: len1+len2 u32][weights: n1+n2 f32, when not all 1.0f]
+	u64 len1 = 0, len2 = 0;
+	for (u32 a = 0; a < n1; ++a) {
+		if (seq1[a] >= n) return fail(c, "mpcgpu_align_alns: sequence index %u out of range", seq1[a]);
+		len1 += c->len[seq1[a]];
 	}
-	const u64 len1 = off[n1], len2 = off[n1 + n2] - off[n1];
-	std::vector<u32> maps(len1 + len2);
-	memcpy(maps.data(), pos2col1, len1 * 4);
-	memcpy(maps.data() + len1, pos2col2, len2 * 4);
+	for (u32 b = 0; b < n2; ++b) {
+		if (seq2[b] >= n) return fail(c, "mpcgpu_align_alns: sequence index %u out of range", seq2[b]);
+		len2 += c->len[seq2[b]];
+	}
+	if ((w1 != nullptr) != (w2 != nullptr)) return fail(c, "mpcgpu_align_alns_w: give both weight arrays or neither");
+	bool weighted = false; // all 1.0f (what MPCFlat::Run sets): (1*1)*P == P, skip the multiply
+	if (w1) {
+		for (u32 a = 0; a < n1; ++a) weighted = weighted || w1[a] != 1.0f;
+		for (u32 b = 0; b < n2; ++b) weighted = weighted || w2[b] != 1.0f;
+	}
+	const u64 npairs12 = (u64)n1 * n2;
+	const u64 o_off = 0, o_coff = o_off + 8 * ((u64)n1 + n2 + 1), o_seqs = o_coff + 8 * (npairs12 + 1), o_maps = o_seqs + 4 * ((u64)n1 + n2),
+		o_w = o_maps + 4 * (len1 + len2), in_bytes = o_w + (weighted ? 4 * ((u64)n1 + n2) : 0);
+	HIPCHK(c, c->h_bp_in.ensure(in_bytes));
+	char *hin = c->h_bp_in.as<char>();
+	u64 *off = (u64 *)(hin + o_off), *coff = (u64 *)(hin + o_coff);
+	u32 *seqs = (u32 *)(hin + o_seqs), *maps = (u32 *)(hin + o_maps);
+	memcpy(seqs, seq1, 4 * (size_t)n1);
+	memcpy(seqs + n1, seq2, 4 * (size_t)n2);
+	off[0] = 0;
+	for (u32 a = 0; a < n1 + n2; ++a) off[a + 1] = off[a] + c->len[seqs[a]];
+	memcpy(maps, pos2col1, len1 * 4);
+	memcpy(maps + len1, pos2col2, len2 * 4);
 	for (u64 q = 0; q < len1; ++q) if (maps[q] >= C1) return fail(c, "mpcgpu_align_alns: column map of MSA1 out of range");
 	for (u64 q = len1; q < len1 + len2; ++q) if (maps[q] >= C2) return fail(c, "mpcgpu_align_alns: column map of MSA2 out of range");
-	std::vector<u64> coff((u64)n1 * n2 + 1, 0);
+	coff[0] = 0;
 	for (u32 a = 0; a < n1; ++a)
 		for (u32 b = 0; b < n2; ++b) {
 			const u32 S = seqs[a], T = seqs[n1 + b];
@@ -1519,41 +1582,36 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 			const u64 k = S < T ? (u64)S * n - ((u64)S * (S + 1)) / 2 + (T - S - 1) : (u64)T * n - ((u64)T * (T + 1)) / 2 + (S - T - 1);
 			coff[(u64)a * n2 + b + 1] = coff[(u64)a * n2 + b] + c->all_nnz[k];
 		}
-	const u64 M = coff[(u64)n1 * n2];
+	if (weighted) {
+		float *w = (float *)(hin + o_w);
+		memcpy(w, w1, 4 * (size_t)n1);
+		memcpy(w + n1, w2, 4 * (size_t)n2);
+	}
+	const u64 M = coff[npairs12];
 	const u64 cells = (u64)C1 * C2;
 	if (cells > 0xffffffffull) return fail(c, "mpcgpu_align_alns: %llu cells exceed this build's cell index", (u64)cells);
 	const u32 bc = bits_for(cells - 1);
 	if (M > 0xffffffffull) return fail(c, "mpcgpu_align_alns: %llu contributions exceed this build's record count", (u64)M);
 	lap(0);
-	if (upload(c, c->d_bp_seq, seqs) || upload(c, c->d_bp_off, off) || upload(c, c->d_bp_map, maps) || upload(c, c->d_bp_coff, coff))
-		return 1;
+	HIPCHK(c, c->d_bp_in.ensure_grow(in_bytes));
+	HIPCHK(c, hipMemcpyAsync(c->d_bp_in.p, hin, in_bytes, hipMemcpyHostToDevice, c->stream));
 	lap(1);
-	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 4 * 2));
-	HIPCHK(c, c->d_bp_vals.ensure(std::max<u64>(M, 1) * 4 * 2));
-	HIPCHK(c, c->d_aln_post.ensure(cells * 4));
+	HIPCHK(c, c->d_bp_keys.ensure_grow(std::max<u64>(M, 1) * 4 * 2));
+	HIPCHK(c, c->d_bp_vals.ensure_grow(std::max<u64>(M, 1) * 4 * 2));
+	HIPCHK(c, c->d_aln_post.ensure_grow(cells * 4));
+	RunBufs rb;
+	if (prepare_runs(c, M, cells, &rb)) return 1;
 	u32 *keys_in = c->d_bp_keys.as<u32>(), *keys_out = keys_in + std::max<u64>(M, 1);
 	float *vals_in = c->d_bp_vals.as<float>(), *vals_out = vals_in + std::max<u64>(M, 1);
+	const char *din = c->d_bp_in.as<char>();
 	BuildPostParams bp;
 	fill_store_params(c, bp.s);
-	bp.seq1 = c->d_bp_seq.as<u32>(); bp.seq2 = bp.seq1 + n1; bp.n1 = n1; bp.n2 = n2;
-	bp.p2c1 = c->d_bp_map.as<u32>(); bp.p2c2 = bp.p2c1; // offsets below are into the one concatenated array
-	bp.p2c1_off = c->d_bp_off.as<u64>(); bp.p2c2_off = bp.p2c1_off + n1;
-	bp.C2 = C2; bp.coff = c->d_bp_coff.as<u64>(); bp.keys = keys_in; bp.vals = vals_in;
-	bp.w1 = bp.w2 = nullptr;
-	if ((w1 != nullptr) != (w2 != nullptr)) return fail(c, "mpcgpu_align_alns_w: give both weight arrays or neither");
-	if (w1) {
-		bool all_one = true; // all 1.0f (what MPCFlat::Run sets): (1*1)*P == P, skip the multiply
-		for (u32 a = 0; a < n1; ++a) all_one = all_one && w1[a] == 1.0f;
-		for (u32 b = 0; b < n2; ++b) all_one = all_one && w2[b] == 1.0f;
-		if (!all_one) {
-			std::vector<float> w(w1, w1 + n1);
-			w.insert(w.end(), w2, w2 + n2);
-			if (upload(c, c->d_bp_w, w)) return 1;
-			HIPCHK(c, hipStreamSynchronize(c->stream)); // `w` dies with this scope
-			bp.w1 = c->d_bp_w.as<float>(); bp.w2 = bp.w1 + n1;
-		}
-	}
-	const u64 npairs12 = (u64)n1 * n2;
+	bp.seq1 = (const u32 *)(din + o_seqs); bp.seq2 = bp.seq1 + n1; bp.n1 = n1; bp.n2 = n2;
+	bp.p2c1 = (const u32 *)(din + o_maps); bp.p2c2 = bp.p2c1; // offsets below are into the one concatenated array
+	bp.p2c1_off = (const u64 *)(din + o_off); bp.p2c2_off = bp.p2c1_off + n1;
+	bp.C2 = C2; bp.coff = (const u64 *)(din + o_coff); bp.keys = keys_in; bp.vals = vals_in;
+	bp.w1 = weighted ? (const float *)(din + o_w) : nullptr; bp.w2 = weighted ? bp.w1 + n1 : nullptr;
+	bp.post = c->d_aln_post.as<float>(); bp.cells = cells; bp.counters = rb.counters;
 	TimedSpan ts_bp;
 	if (span_begin(c, 5, &ts_bp)) return 1;
 	MPC_LAUNCH(build_post_gen_kernel, (u32)std::min<u64>(npairs12, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, bp);
@@ -1563,17 +1621,17 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 	const float *vals_sorted = vals_in;
 	if (span_begin(c, 6, &ts_bp)) return 1;
 	if (M > 1) {
-		HIPCHK(c, mpc_sort_pairs([&](size_t bytes) -> void * { return c->d_bp_tmp.ensure(bytes) == hipSuccess ? c->d_bp_tmp.p : nullptr; },
+		HIPCHK(c, mpc_sort_pairs([&](size_t bytes) -> void * { return c->d_bp_tmp.ensure_grow(bytes) == hipSuccess ? c->d_bp_tmp.p : nullptr; },
 			keys_in, keys_out, vals_in, vals_out, (size_t)M, bc, c->stream));
 		keys_sorted = keys_out;
 		vals_sorted = vals_out;
 	}
 	if (span_end(c, &ts_bp)) return 1;
 	if (span_begin(c, 7, &ts_bp)) return 1;
-	if (reduce_runs(c, keys_sorted, vals_sorted, M, cells)) return 1;
+	if (reduce_runs(c, rb, keys_sorted, vals_sorted, M, cells)) return 1;
 	if (span_end(c, &ts_bp)) return 1;
 	lap(2);
-	// the uploads above came from vectors that die with this call: drain before returning (run_calc_aln syncs)
+	// the staging record is reused by the next call: run_calc_aln ends with a wait for the stream
 	const int rc_aln = run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score);
 	lap(3);
 	if (host_trace && (++acc_n % 100) == 0)
@@ -1624,6 +1682,8 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	HIPCHK(c, c->d_bp_keys.ensure(std::max<u64>(M, 1) * 4 * 2));
 	HIPCHK(c, c->d_bp_vals.ensure(std::max<u64>(M, 1) * 4 * 2));
 	HIPCHK(c, c->d_aln_post.ensure(cells * 4));
+	RunBufs rb;
+	if (prepare_runs(c, M, cells, &rb)) return 1;
 	u32 *keys_in = c->d_bp_keys.as<u32>(), *keys_out = keys_in + std::max<u64>(M, 1);
 	float *vals_in = c->d_bp_vals.as<float>(), *vals_out = vals_in + std::max<u64>(M, 1);
 	BuildPostListParams lp;
@@ -1635,17 +1695,18 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	lp.coff = c->d_bp_coff.as<u64>(); lp.rbase = lp.coff + (npairs + 1);
 	lp.nnz = nullptr; // counts come from coff
 	lp.C2 = C2; lp.keys = keys_in; lp.vals = vals_in;
+	lp.post = c->d_aln_post.as<float>(); lp.cells = cells; lp.counters = rb.counters;
 	MPC_LAUNCH(build_post_list_gen_kernel, (u32)std::min<u64>(npairs, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, lp);
 	HIPCHK(c, hipGetLastError());
 	const u32 *keys_sorted = keys_in;
 	const float *vals_sorted = vals_in;
 	if (M > 1) {
-		HIPCHK(c, mpc_sort_pairs([&](size_t bytes) -> void * { return c->d_bp_tmp.ensure(bytes) == hipSuccess ? c->d_bp_tmp.p : nullptr; },
+		HIPCHK(c, mpc_sort_pairs([&](size_t bytes) -> void * { return c->d_bp_tmp.ensure_grow(bytes) == hipSuccess ? c->d_bp_tmp.p : nullptr; },
 			keys_in, keys_out, vals_in, vals_out, (size_t)M, bc, c->stream));
 		keys_sorted = keys_out;
 		vals_sorted = vals_out;
 	}
-	if (reduce_runs(c, keys_sorted, vals_sorted, M, cells)) return 1;
+	if (reduce_runs(c, rb, keys_sorted, vals_sorted, M, cells)) return 1;
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // syncs before the vectors above die
 }
 
@@ -1667,6 +1728,13 @@ int mpcgpu_timers_reset(mpcgpu_ctx *c)
 	if (!c) return 1;
 	if (spans_collect(c)) return 1;
 	for (int i = 0; i < MPCGPU_NKERNELS; ++i) { c->ms[i] = 0; c->launches[i] = 0; }
+	return 0;
+}
+
+int mpcgpu_timers_enable(mpcgpu_ctx *c, int on)
+{
+	if (!c) return 1;
+	c->timing = on != 0;
 	return 0;
 }
 

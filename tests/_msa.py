@@ -123,7 +123,8 @@ def run_muscle(binary, name, threads=4, timeout=900, env=None):
             with open(os.path.join(d, fn), "w") as f:
                 f.write(text)
         subprocess.run([binary, cmd, fa, "-output", out, "-threads", str(threads), "-quiet"] + cmd_extra + extra,
-                       check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL,
+                       stderr=None if os.environ.get("MUSCLE_GPU_TIMING") else subprocess.DEVNULL,
                        env=None if env is None else dict(os.environ, **env))
         with open(out, "rb") as f:
             data = f.read()
