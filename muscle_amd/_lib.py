@@ -374,6 +374,10 @@ class MpcGpu:
     def timers_reset(self):
         self._ck(self.L.mpcgpu_timers_reset(self.h))
 
+    def timers_enable(self, on=True):
+        """hipEvents around the launches on (default) / off (what the drop-in does unless MUSCLE_GPU_TIMING is set)."""
+        self._ck(self.L.mpcgpu_timers_enable(self.h, 1 if on else 0))
+
     def timers_get(self):
         ms = np.zeros(NKERNELS, np.float32)
         ln = np.zeros(NKERNELS, np.uint64)

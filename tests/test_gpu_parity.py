@@ -326,6 +326,13 @@ def test_align_alns_vs_restatement():
         sc0w, path0w = O.calc_aln(BP.build_post(stage, pidx, grp1, grp2, m1, m2, C1, C2, w1, w2))
         pathw, scw = g.align_alns(grp1, grp2, m1, m2, C1, C2, w1, w2)
         assert pathw == path0w and P.bits(scw) == P.bits(sc0w), ("weighted", cut)
+    # timing off (mpcgpu_timers_enable: what the drop-in runs with): same results, nothing measured
+    g.timers_reset()
+    g.timers_enable(False)
+    path, sc = g.align_alns(grp1, grp2, m1, m2, C1, C2)
+    assert path == path0 and P.bits(sc) == P.bits(sc0)
+    assert all(v == (0.0, 0) for v in g.timers_get().values())
+    g.timers_enable(True)
     g.close()
 
 
