@@ -74,15 +74,15 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 	}
 }
 
-// In-order sum of every output cell's run in the sorted records, ONE WAVE PER CELL. The sum of a cell is a chain
+// In-order sum of every output cell's run in the sorted records, ONE WAVE PER RUN. The sum of a cell is a chain
 //     (((0 + v0) + v1) + v2) ...                      (buildpostflat.cpp:27-30 zeroes Post, :74 / :96 add, w1*w2 == 1.0f)
 // whose order is fixed (float addition is not associative and CalcAlnFlat breaks ties on exact values), and the cells on the
 // alignment path receive a contribution from almost every (s,t) pair — 250 000 terms at the root of a 1000-sequence tree — so
 // the work cannot be one thread per cell (round 1: a serial load -> add chain per thread, 7.7 of the 11.8 s of the
 // progressive + refinement tail at 1000 x L~400, profiles/r02g_e2e_timing.log). Here the wave loads 64 consecutive terms at
 // once (coalesced) and runs the chain through its lanes (mpc_wave_chain_add, mpc_platform.h: one wave instruction per term,
-// every term added exactly once in sequence; lanes past the end of the run add +0.0f, exact for these non-negative sums). The run of a cell is found with two binary
-// searches made of scalar loads (the sorted keys are not written by this kernel).
+// every term added exactly once in sequence; lanes past the end of the run add +0.0f, exact for these non-negative sums).
+//
 // Run boundaries of the sorted records: record q opens a run when its cell differs from record q-1's. The opener appends
 // {cell, q} to the list of runs (one atomic per wave: the lanes that open a run are counted by a ballot) and closes the
 // previous run (run_end[previous cell] = q); the last record closes its own. Cells without records never appear: the matrix
