@@ -942,8 +942,9 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		fp.bnd = nullptr; fp.bnd_stride = 0; fp.bnd_ld = 0; fp.fm_block = 0;
 		// row-list post kernel (no sorts, 3 LDS trips per EA row) when LY fits its LDS arrays; MPCGPU_POST=sort forces the general one
 		const char *post_mode = getenv("MPCGPU_POST");
-		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) && LYmax + 1 <= 2048u &&
-			((size_t)LXmax + 2 + 2 * ((size_t)LYmax + 2)) * 4 + 8 + 8 * (size_t)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2) <= 64 * 1024;
+		// (up to ~12 000 positions: three arrays of one word per position + the sorted-list buffer in the CU's LDS)
+		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) &&
+			((size_t)LXmax + 2 + 2 * ((size_t)LYmax + 2)) * 4 + 8 + 8 * (size_t)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2) <= 150 * 1024;
 
 		TimedSpan sp;
 		u32 pos = 0;
@@ -958,7 +959,11 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			// resident waves are bounded by the forward M planes they keep (LX*LY floats each)
 			size_t freeb2 = 0, totb2 = 0;
 			HIPCHK(c, hipMemGetInfo(&freeb2, &totb2));
-			const u64 fm_budget = std::min<u64>((u64)env_int("MPCGPU_SCRATCH_GB", 16) << 30, (u64)(freeb2 * 0.5));
+			// (up to 45 % of what is free, counting the plane buffer already owned: 36 MB per 3000 x 3000 pair — with the 16 GB the
+			// other scratch is held to, 444 waves were resident where the chip takes 2048. The buffer stays allocated — hipMalloc and
+			// hipFree of ~100 GB take seconds — and is given back only when the store needs the room: mpcgpu_store_import)
+			const char *scratch_env = getenv("MPCGPU_SCRATCH_GB");
+			const u64 fm_budget = std::min<u64>((scratch_env && *scratch_env) ? (u64)atoi(scratch_env) << 30 : ~0ull, (u64)((freeb2 + c->d_fm.cap) * 0.45));
 			const u64 max_waves = fm_budget / (fm_stride * 4 + 16ull * ld * 4);
 			if (max_waves < 1)
 				return fail(c, "mpcgpu_calc_posteriors: not enough device memory for the forward plane of a %u x %u pair", LXlong, LYlong);
@@ -1017,8 +1022,9 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			pr.sort_stride = capc;
 			pr.batch = (u32)std::min(std::max(env_int("MPCGPU_POST_BATCH", 64), 1), 64);
 			const size_t smem = ((((size_t)pr.lx_cap + 2 * (size_t)pr.ly_cap) * 4 + 7) & ~(size_t)7) + (size_t)pr.sort_cap * 8;
+			if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void *)post_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 			int pocc = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_rows_kernel, 64, smem) != hipSuccess || pocc < 1) pocc = 8;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_rows_kernel, 64, smem) != hipSuccess || pocc < 1) pocc = 1;
 			const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
 			HIPCHK(c, c->d_sort_scratch.ensure(capc > pr.sort_cap ? (u64)pgrid * pr.sort_stride * 8 : 8));
 			pr.sort_scratch = c->d_sort_scratch.as<u64>();
@@ -1177,6 +1183,15 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	c->have_store = false;
 	c->tiles_k0 = c->tiles_k1 = ~0ull;
 	const u32 n = c->n;
+	// the forward planes of a row-block stage A may hold a large share of the device: give them back if the store (roughly four
+	// times the packed records) could not be allocated next to them
+	if (c->d_fm.cap > (8ull << 30)) {
+		u64 packed_bytes = 0;
+		for (u32 s = 0; s < nshards; ++s) packed_bytes += bytes[s];
+		size_t free_now = 0, total_now = 0;
+		HIPCHK(c, hipMemGetInfo(&free_now, &total_now));
+		if ((u64)free_now < 5 * packed_bytes + (4ull << 30)) c->d_fm.release();
+	}
 	// ---- read shard headers, check coverage
 	c->all_nnz.assign(c->npairs, 0);
 	c->all_ea.assign(c->npairs, 0.0f);

@@ -1,6 +1,8 @@
 """Parity tests proper (-m gpu): the HIP path through the C ABI vs the CPU oracle / golden fixtures
 on the same inputs. Bit-exact: integer structure (offsets, columns) AND float posteriors/EA (the
 north star allows 1e-4 on floats; we hold 0 ulp because the final MSA depends on exact values)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -83,8 +85,8 @@ def test_ragged_and_extremes():
 
 def test_long_rows_row_blocks():
     """X longer than 64*16 rows: the row-block kernel (fb_kernel<7, MEGA, LONG>: 448-row blocks chained through
-    the line buffers). 1024 is the last single-block length, 1025 the first with blocks; 2049 columns also
-    sends the batch to the general post kernel; the relax of such records takes the gather fallback."""
+    the line buffers). 1024 is the last single-block length, 1025 the first with blocks; with 2049 columns the row-list
+    post kernel needs more than 64 KB of LDS; the relax of such records takes the gather fallback."""
     seqs = [make_family(1, 1500, seed=41)[0][:1500], (make_family(1, 1100, seed=42)[0] * 2)[:1025],
             (make_family(1, 1100, seed=43)[0] * 2)[:1024], make_family(1, 333, seed=44)[0],
             (make_family(1, 2300, seed=45)[0] * 2)[:2049]]
@@ -97,6 +99,21 @@ def test_long_rows_row_lists_and_mega():
     P.assert_same(P.run_lib(seqs), P.run_oracle(seqs, threads=0), "row blocks, row lists")
     mega = P.random_mega(seqs, seed=13)
     P.assert_same(P.run_lib(seqs, mega=mega), P.run_oracle(seqs, mega=mega, threads=0), "row blocks, mega")
+
+
+def test_long_related_sequences():
+    """two RELATED sequences of ~2600 residues (plus a short one): row blocks in both directions of the pair list, more stored
+    cells per pair than the row-list post kernel's LDS list holds (its global scratch), EA rows over 2600 columns"""
+    fam = make_family(2, 2600, seed=61)
+    seqs = [fam[0], fam[1], make_family(1, 120, seed=62)[0]]
+    P.assert_same(P.run_lib(seqs), P.run_oracle(seqs, threads=0), "long related sequences")
+    got = None
+    os.environ["MPCGPU_POST"] = "sort"  # the general post kernel on the same input
+    try:
+        got = P.run_lib(seqs)
+    finally:
+        del os.environ["MPCGPU_POST"]
+    P.assert_same(got, P.run_oracle(seqs, threads=0), "long related sequences, general post kernel")
 
 
 def test_very_long_row_sequence():
