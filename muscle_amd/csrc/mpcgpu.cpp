@@ -1018,13 +1018,23 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			pr.cand = c->d_cand.as<u64>(); pr.capc = capc; pr.cand_cnt = c->d_cand_cnt.as<u32>();
 			pr.use_fma = c->use_fma;
 			pr.lx_cap = LXmax + 2; pr.ly_cap = LYmax + 2;
-			pr.sort_cap = std::min<u32>(capc, (u32)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2));
+			// LDS list of a pair's candidates (larger lists cost resident waves, pairs that exceed it sort through HBM scratch; per
+			// batch of 125 000 pairs at L~400: 512 entries 16.9 ms, 768: 12.3, 896: 11.9, 1024: 11.7, 1280: 12.7, 1408 (holds every
+			// pair): 14.0, 1664: 15.8)
+			const u32 sort_cap = (u32)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2);
+			pr.sort_cap = std::min<u32>(capc, sort_cap);
 			pr.sort_stride = capc;
 			pr.batch = (u32)std::min(std::max(env_int("MPCGPU_POST_BATCH", 64), 1), 64);
-			const size_t smem = ((((size_t)pr.lx_cap + 2 * (size_t)pr.ly_cap) * 4 + 7) & ~(size_t)7) + (size_t)pr.sort_cap * 8;
+			const size_t fixed_lds = ((((size_t)pr.lx_cap + 2 * (size_t)pr.ly_cap) * 4 + 7) & ~(size_t)7);
+			if (fixed_lds + (size_t)pr.sort_cap * 8 > 150 * 1024) pr.sort_cap = (u32)((150 * 1024 - fixed_lds) / 8); // long sequences: the arrays per position come first
+			const size_t smem = fixed_lds + (size_t)pr.sort_cap * 8;
 			if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void *)post_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 			int pocc = 0;
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_rows_kernel, 64, smem) != hipSuccess || pocc < 1) pocc = 1;
+			// The persistent grid must not be larger than what is really resident, or its last workgroups run as a second round
+			// (measured, per batch of 125 000 pairs: 15 248 B of LDS, 10 workgroups per CU reported: 12.7 ms; 15 760 B, still 10
+			// reported: 22.5 ms; 17 296 B, 9 reported: 14.1 ms — 64-thread workgroups stop fitting at ~152 KB per CU, not 160)
+			pocc = std::max(1, std::min(pocc, (int)((152 * 1024) / smem)));
 			const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
 			HIPCHK(c, c->d_sort_scratch.ensure(capc > pr.sort_cap ? (u64)pgrid * pr.sort_stride * 8 : 8));
 			pr.sort_scratch = c->d_sort_scratch.as<u64>();
@@ -1039,7 +1049,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 				HIPCHK(c, hipMemsetAsync(c->d_post_prof.p, 0, 64, c->stream));
 				pr.prof = c->d_post_prof.as<u64>();
 			}
-			if (trace_on()) { fprintf(stderr, "[mpcgpu] post rows: lds=%zu B blocks/CU=%d grid=%u\n", smem, pocc, pgrid); fflush(stderr); }
+			if (trace_on()) { fprintf(stderr, "[mpcgpu] post rows: list of %u candidates in LDS, lds=%zu B blocks/CU=%d grid=%u\n", pr.sort_cap, smem, pocc, pgrid); fflush(stderr); }
 			if (span_begin(c, 1, &sp)) return 1;
 			MPC_LAUNCH(post_rows_kernel, pgrid, 64, smem, c->stream, pr);
 			HIPCHK(c, hipGetLastError());
@@ -1066,6 +1076,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		const size_t psmem0 = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
 		int pocc = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_kernel, 64, psmem0) != hipSuccess || pocc < 1) pocc = 8;
+		if (psmem0) pocc = std::max(1, std::min(pocc, (int)((152 * 1024) / psmem0))); // as for post_rows_kernel above
 		const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
 		if (trace_on()) { fprintf(stderr, "[mpcgpu] post: sort_cap=%u lds=%zu B blocks/CU=%d grid=%u\n", pp.sort_cap, psmem0, pocc, pgrid); fflush(stderr); }
 		pp.sort_stride = next_pow2(capc);
