@@ -37,6 +37,7 @@ struct RelaxVarParams {
 	u64 k0, k1;    // only pairs in [k0,k1) are relaxed (multi-GPU shard)
 	u32 nbuf;      // LDS staging buffers: 2 = DMA of step Z+1 under the merges of step Z, 1 = DMA, wait, merge
 	u32 buf_bytes; // capacity of one staging buffer (the second starts buf_bytes after the first)
+	u32 *tile_next; // 8 counters, zeroed before the launch: next tile of each XCD's range
 };
 
 // THREADS: workgroup size; MAXSLOTS: cells per lane (the host splits any tile whose wave-aligned cells need more);
@@ -57,14 +58,30 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 	mpc_const_u32p rec_off = MPC_CONST_U32(s.rec_off); // read with scalar loads
 	const u32 lds0 = mpc_lds_addr(smem_raw);            // 32-bit LDS address of the dynamic LDS
 
-	// XCD-aware static schedule (block b runs on XCD b % 8 — affinity only): the tile list is cut into 8 contiguous
-	// ranges, the workgroups of one XCD walk their range round-robin.
+	// XCD-aware schedule (block b runs on XCD b % 8 — affinity only): the tile list is cut into 8 contiguous ranges and the
+	// workgroups of one XCD take the tiles of their range one after the other from a counter (neighbouring tiles share the Y
+	// records in that XCD's L2); a workgroup whose range is used up takes from the other ranges, so nobody waits at the end for
+	// a workgroup that happened to get the dearer tiles (tiles differ: 4x4 / 4x2, stored cells).
 	const u32 G = gridDim.x < 8u ? gridDim.x : 8u;
-	const u32 xcd = blockIdx.x % G, lb = blockIdx.x / G, per_xcd = (gridDim.x - xcd + G - 1u) / G;
+	const u32 xcd = blockIdx.x % G;
 	const u32 chunk = (p.ntiles + G - 1u) / G;
-	const u32 t_begin = xcd * chunk, t_end = (t_begin + chunk < p.ntiles) ? t_begin + chunk : p.ntiles;
 
-	for (u32 tl = t_begin + lb; tl < t_end; tl += per_xcd) {
+	for (;;) {
+		__syncthreads(); // the previous tile is done with the pair table and the staging buffers
+		if (tid == 0) {
+			u32 got = 0xffffffffu;
+			for (u32 k = 0; k < G && got == 0xffffffffu; ++k) {
+				const u32 r = (xcd + k) % G;
+				const u32 t_begin = r * chunk, t_end = (t_begin + chunk < p.ntiles) ? t_begin + chunk : p.ntiles;
+				if (t_begin >= t_end) continue;
+				const u32 t = atomicAdd(&p.tile_next[r], 1u);
+				if (t < t_end - t_begin) got = t_begin + t;
+			}
+			ptab[8 * 15 + 7] = got;
+		}
+		__syncthreads();
+		const u32 tl = mpc_wave_first(ptab[8 * 15 + 7]);
+		if (tl == 0xffffffffu) break;
 		const u32 x0 = p.tiles[4 * tl], nx = p.tiles[4 * tl + 1], y0 = p.tiles[4 * tl + 2], ny = p.tiles[4 * tl + 3];
 		// resident sequences: the X range, then the part of the Y range not already in it (wave-uniform, SGPRs)
 		u32 seq[MPC_RV_MAXSEQ];
@@ -87,7 +104,6 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 				++nseq;
 			}
 		}
-		__syncthreads(); // the previous tile is done with the pair table and the staging buffers
 		// ---- pair table: pair (ix, iy) of the tile -> first cell, stored cells, the LDS record slots of its two sequences.
 		// Lane q of wave 0 looks after pair q; a 16-lane inclusive scan lays the pairs' cell ranges end to end, each rounded
 		// up to whole waves so that the 64 cells of any (wave, slot) belong to ONE pair.

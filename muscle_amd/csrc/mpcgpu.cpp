@@ -137,7 +137,7 @@ struct mpcgpu_ctx {
 	u32 max_nnz = 0, max_len = 0;
 	HostBuf h_bp_in, h_aln_res;
 	size_t aln_smem_set[3] = {0, 0, 0}; // largest dynamic LDS each CalcAlnFlat kernel has been allowed so far
-	DevBuf d_bp_in, d_aln_res, d_post_prof, d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_runs;
+	DevBuf d_tile_next, d_bp_in, d_aln_res, d_post_prof, d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_runs;
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev;
 	bool have_pad = false;       // variable-size dense records + relax_var_kernel (else: slabs + gather relax)
 	u32 pad_lcap1 = 0;           // longest sequence (LDS scratch of var_build_kernel)
@@ -471,6 +471,9 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	RelaxVarParams rp;
 	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
 	rp.k0 = k0; rp.k1 = k1; rp.nbuf = nbuf; rp.buf_bytes = buf_bytes;
+	HIPCHK(c, c->d_tile_next.ensure(8 * 4));
+	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 8 * 4, c->stream));
+	rp.tile_next = c->d_tile_next.as<u32>();
 	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only
 	const void *fn = geo == 1024 ? (diag == 1 ? (const void *)relax_var_kernel<1024, 16, 1, 1> : (const void *)relax_var_kernel<1024, 16, 1>)
 	               : geo == 2048 ? (const void *)relax_var_kernel<1024, 14, 2> : geo == 768 ? (const void *)relax_var_kernel<768, 18, 2>
@@ -618,7 +621,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
 		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_pos, &c->d_bp_seq, &c->d_bp_map, &c->d_bp_off, &c->d_bp_coff,
-		&c->d_bp_in, &c->d_aln_res, &c->d_post_prof, &c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev};
+		&c->d_tile_next, &c->d_bp_in, &c->d_aln_res, &c->d_post_prof, &c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev};
 	for (DevBuf *b : all) b->release();
 	c->h_bp_in.release();
 	c->h_aln_res.release();
