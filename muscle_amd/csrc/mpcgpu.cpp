@@ -287,15 +287,18 @@ template <int H, bool MEGA, bool LONG = false> int occ_fb(u32 block, size_t smem
 // Row-block kernels (sequences X longer than 64*MPC_HMAX): H = MPC_LONG_H rows per lane; H = 1 exists so that
 // tests reach several blocks with short sequences (MPCGPU_FB_LONG_H=1 MPCGPU_FB_LONG_MIN=<rows>).
 #define MPC_LONG_H 7
+#define MPC_LONG_H_SMALL 4 // 166 VGPRs (3 waves per SIMD) where H = 7 needs 217 (2): used when memory lets more than 2 waves per SIMD be resident
 int occ_fb_long(int H, bool mega, u32 block, size_t smem)
 {
 	if (H == 1) return mega ? occ_fb<1, true, true>(block, smem) : occ_fb<1, false, true>(block, smem);
+	if (H == MPC_LONG_H_SMALL) return mega ? occ_fb<MPC_LONG_H_SMALL, true, true>(block, smem) : occ_fb<MPC_LONG_H_SMALL, false, true>(block, smem);
 	return mega ? occ_fb<MPC_LONG_H, true, true>(block, smem) : occ_fb<MPC_LONG_H, false, true>(block, smem);
 }
 
 void launch_fb_long(int H, bool mega, const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
 	if (H == 1) { if (mega) launch_fb<1, true, true>(p, grid, block, smem, st); else launch_fb<1, false, true>(p, grid, block, smem, st); }
+	else if (H == MPC_LONG_H_SMALL) { if (mega) launch_fb<MPC_LONG_H_SMALL, true, true>(p, grid, block, smem, st); else launch_fb<MPC_LONG_H_SMALL, false, true>(p, grid, block, smem, st); }
 	else if (mega) launch_fb<MPC_LONG_H, true, true>(p, grid, block, smem, st);
 	else launch_fb<MPC_LONG_H, false, true>(p, grid, block, smem, st);
 }
@@ -845,7 +848,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		c->work_cells += (u64)(LX + 1) * (LY + 1);
 	}
 	// X longer than 64*MPC_HMAX rows: row-block (LONG) kernels, 16-bit row/column candidate keys
-	const u32 long_h = env_int("MPCGPU_FB_LONG_H", MPC_LONG_H) == 1 ? 1u : (u32)MPC_LONG_H;
+	const int long_h_env = env_int("MPCGPU_FB_LONG_H", 0); // 0 = chosen below, 1 / 4 / 7 = forced (1: tests reach several blocks with short sequences)
 	const u32 long_min = (u32)std::min(std::max(env_int("MPCGPU_FB_LONG_MIN", 64 * MPC_HMAX + 1), 2), 64 * MPC_HMAX + 1);
 	u32 LXlong = 0, LYlong = 0; // extents over the LONG pairs
 	for (u64 k = 0; k < np; ++k) {
@@ -955,10 +958,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			const u32 cnt = hcount[MPC_HMAX + 1];
 			u32 first = 0;
 			for (u32 H = 1; H <= MPC_HMAX; ++H) first += hcount[H];
-			const u32 nbmax = (LXlong + 64 * long_h - 1) / (64 * long_h);
-			const u64 fm_block = (u64)(LYlong + 64) * long_h * 64;
-			const u64 fm_stride = fm_block * nbmax;
 			const u32 ld = (LYlong + 2 + 63) & ~63u;
+			auto planes = [&](u32 h, u32 *nb, u64 *blk) { *nb = (LXlong + 64 * h - 1) / (64 * h); *blk = (u64)(LYlong + 64) * h * 64; return *blk * *nb; };
 			// resident waves are bounded by the forward M planes they keep (LX*LY floats each)
 			size_t freeb2 = 0, totb2 = 0;
 			HIPCHK(c, hipMemGetInfo(&freeb2, &totb2));
@@ -967,6 +968,18 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			// hipFree of ~100 GB take seconds — and is given back only when the store needs the room: mpcgpu_store_import)
 			const char *scratch_env = getenv("MPCGPU_SCRATCH_GB");
 			const u64 fm_budget = std::min<u64>((scratch_env && *scratch_env) ? (u64)atoi(scratch_env) << 30 : ~0ull, (u64)((freeb2 + c->d_fm.cap) * 0.45));
+			// rows per lane: 7 (217 VGPRs, 2 waves per SIMD), or 4 (166 VGPRs, 3 waves per SIMD; more blocks, more line-buffer
+			// traffic) when the pairs and the memory for their forward planes can keep more than 2 waves per SIMD busy
+			// (100 x L~3000: 517 -> 407 ms; 64 x L~6000, 875 waves fit: 1985 ms with 7 rows, 2190 with 4)
+			u32 long_h = long_h_env == 1 ? 1u : long_h_env == MPC_LONG_H_SMALL ? (u32)MPC_LONG_H_SMALL : (u32)MPC_LONG_H;
+			u32 nbmax = 0;
+			u64 fm_block = 0;
+			if (long_h_env == 0) {
+				const u64 stride_small = planes(MPC_LONG_H_SMALL, &nbmax, &fm_block);
+				const u64 waves_small = std::min<u64>(cnt, fm_budget / (stride_small * 4 + 16ull * ld * 4));
+				if (waves_small > (u64)cus * 4 * 2) long_h = MPC_LONG_H_SMALL;
+			}
+			const u64 fm_stride = planes(long_h, &nbmax, &fm_block);
 			const u64 max_waves = fm_budget / (fm_stride * 4 + 16ull * ld * 4);
 			if (max_waves < 1)
 				return fail(c, "mpcgpu_calc_posteriors: not enough device memory for the forward plane of a %u x %u pair", LXlong, LYlong);

@@ -114,6 +114,12 @@ def test_long_related_sequences():
     finally:
         del os.environ["MPCGPU_POST"]
     P.assert_same(got, P.run_oracle(seqs, threads=0), "long related sequences, general post kernel")
+    os.environ["MPCGPU_FB_LONG_H"] = "4"  # the 4-rows-per-lane row-block kernel (chosen by itself only when thousands of long pairs are resident)
+    try:
+        got = P.run_lib(seqs)
+    finally:
+        del os.environ["MPCGPU_FB_LONG_H"]
+    P.assert_same(got, P.run_oracle(seqs, threads=0), "long related sequences, 4 rows per lane")
 
 
 def test_very_long_row_sequence():
