@@ -849,7 +849,10 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	}
 	// X longer than 64*MPC_HMAX rows: row-block (LONG) kernels, 16-bit row/column candidate keys
 	const int long_h_env = env_int("MPCGPU_FB_LONG_H", 0); // 0 = chosen below, 1 / 4 / 7 = forced (1: tests reach several blocks with short sequences)
-	const u32 long_min = (u32)std::min(std::max(env_int("MPCGPU_FB_LONG_MIN", 64 * MPC_HMAX + 1), 2), 64 * MPC_HMAX + 1);
+	// Row sequences from 769 residues on take the row-block kernels: one block of 13..16 rows per lane needs 177..219 VGPRs (2 waves
+	// per SIMD), blocks of 4 rows per lane 166 (3 waves): 300 x L~1000 fb 439 -> 366 ms; up to 12 rows per lane (<= 167 VGPRs)
+	// the single block wins (400 x L~600: 228 against 297 ms). 1025 is where a single block stops being possible.
+	const u32 long_min = (u32)std::min(std::max(env_int("MPCGPU_FB_LONG_MIN", 64 * 12 + 1), 2), 64 * MPC_HMAX + 1);
 	u32 LXlong = 0, LYlong = 0; // extents over the LONG pairs
 	for (u64 k = 0; k < np; ++k) {
 		const u32 LX = c->len[px[k]], LY = c->len[py[k]];
