@@ -25,7 +25,8 @@
 // is one rounded multiply either way), every position carries its <= 8 feature letters packed in a
 // u64, and a cell's match score is the in-order sum of <= 8 LDS lookups.
 //
-// Row blocks, LONG = true (X longer than 64*MPC_HMAX rows): the rows are cut into blocks of 64*H; the
+// Row blocks, LONG = true (X longer than 64*MPC_HMAX rows — and, by the host's choice, from 769 rows on, where a single block
+// would need 13+ rows per lane and 177+ VGPRs): the rows are cut into blocks of 64*H; the
 // forward sweep runs block after block, lane 63's last row (all five states, every column) going through
 // a small HBM line buffer to lane 0 of the next block, which reads it back 64 columns at a time (one
 // coalesced load per state every 64 steps + one v_readlane per step). The backward sweep runs the blocks
