@@ -104,8 +104,11 @@ __device__ __forceinline__ float mpc_mega_match(const float *s_tab, const u32 *a
 	return m;
 }
 
+// With 8 rows per lane the kernel is held to 128 VGPRs (4 waves per SIMD: the second launch-bounds argument; it needs 129
+// without it, and 3 waves per SIMD cost 19 %): 400 x L~480 fb 156 -> 139 ms. Fewer rows fit anyway (7 rows: 117;
+// given the bound the compiler schedules them differently and the L~400 headline loses 1.7 %, so they are left alone).
 template <int H, bool MEGA, bool LONG>
-__global__ void __launch_bounds__(256) fb_kernel(FbParams p)
+__global__ void __launch_bounds__(256, (H == 8 && !MEGA && !LONG) ? 4 : 1) fb_kernel(FbParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
 	// LOGEXP1 coefficient table: statically allocated, so its LDS address is a compile-time constant that rides in the

@@ -83,6 +83,12 @@ def test_ragged_and_extremes():
     P.assert_same(P.run_lib(seqs), P.run_oracle(seqs, threads=0), "ragged")
 
 
+def test_eight_rows_per_lane():
+    """449..512 residues: fb_kernel<8>, the instantiation held to 128 VGPRs by its launch bounds (a few spilled dwords)"""
+    seqs = make_family(6, 480, seed=71) + [make_family(1, 512, seed=72)[0][:512], make_family(1, 449, seed=73)[0][:449]]
+    P.assert_same(P.run_lib(seqs), P.run_oracle(seqs, threads=0), "8 rows per lane")
+
+
 def test_long_rows_row_blocks():
     """X longer than 64*16 rows: the row-block kernel (fb_kernel<7, MEGA, LONG>: 448-row blocks chained through
     the line buffers). 1024 is the last single-block length, 1025 the first with blocks; with 2049 columns the row-list
