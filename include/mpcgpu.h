@@ -54,9 +54,11 @@ int mpcgpu_set_hmm(mpcgpu_ctx *ctx, const float start[5], const float trans[25],
  * The bytes are copied; at most 64 distinct byte values may occur over all sequences.
  * Also performs MPCFlat::InitPairs (all i<j pairs). Length overflow check of
  * calcposteriorflat.cpp:54-61 (LX*LY*5+100 > INT_MAX) is preserved as an error. Build limits beyond
- * the reference's: a pair whose row sequence is longer than 1024 takes the row-block kernels, which
- * need both lengths <= 65535 (the reference's own limit is ~21k x 21k); the consistency relax runs
- * LDS-tiled for sequences up to 8191 and through the gather kernel beyond. */
+ * the reference's: a pair whose row sequence is longer than 768 takes the row-block kernels (a choice up to
+ * 1024, the only way beyond), which need both lengths <= 65535 (the reference's own limit is ~21k x 21k); the
+ * consistency relax runs LDS-tiled while the records of a pair fit the CU's LDS (sequences of up to ~1000-2000 residues,
+ * depending on how many cells a row stores; never beyond 4095) and through the gather kernel beyond —
+ * mpcgpu_relax_info says which. */
 int mpcgpu_set_seqs(mpcgpu_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens);
 
 /* Structure-profile ("mega") emissions for stage A. Replaces the Mega statics a .mega input fills
