@@ -173,6 +173,48 @@ def test_emu_align_alns(emu):
     g.close()
 
 
+def test_emu_align_alns_long_runs(emu):
+    """Runs of the in-order reduction longer than one chunk (64 terms) and than one group of chunks (512): 24 x 24 closely
+    related sequences, so the cells on the path collect a term from most of the 1024 pairs."""
+    import _buildpost as BP
+    import _oracle as O
+    from muscle_amd._lib import MpcGpu
+    rng = np.random.default_rng(9)
+    n = 64
+    seqs = make_family(n, 14, seed=31, p_del=0.01, p_ins=0.01, p_sub=0.05)
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, emu)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    g.build_store()
+    stage = g.get_sparse_range()
+    pidx = {p: k for k, p in enumerate((a, b) for a in range(n) for b in range(a + 1, n))}
+    grp1, grp2 = list(range(0, n, 2)), list(range(1, n, 2))  # both orientations of the stored pairs occur
+    rows1, C1 = BP.random_msa(seqs, grp1, rng)
+    rows2, C2 = BP.random_msa(seqs, grp2, rng)
+    m1 = [BP.pos_to_col(r) for r in rows1]
+    m2 = [BP.pos_to_col(r) for r in rows2]
+    post = BP.build_post(stage, pidx, grp1, grp2, m1, m2, C1, C2)
+    # the longest run: contributions to one cell (each stored entry of each cross pair lands in exactly one)
+    cnt = np.zeros((C1, C2), np.int64)
+    for a, S in enumerate(grp1):
+        for b, T in enumerate(grp2):
+            off, val = stage[pidx[(min(S, T), max(S, T))]]
+            col = val[1::2]
+            for i in range(len(off) - 1):
+                for k in range(off[i], off[i + 1]):
+                    if S < T:
+                        cnt[m1[a][i], m2[b][col[k]]] += 1
+                    else:
+                        cnt[m1[a][col[k]], m2[b][i]] += 1
+    assert cnt.max() > 512 and (cnt > 64).sum() > 10
+    sc0, path0 = O.calc_aln(post)
+    path, sc = g.align_alns(grp1, grp2, m1, m2, C1, C2)
+    assert path == path0 and P.bits(sc) == P.bits(sc0)
+    g.close()
+
+
 def test_emu_align_msas(emu):
     """PProg's MSA x MSA join on the device (mpcgpu_align_msas: stage A on an explicit pair list, both
     index orders, + CalcPosteriorFlat3 + CalcAlnFlat) vs the oracle per pair and a numpy restatement
