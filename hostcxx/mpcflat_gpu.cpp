@@ -46,9 +46,10 @@
 #include <thread>
 
 // hostcxx/rand_isolate.cpp
-extern "C" void MuscleGpuRandThreadSeek(unsigned long long Offset);
+struct MuscleGpuRandSnapshot { char m_State[128]; int m_FOff; int m_ROff; }; // hostcxx/rand_isolate.cpp
+extern "C" void MuscleGpuRandSharedSnapshots(const unsigned long long *Draws, unsigned Count, MuscleGpuRandSnapshot *At);
+extern "C" void MuscleGpuRandThreadRestore(const MuscleGpuRandSnapshot *At);
 extern "C" void MuscleGpuRandThreadEnd(void);
-extern "C" void MuscleGpuRandSharedSkip(unsigned long long Count);
 
 namespace
 {
@@ -65,17 +66,29 @@ struct Batch
 // fresh MPCFlat at the same stack address per query) must get a new batch, not the previous one's numbers
 	vector<const byte *> m_SeqPtrs;
 	vector<uint> m_SeqLens;
-	vector<uint64_t> m_SeqEnds; // first and last 4 bytes of every sequence
+	vector<uint64_t> m_SeqEnds; // 64-bit content hash of every sequence (all bytes)
 	};
 
+// 64-bit hash of ALL bytes of a sequence, 8 bytes per step (multiply-xorshift rounds): ~50 ns for 400 residues, so every
+// CalcPosterior call can afford to re-check both of its sequences — a caller that rewrites the middle of a buffer in place
+// (same pointer, same length, same ends) gets a new batch instead of the previous contents' posteriors.
 uint64_t SeqEnds(const byte *p, uint L)
 	{
-	uint64_t v = 0;
-	for (uint i = 0; i < 4 && i < L; ++i)
-		v = (v << 8) | p[i];
-	for (uint i = 0; i < 4 && i < L; ++i)
-		v = (v << 8) | p[L - 1 - i];
-	return v;
+	uint64_t h = 0x9e3779b97f4a7c15ull ^ ((uint64_t) L * 0xff51afd7ed558ccdull);
+	uint i = 0;
+	for (; i + 8 <= L; i += 8)
+		{
+		uint64_t w;
+		memcpy(&w, p + i, 8);
+		h = (h ^ w) * 0x9fb21c651e98df25ull;
+		h ^= h >> 29;
+		}
+	uint64_t w = 0;
+	for (uint k = 0; i + k < L; ++k)
+		w |= (uint64_t) p[i + k] << (8 * k);
+	h = (h ^ w) * 0x9fb21c651e98df25ull;
+	h ^= h >> 32;
+	return h;
 	}
 
 // One Slot = one device context (or one group of contexts) with the state of the MPCFlat run it is serving. Slot 0 serves every
@@ -808,19 +821,28 @@ void Super7::IntraAlignShrubs()
 		return;
 		}
 
-// where the sequential loop's rand() stream stands when shrub k starts
-	vector<unsigned long long> RandOffset(ShrubCount + 1, 0);
+// where the sequential loop's rand() stream stands when shrub k starts: the shared generator is advanced ONCE past all
+// shrubs (linear in the number of draws) and its state is snapshotted at every shrub's first draw
+	vector<unsigned long long> RandDraws(ShrubCount, 0);
 	for (uint ShrubIndex = 0; ShrubIndex < ShrubCount; ++ShrubIndex)
 		{
 		vector<uint> LeafNodes;
 		m_GuideTree->GetSubtreeLeafNodes(m_ShrubLCAs[ShrubIndex], LeafNodes);
 		const unsigned long long n = SIZE(LeafNodes);
-		const unsigned long long Draws = (n >= 3) ? n*m_MPC->m_RefineIterCount : 0; // mpcflat.cpp:254-264
-		RandOffset[ShrubIndex + 1] = RandOffset[ShrubIndex] + Draws;
+		RandDraws[ShrubIndex] = (n >= 3) ? n*m_MPC->m_RefineIterCount : 0; // mpcflat.cpp:254-264
 		}
+	vector<MuscleGpuRandSnapshot> RandAt(ShrubCount);
+	MuscleGpuRandSharedSnapshots(RandDraws.data(), ShrubCount, RandAt.data());
 
 	const double ShrubsBegin = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count();
 	m_ShrubMSAs.assign(ShrubCount, (const MultiSequence *) 0);
+// MPCFlat::Run reports through ProgressStep / Progress (myutils.cpp:1542-1870), which keep their state in unguarded process
+// globals (g_ProgressDesc, g_StepCalls, g_CountsInterval — the latter passes through 0, and another thread's
+// `g_StepCalls % g_CountsInterval` would then trap). The worker threads therefore run quiet; the shrub count is reported
+// from here, as the sequential loop's "Aligning shrub i / N" lines would have.
+	const bool SavedQuiet = opt_quiet;
+	ProgressLog("Aligning %u shrubs on %u device contexts\n", ShrubCount, Workers);
+	opt_quiet = true;
 	std::atomic<uint> Next(0);
 	vector<std::thread> Threads;
 	for (uint w = 0; w < Workers; ++w)
@@ -839,7 +861,7 @@ void Super7::IntraAlignShrubs()
 				const uint ShrubIndex = Next.fetch_add(1);
 				if (ShrubIndex >= ShrubCount)
 					break;
-				MuscleGpuRandThreadSeek(RandOffset[ShrubIndex]);
+				MuscleGpuRandThreadRestore(&RandAt[ShrubIndex]);
 				MultiSequence ShrubInput;
 				MakeShrubInput(m_ShrubLCAs[ShrubIndex], ShrubInput); // super7.cpp:116-126
 				Local.m_TreePerm = TP_None;
@@ -858,8 +880,8 @@ void Super7::IntraAlignShrubs()
 			});
 	for (size_t t = 0; t < Threads.size(); ++t)
 		Threads[t].join();
+	opt_quiet = SavedQuiet;
 	if (TimingOn())
 		fprintf(stderr, "[muscle_gpu] %u shrubs on %u worker contexts: entered %.3f s after process start, took %.3f s\n", ShrubCount, Workers,
 		  ShrubsBegin, std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count() - ShrubsBegin);
-	MuscleGpuRandSharedSkip(RandOffset[ShrubCount]);
 	}

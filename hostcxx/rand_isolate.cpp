@@ -14,6 +14,7 @@
 #include <mutex>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace
 {
@@ -25,7 +26,8 @@ std::mutex g_Mu;
 // Parallel shrub loop of -super7 (hostcxx/mpcflat_gpu.cpp, Super7::IntraAlignShrubs): the reference aligns the shrubs one after
 // the other, so shrub k's refinement sees the stream from position sum_{j<k} calls_j on. A worker thread that runs shrub k
 // positions a PRIVATE copy of the same generator there (same seed, that many values discarded) and draws from it until it
-// says otherwise; the shared stream is advanced past all shrubs at the end, as the sequential loop would have left it.
+// says otherwise. The positions are recorded in ONE pass over the shared stream (MuscleGpuRandSharedSnapshots), which also
+// leaves the shared stream where the sequential loop would have left it.
 struct ThreadStream
 	{
 	bool m_On = false;
@@ -35,14 +37,52 @@ struct ThreadStream
 thread_local ThreadStream t_Stream;
 }
 
-extern "C" void MuscleGpuRandThreadSeek(unsigned long long Offset)
+// A position of the shared stream: the generator's 128 state bytes and where its two taps stand (in words from `state`).
+struct MuscleGpuRandSnapshot
+	{
+	char m_State[128];
+	int m_FOff;
+	int m_ROff;
+	};
+
+namespace
+{
+void InitShared()
+	{
+	if (g_Init)
+		return;
+	g_Data.state = 0; // initstate_r requires this on first use
+	initstate_r(1, g_State, sizeof(g_State), &g_Data);
+	g_Init = true;
+	}
+}
+
+// Advances the SHARED stream past Draws[0] + ... + Draws[Count-1] values, as the sequential shrub loop would, and records in
+// At[k] where it stood before shrub k's draws: one pass, linear in the number of draws, from wherever the stream stands now.
+extern "C" void MuscleGpuRandSharedSnapshots(const unsigned long long *Draws, unsigned Count, MuscleGpuRandSnapshot *At)
+	{
+	std::lock_guard<std::mutex> Guard(g_Mu);
+	InitShared();
+	for (unsigned k = 0; k < Count; ++k)
+		{
+		memcpy(At[k].m_State, g_State, sizeof(g_State));
+		At[k].m_FOff = (int) (g_Data.fptr - g_Data.state);
+		At[k].m_ROff = (int) (g_Data.rptr - g_Data.state);
+		int32_t r = 0;
+		for (unsigned long long i = 0; i < Draws[k]; ++i)
+			random_r(&g_Data, &r);
+		}
+	}
+
+// The calling thread's rand() now continues from a recorded position of the shared stream, privately.
+extern "C" void MuscleGpuRandThreadRestore(const MuscleGpuRandSnapshot *At)
 	{
 	ThreadStream &T = t_Stream;
 	T.m_Data.state = 0;
-	initstate_r(1, T.m_State, sizeof(T.m_State), &T.m_Data);
-	int32_t r = 0;
-	for (unsigned long long i = 0; i < Offset; ++i)
-		random_r(&T.m_Data, &r);
+	initstate_r(1, T.m_State, sizeof(T.m_State), &T.m_Data); // type, degree, separation, end pointer
+	memcpy(T.m_State, At->m_State, sizeof(T.m_State));
+	T.m_Data.fptr = T.m_Data.state + At->m_FOff;
+	T.m_Data.rptr = T.m_Data.state + At->m_ROff;
 	T.m_On = true;
 	}
 
@@ -50,17 +90,6 @@ extern "C" void MuscleGpuRandThreadEnd(void)
 	{
 	t_Stream.m_On = false;
 	}
-
-extern "C" int __wrap_rand(void);
-extern "C" void MuscleGpuRandSharedSkip(unsigned long long Count)
-	{
-	for (unsigned long long i = 0; i < Count; ++i)
-		(void) __wrap_rand();
-	}
-
-namespace
-{
-}
 
 extern "C" int __wrap_rand(void)
 	{
@@ -71,12 +100,7 @@ extern "C" int __wrap_rand(void)
 		return (int) r;
 		}
 	std::lock_guard<std::mutex> Guard(g_Mu);
-	if (!g_Init)
-		{
-		g_Data.state = 0; // initstate_r requires this on first use
-		initstate_r(1, g_State, sizeof(g_State), &g_Data);
-		g_Init = true;
-		}
+	InitShared();
 	int32_t r = 0;
 	random_r(&g_Data, &r);
 	return (int) r;

@@ -135,6 +135,16 @@ int mpcgpu_get_sparse(mpcgpu_ctx *ctx, uint64_t k, uint32_t *offsets, void *valu
  * (8*sum nnz bytes). Sizes via mpcgpu_get_nnz and the sequence lengths. */
 int mpcgpu_get_sparse_range(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1, uint32_t *offsets, void *values);
 
+/* The finishing kernels on one caller-supplied candidate list (cells (rows[q], cols[q]) with log-space Score scores[q] >=
+ * MIN_SPARSE_SCORE, any order, no duplicates): the expf half of CalcPostFlat (calcposteriorflat.cpp:16-22),
+ * MySparseMx::FromPost (mysparsemx.cpp:115-152) and CalcAlnScoreFlat / EA (calcalnscoreflat.cpp:4-32,
+ * calcposteriorflat.cpp:89) for ONE pair of lengths LX, LY. kernel: 0 = row-list kernel, 1 = general (sort) kernel;
+ * batch: cells of a row per EA pass (64; smaller values exercise the multi-pass path). offsets[LX+1] / values (8 bytes per
+ * kept entry, capacity ncand) may be NULL. A unit-test reach into inputs the pair-HMM itself never produces. */
+int mpcgpu_post_scores(mpcgpu_ctx *ctx, uint32_t LX, uint32_t LY, uint32_t ncand, const uint32_t *rows,
+                       const uint32_t *cols, const float *scores, int kernel, uint32_t batch, float *ea, uint32_t *nnz,
+                       uint32_t *offsets, void *values);
+
 /* Posterior-DP alignment of one dense LX x LY matrix resident in HOST memory: replaces
  * CalcAlnFlat (calcalnflat.cpp:6-46) + TraceBackFlat (tracebackflat.cpp:3-37), tie order of
  * best3.h:5-28. path receives the B/X/Y string (capacity >= LX+LY), not NUL-terminated. */

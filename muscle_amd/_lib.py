@@ -19,7 +19,7 @@ SYMBOLS = [
     "mpcgpu_set_seqs", "mpcgpu_set_mega", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
-    "mpcgpu_get_sparse_range", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
+    "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
@@ -69,6 +69,7 @@ def load(lib_path=None):
     L.mpcgpu_get_nnz.argtypes = [vp, u64, u64, vp]
     L.mpcgpu_get_sparse.argtypes = [vp, u64, vp, vp]
     L.mpcgpu_get_sparse_range.argtypes = [vp, u64, u64, vp, vp]
+    L.mpcgpu_post_scores.argtypes = [vp, u32, u32, u32, vp, vp, vp, i32, u32, C.POINTER(C.c_float), C.POINTER(u32), vp, vp]
     L.mpcgpu_calc_aln.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.mpcgpu_align_alns.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.mpcgpu_align_alns_w.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float)]
@@ -336,6 +337,17 @@ class MpcGpu:
             po += lx[q]
             pv += 2 * nnz[q]
         return out
+
+    def post_scores(self, LX, LY, rows, cols, scores, kernel=0, batch=64):
+        """finishing kernels on one candidate list -> (ea, offsets, values) (include/mpcgpu.h: mpcgpu_post_scores)"""
+        rows, cols = np.ascontiguousarray(rows, np.uint32), np.ascontiguousarray(cols, np.uint32)
+        scores = np.ascontiguousarray(scores, np.float32)
+        ea, nnz = C.c_float(), C.c_uint32()
+        off = np.empty(LX + 1, np.uint32)
+        val = np.empty(max(len(rows), 1) * 2, np.uint32)
+        self._ck(self.L.mpcgpu_post_scores(self.h, LX, LY, len(rows), rows.ctypes.data, cols.ctypes.data, scores.ctypes.data,
+                                           kernel, batch, C.byref(ea), C.byref(nnz), off.ctypes.data, val.ctypes.data))
+        return np.float32(ea.value), off, val[:2 * nnz.value].copy()
 
     def calc_aln(self, post):
         """post: (LX, LY) float32 dense matrix in host memory -> (path str of B/X/Y, score)"""

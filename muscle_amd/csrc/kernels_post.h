@@ -365,7 +365,10 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 						const u32 k = (e - c0 < p.batch) ? (e - c0) : p.batch;
 						const u32 last = mpc_read_lane(col, k - 1) + 1u;
 						const u32 hi = last > cmax ? last : cmax;
-						for (u32 j0 = mpc_wave_first(col) + 1u; j0 <= hi; j0 += 64) {
+						// from the first column behind the frontier at the latest: a batch that starts right of cmax + 1 leaves a
+						// gap (cmax, first cell] that becomes explicit with this row and has to hold the flat suffix S(i-1, cmax)
+						const u32 jb0 = mpc_wave_first(col) + 1u;
+						for (u32 j0 = jb0 < cmax + 1u ? jb0 : cmax + 1u; j0 <= hi; j0 += 64) {
 							const u32 j = j0 + (u32)t;
 							float cur = 0.0f;
 							for (u32 l = 0; l < k; ++l) {
@@ -397,7 +400,10 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 				const float V = mpc_wave_scan_max_nonneg(val); // running maximum in column order
 				const u32 last = mpc_read_lane(col, k - 1) + 1u; // right-most column the row's cells start at
 				const u32 hi = last > cmax ? last : cmax;        // explicit range after this row
-				for (u32 j0 = jfirst; j0 <= hi; j0 += 64) {
+				// The update starts at the row's first cell or, when that lies beyond the frontier, right behind the frontier:
+				// the columns in between become explicit with this row (cmax = hi below) and must receive S(i-1, cmax) — left
+				// unwritten they would keep their initial 0.0f and later rows would read it as S(., j).
+				for (u32 j0 = jfirst < cmax + 1u ? jfirst : cmax + 1u; j0 <= hi; j0 += 64) {
 					const u32 j = j0 + (u32)t;
 					const float old = s_pm[j <= cmax ? j : cmax];
 					float cur = 0.0f;

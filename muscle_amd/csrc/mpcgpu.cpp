@@ -163,6 +163,8 @@ struct mpcgpu_ctx {
 	float ms[MPCGPU_NKERNELS] = {0};
 	u64 launches[MPCGPU_NKERNELS] = {0};
 	u64 work_cells = 0, work_entry_z = 0;
+	double aa_trace_t[5] = {0, 0, 0, 0, 0}; // MPCGPU_TRACE_HOST: host seconds of mpcgpu_align_alns' phases
+	u64 aa_trace_n = 0;
 };
 
 namespace {
@@ -624,7 +626,8 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 		&c->d_vnext, &c->d_own_packed, &c->d_queue, &c->d_order, &c->d_bx, &c->d_by, &c->d_fm, &c->d_cand,
 		&c->d_cand_cnt, &c->d_total, &c->d_res, &c->d_nnz, &c->d_ea, &c->d_flags, &c->d_sort_scratch,
 		&c->d_srow_scratch, &c->d_dstbase, &c->d_recwords, &c->d_exp_off, &c->d_exp_val, &c->d_exp_offbase, &c->d_tiles, &c->d_pad, &c->d_pos, &c->d_bp_seq, &c->d_bp_map, &c->d_bp_off, &c->d_bp_coff,
-		&c->d_tile_next, &c->d_bp_in, &c->d_aln_res, &c->d_post_prof, &c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev};
+		&c->d_tile_next, &c->d_bp_in, &c->d_aln_res, &c->d_post_prof, &c->d_bp_keys, &c->d_bp_vals, &c->d_bp_tmp, &c->d_bp_runs, &c->d_aln_post, &c->d_aln_tb, &c->d_aln_rev,
+		&c->d_rec_off, &c->d_sizes, &c->d_tilefit};
 	for (DevBuf *b : all) b->release();
 	c->h_bp_in.release();
 	c->h_aln_res.release();
@@ -1523,6 +1526,90 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	return 0;
 }
 
+// The finishing kernels (kernels_post.h) on ONE caller-supplied list of cells with Score >= MIN_SPARSE_SCORE — what fb_kernel
+// would have emitted for a pair. Lets tests reach shapes of the candidate list the pair-HMM never produces (rows whose first
+// cell lies beyond the EA frontier, empty rows, one-column matrices) and compare both kernels with the dense
+// CalcAlnScoreFlat (calcalnscoreflat.cpp:4-32) / MySparseMx::FromPost (mysparsemx.cpp:115-152).
+int mpcgpu_post_scores(mpcgpu_ctx *c, uint32_t LX, uint32_t LY, uint32_t ncand, const uint32_t *rows, const uint32_t *cols,
+	const float *scores, int kernel, uint32_t batch, float *ea, uint32_t *nnz, uint32_t *offsets, void *values)
+{
+	if (!c) return 1;
+	if (!c->have_hmm) return fail(c, "mpcgpu_post_scores: set_hmm first (expf variant)");
+	if (LX == 0 || LY == 0 || LX > MPC_KEY_COL_MASK_LONG || LY > MPC_KEY_COL_MASK_LONG) return fail(c, "mpcgpu_post_scores: bad shape %u x %u", LX, LY);
+	HIPCHK(c, hipSetDevice(c->device));
+	const u32 capc = std::max<u32>(ncand, 1);
+	std::vector<u64> cand(capc, 0);
+	const u32 long_min = LX > 1023u ? LX : 0xffffffffu; // 22-bit column keys unless the rows need more than 10 bits
+	const u32 kshift = LX >= long_min ? MPC_KEY_ROW_SHIFT_LONG : MPC_KEY_ROW_SHIFT;
+	for (u32 q = 0; q < ncand; ++q) {
+		if (rows[q] >= LX || cols[q] >= LY) return fail(c, "mpcgpu_post_scores: cell %u out of range", q);
+		u32 bits;
+		memcpy(&bits, &scores[q], 4);
+		cand[q] = ((u64)((rows[q] << kshift) | cols[q]) << 32) | bits;
+	}
+	const std::vector<u32> lens = {LX, LY}, zero = {0}, one = {1}, cnt = {ncand};
+	DevBuf d_len, d_x, d_y, d_cnt, d_cand, d_res, d_out, d_sort, d_srow;
+	auto free_all = [&]() { for (DevBuf *b : {&d_len, &d_x, &d_y, &d_cnt, &d_cand, &d_res, &d_out, &d_sort, &d_srow}) b->release(); };
+	const u64 res_stride = (u64)LX + LY + 4 * (u64)capc;
+	int rc = 0;
+	do {
+		if (upload(c, d_len, lens) || upload(c, d_x, zero) || upload(c, d_y, one) || upload(c, d_cnt, cnt) || upload(c, d_cand, cand)) { rc = 1; break; }
+		if (d_res.ensure(res_stride * 4) != hipSuccess || d_out.ensure(16) != hipSuccess) { rc = fail(c, "mpcgpu_post_scores: out of device memory"); break; }
+		if (kernel == 0) {
+			PostRowsParams pr;
+			pr.pair_x = d_x.as<u32>(); pr.pair_y = d_y.as<u32>(); pr.seq_len = d_len.as<u32>();
+			pr.cand = d_cand.as<u64>(); pr.capc = capc; pr.cand_cnt = d_cnt.as<u32>();
+			pr.use_fma = c->use_fma;
+			pr.lx_cap = LX + 2; pr.ly_cap = LY + 2;
+			pr.sort_cap = std::min<u32>(capc, 1024u); pr.sort_stride = capc;
+			pr.batch = std::min<u32>(std::max<u32>(batch, 1u), 64u);
+			const size_t fixed_lds = ((((size_t)pr.lx_cap + 2 * (size_t)pr.ly_cap) * 4 + 7) & ~(size_t)7);
+			if (fixed_lds + 16 > 150 * 1024) { rc = fail(c, "mpcgpu_post_scores: %u x %u does not fit the row-list kernel", LX, LY); break; }
+			if (fixed_lds + (size_t)pr.sort_cap * 8 > 150 * 1024) pr.sort_cap = (u32)((150 * 1024 - fixed_lds) / 8);
+			const size_t smem = fixed_lds + (size_t)pr.sort_cap * 8;
+			if (smem > 64 * 1024 && hipFuncSetAttribute((const void *)post_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { rc = fail(c, "mpcgpu_post_scores: LDS"); break; }
+			if (d_sort.ensure((u64)capc * 8 + 8) != hipSuccess) { rc = fail(c, "mpcgpu_post_scores: out of device memory"); break; }
+			pr.sort_scratch = d_sort.as<u64>();
+			pr.res = d_res.as<u32>(); pr.res_stride = res_stride;
+			pr.nnz = d_out.as<u32>(); pr.ea = d_out.as<float>() + 1; pr.flags = d_out.as<u32>() + 2;
+			pr.count = 1; pr.long_min = long_min; pr.prof = nullptr;
+			MPC_LAUNCH(post_rows_kernel, 1, 64, smem, c->stream, pr);
+		} else {
+			PostParams pp;
+			pp.pair_x = d_x.as<u32>(); pp.pair_y = d_y.as<u32>(); pp.seq_len = d_len.as<u32>();
+			pp.cand = d_cand.as<u64>(); pp.capc = capc; pp.cand_cnt = d_cnt.as<u32>();
+			pp.use_fma = c->use_fma;
+			pp.sort_cap = std::min<u32>(next_pow2(std::max<u32>(capc, 2)), 1024u);
+			pp.srow_cap = std::min<u32>(LY + 1, 2048u);
+			pp.sort_stride = next_pow2(std::max<u32>(capc, 2));
+			pp.srow_stride = 2 * ((u64)LY + 1);
+			if (d_sort.ensure(pp.sort_stride * 8) != hipSuccess || d_srow.ensure(pp.srow_stride * 4) != hipSuccess) { rc = fail(c, "mpcgpu_post_scores: out of device memory"); break; }
+			pp.sort_scratch = d_sort.as<u64>(); pp.srow_scratch = d_srow.as<float>();
+			pp.res = d_res.as<u32>(); pp.res_stride = res_stride;
+			pp.nnz = d_out.as<u32>(); pp.ea = d_out.as<float>() + 1; pp.flags = d_out.as<u32>() + 2;
+			pp.count = 1; pp.long_min = long_min;
+			const size_t psmem = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
+			MPC_LAUNCH(post_kernel, 1, 64, psmem, c->stream, pp);
+		}
+		if (hipGetLastError() != hipSuccess) { rc = fail(c, "mpcgpu_post_scores: launch failed"); break; }
+		u32 out[4] = {0, 0, 0, 0};
+		if (hipMemcpyAsync(out, d_out.p, 12, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, "mpcgpu_post_scores: copy failed"); break; }
+		if (out[2] & 1u) { rc = fail(c, "mpcgpu_post_scores: candidate overflow"); break; }
+		if (nnz) *nnz = out[0];
+		if (ea) memcpy(ea, &out[1], 4);
+		if (offsets && values) { // MySparseMx layout: offsets[LX+1], {P, col} per entry
+			std::vector<u32> rec(res_stride);
+			if (hipMemcpyAsync(rec.data(), d_res.p, res_stride * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, "mpcgpu_post_scores: copy failed"); break; }
+			u32 acc = 0;
+			for (u32 i = 0; i < LX; ++i) { offsets[i] = acc; acc += rec[i]; }
+			offsets[LX] = acc;
+			memcpy(values, rec.data() + LX + LY, (size_t)out[0] * 8);
+		}
+	} while (0);
+	free_all();
+	return rc;
+}
+
 int mpcgpu_calc_aln(mpcgpu_ctx *c, const float *post, uint32_t LX, uint32_t LY, char *path, uint32_t *pathlen, float *score)
 {
 	if (!c) return 1;
@@ -1582,8 +1669,8 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 	HIPCHK(c, hipSetDevice(c->device));
 	const u32 n = c->n;
 	static const bool host_trace = env_int("MPCGPU_TRACE_HOST", 0) != 0; // diagnostics: host wall time of this call's phases, summed
-	static double acc_t[5] = {0, 0, 0, 0, 0};
-	static u64 acc_n = 0;
+	double *acc_t = c->aa_trace_t; // per context: the shrub workers of -super7 call this concurrently on their own contexts
+	u64 &acc_n = c->aa_trace_n;
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double t_prev = host_trace ? now() : 0.0;
 	auto lap = [&](int k) { if (host_trace) { const double t = now(); acc_t[k] += t - t_prev; t_prev = t; } };

@@ -141,10 +141,12 @@ int all_gather_segments(mpcgpu_group *g, const std::vector<const void *> &src, c
 		// one group: every rank sends its segment to every peer and receives every peer's segment at its final offset
 		int rc = g->rccl.GroupStart();
 		if (rc) return gfail(g, "ncclGroupStart: %s", g->rccl.GetErrorString(rc));
-		for (uint32_t r = 0; r < R && !rc; ++r) {
-			GHIP(g, hipSetDevice(g->dev[r]));
-			if (!in_place && seg_bytes[r])
-				GHIP(g, hipMemcpyAsync((char *)dst[r] + seg_off[r], src[r], seg_bytes[r], hipMemcpyDeviceToDevice, g->xs[r]));
+		hipError_t herr = hipSuccess; // a HIP error inside the group must not leave RCCL with an open group: record it, close, then fail
+		for (uint32_t r = 0; r < R && !rc && herr == hipSuccess; ++r) {
+			herr = hipSetDevice(g->dev[r]);
+			if (herr == hipSuccess && !in_place && seg_bytes[r])
+				herr = hipMemcpyAsync((char *)dst[r] + seg_off[r], src[r], seg_bytes[r], hipMemcpyDeviceToDevice, g->xs[r]);
+			if (herr != hipSuccess) break;
 			for (uint32_t d = 0; d < R && !rc; ++d) {
 				if (d == r) continue;
 				if (seg_bytes[r]) rc = g->rccl.Send(src[r], seg_bytes[r], 0 /* ncclChar */, (int)d, g->comm[r], g->xs[r]);
@@ -152,6 +154,7 @@ int all_gather_segments(mpcgpu_group *g, const std::vector<const void *> &src, c
 			}
 		}
 		const int rc2 = g->rccl.GroupEnd();
+		if (herr != hipSuccess) return gfail(g, "exchange: %s", hipGetErrorString(herr));
 		if (rc || rc2) return gfail(g, "RCCL exchange: %s", g->rccl.GetErrorString(rc ? rc : rc2));
 		for (uint32_t r = 0; r < R; ++r) {
 			GHIP(g, hipSetDevice(g->dev[r]));

@@ -101,7 +101,7 @@ def mega_input(name):
     return _mega.mega_text(base), extra
 
 
-def run_muscle(binary, name, threads=4, timeout=900, env=None):
+def run_muscle(binary, name, threads=4, timeout=900, env=None, quiet=True):
     mega = name.startswith("mega_")
     if mega:
         text, extra = mega_input(name)
@@ -122,7 +122,7 @@ def run_muscle(binary, name, threads=4, timeout=900, env=None):
         for fn, text in files.items():
             with open(os.path.join(d, fn), "w") as f:
                 f.write(text)
-        subprocess.run([binary, cmd, fa, "-output", out, "-threads", str(threads), "-quiet"] + cmd_extra + extra,
+        subprocess.run([binary, cmd, fa, "-output", out, "-threads", str(threads)] + (["-quiet"] if quiet else []) + cmd_extra + extra,
                        check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL,
                        stderr=None if os.environ.get("MUSCLE_GPU_TIMING") else subprocess.DEVNULL,
                        env=None if env is None else dict(os.environ, **env))

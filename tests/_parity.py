@@ -85,3 +85,56 @@ def assert_same(a, b, what=""):
         for k, ((o1, v1), (o2, v2)) in enumerate(zip(x, y)):
             assert np.array_equal(o1, o2), "%s stage %d pair %d offsets" % (what, s, k)
             assert np.array_equal(v1, v2), "%s stage %d pair %d values" % (what, s, k)
+
+
+def check_post_scores(lib_path=None, seed=11, trials=60):
+    """mpcgpu_post_scores (both finishing kernels, one- and multi-pass EA) vs the dense CalcAlnScoreFlat / FromPost of the
+    oracle on random candidate lists with what the pair-HMM rarely produces: empty rows and columns, rows whose first cell
+    lies right of everything seen so far (a gap beyond the EA frontier), rows of more than 64 cells, 1-wide shapes."""
+    rng = np.random.default_rng(seed)
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, lib_path)
+    variant = 1
+    g.set_hmm(s, t, m, i, thr, variant)
+    L = O.lib()
+    shapes = [(1, 1), (1, 9), (7, 1), (3, 6), (12, 40), (40, 12), (30, 30), (5, 200), (90, 70)]
+    # the advisor's minimal case (ADVICE r2): the dense DP gives 1.4
+    fixed = [((3, 6), [(0, 3, 0.9), (1, 5, 0.3), (2, 2, 0.3), (2, 5, 0.5)])]
+    cases = []
+    for (LX, LY), cells in fixed:
+        cases.append((LX, LY, [c[0] for c in cells], [c[1] for c in cells], np.log(np.array([c[2] for c in cells], np.float32))))
+    for tr in range(trials):
+        LX, LY = shapes[tr % len(shapes)]
+        dens = [0.02, 0.08, 0.3, 0.9][tr % 4]
+        mask = rng.random((LX, LY)) < dens
+        if tr % 5 == 0:  # staircase with jumps: each row starts right of the previous frontier
+            mask[:] = False
+            c = 0
+            for r in range(LX):
+                c += int(rng.integers(1, 5))
+                if c >= LY:
+                    break
+                mask[r, c] = True
+                if rng.random() < 0.3 and c + 2 < LY:
+                    mask[r, c + 2] = True
+        rows, cols = np.nonzero(mask)
+        perm = rng.permutation(len(rows))
+        rows, cols = rows[perm], cols[perm]
+        # scores from log(0.0098) (dropped by FromPost: P < 0.01) up to slightly above 0 (P = 1)
+        sc = rng.uniform(np.log(0.0098), 0.05, len(rows)).astype(np.float32)
+        sc = np.maximum(sc, np.float32(thr))
+        cases.append((LX, LY, rows, cols, sc))
+    for LX, LY, rows, cols, sc in cases:
+        Pd = np.zeros((LX, LY), np.float32)
+        for r, c, x in zip(rows, cols, sc):
+            Pd[r, c] = np.float32(1.0) if x >= 0 else np.float32(L.orc_expf_emul(float(x), variant))
+        want_score = O.aln_score(Pd)
+        want_ea = np.float32(want_score) / np.float32(min(LX, LY))
+        woff, wval = O.sparse_from_post(Pd)
+        for kernel, batch in ((0, 64), (0, 3), (1, 64)):
+            ea, off, val = g.post_scores(LX, LY, rows, cols, sc, kernel, batch)
+            what = "%dx%d, %d cells, kernel %d batch %d" % (LX, LY, len(rows), kernel, batch)
+            assert bits(ea) == bits(want_ea), "EA %s: %r vs %r" % (what, ea, want_ea)
+            assert np.array_equal(off, woff), what
+            assert np.array_equal(val, wval), what
+    g.close()

@@ -59,3 +59,10 @@ def test_super7_shrubs_over_worker_contexts(emu_muscle, name, workers):
     the final MSA is the reference's whatever the number of workers (1 = the reference's sequential loop)."""
     md5, _ = _msa.run_muscle(emu_muscle, name, threads=2, env={"MUSCLE_GPU_SHRUB_CONTEXTS": workers})
     assert md5 == _msa.golden_md5()[name]
+
+
+def test_super7_parallel_shrubs_with_progress_output(emu_muscle):
+    """Default verbosity (no -quiet): MPCFlat::Run's ProgressStep keeps unguarded process globals (myutils.cpp:1453-1870), so the
+    worker threads of the parallel shrub loop must not call it concurrently (round-2 advisor finding); same MSA, no crash."""
+    md5, _ = _msa.run_muscle(emu_muscle, "super7_8x18_b4", threads=2, env={"MUSCLE_GPU_SHRUB_CONTEXTS": "4"}, quiet=False)
+    assert md5 == _msa.golden_md5()["super7_8x18_b4"]

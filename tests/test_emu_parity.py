@@ -450,3 +450,9 @@ def test_emu_group_more_contexts_than_work(n, nctx):
         P.assert_same((st[r], ea[r]), want, "n=%d, %d contexts, rank %d" % (n, nctx, r))
     del views
     grp.close()
+
+
+def test_emu_post_candidate_lists_with_gaps(emu):
+    """EA frontier of post_rows_kernel: columns between the frontier and a row's first cell must receive the flat suffix
+    (round-2 advisor finding); both finishing kernels against the dense DP on synthetic candidate lists."""
+    P.check_post_scores(emu, trials=36)

@@ -64,3 +64,12 @@ def test_super7_with_distmx_and_parallel_shrubs(gpu_muscle, name, workers):
     from muscle_amd.hostinfo import usable_cores
     md5, _ = _msa.run_muscle(gpu_muscle, name, threads=usable_cores(), env={"MUSCLE_GPU_SHRUB_CONTEXTS": workers})
     assert md5 == _msa.golden_md5()[name]
+
+
+def test_super7_parallel_shrubs_with_progress_output(gpu_muscle):
+    """The same without -quiet: the reference's progress reporting is not thread-safe (myutils.cpp:1453-1870), the parallel shrub
+    loop keeps its workers quiet and reports from the main thread; 40 shrubs on 8 workers, 3 repetitions."""
+    from muscle_amd.hostinfo import usable_cores
+    for _ in range(3):
+        md5, _d = _msa.run_muscle(gpu_muscle, "super7dm_300x100_b16", threads=usable_cores(), env={"MUSCLE_GPU_SHRUB_CONTEXTS": "8"}, quiet=False)
+        assert md5 == _msa.golden_md5()["super7dm_300x100_b16"]

@@ -495,3 +495,9 @@ def test_group_rccl_loader_one_device():
     want, _ = P.run_oracle(seqs, iters=1)
     for (o1, v1), (o2, v2) in zip(got, want[1]):
         assert np.array_equal(o1, o2) and np.array_equal(v1, v2)
+
+
+def test_post_candidate_lists_with_gaps():
+    """Both finishing kernels (and the multi-pass EA path) on synthetic candidate lists against the dense CalcAlnScoreFlat /
+    FromPost: rows whose first cell lies beyond the EA frontier, empty rows, rows of > 64 cells (round-2 advisor finding)."""
+    P.check_post_scores(None, trials=120)
