@@ -6,29 +6,30 @@
 //     acc = 2*P_XY(x,y);  for Z = 0..N-1: acc += sum_z M(X,Z)(x,z) * M(Y,Z)(y,z)  (z ascending);  P' = acc / N
 // product rounded, then added (no FMA): bit-identical to the reference.
 //
-// What the round-2 measurements of relax_dense_kernel (fixed-size records, register staging, two barriers per Z;
-// profiles/r02a_*) said, and what this kernel does about each:
-//  * every record was padded to the worst of the N^2 (13.3 KB at 1000 x L~400 against 8.1 KB mean): 40 % of the HBM
-//    traffic, of the LDS writes and of the LDS footprint carried nothing. Records are now exactly len(A) first blocks +
-//    their own overflow blocks (kernels_store.h, var_*), found through a block-offset table read with scalar loads one
-//    step ahead, and packed back to back in LDS in the order of the tile's sequences.
-//  * staging went HBM -> VGPR -> ds_write_b128 -> LDS between two barriers (0.8 us of every 8.7 us step, 32 VGPRs).
-//    It is now LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write issue): each wave moves 1 KiB per instruction.
-//  * with the smaller footprint two staging buffers fit the CU's 160 KB for almost every tile (the host checks each
-//    tile's worst step with var_tile_fit_kernel and splits the few that do not): the DMA of step Z+1 is in flight
-//    while step Z is computed and a step costs ONE barrier. With one buffer (nbuf = 1; two 512-thread workgroups per CU,
-//    each hiding the other's DMA wait) it costs two.
-//  * a cell found its rows through two per-lane 16-bit block indices relative to fixed record slots; records now sit
-//    at step-dependent LDS addresses, so the cells of a pair are laid out in whole waves (a pair's cell range is rounded
-//    up to 64): the two records a (wave, slot) reads are wave-uniform, their LDS bases are two v_readlane of a
-//    register that holds the step's 8 record bases, and a lane keeps only the byte offsets of its two rows.
+// Shape of the kernel (round 3; what rounds 1-2 measured is in DESIGN.md 4.3):
+//  * A workgroup owns the pairs {X in [x0,x0+nx)} x {Y in [y0,y0+ny)}, X < Y, and walks Z = 0..N-1 once. Per step it needs
+//    the records M(S,Z) of its <= 8 sequences S. Records are stored Z-major (kernels_store.h), so these are TWO contiguous
+//    runs of HBM — the X range, and the part of the Y range beyond it — staged HBM -> LDS by LDS-DMA
+//    (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, no ds_write) exactly as they lie in memory. Where each
+//    record starts is read from 5 + 5 consecutive entries of the block-offset table by ONE vector load per step (lane i =
+//    record i), one step ahead; the lane-indexed result IS the register the merges take their record bases from.
+//  * The cells of the tile's pairs are laid end to end over (slot, lane), every pair rounded up to whole waves, so the 64
+//    cells of a (wave, slot) belong to ONE pair: its two record bases are two v_readlane of that register. A lane keeps,
+//    per slot, the accumulator and the byte offsets of its cell's two rows (16*x | 16*y << 16) in VGPRs for the whole walk.
+//  * Per (cell, Z): a block merge of row x of M(X,Z) and row y of M(Y,Z), 2 entries per block and step. The FIRST step of
+//    every slot is straight-line code for all lanes, and the two LDS reads of slot q+1's first step are issued before slot
+//    q's arithmetic, so a wave always has reads in flight. Only lanes whose rows go on (a third entry on the side that has
+//    to advance) enter the loop for the further steps. Blocks with one entry repeat their column (kernels_store.h), so
+//    advance / stop decisions compare real last columns: 2.45 steps per wave and (cell, Z) at 1000 x L~400, was 2.76.
 #pragma once
 #include "kernels_store.h"
+#include <type_traits>
 
 #define MPC_RV_MAXSEQ 8        // records resident per step (4 + 4 sequences)
 #define MPC_RV_MAXLEN 4095u    // a cell keeps 16 * row and 16 * column in 16 bits each; a block's distance field is 16 bits of bytes
 #define MPC_RV_TAB_BYTES 512   // pair table of the tile at the head of the dynamic LDS: 16 pairs x 8 dwords
 #define MPC_RV_WAVE 64u
+#define MPC_RV_YLANE 8u        // lanes 0..4 of the step table: X run (record i -> lane i); lanes 8..12: Y run
 
 struct RelaxVarParams {
 	StoreParams s;
@@ -40,8 +41,24 @@ struct RelaxVarParams {
 	u32 *tile_next; // 8 counters, zeroed before the launch: next tile of each XCD's range
 };
 
+// One merge step on the blocks va (row x of M(X,Z)) and vb (row y of M(Y,Z)), block = {p0, p1, c0 | dist << 16, c1}:
+// the 2x2 column compare, two products, two adds in z order (relaxflat.cpp:16-29 / :41-58 / :78-92: an unmatched entry, a
+// repeated column and an empty block contribute pa * 0.0f = +0.0f, which leaves the strictly positive sum unchanged bit for
+// bit). Of two equal columns in vb the first wins (the second is the zero-probability repeat).
+#define MPC_RV_TERMS(sum, va, vb)                                                                                           \
+	do {                                                                                                                \
+		const u32 ca0_ = (va).z & 0xffffu, cb0_ = (vb).z & 0xffffu;                                                     \
+		float pb0_ = (ca0_ == (vb).w) ? __uint_as_float((vb).y) : 0.0f;                                                 \
+		pb0_ = (ca0_ == cb0_) ? __uint_as_float((vb).x) : pb0_;                                                          \
+		float pb1_ = ((va).w == (vb).w) ? __uint_as_float((vb).y) : 0.0f;                                               \
+		pb1_ = ((va).w == cb0_) ? __uint_as_float((vb).x) : pb1_;                                                        \
+		sum += __uint_as_float((va).x) * pb0_; /* relaxflat.cpp:27 (w == 1.0f): product rounded, then added */           \
+		sum += __uint_as_float((va).y) * pb1_;                                                                          \
+	} while (0)
+
 // THREADS: workgroup size; MAXSLOTS: cells per lane (the host splits any tile whose wave-aligned cells need more);
-// DIAG (measurement only, results wrong): 1 = staging and barriers only.
+// DIAG (measurement only, results wrong): 1 = staging and barriers only, 2 = merges only (step 0's records for every step,
+// no further staging, no barriers).
 // WGS: workgroups per CU the register allocation has to allow (waves per SIMD = WGS * THREADS / 256).
 template <int THREADS, int MAXSLOTS, int WGS, int DIAG = 0>
 __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel(RelaxVarParams p)
@@ -55,7 +72,6 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 	const u32 wave = mpc_wave_first(tid >> 6); // scalar
 	u32 *ptab = (u32 *)smem_raw;                       // [16][8]: cell base, nnz, sel, k lo, k hi, cells (aligned), -, -
 	const unsigned char *padb = (const unsigned char *)s.pad;
-	mpc_const_u32p rec_off = MPC_CONST_U32(s.rec_off); // read with scalar loads
 	const u32 lds0 = mpc_lds_addr(smem_raw);            // 32-bit LDS address of the dynamic LDS
 
 	// XCD-aware schedule (block b runs on XCD b % 8 — affinity only): the tile list is cut into 8 contiguous ranges and the
@@ -82,29 +98,11 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 		__syncthreads();
 		const u32 tl = mpc_wave_first(ptab[8 * 15 + 7]);
 		if (tl == 0xffffffffu) break;
-		const u32 x0 = p.tiles[4 * tl], nx = p.tiles[4 * tl + 1], y0 = p.tiles[4 * tl + 2], ny = p.tiles[4 * tl + 3];
-		// resident sequences: the X range, then the part of the Y range not already in it (wave-uniform, SGPRs)
-		u32 seq[MPC_RV_MAXSEQ];
-		u32 nseq = 0;
-#pragma unroll
-		for (int i = 0; i < MPC_RV_MAXSEQ; ++i) seq[i] = 0;
-#pragma unroll
-		for (int i = 0; i < 4; ++i)
-			if ((u32)i < nx) {
-#pragma unroll
-				for (int q = 0; q < MPC_RV_MAXSEQ; ++q) if ((u32)q == nseq) seq[q] = x0 + i;
-				++nseq;
-			}
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const u32 Y = y0 + i;
-			if ((u32)i < ny && !(Y >= x0 && Y < x0 + nx)) {
-#pragma unroll
-				for (int q = 0; q < MPC_RV_MAXSEQ; ++q) if ((u32)q == nseq) seq[q] = Y;
-				++nseq;
-			}
-		}
-		// ---- pair table: pair (ix, iy) of the tile -> first cell, stored cells, the LDS record slots of its two sequences.
+		const u32 x0 = mpc_wave_first(p.tiles[4 * tl]), nx = mpc_wave_first(p.tiles[4 * tl + 1]);
+		const u32 y0 = mpc_wave_first(p.tiles[4 * tl + 2]), ny = mpc_wave_first(p.tiles[4 * tl + 3]);
+		u32 ys, nys; // the run of Y records beyond the X range (kernels_store.h: mpc_tile_runs)
+		mpc_tile_runs(x0, nx, y0, ny, &ys, &nys);
+		// ---- pair table: pair (ix, iy) of the tile -> first cell, stored cells, the step-table lanes of its two records.
 		// Lane q of wave 0 looks after pair q; a 16-lane inclusive scan lays the pairs' cell ranges end to end, each rounded
 		// up to whole waves so that the 64 cells of any (wave, slot) belong to ONE pair.
 		if (tid < 64u) {
@@ -115,13 +113,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 			if (lane < 16u && ix < nx && iy < ny && X < Y) {
 				k = mpc_pair_index(n, X, Y);
 				if (k >= p.k0 && k < p.k1) nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
-				u32 mb = 0; // record slot of Y
-				if (Y >= x0 && Y < x0 + nx) mb = Y - x0;
-				else {
-					u32 before = 0; // Y's rank among the Y-range sequences that are not in the X range
-					for (u32 j = 0; j < iy; ++j) { const u32 Yj = y0 + j; if (!(Yj >= x0 && Yj < x0 + nx)) ++before; }
-					mb = nx + before;
-				}
+				const u32 mb = (Y < x0 + nx) ? Y - x0 : MPC_RV_YLANE + (Y - ys); // Y >= x0 here (X < Y), so Y is in one of the runs
 				sel = ix | (mb << 8);
 			}
 			const u32 cells = (nnz + MPC_RV_WAVE - 1u) & ~(MPC_RV_WAVE - 1u);
@@ -138,10 +130,12 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 		}
 		__syncthreads();
 		const u32 total = mpc_wave_first(ptab[8 * 15 + 6]);
+		// slots of this wave that hold cells: slot q covers cells [q*THREADS + wave*64, +64)
+		const u32 wave_first = wave * 64u;
+		const u32 nact = total > wave_first ? (total - wave_first + THREADS - 1u) / THREADS : 0u;
 
-		// ---- my cells: slot q of this wave covers cells [q*THREADS + wave*64, +64) — one pair (found by a scalar scan of the
-		// table), or nothing. Accumulator and row offsets stay in VGPRs for the whole walk; the pair's two record slots go into
-		// lane q of `vsel` (one register per wave for all slots).
+		// ---- my cells: one pair per (wave, slot) (found by a scalar scan of the table), or nothing. Accumulator and row
+		// offsets stay in VGPRs for the whole walk; the pair's two step-table lanes go into lane q of `vsel`.
 		float acc[MAXSLOTS];
 		u32 xy[MAXSLOTS]; // 16 * x | (16 * y) << 16: byte offsets of row x of M(X,.) and row y of M(Y,.) inside their records
 		u32 vsel = 0;
@@ -149,8 +143,8 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 		for (int q = 0; q < MAXSLOTS; ++q) {
 			MPC_SCHED_BARRIER();
 			acc[q] = 1.0f; xy[q] = 0u;
-			const u32 g0 = (u32)q * THREADS + wave * 64u;
-			if (g0 < total) {
+			const u32 g0 = (u32)q * THREADS + wave_first;
+			if ((u32)q < nact) {
 				u32 pi = 0;
 				for (u32 j = 1; j < 16u; ++j) if (mpc_wave_first(ptab[8 * j]) <= g0 && mpc_wave_first(ptab[8 * j + 5]) != 0u) pi = j;
 				const u32 base = mpc_wave_first(ptab[8 * pi]), nnz = mpc_wave_first(ptab[8 * pi + 1]), sel = mpc_wave_first(ptab[8 * pi + 2]);
@@ -165,106 +159,125 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 			}
 		}
 
-		// ---- walk Z. Record (A,Z) = blocks [rec_off[A*n+Z], rec_off[A*n+Z+1]) of `pad`; the step's records are packed
-		// back to back in the staging buffer in the order of seq[]. cur_off/cur_sz describe the step whose DMA is issued
-		// next; they are loaded (scalar loads: wave-uniform addresses) one step before they are used.
-		u32 nxt_off[MPC_RV_MAXSEQ], nxt_sz[MPC_RV_MAXSEQ];
-		auto load_table = [&](u32 Z) {
-#pragma unroll
-			for (int i = 0; i < MPC_RV_MAXSEQ; ++i) {
-				nxt_off[i] = 0; nxt_sz[i] = 0;
-				if ((u32)i < nseq) {
-					mpc_const_u32p ro = rec_off + ((u64)seq[i] * n + Z);
-					const u32 a = ro[0], b = ro[1];
-					nxt_off[i] = a; nxt_sz[i] = b - a;
+		// ---- walk Z. The step table of step Z, one entry per lane: lane i (i <= nx) = block offset of record (x0+i, Z) — lane
+		// nx: the end of the X run; lane 8+j (j <= nys) the same for the Y run. Loaded one step ahead with one vector load.
+		const u32 tab_a = lane < MPC_RV_YLANE ? x0 + (lane < nx ? lane : nx) : ys + (lane - MPC_RV_YLANE < nys ? lane - MPC_RV_YLANE : nys);
+		const u32 *tab_src = s.rec_off + tab_a; // + Z*n per step (rec_off has n*n+1 entries: the run ends are in range)
+		auto load_table = [&](u32 Z) -> u32 { return tab_src[(u64)Z * n]; };
+		// Issues the DMA of the step whose table is `tab` into staging buffer `buf`: the X run, then the Y run, as they lie in
+		// HBM, in chunks of 64 blocks = 1 KiB dealt round-robin to the waves. Returns the register that holds in lane i the LDS
+		// byte address of record i (X run) / in lane 8+j that of record j of the Y run.
+		auto issue_dma = [&](u32 tab, u32 buf) -> u32 {
+			const u32 xs = mpc_read_lane(tab, 0u), xe = mpc_read_lane(tab, nx);
+			const u32 yb = mpc_read_lane(tab, MPC_RV_YLANE), ye = mpc_read_lane(tab, MPC_RV_YLANE + nys);
+			const u32 at = MPC_RV_TAB_BYTES + buf * p.buf_bytes; // byte offset of the buffer in the dynamic LDS
+			const u32 xlen = xe - xs;
+			{
+				for (u32 c0 = wave * 64u; c0 < xlen; c0 += NWAVES * 64u) {
+					const u32 blk = c0 + lane;
+					if (blk < xlen) mpc_dma16(padb + 16 * ((u64)xs + blk), smem_raw + at + 16 * c0);
+				}
+				const u32 ylen = ye - yb;
+				// the waves that got the fewest chunks of the X run take the first of the Y run
+				const u32 shift = (xlen + 63u) / 64u % NWAVES;
+				const u32 w2 = wave >= shift ? wave - shift : wave + NWAVES - shift;
+				for (u32 c0 = w2 * 64u; c0 < ylen; c0 += NWAVES * 64u) {
+					const u32 blk = c0 + lane;
+					if (blk < ylen) mpc_dma16(padb + 16 * ((u64)yb + blk), smem_raw + at + 16 * (xlen + c0));
 				}
 			}
-		};
-		// issues the DMA of the step described by nxt_* into staging buffer `buf`; returns the register holding the LDS byte
-		// address of record i in lane i
-		auto issue_dma = [&](u32 buf) -> u32 {
-			u32 vb = 0;
-			u32 at = MPC_RV_TAB_BYTES + buf * p.buf_bytes; // byte offset in the dynamic LDS
-#pragma unroll
-			for (int i = 0; i < MPC_RV_MAXSEQ; ++i) {
-				if ((u32)i < nseq) {
-					vb = mpc_write_lane(vb, lds0 + at, (u32)i);
-					const u32 sz = nxt_sz[i];
-					for (u32 c0 = wave * 64u; c0 < sz; c0 += NWAVES * 64u) { // chunks of 64 blocks = 1 KiB, dealt round-robin to the waves
-						const u32 blk = c0 + lane;
-						if (blk < sz)
-							mpc_dma16(padb + 16 * ((u64)nxt_off[i] + blk), smem_raw + at + 16 * c0);
-					}
-					at += 16u * sz;
-				}
-			}
-			return vb;
+			const u32 rel = lane < MPC_RV_YLANE ? tab - xs : tab - yb + xlen;
+			return lds0 + at + 16u * rel;
 		};
 
+		u32 tab_nxt = 0;
 		u32 vbase_cur = 0, vbase_nxt = 0; // lane i: LDS byte address of record i of the step being merged / being staged
-		const u32 wave_first = wave * 64u;
 		if (p.nbuf == 2) {
-			load_table(0);
-			vbase_cur = issue_dma(0);
-			if (n > 1) load_table(1);
+			const u32 tab0 = load_table(0);
+			vbase_cur = issue_dma(tab0, 0);
+			if (n > 1) tab_nxt = load_table(1);
 			mpc_dma_wait();
-		}
+		} else tab_nxt = load_table(0);
 		for (u32 Z = 0; Z < n; ++Z) {
-			if (p.nbuf == 2) {
+			if (DIAG == 2 && Z > 0) {
+				// measurement only: every step merges step 0's records
+			} else if (p.nbuf == 2) {
 				__syncthreads(); // step Z's records have landed (every wave waited for its own DMA) and step Z-1's readers are done
-				if (Z + 1 < n) {
-					vbase_nxt = issue_dma((Z + 1) & 1u);
-					if (Z + 2 < n) load_table(Z + 2);
+				if (DIAG != 2 && Z + 1 < n) {
+					vbase_nxt = issue_dma(tab_nxt, (Z + 1) & 1u);
+					if (Z + 2 < n) tab_nxt = load_table(Z + 2);
 				}
 			} else {
-				if (Z == 0) load_table(0);
 				__syncthreads(); // step Z-1's readers are done
-				vbase_cur = issue_dma(0);
-				if (Z + 1 < n) load_table(Z + 1);
+				vbase_cur = issue_dma(tab_nxt, 0);
+				if (Z + 1 < n) tab_nxt = load_table(Z + 1);
 				mpc_dma_wait();
 				__syncthreads();
 			}
-#pragma unroll
-			for (int q = 0; q < MAXSLOTS; ++q) {
-				if (DIAG != 1 && (u32)q * THREADS + wave_first < total) { // wave-uniform: my wave holds cells of this slot
-					const u32 sel = mpc_read_lane(vsel, (u32)q);
+			if (DIAG != 1 && nact != 0u) {
+				// first blocks of slot 0; from then on slot q+1's are read while slot q is computed
+				u32 nia, nib;
+				MpcQuad na, nb;
+				{
+					const u32 sel = mpc_read_lane(vsel, 0u);
 					const u32 sa = mpc_read_lane(vbase_cur, sel & 0xffu), sb = mpc_read_lane(vbase_cur, sel >> 8);
-					u32 c = xy[q];
+					u32 c = xy[0];
 					MPC_OPAQUE(c); // one register per slot: the two row offsets are unpacked per step
-					u32 ia = sa + (c & 0xffffu), ib = sb + (c >> 16);
-					float sum = acc[q];
-					// Block merge of the two sorted rows, one block of 2 entries of each per step: two aligned 16-byte LDS reads,
-					// a 2x2 column compare, two products, two adds (z ascending: relaxflat.cpp:16-29 / :41-58 / :78-92; an unmatched
-					// entry and a sentinel {0.0f, 0x1fff} contribute pa * 0.0f = +0.0f, which leaves the strictly positive sum
-					// unchanged bit for bit). The row whose last column is not larger moves to its next block (the distance in
-					// bytes rides in the upper half of the block's first column word); when that row has none the merge is over.
-					for (;;) {
-						const MpcQuad va = mpc_lds_load16(ia), vb = mpc_lds_load16(ib); // {p0, p1, c0 | dist << 16, c1}
-						const u32 ca0 = va.z & 0xffffu, cb0 = vb.z & 0xffffu;
-						const float pb0 = (ca0 == cb0) ? __uint_as_float(vb.x) : ((ca0 == vb.w) ? __uint_as_float(vb.y) : 0.0f);
-						const float pb1 = (va.w == cb0) ? __uint_as_float(vb.x) : ((va.w == vb.w) ? __uint_as_float(vb.y) : 0.0f);
-						sum += __uint_as_float(va.x) * pb0; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
-						sum += __uint_as_float(va.y) * pb1;
-						const bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
-						const u32 da = va.z >> 16, db = vb.z >> 16; // bytes to the next block of the row, 0: none
-						if ((adv_a && da == 0u) || (adv_b && db == 0u)) break;
-						ia += adv_a ? da : 0u;
-						ib += adv_b ? db : 0u;
-					}
-					acc[q] = sum;
+					nia = sa + (c & 0xffffu); nib = sb + (c >> 16);
+					na = mpc_lds_load16(nia); nb = mpc_lds_load16(nib);
 				}
+				// slots 0 .. nact-1, unrolled by recursion over the slot number (a loop with an early exit is not unrolled, and
+				// acc[] / xy[] must stay registers)
+				auto slot = [&](auto &&self, auto qc) __attribute__((always_inline)) {
+					constexpr int q = decltype(qc)::value;
+					if constexpr (q < MAXSLOTS) {
+						if ((u32)q >= nact) return; // wave-uniform: the slots a wave holds cells of are the first nact
+						u32 ia = nia, ib = nib;
+						MpcQuad va = na, vb = nb;
+						{
+							// slot q+1's first blocks, unconditionally (a slot without cells has sel 0 and offsets 0: row 0 of record 0)
+							constexpr int qn = q + 1 < MAXSLOTS ? q + 1 : q;
+							const u32 sel = mpc_read_lane(vsel, (u32)qn);
+							const u32 sa = mpc_read_lane(vbase_cur, sel & 0xffu), sb = mpc_read_lane(vbase_cur, sel >> 8);
+							u32 c = xy[qn];
+							MPC_OPAQUE(c);
+							nia = sa + (c & 0xffffu); nib = sb + (c >> 16);
+							na = mpc_lds_load16(nia); nb = mpc_lds_load16(nib);
+						}
+						float sum = acc[q];
+						MPC_RV_TERMS(sum, va, vb);
+						// The row whose last column is not larger moves to its next block (the distance in bytes rides in the
+						// upper half of the block's first column word; 0: the row ends here); when that row has none the merge
+						// is over. Most lanes stop here.
+						bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
+						u32 da = va.z >> 16, db = vb.z >> 16;
+						bool more = !((adv_a && da == 0u) || (adv_b && db == 0u));
+						while (more) {
+							ia += adv_a ? da : 0u;
+							ib += adv_b ? db : 0u;
+							va = mpc_lds_load16(ia); vb = mpc_lds_load16(ib);
+							MPC_RV_TERMS(sum, va, vb);
+							adv_a = va.w <= vb.w; adv_b = vb.w <= va.w;
+							da = va.z >> 16; db = vb.z >> 16;
+							more = !((adv_a && da == 0u) || (adv_b && db == 0u));
+						}
+						acc[q] = sum;
+						self(self, std::integral_constant<int, q + 1>{});
+					}
+				};
+				slot(slot, std::integral_constant<int, 0>{});
 			}
-			if (p.nbuf == 2) {
+			if (p.nbuf == 2 && DIAG != 2) {
 				mpc_dma_wait(); // my part of step Z+1's records is in LDS
-				vbase_cur = vbase_nxt;
+				if (Z + 1 < n) vbase_cur = vbase_nxt;
 			}
 		}
 		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern
 #pragma unroll
 		for (int q = 0; q < MAXSLOTS; ++q) {
 			MPC_SCHED_BARRIER();
-			const u32 g0 = (u32)q * THREADS + wave * 64u;
-			if (g0 < total) {
+			const u32 g0 = (u32)q * THREADS + wave_first;
+			if ((u32)q < nact) {
 				u32 pi = 0;
 				for (u32 j = 1; j < 16u; ++j) if (mpc_wave_first(ptab[8 * j]) <= g0 && mpc_wave_first(ptab[8 * j + 5]) != 0u) pi = j;
 				const u32 base = mpc_wave_first(ptab[8 * pi]), nnz = mpc_wave_first(ptab[8 * pi + 1]);

@@ -42,11 +42,18 @@ struct StoreParams {
 	// limits: one record per ORDERED pair (A,Z), a 16-byte-aligned verbatim copy of what the kernel wants in LDS:
 	//   [first block of every row: len(A) blocks, row a at block a][its overflow blocks]
 	// block = 16 bytes = {P0 bits, P1 bits, col0 | dist << 16, col1}: 2 entries (the two probabilities adjacent), dist = bytes to the
-	// next block of the same row (0 in its last); unused entries are sentinels {0.0f, MPC_PAD_SENTINEL}. A row is reached by its
-	// index alone (no row pointers); rows of up to 2 entries — most of them — never leave the first-block region. Record (A,Z)
-	// starts at block rec_off[A*n+Z] of `pad` (rec_off: n*n+1 entries, 16-byte units) and is exactly as long as it needs to be:
-	// 8.1 KB on average at 1000 x L~400 (padding every record to the worst one cost 13.3 KB). pos_f / pos_t give, per canonical
-	// entry, its entry index (block * 2 + slot) inside the record of (X,Y) and of (Y,X): written by var_build, used by commit.
+	// next block of the same row (0 in its last). A block that holds ONE entry (the last block of a row with an odd count)
+	// repeats its column with a zero probability, {P0, 0.0f, col0 | 0, col0}: its last column is then the row's real last
+	// column, which is what the merge's advance / stop decisions compare (a sentinel there kept the merge running one more
+	// step whenever the other row went on: 2.76 -> 2.45 steps per wave at 1000 x L~400, oracle statistics), and the repeated
+	// column contributes P * 0.0f = +0.0f. The block of an EMPTY row is {0.0f, 0.0f, MPC_PAD_SENTINEL, MPC_PAD_SENTINEL}. A row
+	// is reached by its index alone (no row pointers); rows of up to 2 entries — most of them — never leave the first-block
+	// region. Records are stored Z-MAJOR: record (A,Z) starts at block rec_off[Z*n+A] of `pad` (rec_off: n*n+1 entries, 16-byte
+	// units; mpc_rec_index), so the records a relax tile needs at step Z — those of 4 consecutive sequences A — are ONE
+	// contiguous run in HBM, staged by one stream of LDS-DMA chunks and described by 5 consecutive table entries. A record is
+	// exactly as long as it needs to be: 8.1 KB on average at 1000 x L~400 (padding every record to the worst one cost 13.3 KB).
+	// pos_f / pos_t give, per canonical entry, its entry index (block * 2 + slot) inside the record of (X,Y) and of (Y,X):
+	// written by var_build, used by commit.
 	u32 *pad;
 	u32 lcap1; // >= the longest sequence: LDS scratch of var_build_kernel
 	unsigned short *pos_f, *pos_t;
@@ -60,6 +67,9 @@ __device__ __forceinline__ u64 mpc_pair_index(u32 n, u32 i, u32 j) // i<j, mpcfl
 {
 	return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1);
 }
+
+// index of record (A,Z) in rec_off: Z-major (see StoreParams::pad)
+__device__ __forceinline__ u64 mpc_rec_index(u32 n, u32 A, u32 Z) { return (u64)Z * n + A; }
 
 // One 64-thread workgroup per ordered pair (A,Z): row pointers (exclusive scan of the per-row or
 // per-column counts) and entries (row-major copy, or column-major through tperm).
@@ -115,7 +125,7 @@ __global__ void __launch_bounds__(64) var_size_kernel(StoreParams s, u32 *sizes)
 	const int t = threadIdx.x;
 	const u64 total = (u64)s.n * s.n;
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
-		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n); // b == mpc_rec_index(n, A, Z)
 		const u32 LA = s.seq_len[A];
 		u32 mine = 0;
 		if (A != Z) {
@@ -142,7 +152,7 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 	const int t = threadIdx.x;
 	const u64 total = (u64)s.n * s.n;
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
-		const u32 A = (u32)(b / s.n), Z = (u32)(b % s.n);
+		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n); // b == mpc_rec_index(n, A, Z)
 		const u32 LA = s.seq_len[A];
 		u32 *rec_out = s.pad + 4 * (u64)s.rec_off[b];
 		const u32 units = s.rec_off[b + 1] - s.rec_off[b];
@@ -194,29 +204,35 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 			const u32 delta = j + 1 < nb ? (j == 0 ? ovf0 - r : 1u) : 0u; // blocks to the row's next block
 			rec_out[4 * unit + slot] = pbits;
 			rec_out[4 * unit + 2 + slot] = slot == 0 ? (c | (delta << 20)) : c; // << 16 and * 16: bytes
+			if (slot == 0 && within + 1 == cnt[r]) rec_out[4 * unit + 3] = c; // one-entry block: its column once more (P1 stays 0.0f)
 			pos[q] = (unsigned short)(unit * MPC_PAD_ROW + slot);
 		}
 		__syncthreads(); // s_start is reused by the next record
 	}
 }
 
-// Largest LDS footprint of a tile's records over one walk: out[t] = max over Z of the sum over the tile's resident sequences
-// (the X range, then the part of the Y range not in it) of blocks(seq, Z). One wave per tile, lanes stride over Z.
+// Largest LDS footprint of a tile's records over one walk: out[t] = max over Z of the blocks of the two runs relax_var_kernel
+// stages per step — records (x0..x0+nx-1, Z) and, of the Y range, the records beyond the X range (y >= x0+nx; a Y inside the X
+// range is already resident, a Y below it has no pair X < Y in the tile). One wave per tile, lanes stride over Z.
+__device__ __forceinline__ void mpc_tile_runs(u32 x0, u32 nx, u32 y0, u32 ny, u32 *ys, u32 *nys)
+{
+	const u32 lo = y0 > x0 + nx ? y0 : x0 + nx, hi = y0 + ny;
+	*ys = lo;
+	*nys = hi > lo ? hi - lo : 0u;
+}
+
 __global__ void __launch_bounds__(64) var_tile_fit_kernel(StoreParams s, const u32 *tiles, u32 ntiles, u32 *out)
 {
 	const u32 t = threadIdx.x, n = s.n;
 	for (u32 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
 		const u32 x0 = tiles[4 * tl], nx = tiles[4 * tl + 1], y0 = tiles[4 * tl + 2], ny = tiles[4 * tl + 3];
+		u32 ys, nys;
+		mpc_tile_runs(x0, nx, y0, ny, &ys, &nys);
 		u32 best = 0;
 		for (u32 Z = t; Z < n; Z += 64) {
-			u32 sum = 0;
-			for (u32 i = 0; i < nx; ++i) { const u64 b = (u64)(x0 + i) * n + Z; sum += s.rec_off[b + 1] - s.rec_off[b]; }
-			for (u32 i = 0; i < ny; ++i) {
-				const u32 Y = y0 + i;
-				if (Y >= x0 && Y < x0 + nx) continue;
-				const u64 b = (u64)Y * n + Z;
-				sum += s.rec_off[b + 1] - s.rec_off[b];
-			}
+			const u64 bx = mpc_rec_index(n, x0, Z);
+			u32 sum = s.rec_off[bx + nx] - s.rec_off[bx];
+			if (nys) { const u64 by = mpc_rec_index(n, ys, Z); sum += s.rec_off[by + nys] - s.rec_off[by]; }
 			best = sum > best ? sum : best;
 		}
 		for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_down(best, d); best = o > best ? o : best; }
@@ -316,8 +332,8 @@ __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
 		ent[2 * (u64)idx] = pb;
 		// entry `pos` of a record = block pos / 2, slot pos % 2: its probability is dword block * 4 + slot
 		const u32 pf = s.pos_f[e], pt = s.pos_t[e];
-		s.pad[4 * (u64)s.rec_off[(u64)X * s.n + Y] + (pf >> 1) * 4u + (pf & 1u)] = pb;
-		s.pad[4 * (u64)s.rec_off[(u64)Y * s.n + X] + (pt >> 1) * 4u + (pt & 1u)] = pb;
+		s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, X, Y)] + (pf >> 1) * 4u + (pf & 1u)] = pb;
+		s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, Y, X)] + (pt >> 1) * 4u + (pt & 1u)] = pb;
 	}
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes into profiles/pmc_traffic.json.
-usage: scripts/pmc_summary.py N LEN fetch_dir write_dir [out.json]
+usage: scripts/pmc_summary.py N LEN fetch_dir write_dir [out.json [sq_dir ...]]   (LEN 0 = the rdrp input)
 Each dir holds the csv output of `rocprofv3 --pmc FETCH_SIZE` (resp. WRITE_SIZE) `--output-format csv`.
 HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md §HBM (FETCH_SIZE on gfx950
 reports half the bytes of wide coalesced reads; both counters are in KiB); per launch = mean over
@@ -48,8 +48,9 @@ def main():
     # SQ passes next to the FETCH/WRITE directories (prof_sq, prof_sq2), when present: instruction counts per launch
     base = os.path.dirname(os.path.normpath(fdir))
     sq = defaultdict(lambda: defaultdict(list))
-    for sub in ("prof_sq", "prof_sq2"):
-        for fn in glob.glob(os.path.join(base, sub, "**", "*counter_collection.csv"), recursive=True):
+    sq_dirs = sys.argv[6:] if len(sys.argv) > 6 else [os.path.join(base, "prof_sq"), os.path.join(base, "prof_sq2")]
+    for sub in sq_dirs:
+        for fn in glob.glob(os.path.join(sub, "**", "*counter_collection.csv"), recursive=True):
             with open(fn) as f:
                 for row in csv.DictReader(f):
                     sq[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
