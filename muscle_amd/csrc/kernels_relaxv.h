@@ -14,7 +14,7 @@
 //    record starts is read from 5 + 5 consecutive entries of the block-offset table by ONE vector load per step (lane i =
 //    record i), one step ahead; the lane-indexed result IS the register the merges take their record bases from.
 //  * The cells of the tile's pairs are laid end to end over (slot, lane), every pair rounded up to whole waves, so the 64
-//    cells of a (wave, slot) belong to ONE pair: its two record bases are two v_readlane of that register. A lane keeps,
+//    cells of a (wave, slot) belong to ONE pair: its two record bases come out of that register (one gather per step). A lane keeps,
 //    per slot, the accumulator and the byte offsets of its cell's two rows (16*x | 16*y << 16) in VGPRs for the whole walk.
 //  * Per (cell, Z): a block merge of row x of M(X,Z) and row y of M(Y,Z), 2 entries per block and step. The FIRST step of
 //    every slot is straight-line code for all lanes, and the two LDS reads of slot q+1's first step are issued before slot
@@ -56,11 +56,43 @@ struct RelaxVarParams {
 		sum += __uint_as_float((va).y) * pb1_;                                                                          \
 	} while (0)
 
+// The merge of one (cell, Z) in C++: the statement of what MpcRvBlocksAsm (mpc_platform.h) does with hand-scheduled
+// instructions. The emulator runs this one; on the device it is the MPCGPU_RELAX_MERGE=cxx instantiation (A/B).
+struct MpcRvBlocksCxx {
+	MpcQuad a[2], b[2];
+	__device__ __forceinline__ void load(int set, u32 ia, u32 ib) { a[set] = mpc_lds_load16(ia); b[set] = mpc_lds_load16(ib); }
+	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32 ib, u32 nia, u32 nib)
+	{
+		MpcQuad va = a[SET], vb = b[SET];
+		load(SET ^ 1, nia, nib); // the next slot's first blocks: in flight during this slot's arithmetic
+		MPC_RV_TERMS(sum, va, vb);
+		// The row whose last column is not larger moves to its next block (the distance in bytes rides in the upper half of
+		// the block's first column word; 0: the row ends here); when that row has none the merge is over. Most lanes stop
+		// after the first step.
+		bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
+		u32 da = va.z >> 16, db = vb.z >> 16;
+		bool more = !((adv_a && da == 0u) || (adv_b && db == 0u));
+		while (more) {
+			ia += adv_a ? da : 0u;
+			ib += adv_b ? db : 0u;
+			va = mpc_lds_load16(ia); vb = mpc_lds_load16(ib);
+			MPC_RV_TERMS(sum, va, vb);
+			adv_a = va.w <= vb.w; adv_b = vb.w <= va.w;
+			da = va.z >> 16; db = vb.z >> 16;
+			more = !((adv_a && da == 0u) || (adv_b && db == 0u));
+		}
+	}
+};
+#ifndef MPC_RV_HAVE_ASM
+typedef MpcRvBlocksCxx MpcRvBlocksAsm; // the emulator has one implementation
+#endif
+
 // THREADS: workgroup size; MAXSLOTS: cells per lane (the host splits any tile whose wave-aligned cells need more);
 // DIAG (measurement only, results wrong): 1 = staging and barriers only, 2 = merges only (step 0's records for every step,
 // no further staging, no barriers).
 // WGS: workgroups per CU the register allocation has to allow (waves per SIMD = WGS * THREADS / 256).
-template <int THREADS, int MAXSLOTS, int WGS, int DIAG = 0>
+// BLOCKS: MpcRvBlocksAsm (hand-scheduled merge, the default) or MpcRvBlocksCxx.
+template <int THREADS, int MAXSLOTS, int WGS, int DIAG = 0, class BLOCKS = MpcRvBlocksAsm>
 __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel(RelaxVarParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
@@ -138,7 +170,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 		// offsets stay in VGPRs for the whole walk; the pair's two step-table lanes go into lane q of `vsel`.
 		float acc[MAXSLOTS];
 		u32 xy[MAXSLOTS]; // 16 * x | (16 * y) << 16: byte offsets of row x of M(X,.) and row y of M(Y,.) inside their records
-		u32 vsel = 0;
+		u32 vsel_a = 0, vsel_b = 0; // lane q: 4 * (step-table lane of slot q's X record / Y record): index registers of the gather below
 #pragma unroll
 		for (int q = 0; q < MAXSLOTS; ++q) {
 			MPC_SCHED_BARRIER();
@@ -149,7 +181,8 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 				for (u32 j = 1; j < 16u; ++j) if (mpc_wave_first(ptab[8 * j]) <= g0 && mpc_wave_first(ptab[8 * j + 5]) != 0u) pi = j;
 				const u32 base = mpc_wave_first(ptab[8 * pi]), nnz = mpc_wave_first(ptab[8 * pi + 1]), sel = mpc_wave_first(ptab[8 * pi + 2]);
 				const u64 k = (u64)mpc_wave_first(ptab[8 * pi + 3]) | ((u64)mpc_wave_first(ptab[8 * pi + 4]) << 32);
-				vsel = mpc_write_lane(vsel, sel, (u32)q);
+				vsel_a = mpc_write_lane(vsel_a, 4u * (sel & 0xffu), (u32)q);
+				vsel_b = mpc_write_lane(vsel_b, 4u * (sel >> 8), (u32)q);
 				const u32 idx = g0 + lane - base;
 				if (idx < nnz) {
 					const u32 *ent = s.packed + s.pbase[k] + s.seq_len[s.pair_x[k]] + s.seq_len[s.pair_y[k]];
@@ -215,16 +248,16 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 				__syncthreads();
 			}
 			if (DIAG != 1 && nact != 0u) {
-				// first blocks of slot 0; from then on slot q+1's are read while slot q is computed
+				// lane q of base_a / base_b: LDS address of slot q's two records at this step (one cross-lane gather each per step;
+				// a slot then takes its bases with two v_readlane of a constant lane)
+				const u32 base_a = mpc_lane_gather(vbase_cur, vsel_a), base_b = mpc_lane_gather(vbase_cur, vsel_b);
+				// first blocks of slot 0; from then on slot q+1's are read while slot q is merged
+				BLOCKS blk;
 				u32 nia, nib;
-				MpcQuad na, nb;
 				{
-					const u32 sel = mpc_read_lane(vsel, 0u);
-					const u32 sa = mpc_read_lane(vbase_cur, sel & 0xffu), sb = mpc_read_lane(vbase_cur, sel >> 8);
-					u32 c = xy[0];
-					MPC_OPAQUE(c); // one register per slot: the two row offsets are unpacked per step
-					nia = sa + (c & 0xffffu); nib = sb + (c >> 16);
-					na = mpc_lds_load16(nia); nb = mpc_lds_load16(nib);
+					const u32 c = xy[0]; // one register per slot: the two row offsets are unpacked per step
+					nia = mpc_read_lane(base_a, 0u) + (c & 0xffffu); nib = mpc_read_lane(base_b, 0u) + (c >> 16);
+					blk.load(0, nia, nib);
 				}
 				// slots 0 .. nact-1, unrolled by recursion over the slot number (a loop with an early exit is not unrolled, and
 				// acc[] / xy[] must stay registers)
@@ -232,35 +265,15 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 					constexpr int q = decltype(qc)::value;
 					if constexpr (q < MAXSLOTS) {
 						if ((u32)q >= nact) return; // wave-uniform: the slots a wave holds cells of are the first nact
-						u32 ia = nia, ib = nib;
-						MpcQuad va = na, vb = nb;
+						const u32 ia = nia, ib = nib;
 						{
 							// slot q+1's first blocks, unconditionally (a slot without cells has sel 0 and offsets 0: row 0 of record 0)
 							constexpr int qn = q + 1 < MAXSLOTS ? q + 1 : q;
-							const u32 sel = mpc_read_lane(vsel, (u32)qn);
-							const u32 sa = mpc_read_lane(vbase_cur, sel & 0xffu), sb = mpc_read_lane(vbase_cur, sel >> 8);
-							u32 c = xy[qn];
-							MPC_OPAQUE(c);
-							nia = sa + (c & 0xffffu); nib = sb + (c >> 16);
-							na = mpc_lds_load16(nia); nb = mpc_lds_load16(nib);
+							const u32 c = xy[qn];
+							nia = mpc_read_lane(base_a, (u32)qn) + (c & 0xffffu); nib = mpc_read_lane(base_b, (u32)qn) + (c >> 16);
 						}
 						float sum = acc[q];
-						MPC_RV_TERMS(sum, va, vb);
-						// The row whose last column is not larger moves to its next block (the distance in bytes rides in the
-						// upper half of the block's first column word; 0: the row ends here); when that row has none the merge
-						// is over. Most lanes stop here.
-						bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
-						u32 da = va.z >> 16, db = vb.z >> 16;
-						bool more = !((adv_a && da == 0u) || (adv_b && db == 0u));
-						while (more) {
-							ia += adv_a ? da : 0u;
-							ib += adv_b ? db : 0u;
-							va = mpc_lds_load16(ia); vb = mpc_lds_load16(ib);
-							MPC_RV_TERMS(sum, va, vb);
-							adv_a = va.w <= vb.w; adv_b = vb.w <= va.w;
-							da = va.z >> 16; db = vb.z >> 16;
-							more = !((adv_a && da == 0u) || (adv_b && db == 0u));
-						}
+						blk.template merge<q & 1>(sum, ia, ib, nia, nib);
 						acc[q] = sum;
 						self(self, std::integral_constant<int, q + 1>{});
 					}

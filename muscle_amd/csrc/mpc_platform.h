@@ -82,6 +82,8 @@ __device__ __forceinline__ float mpc_wave_scan_max_nonneg(float v)
 // value of lane `l` (wave-uniform index) as a scalar: v_readlane_b32, no LDS
 __device__ __forceinline__ unsigned mpc_read_lane(unsigned v, unsigned l) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ float mpc_read_lane(float v, unsigned l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l)); }
+// cross-lane gather: lane l receives v of lane byte_index[l] / 4 (ds_bpermute_b32: the LDS crossbar, no LDS memory)
+__device__ __forceinline__ unsigned mpc_lane_gather(unsigned v, unsigned byte_index) { return (unsigned)__builtin_amdgcn_ds_bpermute((int)byte_index, (int)v); }
 // optimisation barrier on one VGPR value (no code): stops hoisting of what is derived from it
 #define MPC_OPAQUE(v) asm volatile("" : "+v"(v))
 // orders this wave's earlier global stores before its later global loads (other lanes' data): s_waitcnt only,
@@ -113,6 +115,85 @@ __device__ __forceinline__ MpcQuad mpc_lds_load16(unsigned addr)
 	MpcQuad q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
 	return q;
 }
+// ---- relax_var_kernel's merge of one (cell, Z), hand-scheduled (kernels_relaxv.h holds the C++ statement of the same merge:
+// MpcRvBlocksCxx — what the emulator runs and what MPCGPU_RELAX_MERGE=cxx selects on the device for A/B).
+// Two sets of 2 x 4 VGPRs hold the blocks {p0, p1, c0 | dist << 16, c1} of the two rows: the set of the slot being merged and
+// the set the NEXT slot's first blocks are read into meanwhile. ds_read_b128 wants register quadruples and the arithmetic
+// wants their single registers, which inline asm can only name when the quadruples are physical registers: v[24:39].
+// Per step of the merge (the loop below): 8 compares, 4 selects, 2 products, 2 adds, and — only for the lanes that go on — two
+// adds under the advance masks (exec), against 23 VALU instructions from the compiler (two redundant compares, three
+// selects and a shift for the advance). "s_orn2 nl, nl, adv" is "the row has a next block, or it is not the row that advances".
+typedef unsigned long long mpc_u64s;
+struct MpcRvBlocksAsm {
+	mpc_uint4v a0, b0, a1, b1; // set 0: v[24:27], v[28:31]; set 1: v[32:35], v[36:39]
+	__device__ __forceinline__ void load(int set, unsigned ia, unsigned ib)
+	{
+		if (set == 0) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "={v[24:27]}"(a0), "={v[28:31]}"(b0) : "v"(ia), "v"(ib) : "memory");
+		else asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "={v[32:35]}"(a1), "={v[36:39]}"(b1) : "v"(ia), "v"(ib) : "memory");
+	}
+#define MPC_RV_MERGE_ASM(A0_, A1_, A2_, A3_, B0_, B1_, B2_, B3_, CURA_, CURB_, NXTA_, NXTB_)                           \
+	"s_waitcnt lgkmcnt(0)\n\t" /* this slot's first blocks (read during the previous slot) have landed */               \
+	"ds_read_b128 " NXTA_ ", %[nia]\n\t"                                                                                 \
+	"ds_read_b128 " NXTB_ ", %[nib]\n\t"                                                                                 \
+	"s_mov_b64 %[sv], exec\n"                                                                                            \
+	".Lrv_step_%=:\n\t"                                                                                                  \
+	"v_cmp_eq_u32_sdwa %[e01], " A2_ ", " B3_ " src0_sel:WORD_0 src1_sel:DWORD\n\t"                                      \
+	"v_cmp_eq_u32_sdwa %[e00], " A2_ ", " B2_ " src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                     \
+	"v_cmp_eq_u32_e64 %[e11], " A3_ ", " B3_ "\n\t"                                                                      \
+	"v_cmp_eq_u32_sdwa %[e10], " A3_ ", " B2_ " src0_sel:DWORD src1_sel:WORD_0\n\t"                                      \
+	"v_cmp_le_u32_e64 %[ada], " A3_ ", " B3_ "\n\t"                                                                      \
+	"v_cmp_le_u32_e64 %[adb], " B3_ ", " A3_ "\n\t"                                                                      \
+	"v_cmp_lt_u32_e64 %[nla], %[kf], " A2_ "\n\t"                                                                        \
+	"v_cmp_lt_u32_e64 %[nlb], %[kf], " B2_ "\n\t"                                                                        \
+	"v_cndmask_b32_e64 %[t0], 0, " B1_ ", %[e01]\n\t"                                                                    \
+	"v_cndmask_b32_e64 %[t1], 0, " B1_ ", %[e11]\n\t"                                                                    \
+	"v_cndmask_b32_e64 %[t0], %[t0], " B0_ ", %[e00]\n\t" /* of two equal columns in B the first wins */                 \
+	"v_cndmask_b32_e64 %[t1], %[t1], " B0_ ", %[e10]\n\t"                                                                \
+	"v_mul_f32_e32 %[t0], " A0_ ", %[t0]\n\t"                                                                            \
+	"v_mul_f32_e32 %[t1], " A1_ ", %[t1]\n\t"                                                                            \
+	"v_add_f32_e32 %[sum], %[sum], %[t0]\n\t" /* z ascending: relaxflat.cpp:27, product rounded, then added */           \
+	"v_add_f32_e32 %[sum], %[sum], %[t1]\n\t"                                                                            \
+	"s_orn2_b64 %[nla], %[nla], %[ada]\n\t"                                                                              \
+	"s_orn2_b64 %[nlb], %[nlb], %[adb]\n\t"                                                                              \
+	"s_and_b64 %[nla], %[nla], %[nlb]\n\t"                                                                               \
+	"s_and_b64 exec, exec, %[nla]\n\t" /* the lanes that go on; scc = any */                                             \
+	"s_cbranch_scc0 .Lrv_done_%=\n\t"                                                                                    \
+	"s_mov_b64 %[nlb], exec\n\t"                                                                                         \
+	"s_and_b64 exec, %[nlb], %[ada]\n\t"                                                                                 \
+	"v_add_u32_sdwa %[ia], %[ia], " A2_ " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"        \
+	"s_and_b64 exec, %[nlb], %[adb]\n\t"                                                                                 \
+	"v_add_u32_sdwa %[ib], %[ib], " B2_ " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"        \
+	"s_mov_b64 exec, %[nlb]\n\t"                                                                                         \
+	"ds_read_b128 " CURA_ ", %[ia]\n\t"                                                                                  \
+	"ds_read_b128 " CURB_ ", %[ib]\n\t"                                                                                  \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
+	"s_branch .Lrv_step_%=\n"                                                                                            \
+	".Lrv_done_%=:\n\t"                                                                                                  \
+	"s_mov_b64 exec, %[sv]"
+	// merges the slot whose first blocks are in set SET (addresses ia, ib) onto sum; reads the blocks at nia, nib into the other set
+	template <int SET> __device__ __forceinline__ void merge(float &sum, unsigned ia, unsigned ib, unsigned nia, unsigned nib)
+	{
+		mpc_u64s sv, e00, e01, e10, e11, ada, adb, nla, nlb;
+		float t0, t1;
+		const unsigned kf = 0xffffu;
+		if (SET == 0)
+			asm volatile(MPC_RV_MERGE_ASM("v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v[24:27]", "v[28:31]", "v[32:35]", "v[36:39]")
+				: [sum] "+v"(sum), [ia] "+v"(ia), [ib] "+v"(ib), "+{v[24:27]}"(a0), "+{v[28:31]}"(b0), "=&{v[32:35]}"(a1), "=&{v[36:39]}"(b1),
+				  [t0] "=&v"(t0), [t1] "=&v"(t1), [sv] "=&s"(sv), [e00] "=&s"(e00), [e01] "=&s"(e01), [e10] "=&s"(e10), [e11] "=&s"(e11),
+				  [ada] "=&s"(ada), [adb] "=&s"(adb), [nla] "=&s"(nla), [nlb] "=&s"(nlb)
+				: [nia] "v"(nia), [nib] "v"(nib), [kf] "s"(kf)
+				: "vcc", "scc", "memory");
+		else
+			asm volatile(MPC_RV_MERGE_ASM("v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v[32:35]", "v[36:39]", "v[24:27]", "v[28:31]")
+				: [sum] "+v"(sum), [ia] "+v"(ia), [ib] "+v"(ib), "+{v[32:35]}"(a1), "+{v[36:39]}"(b1), "=&{v[24:27]}"(a0), "=&{v[28:31]}"(b0),
+				  [t0] "=&v"(t0), [t1] "=&v"(t1), [sv] "=&s"(sv), [e00] "=&s"(e00), [e01] "=&s"(e01), [e10] "=&s"(e10), [e11] "=&s"(e11),
+				  [ada] "=&s"(ada), [adb] "=&s"(adb), [nla] "=&s"(nla), [nlb] "=&s"(nlb)
+				: [nia] "v"(nia), [nib] "v"(nib), [kf] "s"(kf)
+				: "vcc", "scc", "memory");
+	}
+#undef MPC_RV_MERGE_ASM
+};
+#define MPC_RV_HAVE_ASM 1
 // A pointer through which wave-uniform reads of memory that this kernel never writes become scalar loads (s_load_dword*:
 // SGPR results, no VGPRs, no vmcnt): the constant address space. (Through a plain global pointer the compiler has to assume
 // the kernel's own stores may alias and issues vector loads.)

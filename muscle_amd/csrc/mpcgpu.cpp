@@ -377,9 +377,9 @@ u32 var_geo_from_env()
 	return t == 512 ? 512u : t == 1024 ? 1024u : t == 2048 ? 2048u : 768u;
 }
 
-template <int TH, int SL, int WGS, int DG = 0> void launch_relax_var(const RelaxVarParams &rp, u32 grid, size_t smem, hipStream_t st)
+template <int TH, int SL, int WGS, int DG = 0, class BL = MpcRvBlocksAsm> void launch_relax_var(const RelaxVarParams &rp, u32 grid, size_t smem, hipStream_t st)
 {
-	auto kern = relax_var_kernel<TH, SL, WGS, DG>;
+	auto kern = relax_var_kernel<TH, SL, WGS, DG, BL>;
 	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
 }
 
@@ -479,9 +479,13 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	HIPCHK(c, c->d_tile_next.ensure(8 * 4));
 	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 8 * 4, c->stream));
 	rp.tile_next = c->d_tile_next.as<u32>();
-	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only
-	const void *fn = geo == 1024 ? (diag == 1 ? (const void *)relax_var_kernel<1024, 16, 1, 1> : (const void *)relax_var_kernel<1024, 16, 1>)
-	               : geo == 2048 ? (const void *)relax_var_kernel<1024, 14, 2> : geo == 768 ? (const void *)relax_var_kernel<768, 18, 2>
+	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only (results wrong): 1 = staging only, 2 = merges only
+	const char *merge_env = getenv("MPCGPU_RELAX_MERGE"); // "cxx": the compiler's code for the merge instead of the hand-scheduled one (A/B, 768 geometry)
+	const bool merge_cxx = merge_env && !strcmp(merge_env, "cxx");
+	const void *fn = geo == 1024 ? (const void *)relax_var_kernel<1024, 16, 1>
+	               : geo == 2048 ? (const void *)relax_var_kernel<1024, 14, 2>
+	               : geo == 768 ? (diag == 1 ? (const void *)relax_var_kernel<768, 18, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<768, 18, 2, 2>
+	                               : merge_cxx ? (const void *)relax_var_kernel<768, 18, 2, 0, MpcRvBlocksCxx> : (const void *)relax_var_kernel<768, 18, 2>)
 	               : (const void *)relax_var_kernel<512, 26, 2>;
 	HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 	int occ = 0;
@@ -493,11 +497,14 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
-	if (geo == 1024) {
-		if (diag == 1) launch_relax_var<1024, 16, 1, 1>(rp, grid, smem, c->stream);
-		else launch_relax_var<1024, 16, 1>(rp, grid, smem, c->stream);
-	} else if (geo == 2048) launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
-	else if (geo == 768) launch_relax_var<768, 18, 2>(rp, grid, smem, c->stream);
+	if (geo == 1024) launch_relax_var<1024, 16, 1>(rp, grid, smem, c->stream);
+	else if (geo == 2048) launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
+	else if (geo == 768) {
+		if (diag == 1) launch_relax_var<768, 18, 2, 1>(rp, grid, smem, c->stream);
+		else if (diag == 2) launch_relax_var<768, 18, 2, 2>(rp, grid, smem, c->stream);
+		else if (merge_cxx) launch_relax_var<768, 18, 2, 0, MpcRvBlocksCxx>(rp, grid, smem, c->stream);
+		else launch_relax_var<768, 18, 2>(rp, grid, smem, c->stream);
+	}
 	else launch_relax_var<512, 26, 2>(rp, grid, smem, c->stream);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
