@@ -217,52 +217,80 @@ def main():
                  else "relax_tile_kernel" if "relax_tile_kernel" in geo else "relax_kernel")
         fixture_shape = (a.n, a.len) if not a.fasta else (a.n, 0)
 
+        CHIP_SIMDS, CHIP_CUS, CLOCK_HZ = 1024, 256, 2.1e9  # MI355X: 256 CUs x 4 SIMDs; the clock the chip sustains under these kernels
+
         def issue_fraction(pmc, avg_s, units_per_inst):
             """VALU issue time / launch time from the committed SQ pass: wave-instructions x issue cost (diag/pkbench: a full-rate
             VALU op = 2 cycles per wave on a SIMD; units_per_inst = the mix's mean cost in such ops from scripts/isa_cost.py)
             over 1024 SIMDs at the 2.1 GHz the chip sustains under this load."""
             if not pmc or "sq_per_launch" not in pmc or "SQ_INSTS_VALU" not in pmc["sq_per_launch"]:
                 return None
-            return pmc["sq_per_launch"]["SQ_INSTS_VALU"] * units_per_inst * 2.0 / (1024 * 2.1e9) / avg_s
+            return pmc["sq_per_launch"]["SQ_INSTS_VALU"] * units_per_inst * 2.0 / (CHIP_SIMDS * CLOCK_HZ) / avg_s
+
+        def lds_fraction(pmc, avg_s):
+            """LDS-array cycles (SQ_LDS_IDX_ACTIVE, conflicts included) / cycles of the launch, per CU."""
+            if not pmc or "SQ_LDS_IDX_ACTIVE" not in pmc.get("sq_per_launch", {}):
+                return None
+            return pmc["sq_per_launch"]["SQ_LDS_IDX_ACTIVE"] / (CHIP_CUS * CLOCK_HZ) / avg_s
+
+        def measured_roof(r, pmc, avg_s, units_per_inst, launched_kernel):
+            """roofline.bound / frac from MEASURED counters: the binding resource is the one with the largest measured fraction of
+            its own roof (HBM bytes per launch / 8 TB/s, VALU issue time / launch time, LDS-array cycles / launch cycles); frac is
+            that fraction, always <= 1. Counters are taken only from a committed PMC pass of the SAME kernel instantiation that just
+            ran (profiles/pmc_traffic.json records rocprofv3's kernel name; mpcgpu_relax_info reports what was launched)."""
+            if pmc is not None and launched_kernel is not None and launched_kernel not in pmc.get("kernel", ""):
+                r["pmc_rejected"] = "committed PMC pass is of %r, this run launched %r" % (pmc.get("kernel"), launched_kernel)
+                pmc = None
+            traffic = None if pmc is None else float(pmc["hbm_bytes_per_launch"])
+            fr = {"hbm": None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
+                  "valu_issue": issue_fraction(pmc, avg_s, units_per_inst), "lds": lds_fraction(pmc, avg_s)}
+            r["traffic"] = traffic
+            r["measured_fractions"] = fr
+            known = {k: v for k, v in fr.items() if v is not None}
+            if known:
+                b = max(known, key=known.get)
+                r["bound"], r["frac"] = b, known[b]
+                if b == "hbm":
+                    r["achieved"], r["peak"], r["unit"] = traffic / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+                else:
+                    r["achieved"], r["peak"], r["unit"] = known[b], 1.0, "fraction of %s cycles" % ("VALU issue" if b == "valu_issue" else "LDS array")
+                r["counter_source"] = pmc.get("source")
+            else:
+                r["bound"], r["frac"], r["achieved"], r["peak"], r["unit"] = None, None, None, None, None
+            return r
 
         def relax_roof():
             ms, launches = timers["relax"]
             avg_s = ms * 1e-3 / max(launches, 1)
             per_launch = stage_b_bytes(lens, nnz) * my_frac  # one launch = one relax iteration over this rank's pairs
-            achieved = per_launch / avg_s / 1e9
-            pmc = pmc_entry(kname, *fixture_shape)
-            traffic = None if pmc is None else float(pmc["hbm_bytes_per_launch"])
-            r = {"kernel": kname + " (consistency relax: sampled sparse product over the all-pairs store, LDS-tiled)",
-                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                 "traffic": traffic, "algorithmic_bytes_per_launch": per_launch, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
-                 "measured_hbm_frac": None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
-                 "valu_issue_frac": issue_fraction(pmc, avg_s, 1.30),
-                 "note": "achieved = ALGORITHMIC bytes per launch (SURVEY.md 8d stage B: every (pair,Z) reads both operand matrices once = "
-                         "sum of 8*(nnz_XZ+nnz_YZ)+4*(LX+LY+2), + 4*nnz written) / average launch time (hipEvents on the library stream; "
-                         "profiles/*kernel_stats*.csv agrees). The LDS tiling serves 16 pairs from 8 records, so the bytes that really cross "
-                         "the fabric are FEWER than the algorithmic ones and `frac` can exceed 1: it is a progress figure. The real roofs: "
-                         "`traffic` = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                         "(2*FETCH_SIZE + WRITE_SIZE, KiB; MI355X_MICROARCH.md HBM section) -> measured_hbm_frac of the 8 TB/s spec; "
-                         "valu_issue_frac = VALU issue time / launch time from the SQ pass (the kernel is bound by instruction issue and LDS "
-                         "latency, DESIGN.md 4.3). null = no committed PMC pass for this workload."}
-            return r
+            launched = geo.split("kernel=")[1].split(";")[0].strip() if "kernel=" in geo else None
+            r = {"kernel": (launched or kname) + " (consistency relax: sampled sparse product over the all-pairs store, LDS-tiled)",
+                 "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+                 "algorithmic_bytes_per_launch": per_launch, "algorithmic_rate_GBs": per_launch / avg_s / 1e9,
+                 "note": "bound / frac: the resource with the largest MEASURED fraction of its roof (see measured_fractions): HBM = "
+                         "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch from separate rocprofv3 --pmc passes / launch time / 8 TB/s "
+                         "(MI355X_MICROARCH.md HBM section); valu_issue = SQ_INSTS_VALU x mean issue cost x 2 cycles / (1024 SIMDs x 2.1 GHz) "
+                         "/ launch time; lds = SQ_LDS_IDX_ACTIVE / (256 CUs x 2.1 GHz) / launch time. Launch time: hipEvents on the "
+                         "library's stream (profiles/*kernel_stats*.csv agrees). algorithmic_rate_GBs = SURVEY.md 8d stage-B bytes "
+                         "(every (pair,Z) reads both operand matrices once: sum of 8*(nnz_XZ+nnz_YZ)+4*(LX+LY+2), + 4*nnz written) / "
+                         "launch time: a progress figure, NOT a fraction of a roof (the LDS tiling serves 16 pairs from 8 records, so "
+                         "far fewer bytes cross the fabric). null = no committed PMC pass for this workload and this kernel."}
+            return measured_roof(r, pmc_entry(kname, *fixture_shape), avg_s, 1.20, launched)
 
         def fb_roof():
             ms, launches = timers["fb"]
             avg_s = ms * 1e-3 / max(launches, 1)
             per_launch = stage_a_flops(lens) * my_frac * a.steps / max(launches, 1)  # all pairs of this rank per step, over launches/steps batches
             achieved = per_launch / avg_s / 1e12
-            pmc = pmc_entry("fb_kernel", *fixture_shape)
-            return {"kernel": "fb_kernel<H> (pair-HMM fwd+bwd+posterior threshold, one wave per pair)", "bound": "valu",
-                    "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                    "traffic": None if pmc is None else float(pmc["hbm_bytes_per_launch"]), "launches": launches,
-                    "avg_launch_ms": ms / max(launches, 1), "valu_issue_frac": issue_fraction(pmc, avg_s, 1.27),
-                    "no_fma_add_mul_peak_TFLOPs": 63.0,
-                    "note": "FP32 vector-ALU bound log-space recurrence: no contraction (parity), no MFMA shape. peak = 157.3 TFLOP/s FP32 vector = "
-                            "FP32 dense MFMA peak, which counts v_pk_fma_f32; measured on this chip (diag/pkbench, profiles/r02b_pkbench.log) plain "
-                            "add/mul issue at 63 Tlane-op/s and min/max/cvt/select at 0.6 of that, so 63 TFLOP/s is the ceiling of an FMA-free "
-                            "stream. Algorithmic flops per launch = sum over its pairs of 164(LX+1)(LY+1)+5LXLY (SURVEY.md 8d). valu_issue_frac "
-                            "(SQ pass) says how much of the launch the VALU is issuing."}
+            r = {"kernel": "fb_kernel<H> (pair-HMM fwd+bwd+posterior threshold, one wave per pair)",
+                 "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+                 "algorithmic_TFLOPs": achieved, "frac_of_fp32_vector_peak": achieved / FP32_PEAK_TFLOPS, "no_fma_add_mul_peak_TFLOPs": 63.0,
+                 "note": "FP32 vector-ALU bound log-space recurrence: no contraction (parity), no MFMA shape. bound / frac as for the relax "
+                         "kernel (measured fractions; valu_issue = how much of the launch the VALU is issuing). algorithmic_TFLOPs = sum over "
+                         "the launch's pairs of 164(LX+1)(LY+1)+5LXLY flop (SURVEY.md 8d) / launch time; frac_of_fp32_vector_peak is against "
+                         "157.3 TFLOP/s, which counts v_pk_fma_f32 — measured on this chip (diag/pkbench, profiles/r02b_pkbench.log) plain "
+                         "add/mul issue at 63 Tlane-op/s and min/max/cvt/select at 0.6 of that, so 63 TFLOP/s is the ceiling of an FMA-free stream."}
+            return measured_roof(r, pmc_entry("fb_kernel", *fixture_shape), avg_s, 1.27, None)
 
         roof = relax_roof() if timers["relax"][0] >= timers["fb"][0] else fb_roof()
         roof_other = fb_roof() if timers["relax"][0] >= timers["fb"][0] else relax_roof()

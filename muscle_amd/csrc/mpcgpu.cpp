@@ -145,7 +145,7 @@ struct mpcgpu_ctx {
 	u32 var_max_rec_blocks = 0;  // largest record, 16-byte blocks
 	u64 var_total_blocks = 0;
 	u32 var_threads = 1024, var_nbuf = 2, var_buf_bytes = 0;
-	std::string store_desc, tiles_desc; // mpcgpu_relax_info
+	std::string store_desc, tiles_desc, relax_kernel_name; // mpcgpu_relax_info
 	bool relax_fallback = false;
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
 	std::vector<u32> h_tiles;
@@ -488,6 +488,12 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	                               : merge_cxx ? (const void *)relax_var_kernel<768, 18, 2, 0, MpcRvBlocksCxx> : (const void *)relax_var_kernel<768, 18, 2>)
 	               : (const void *)relax_var_kernel<512, 26, 2>;
 	HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+	{
+		char kn[128];
+		snprintf(kn, sizeof(kn), "relax_var_kernel<%u, %u, %d, %d, %s>", threads, geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : 26u,
+			geo == 1024 ? 1 : 2, geo == 768 ? diag : 0, (geo == 768 && merge_cxx && !diag) ? "MpcRvBlocksCxx" : "MpcRvBlocksAsm");
+		c->relax_kernel_name = kn;
+	}
 	int occ = 0;
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)threads, smem) != hipSuccess || occ < 1) occ = 1;
 	u32 grid = std::max(std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ), 1u);
@@ -572,7 +578,7 @@ int build_var_store(mpcgpu_ctx *c)
 			threads == 2048 ? "2 x 1024-thread workgroups per CU" : threads == 1024 ? "1 x 1024-thread workgroup per CU" :
 			threads == 768 ? "2 x 768-thread workgroups per CU" : "2 x 512-thread workgroups per CU",
 			nbuf, nbuf == 1 ? "" : "s", buf_bytes);
-		c->store_desc = b; c->tiles_desc.clear(); c->relax_fallback = false;
+		c->store_desc = b; c->tiles_desc.clear(); c->relax_kernel_name.clear(); c->relax_fallback = false;
 	}
 	StoreParams sp;
 	fill_store_params(c, sp);
@@ -1297,6 +1303,7 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 		const char *rm = getenv("MPCGPU_RELAX");
 		c->store_desc = "CSR slabs per sequence; relax_kernel (one thread per stored cell gathers its rows from HBM: the slow path, ~5x the LDS-tiled kernels)";
 		c->tiles_desc.clear();
+		c->relax_kernel_name = "relax_kernel";
 		c->relax_fallback = !(rm && !strcmp(rm, "gather"));
 	}
 	// ---- slab geometry: per ordered pair entry counts -> mbase (within slab), slab bases
@@ -1856,6 +1863,7 @@ int mpcgpu_relax_info(mpcgpu_ctx *c, char *buf, uint32_t buflen, int *is_fallbac
 	if (buf && buflen) {
 		std::string d = c->store_desc;
 		if (!c->tiles_desc.empty()) d += "; " + c->tiles_desc;
+		if (!c->relax_kernel_name.empty()) d += "; kernel=" + c->relax_kernel_name; // the instantiation the last relax launched (as rocprofv3 names it)
 		snprintf(buf, buflen, "%s", d.c_str());
 	}
 	if (is_fallback) *is_fallback = c->relax_fallback ? 1 : 0;

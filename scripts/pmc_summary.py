@@ -44,6 +44,8 @@ def main():
             "kernel": kname, "launches_sampled": max(len(fv), len(wv)), "FETCH_SIZE_KiB_mean": fm, "WRITE_SIZE_KiB_mean": wm,
             "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0,
             "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}
+        if os.environ.get("PMC_SOURCE"):
+            d["%s@%dx%d" % (short, n, length)]["source"] = os.environ["PMC_SOURCE"]
         print(short, d["%s@%dx%d" % (short, n, length)])
     # SQ passes next to the FETCH/WRITE directories (prof_sq, prof_sq2), when present: instruction counts per launch
     base = os.path.dirname(os.path.normpath(fdir))
