@@ -72,7 +72,7 @@ def parity_check(g, a):
     iterations) and the EA values against the digests the compiled reference produced for this exact workload
     (tests/golden/mpcbig_*.npz, tests/golden/make_golden.py big). -> ("match" | "MISMATCH" | None, detail)."""
     import _bigdigest as D
-    name = None if a.fasta else D.fixture_for(a.n, a.len, a.seed)
+    name = D.fixture_for_fasta(a.fasta, a.n) if a.fasta else D.fixture_for(a.n, a.len, a.seed)
     if name is None:
         return None, "no reference-generated digest fixture for this workload (fixtures: %s)" % ", ".join(sorted(D.BIG_SETS))
     z = D.load(name)

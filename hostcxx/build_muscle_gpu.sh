@@ -5,8 +5,8 @@
 # of the reference is copied into the repo, and the combined (GPL-3.0) binary is git-ignored; it
 # travels to the GPU box as a built artefact.
 #
-#   reference objects  - consflat.o, alnalnsflat.o, alnmsasflat.o  (MPCFlat::ConsIter, MPCFlat::AlignAlns and
-#                        PProg::AlignMSAsFlat are ours)
+#   reference objects  - consflat.o, alnalnsflat.o, alnmsasflat.o, buildpostflat.o  (MPCFlat::ConsIter, MPCFlat::AlignAlns,
+#                        PProg::AlignMSAsFlat and MPCFlat::BuildPost are ours)
 #                      - calcposteriorflat.o's CalcPosterior symbol, weakened with objcopy so that
 #                        hostcxx/mpcflat_gpu.cpp's strong definition wins while CalcPostFlat and the
 #                        two vestigial virtuals in the same object stay available
@@ -27,9 +27,8 @@ CXXFLAGS="-std=c++17 -O3 -fopenmp -DNDEBUG -pthread -fPIC -w -I$ROOT/oracle/_ref
 g++ $CXXFLAGS -c "$HERE/mpcflat_gpu.cpp" -o "$OUT/mpcflat_gpu.o"
 g++ $CXXFLAGS -c "$HERE/rand_isolate.cpp" -o "$OUT/rand_isolate.o"
 objcopy --weaken-symbol=_ZN7MPCFlat13CalcPosteriorEj "$REFOBJ/calcposteriorflat.o" "$OUT/calcposteriorflat_weak.o"
-# MPCFlat::BuildPost: the reference's definition stays in use under another name; hostcxx/mpcflat_gpu.cpp defines the member
-# (copies the device matrices to the host first, then calls it) for the callers outside MPCFlat::Run, e.g. -profseq
-objcopy --redefine-sym _ZN7MPCFlat9BuildPostERK13MultiSequenceS2_Pf=MPCFlat_BuildPost_ref "$REFOBJ/buildpostflat.o" "$OUT/buildpostflat_ref.o"
+# MPCFlat::BuildPost is ours too (hostcxx/mpcflat_gpu.cpp -> mpcgpu_build_post): buildpostflat.o is not linked at all
+rm -f "$OUT/buildpostflat_ref.o"
 # Super7::IntraAlignShrubs: ours (parallel over device contexts); the rest of super7.o stays
 objcopy --weaken-symbol=_ZN6Super716IntraAlignShrubsEv "$REFOBJ/super7.o" "$OUT/super7_weak.o"
 OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$')
@@ -41,6 +40,6 @@ LIBNAME="${MPCGPU_LIBNAME:-mpcgpu}"
 BIN="${MPCGPU_BIN:-muscle_gpu}"
 # --wrap=rand: the reference's rand() (refineflat.cpp:14) gets a private copy of glibc's default
 # stream; the HIP runtime in the same process otherwise consumes it (hostcxx/rand_isolate.cpp)
-g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/buildpostflat_ref.o" "$OUT/super7_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
+g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/super7_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
   -L"$LIBDIR" -l"$LIBNAME" -Wl,-rpath,"$LIBDIR" -Wl,-rpath,'$ORIGIN/../../muscle_amd/csrc' -Wl,-rpath,/opt/rocm/lib -o "$OUT/$BIN"
 echo "built: $OUT/$BIN"

@@ -580,28 +580,54 @@ void MPCFlat::ConsIter(uint Iter)
 	swap(m_ptrSparsePosts, m_ptrUpdatedSparsePosts); // consflat.cpp:22
 	}
 
-// MPCFlat::BuildPost (buildpostflat.cpp:18-106) stays the reference's: its definition is renamed at link time
-// (hostcxx/build_muscle_gpu.sh: objcopy --redefine-sym) and called from here after the sparse matrices it reads
-// (GetSparsePost, mpcflat.h) have been copied back from the device. MPCFlat::AlignAlns above never takes this road (it builds
-// the matrix on the device); the callers that do are outside MPCFlat::Run — cmd_profseq (profseq.cpp:49) computes a
-// few posteriors and goes straight to BuildPost.
-void MPCFlat_BuildPost_ref(MPCFlat *This, const MultiSequence &MSA1, const MultiSequence &MSA2, float *Post) asm("MPCFlat_BuildPost_ref");
+// MPCFlat::BuildPost (buildpostflat.cpp:18-106) for its callers outside MPCFlat::Run — cmd_profseq (profseq.cpp:33-49) computes
+// a few posteriors and goes straight to BuildPost: the matrix is built on the device store (mpcgpu_build_post: the kernels
+// MPCFlat::AlignAlns below uses) and copied into the caller's buffer. There is no host implementation behind it.
+namespace
+{
+// sequence indices and position -> column maps of the rows of an alignment, as the library wants them
+void RowsOf(MPCFlat &M, const MultiSequence &MSA, vector<uint32_t> &Seqs, vector<uint32_t> &Map)
+	{
+	const uint SeqCount = MSA.GetSeqCount();
+	Seqs.resize(SeqCount);
+	Map.clear();
+	vector<uint> PosToCol;
+	for (uint i = 0; i < SeqCount; ++i)
+		{
+		const Sequence *Seq = MSA.GetSequence(i);
+		uint SMI = M.GetMyInputSeqIndex(Seq->m_Label);
+		asserta(SMI != UINT_MAX);
+		Seqs[i] = SMI;
+		Seq->GetPosToCol(PosToCol);
+		asserta(SIZE(PosToCol) == M.GetSeqLength(SMI));
+		Map.insert(Map.end(), PosToCol.begin(), PosToCol.end());
+		}
+	}
+}
 
 void MPCFlat::BuildPost(const MultiSequence &MSA1, const MultiSequence &MSA2, float *Post)
 	{
-		{
-		const int SlotIndex = SlotIndexOf(this);
-		Slot &S = g_Slots[SlotIndex];
-		std::lock_guard<std::mutex> Guard(S.m_Mu);
-		Batch &B = BatchOf(this);
-		if (B.m_PairCount != 0 && S.m_StoreOwner == this && !B.m_OnHost)
-			{
-			mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
-			Download(Ctx, *this, B.m_PairCount, [this](uint k) -> MySparseMx & { return GetSparsePost(k); });
-			B.m_OnHost = true;
-			}
-		}
-	MPCFlat_BuildPost_ref(this, MSA1, MSA2, Post);
+	const uint SeqCount1 = MSA1.GetSeqCount();
+	const uint SeqCount2 = MSA2.GetSeqCount();
+	const uint ColCount1 = MSA1.GetColCount();
+	const uint ColCount2 = MSA2.GetColCount();
+	const int SlotIndex = SlotIndexOf(this);
+	Slot &S = g_Slots[SlotIndex];
+	if (S.m_StoreOwner != this)
+		Die("GPU posterior stage: BuildPost on an MPCFlat whose posteriors are not the ones on the device");
+// weights by the ROW index in MSA1 / MSA2 (buildpostflat.cpp:41,52,74); callers outside Run may never have sized m_Weights
+	vector<float> W1(SeqCount1, 1.0f), W2(SeqCount2, 1.0f);
+	for (uint i = 0; i < SeqCount1 && i < SIZE(m_Weights); ++i)
+		W1[i] = m_Weights[i];
+	for (uint i = 0; i < SeqCount2 && i < SIZE(m_Weights); ++i)
+		W2[i] = m_Weights[i];
+	vector<uint32_t> Seqs1, Seqs2, Map1, Map2;
+	RowsOf(*this, MSA1, Seqs1, Map1);
+	RowsOf(*this, MSA2, Seqs2, Map2);
+	std::lock_guard<std::mutex> Guard(S.m_Mu);
+	mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
+	GPUCHK(mpcgpu_build_post(Ctx, SeqCount1, Seqs1.data(), SeqCount2, Seqs2.data(), ColCount1, ColCount2,
+	  Map1.data(), Map2.data(), W1.data(), W2.data(), Post));
 	}
 
 MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,

@@ -170,6 +170,17 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *ctx, uint32_t n1, const uint32_t *seq1, uint
                         uint32_t C1, uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2,
                         const float *w1, const float *w2, char *path, uint32_t *pathlen, float *score);
 
+/* MPCFlat::BuildPost alone (buildpostflat.cpp:18-106): the C1 x C2 matrix (row-major floats, host memory) that
+ * mpcgpu_align_alns_w would align — for the callers of BuildPost outside MPCFlat::Run (profseq.cpp:33-49). Arguments as
+ * for mpcgpu_align_alns_w (w1 / w2 may be NULL: all weights 1.0f). */
+int mpcgpu_build_post(mpcgpu_ctx *ctx, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
+                      uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, const float *w1, const float *w2,
+                      float *post);
+/* The dense matrix of the last mpcgpu_align_alns(_w) / mpcgpu_build_post / mpcgpu_align_msas / mpcgpu_calc_aln call on this
+ * context (C1 x C2 must be that call's shape): what BuildPost (buildpostflat.cpp:18-106) resp. CalcPosteriorFlat3
+ * (buildposterior3flat.cpp:19-85) left for CalcAlnFlat. */
+int mpcgpu_get_last_post(mpcgpu_ctx *ctx, uint32_t C1, uint32_t C2, float *post);
+
 /* The MSA x MSA join of PProg (pprog2.cpp:7-56 -> PProg::AlignMSAsFlat, alnmsasflat.cpp:4-50) for an
  * explicit list of cross pairs (getpairs.cpp:33-69 samples at most 2000): per pair
  * PProg::GetPostPairsAlignedFlat (getpostpairsalignedflat.cpp:5-98) = CalcPost + MySparseMx::FromPost

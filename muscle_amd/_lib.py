@@ -19,7 +19,7 @@ SYMBOLS = [
     "mpcgpu_set_seqs", "mpcgpu_set_mega", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
-    "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
+    "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
@@ -73,6 +73,8 @@ def load(lib_path=None):
     L.mpcgpu_calc_aln.argtypes = [vp, vp, u32, u32, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.mpcgpu_align_alns.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.mpcgpu_align_alns_w.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float)]
+    L.mpcgpu_build_post.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, vp, vp]
+    L.mpcgpu_get_last_post.argtypes = [vp, u32, u32, vp]
     L.mpcgpu_set_seqs_registry.argtypes = [vp, u32, vp, vp]
     L.mpcgpu_align_msas.argtypes = [vp, u32, vp, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float), vp]
     L.mpcgpu_timers_reset.argtypes = [vp]
@@ -375,6 +377,24 @@ class MpcGpu:
         self._ck(self.L.mpcgpu_align_alns(self.h, len(s1), s1.ctypes.data, len(s2), s2.ctypes.data, C1, C2,
                                            m1.ctypes.data, m2.ctypes.data, path.ctypes.data, C.byref(n), C.byref(sc)))
         return path[:n.value].tobytes().decode(), float(np.float32(sc.value))
+
+    def build_post(self, seq1, seq2, p2c1, p2c2, C1, C2, w1=None, w2=None):
+        """MPCFlat::BuildPost on the device store -> (C1, C2) float32 matrix (include/mpcgpu.h: mpcgpu_build_post)"""
+        s1, s2 = np.asarray(seq1, np.uint32), np.asarray(seq2, np.uint32)
+        m1 = np.concatenate([np.asarray(x, np.uint32) for x in p2c1]).astype(np.uint32)
+        m2 = np.concatenate([np.asarray(x, np.uint32) for x in p2c2]).astype(np.uint32)
+        post = np.empty((C1, C2), np.float32)
+        a1 = None if w1 is None else np.ascontiguousarray(w1, np.float32)
+        a2 = None if w2 is None else np.ascontiguousarray(w2, np.float32)
+        self._ck(self.L.mpcgpu_build_post(self.h, len(s1), s1.ctypes.data, len(s2), s2.ctypes.data, C1, C2, m1.ctypes.data, m2.ctypes.data,
+                                          None if a1 is None else a1.ctypes.data, None if a2 is None else a2.ctypes.data, post.ctypes.data))
+        return post
+
+    def last_post(self, C1, C2):
+        """the dense matrix the last alignment / BuildPost call on this context built"""
+        post = np.empty((C1, C2), np.float32)
+        self._ck(self.L.mpcgpu_get_last_post(self.h, C1, C2, post.ctypes.data))
+        return post
 
     def relax_info(self):
         """-> (description of the store layout / relax geometry in use, is_fallback)"""

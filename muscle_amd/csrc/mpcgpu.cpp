@@ -163,6 +163,7 @@ struct mpcgpu_ctx {
 	float ms[MPCGPU_NKERNELS] = {0};
 	u64 launches[MPCGPU_NKERNELS] = {0};
 	u64 work_cells = 0, work_entry_z = 0;
+	u64 last_post_cells = 0; // cells of the dense matrix in d_aln_post (mpcgpu_get_last_post)
 	double aa_trace_t[5] = {0, 0, 0, 0, 0}; // MPCGPU_TRACE_HOST: host seconds of mpcgpu_align_alns' phases
 	u64 aa_trace_n = 0;
 };
@@ -1632,6 +1633,7 @@ int mpcgpu_calc_aln(mpcgpu_ctx *c, const float *post, uint32_t LX, uint32_t LY, 
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, c->d_aln_post.ensure((u64)LX * LY * 4));
 	HIPCHK(c, hipMemcpyAsync(c->d_aln_post.p, post, (u64)LX * LY * 4, hipMemcpyHostToDevice, c->stream));
+	c->last_post_cells = (u64)LX * LY;
 	return run_calc_aln(c, c->d_aln_post.as<float>(), LX, LY, path, pathlen, score); // syncs: the caller's buffer is done with
 }
 
@@ -1672,13 +1674,14 @@ static int reduce_runs(mpcgpu_ctx *c, const RunBufs &rb, const u32 *keys_sorted,
 	return 0;
 }
 
-int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
+// BuildPost on the device store (+ CalcAlnFlat when path != NULL): the body of mpcgpu_align_alns_w and mpcgpu_build_post
+static int build_post_impl(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
 	uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, const float *w1, const float *w2, char *path,
 	uint32_t *pathlen, float *score)
 {
 	if (!c) return 1;
 	if (!c->have_store) return fail(c, "mpcgpu_align_alns: no store (call mpcgpu_build_store / mpcgpu_store_import)");
-	if (!seq1 || !seq2 || !pos2col1 || !pos2col2 || !path || !pathlen) return fail(c, "mpcgpu_align_alns: NULL argument");
+	if (!seq1 || !seq2 || !pos2col1 || !pos2col2 || (path && !pathlen)) return fail(c, "mpcgpu_align_alns: NULL argument");
 	if (n1 == 0 || n2 == 0 || C1 == 0 || C2 == 0) return fail(c, "mpcgpu_align_alns: empty alignment");
 	HIPCHK(c, hipSetDevice(c->device));
 	const u32 n = c->n;
@@ -1777,6 +1780,11 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 	if (reduce_runs(c, rb, keys_sorted, vals_sorted, M, cells)) return 1;
 	if (span_end(c, &ts_bp)) return 1;
 	lap(2);
+	c->last_post_cells = cells;
+	if (!path) { // matrix only (mpcgpu_build_post); the staging record is reused by the next call: drain the stream
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		return 0;
+	}
 	// the staging record is reused by the next call: run_calc_aln ends with a wait for the stream
 	const int rc_aln = run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score);
 	lap(3);
@@ -1784,6 +1792,36 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32
 		fprintf(stderr, "[mpcgpu] align_alns host seconds after %llu calls: vectors %.3f, uploads %.3f, launches %.3f, calc_aln+syncs %.3f\n",
 			(unsigned long long)acc_n, acc_t[0], acc_t[1], acc_t[2], acc_t[3]);
 	return rc_aln;
+}
+
+int mpcgpu_align_alns_w(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
+	uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, const float *w1, const float *w2, char *path,
+	uint32_t *pathlen, float *score)
+{
+	if (!c) return 1;
+	if (!path || !pathlen) return fail(c, "mpcgpu_align_alns: NULL argument");
+	return build_post_impl(c, n1, seq1, n2, seq2, C1, C2, pos2col1, pos2col2, w1, w2, path, pathlen, score);
+}
+
+int mpcgpu_build_post(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uint32_t n2, const uint32_t *seq2, uint32_t C1,
+	uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, const float *w1, const float *w2, float *post)
+{
+	if (!c) return 1;
+	if (!post) return fail(c, "mpcgpu_build_post: NULL argument");
+	if (build_post_impl(c, n1, seq1, n2, seq2, C1, C2, pos2col1, pos2col2, w1, w2, nullptr, nullptr, nullptr)) return 1;
+	return mpcgpu_get_last_post(c, C1, C2, post);
+}
+
+int mpcgpu_get_last_post(mpcgpu_ctx *c, uint32_t C1, uint32_t C2, float *post)
+{
+	if (!c) return 1;
+	if (!post) return fail(c, "mpcgpu_get_last_post: NULL argument");
+	if (c->last_post_cells == 0 || (u64)C1 * C2 != c->last_post_cells)
+		return fail(c, "mpcgpu_get_last_post: the last matrix built on this context has %llu cells, not %u x %u", (u64)c->last_post_cells, C1, C2);
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemcpyAsync(post, c->d_aln_post.p, (size_t)c->last_post_cells * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
 }
 
 int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, const uint32_t *seq2, uint32_t C1, uint32_t C2,
@@ -1853,6 +1891,7 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 		vals_sorted = vals_out;
 	}
 	if (reduce_runs(c, rb, keys_sorted, vals_sorted, M, cells)) return 1;
+	c->last_post_cells = cells;
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // syncs before the vectors above die
 }
 

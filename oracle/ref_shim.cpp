@@ -8,6 +8,7 @@
 // out of a reference function, cited below.
 #include "muscle.h"      // reference header (-I/root/reference/src)
 #include "mpcflat.h"
+#include "pprog.h"
 #include "pairhmm.h"
 #include "hmmparams.h"
 #include "mega.h"
@@ -17,6 +18,8 @@ string g_Arg1; // normally defined in main.cpp:4 (main.o is not linked)
 
 float CalcAlnScoreFlat(const float *Post, uint LX, uint LY, float *DPRows); // calcalnscoreflat.cpp:4
 void CalcPostFlat(const float *FlatFwd, const float *FlatBwd, uint LX, uint LY, float *Post); // calcposteriorflat.cpp:4
+void CalcPosteriorFlat3(const MultiSequence &MSA1, const MultiSequence &MSA2, const vector<uint> &SeqIndexes1,
+  const vector<uint> &SeqIndexes2, const vector<MySparseMx *> &SparseMxs, float *Flat); // buildposterior3flat.cpp:19
 
 extern "C" {
 
@@ -201,6 +204,100 @@ void ref_mpc_sparse(uint k, uint *offsets, byte *values)
 	const MySparseMx &S = g_M->GetSparsePost(k);
 	memcpy(offsets, S.m_Offsets, sizeof(uint)*(S.m_LX+1));
 	memcpy(values, S.m_ValueVec, 8*(size_t)S.m_Offsets[S.m_LX]);
+	}
+
+
+// ---- alignments of alignments on the store of g_M (after ref_mpc_calc_posteriors / ref_mpc_cons_iter) --------------------
+// rows = gapped rows of one alignment (all of one width), idx = input sequence index of each row (its label is s<idx>).
+static MultiSequence *MakeMSA(uint n, const char **rows, const uint *idx)
+	{
+	vector<string> Labels, Seqs;
+	for (uint i = 0; i < n; ++i)
+		{
+		char tmp[32];
+		snprintf(tmp, sizeof(tmp), "s%u", idx[i]);
+		Labels.push_back(tmp);
+		Seqs.push_back(rows[i]);
+		}
+	MultiSequence *MSA = new MultiSequence;
+	MSA->FromStrings(Labels, Seqs);
+	return MSA;
+	}
+
+// MPCFlat::BuildPost (buildpostflat.cpp:18-106). weights: what m_Weights holds (indexed by the ROW number inside each
+// alignment at buildpostflat.cpp:42,52), n_weights entries; NULL = all 1.0f (mpcflat.cpp:324). post: C1 x C2 floats.
+int ref_mpc_build_post(uint n1, const char **rows1, const uint *idx1, uint n2, const char **rows2, const uint *idx2,
+  const float *weights, uint n_weights, float *post)
+	{
+	if (g_M == 0)
+		return -1;
+	MultiSequence *MSA1 = MakeMSA(n1, rows1, idx1);
+	MultiSequence *MSA2 = MakeMSA(n2, rows2, idx2);
+	const uint SeqCount = g_M->GetSeqCount();
+	g_M->m_Weights.assign(SeqCount, 1.0f);
+	if (weights != 0)
+		for (uint i = 0; i < n_weights && i < SeqCount; ++i)
+			g_M->m_Weights[i] = weights[i];
+	g_M->BuildPost(*MSA1, *MSA2, post);
+	g_M->m_Weights.assign(SeqCount, 1.0f);
+	delete MSA1;
+	delete MSA2;
+	return 0;
+	}
+
+// MPCFlat::AlignAlns (alnalnsflat.cpp:7-52): BuildPost + CalcAlnFlat; path gets the B/X/Y string (capacity C1+C2)
+int ref_mpc_align_alns(uint n1, const char **rows1, const uint *idx1, uint n2, const char **rows2, const uint *idx2,
+  char *path, uint *pathlen, float *score)
+	{
+	if (g_M == 0)
+		return -1;
+	MultiSequence *MSA1 = MakeMSA(n1, rows1, idx1);
+	MultiSequence *MSA2 = MakeMSA(n2, rows2, idx2);
+	const uint C1 = MSA1->GetColCount(), C2 = MSA2->GetColCount();
+	g_M->m_Weights.assign(g_M->GetSeqCount(), 1.0f);
+	float *Post = AllocPost(C1, C2);
+	g_M->BuildPost(*MSA1, *MSA2, Post);
+	float *DPRows = AllocDPRows(C1, C2);
+	char *TB = AllocTB(C1, C2);
+	string Path;
+	*score = CalcAlnFlat(Post, C1, C2, DPRows, TB, Path);
+	memcpy(path, Path.data(), Path.size());
+	*pathlen = (uint) Path.size();
+	myfree(Post); myfree(DPRows); myfree(TB);
+	delete MSA1;
+	delete MSA2;
+	return 0;
+	}
+
+// The pieces of PProg::AlignMSAsFlat (alnmsasflat.cpp:4-50) on an explicit pair list (seq1[k] = row of MSA1, seq2[k] = row
+// of MSA2): GetPostPairsAlignedFlat (getpostpairsalignedflat.cpp:5-98: fresh posteriors per pair, no consistency) ->
+// CalcPosteriorFlat3 (buildposterior3flat.cpp:19-85) -> CalcAlnFlat. Needs the global input of ref_mpc_begin (labels s<i>).
+// post: C1 x C2 floats out; ea_avg: the function's return value (sum in pair order when run with one thread).
+int ref_align_msas(uint n1, const char **rows1, const uint *idx1, uint n2, const char **rows2, const uint *idx2,
+  uint npairs, const uint *seq1, const uint *seq2, float *post, char *path, uint *pathlen, float *ea_avg)
+	{
+	if (g_MS == 0)
+		return -1;
+	MultiSequence *MSA1 = MakeMSA(n1, rows1, idx1);
+	MultiSequence *MSA2 = MakeMSA(n2, rows2, idx2);
+	const uint C1 = MSA1->GetColCount(), C2 = MSA2->GetColCount();
+	vector<uint> S1(seq1, seq1 + npairs), S2(seq2, seq2 + npairs);
+	vector<MySparseMx *> SparseMxs;
+	PProg PP;
+	*ea_avg = PP.GetPostPairsAlignedFlat("golden", *MSA1, *MSA2, S1, S2, SparseMxs);
+	CalcPosteriorFlat3(*MSA1, *MSA2, S1, S2, SparseMxs, post);
+	for (uint i = 0; i < npairs; ++i)
+		delete SparseMxs[i];
+	float *DPRows = AllocDPRows(C1, C2);
+	char *TB = AllocTB(C1, C2);
+	string Path;
+	CalcAlnFlat(post, C1, C2, DPRows, TB, Path);
+	memcpy(path, Path.data(), Path.size());
+	*pathlen = (uint) Path.size();
+	myfree(DPRows); myfree(TB);
+	delete MSA1;
+	delete MSA2;
+	return 0;
 	}
 
 } // extern "C"

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 GDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-BIG_SETS = {"n256_L300": (256, 300, 1), "n1000_L400": (1000, 400, 1)}
+BIG_SETS = {"n256_L300": (256, 300, 1), "n1000_L400": (1000, 400, 1), "rdrp256": (256, 0, 0), "rdrp384": (384, 0, 0)}  # length 0: first n rdrp records
 
 
 def fixture_for(n, length, seed):
@@ -17,6 +17,22 @@ def fixture_for(n, length, seed):
         if key == (n, length, seed) and os.path.exists(os.path.join(GDIR, "mpcbig_%s.npz" % name)):
             return name
     return None
+
+
+def fixture_for_fasta(path, n):
+    """first n records of tests/golden/rdrp_first1000.fa.gz -> fixture name, when the compiled reference has digested that prefix"""
+    if os.path.basename(path) != "rdrp_first1000.fa.gz":
+        return None
+    return fixture_for(n, 0, 0)
+
+
+def seqs_of(name):
+    """the sequences of a big set (synthetic family or rdrp prefix)"""
+    from muscle_amd.synth import make_family, read_fasta
+    n, length, seed = BIG_SETS[name]
+    if length == 0:
+        return read_fasta(os.path.join(GDIR, "rdrp_first1000.fa.gz"))[:n]
+    return make_family(n, length, seed=seed)
 
 
 def load(name):

@@ -134,3 +134,25 @@ def run_muscle(binary, name, threads=4, timeout=900, env=None, quiet=True):
 def golden_md5():
     with open(GOLDEN) as f:
         return json.load(f)
+
+
+def run_profseq(binary, fixture, threads=2, timeout=600):
+    """`muscle -profseq msa.afa -input2 query.fa` (profseq.cpp:59-100) on the alignment and the query of a bp_* fixture
+    (tests/golden/make_golden.py bp): -> the path it logs. The command's hot path is CalcPosterior for the (row, query) pairs and
+    MPCFlat::BuildPost + CalcAlnFlat."""
+    import re
+    z = G.load(fixture)
+    seqs = [str(x) for x in z["seqs"]]
+    rows = [str(x) for x in z["ps_rows"]]
+    n = len(seqs)
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "msa.afa"), "w") as f:
+            for i, r in enumerate(rows):
+                f.write(">s%d\n%s\n" % (i, r))
+        write_fasta(os.path.join(d, "q.fa"), [seqs[n - 1]], ["s%d" % (n - 1)])
+        subprocess.run([binary, "-profseq", "msa.afa", "-input2", "q.fa", "-log", "ps.log", "-threads", str(threads), "-quiet"],
+                       check=True, timeout=timeout, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        with open(os.path.join(d, "ps.log")) as f:
+            paths = [ln.strip() for ln in f if re.fullmatch(r"[BXY]+", ln.strip())]
+    assert len(paths) == 1, paths
+    return paths[0], str(z["ps_path"])

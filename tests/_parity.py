@@ -138,3 +138,58 @@ def check_post_scores(lib_path=None, seed=11, trials=60):
             assert np.array_equal(off, woff), what
             assert np.array_equal(val, wval), what
     g.close()
+
+
+BP_SETS = ["bp_n12_L70", "bp_n9_L40"]  # tests/golden/make_golden.py bp: matrices, paths, scores from the compiled reference
+
+
+def check_buildpost_golden(name, lib_path=None):
+    """Device BuildPost / AlignAlns / AlignMSAs against what the compiled reference produced for the same joins
+    (tests/golden/<name>.npz): the C1 x C2 matrix of MPCFlat::BuildPost bit for bit (plain, weighted, both stored
+    orientations), path and score of MPCFlat::AlignAlns; for explicit pair lists the matrix of CalcPosteriorFlat3, the path
+    and the mean EA of PProg::AlignMSAsFlat's pieces."""
+    import _buildpost as BP
+    z = G.load(name)
+    seqs = [str(x) for x in z["seqs"]]
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, lib_path)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    g.build_store()
+    for _ in range(2):
+        g.cons_iter()
+        g.cons_commit()
+    for j in range(int(z["njoins"])):
+        k = "j%d_" % j
+        grp1, grp2 = [int(x) for x in z[k + "idx1"]], [int(x) for x in z[k + "idx2"]]
+        rows1, rows2 = [str(x) for x in z[k + "rows1"]], [str(x) for x in z[k + "rows2"]]
+        C1, C2 = len(rows1[0]), len(rows2[0])
+        m1, m2 = [BP.pos_to_col(r) for r in rows1], [BP.pos_to_col(r) for r in rows2]
+        assert np.array_equal(bits(g.build_post(grp1, grp2, m1, m2, C1, C2)), bits(z[k + "post"])), (name, j, "matrix")
+        w = z[k + "w"]  # the reference indexes m_Weights by the row number inside each alignment (buildpostflat.cpp:42,52)
+        got = g.build_post(grp1, grp2, m1, m2, C1, C2, w[:len(grp1)], w[:len(grp2)])
+        assert np.array_equal(bits(got), bits(z[k + "postw"])), (name, j, "weighted matrix")
+        path, sc = g.align_alns(grp1, grp2, m1, m2, C1, C2)
+        assert path == str(z[k + "path"]) and bits(sc) == bits(z[k + "score"]), (name, j, "path / score")
+        assert np.array_equal(bits(g.last_post(C1, C2)), bits(z[k + "post"])), (name, j, "matrix after align_alns")
+    g.close()
+    g = MpcGpu(0, lib_path)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs_registry(seqs)
+    for j in range(int(z["nmsas"])):
+        k = "m%d_" % j
+        grp1, grp2 = [int(x) for x in z[k + "idx1"]], [int(x) for x in z[k + "idx2"]]
+        rows1, rows2 = [str(x) for x in z[k + "rows1"]], [str(x) for x in z[k + "rows2"]]
+        C1, C2 = len(rows1[0]), len(rows2[0])
+        r1, r2 = [int(x) for x in z[k + "row1"]], [int(x) for x in z[k + "row2"]]
+        seq1, seq2 = [grp1[a] for a in r1], [grp2[b] for b in r2]
+        m1, m2 = [BP.pos_to_col(rows1[a]) for a in r1], [BP.pos_to_col(rows2[b]) for b in r2]
+        path, sc, ea = g.align_msas(seq1, seq2, m1, m2, C1, C2)
+        assert path == str(z[k + "path"]), (name, j, "msas path")
+        assert np.array_equal(bits(g.last_post(C1, C2)), bits(z[k + "post"])), (name, j, "msas matrix")
+        tot = np.float32(0)
+        for e in ea:  # getpostpairsalignedflat.cpp:90-96 with one thread: SumEA += EA in pair order, then / PairCount
+            tot = np.float32(tot + np.float32(e))
+        assert bits(np.float32(tot / np.float32(len(ea)))) == bits(z[k + "ea_avg"]), (name, j, "msas mean EA")
+    g.close()

@@ -169,8 +169,12 @@ def _mpc_big_worker(args):
     import ctypes as C
     import time
     import _ref as R
-    from muscle_amd.synth import make_family
-    seqs = make_family(n, length, seed=seed)
+    from muscle_amd.synth import make_family, read_fasta
+    if length == 0:  # real data: the first n records of the reference's test_data/rdrp/rdrp.fa (tests/golden/rdrp_first1000.fa.gz)
+        seqs = read_fasta(os.path.join(HERE, "rdrp_first1000.fa.gz"))[:n]
+        assert len(seqs) == n
+    else:
+        seqs = make_family(n, length, seed=seed)
     R.init_hmm(False, 0)
     L = R.lib()
     arr = (C.c_char_p * len(seqs))(*[s.encode() for s in seqs])
@@ -223,7 +227,9 @@ def _mpc_big_worker(args):
     return name, n, [st[2] for st in stages], [tA] + tB
 
 
-BIG_SETS = {"n256_L300": (256, 300, 1), "n1000_L400": (1000, 400, 1)}  # BASELINE configs 2 and 3 (bench.py's families)
+# BASELINE configs 2 and 3 (bench.py's families), and real data (length 0 = first n rdrp records) large enough for the
+# relax tile mix of the 1000-record run (records of tens of KB: 4x1 / 2x1 tiles in the 160 KB geometry)
+BIG_SETS = {"n256_L300": (256, 300, 1), "n1000_L400": (1000, 400, 1), "rdrp256": (256, 0, 0), "rdrp384": (384, 0, 0)}
 
 
 def gen_mpc_big(names, threads):
@@ -273,7 +279,115 @@ def gen_mega():
             print(pool.map(_mega_worker, [name])[0])
 
 
+# ---- alignments of alignments: MPCFlat::BuildPost / AlignAlns and the pieces of PProg::AlignMSAsFlat, from the reference ----
+BP_SETS = {"bp_n12_L70": (12, 70, 29), "bp_n9_L40": (9, 40, 3)}
+
+
+def _bp_worker(args):
+    """joins on the reference's own store after 2 ConsIter: the C1 x C2 matrix MPCFlat::BuildPost fills (buildpostflat.cpp:18-106),
+    with and without weights, in both stored orientations (SMI_1 < SMI_2 and SMI_1 > SMI_2: :56-77 / :78-100), path and score of
+    MPCFlat::AlignAlns (alnalnsflat.cpp:7-52); and for explicit pair lists the matrix of CalcPosteriorFlat3
+    (buildposterior3flat.cpp:19-85), the path of CalcAlnFlat and the mean EA of GetPostPairsAlignedFlat (one thread)."""
+    name, n, length, seed = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import _buildpost as BP
+    import _ref as R
+    from muscle_amd.synth import make_family
+    seqs = make_family(n, length, seed=seed)
+    R.init_hmm(False, 0)
+    L = R.lib()
+    arr = (C.c_char_p * n)(*[s.encode() for s in seqs])
+    assert L.ref_mpc_begin(n, arr, 1) == 0
+    L.ref_mpc_calc_posteriors()
+    rng = np.random.default_rng(seed + 100)
+    d = {"seqs": np.array(seqs)}
+    u32p = C.POINTER(C.c_uint)
+
+    def cargs(rows, idx):
+        return len(rows), (C.c_char_p * len(rows))(*[r.encode() for r in rows]), np.ascontiguousarray(idx, np.uint32)
+
+    # what `muscle -profseq msa -input2 query` logs (profseq.cpp:4-57: CalcPosterior for the pairs (row, query) only, NO
+    # consistency, then MPCFlat::BuildPost + CalcAlnFlat): the path for an alignment of sequences 0..n-2 against sequence n-1,
+    # from the stage-A store. (The reference's own command dies in GetGSIByLabel before it gets there.)
+    ps_rows, _w = BP.random_msa(seqs, list(range(n - 1)), rng)
+    n1, r1, i1 = cargs(ps_rows, list(range(n - 1)))
+    n2, r2, i2 = cargs([seqs[n - 1]], [n - 1])
+    buf = C.create_string_buffer(len(ps_rows[0]) + len(seqs[n - 1]) + 8)
+    plen, score = C.c_uint(0), C.c_float(0)
+    assert L.ref_mpc_align_alns(n1, r1, i1.ctypes.data_as(u32p), n2, r2, i2.ctypes.data_as(u32p), buf, C.byref(plen), C.byref(score)) == 0
+    d["ps_rows"], d["ps_path"] = np.array(ps_rows), np.array(buf.raw[:plen.value].decode())
+    for it in range(2):
+        L.ref_mpc_cons_iter(it)
+
+    joins = []
+    order = [int(x) for x in rng.permutation(n)]
+    for cut in (1, n // 2, n - 2):
+        joins.append((order[:cut], order[cut:]))
+    joins.append((sorted(order[:n // 2]), sorted(order[n // 2:])))
+    joins.append(([n - 1], [0]))           # SMI_1 > SMI_2: the stored matrix read transposed
+    joins.append(([1, 0], [n - 1, 2, 3]))  # both orientations inside one join
+    nj = 0
+    for grp1, grp2 in joins:
+        rows1, C1 = BP.random_msa(seqs, grp1, rng)
+        rows2, C2 = BP.random_msa(seqs, grp2, rng)
+        n1, r1, i1 = cargs(rows1, grp1)
+        n2, r2, i2 = cargs(rows2, grp2)
+        post = np.zeros((C1, C2), np.float32)
+        assert L.ref_mpc_build_post(n1, r1, i1.ctypes.data_as(u32p), n2, r2, i2.ctypes.data_as(u32p), None, 0, post.ctypes.data_as(R.f32p)) == 0
+        # weights as m_Weights holds them: indexed by the row number inside each alignment (buildpostflat.cpp:42,52)
+        w = rng.uniform(0.2, 1.8, n).astype(np.float32)
+        postw = np.zeros((C1, C2), np.float32)
+        assert L.ref_mpc_build_post(n1, r1, i1.ctypes.data_as(u32p), n2, r2, i2.ctypes.data_as(u32p), w.ctypes.data_as(R.f32p), n, postw.ctypes.data_as(R.f32p)) == 0
+        buf = C.create_string_buffer(C1 + C2 + 8)
+        plen, score = C.c_uint(0), C.c_float(0)
+        assert L.ref_mpc_align_alns(n1, r1, i1.ctypes.data_as(u32p), n2, r2, i2.ctypes.data_as(u32p), buf, C.byref(plen), C.byref(score)) == 0
+        k = "j%d_" % nj
+        d[k + "idx1"], d[k + "idx2"] = np.array(grp1, np.uint32), np.array(grp2, np.uint32)
+        d[k + "rows1"], d[k + "rows2"] = np.array(rows1), np.array(rows2)
+        d[k + "post"], d[k + "postw"], d[k + "w"] = post, postw, w
+        d[k + "path"], d[k + "score"] = np.array(buf.raw[:plen.value].decode()), np.float32(score.value)
+        nj += 1
+    d["njoins"] = np.int32(nj)
+    # explicit pair lists (PProg joins): all pairs, and a subset in scrambled order
+    nm = 0
+    for grp1, grp2, keep in ((order[:3], order[3:8], None), (order[5:], order[:4], lambda a, b: (a * 7 + b) % 5 != 2)):
+        rows1, C1 = BP.random_msa(seqs, grp1, rng)
+        rows2, C2 = BP.random_msa(seqs, grp2, rng)
+        pairs = [(a, b) for a in range(len(grp1)) for b in range(len(grp2)) if keep is None or keep(a, b)]
+        if keep is not None:
+            pairs = [pairs[int(q)] for q in rng.permutation(len(pairs))]
+        s1 = np.array([a for a, b in pairs], np.uint32)
+        s2 = np.array([b for a, b in pairs], np.uint32)
+        n1, r1, i1 = cargs(rows1, grp1)
+        n2, r2, i2 = cargs(rows2, grp2)
+        post = np.zeros((C1, C2), np.float32)
+        buf = C.create_string_buffer(C1 + C2 + 8)
+        plen, ea = C.c_uint(0), C.c_float(0)
+        assert L.ref_align_msas(n1, r1, i1.ctypes.data_as(u32p), n2, r2, i2.ctypes.data_as(u32p), len(pairs), s1.ctypes.data_as(u32p),
+                                s2.ctypes.data_as(u32p), post.ctypes.data_as(R.f32p), buf, C.byref(plen), C.byref(ea)) == 0
+        k = "m%d_" % nm
+        d[k + "idx1"], d[k + "idx2"] = np.array(grp1, np.uint32), np.array(grp2, np.uint32)
+        d[k + "rows1"], d[k + "rows2"] = np.array(rows1), np.array(rows2)
+        d[k + "row1"], d[k + "row2"] = s1, s2  # per pair: row of MSA1 / row of MSA2
+        d[k + "post"], d[k + "path"], d[k + "ea_avg"] = post, np.array(buf.raw[:plen.value].decode()), np.float32(ea.value)
+        nm += 1
+    d["nmsas"] = np.int32(nm)
+    np.savez_compressed(os.path.join(HERE, "%s.npz" % name), **d)
+    return name, nj, nm
+
+
+def gen_bp():
+    ctx = mp.get_context("spawn")
+    for name, (n, length, seed) in BP_SETS.items():
+        with ctx.Pool(1) as pool:
+            print(pool.map(_bp_worker, [(name, n, length, seed)])[0], flush=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["bp"]:
+        gen_bp()
+        sys.exit(0)
     if sys.argv[1:] == ["mega"]:
         gen_mega()
         sys.exit(0)

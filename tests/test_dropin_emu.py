@@ -66,3 +66,13 @@ def test_super7_parallel_shrubs_with_progress_output(emu_muscle):
     worker threads of the parallel shrub loop must not call it concurrently (round-2 advisor finding); same MSA, no crash."""
     md5, _ = _msa.run_muscle(emu_muscle, "super7_8x18_b4", threads=2, env={"MUSCLE_GPU_SHRUB_CONTEXTS": "4"}, quiet=False)
     assert md5 == _msa.golden_md5()["super7_8x18_b4"]
+
+
+@pytest.mark.parametrize("fixture", ["bp_n9_L40"])
+def test_profseq_drives_buildpost_on_the_device(emu_muscle, fixture):
+    """`-profseq` is the caller of MPCFlat::BuildPost outside MPCFlat::Run (profseq.cpp:33-49). The drop-in's BuildPost builds the
+    matrix on the device (mpcgpu_build_post; no reference code behind it: buildpostflat.o is not linked); the path the command
+    logs equals what the compiled reference's BuildPost + CalcAlnFlat give for the same alignment and query
+    (tests/golden/bp_*.npz: ps_rows / ps_path)."""
+    got, want = _msa.run_profseq(emu_muscle, fixture)
+    assert got == want

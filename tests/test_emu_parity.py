@@ -456,3 +456,9 @@ def test_emu_post_candidate_lists_with_gaps(emu):
     """EA frontier of post_rows_kernel: columns between the frontier and a row's first cell must receive the flat suffix
     (round-2 advisor finding); both finishing kernels against the dense DP on synthetic candidate lists."""
     P.check_post_scores(emu, trials=36)
+
+
+@pytest.mark.parametrize("name", P.BP_SETS)
+def test_emu_buildpost_vs_reference_golden(emu, name):
+    """mpcgpu_build_post / align_alns / align_msas against matrices, paths and scores generated by the compiled reference."""
+    P.check_buildpost_golden(name, emu)

@@ -73,3 +73,14 @@ def test_super7_parallel_shrubs_with_progress_output(gpu_muscle):
     for _ in range(3):
         md5, _d = _msa.run_muscle(gpu_muscle, "super7dm_300x100_b16", threads=usable_cores(), env={"MUSCLE_GPU_SHRUB_CONTEXTS": "8"}, quiet=False)
         assert md5 == _msa.golden_md5()["super7dm_300x100_b16"]
+
+
+@pytest.mark.parametrize("fixture", ["bp_n9_L40", "bp_n12_L70"])
+def test_profseq_drives_buildpost_on_the_device(gpu_muscle, fixture):
+    """`-profseq` (profseq.cpp:33-49) -> MPCFlat::BuildPost of the drop-in -> mpcgpu_build_post: the logged path equals what the
+    compiled reference's BuildPost + CalcAlnFlat give (tests/golden/bp_*.npz); no reference BuildPost is linked into muscle_gpu."""
+    import subprocess
+    got, want = _msa.run_profseq(gpu_muscle, fixture)
+    assert got == want
+    syms = subprocess.run(["nm", gpu_muscle], capture_output=True, text=True).stdout
+    assert "MPCFlat_BuildPost_ref" not in syms

@@ -422,17 +422,18 @@ def test_errors_are_loud():
     g.close()
 
 
-@pytest.mark.parametrize("name", ["n256_L300", "n1000_L400"])
+@pytest.mark.parametrize("name", ["n256_L300", "n1000_L400", "rdrp256"])
 def test_baseline_configs_vs_reference_digests(name):
     """BASELINE configs 2 (256 x L~300) and 3 (1000 x L~400, the benchmarked workload) in full through the default
     kernels: EA bits and all three stage snapshots (after CalcPosteriors, after each ConsIter) against digests
-    generated by the compiled reference (tests/golden/mpcbig_*.npz; mpcflat.cpp:313,328, mysparsemx.cpp:87-113)."""
+    generated by the compiled reference (tests/golden/mpcbig_*.npz; mpcflat.cpp:313,328, mysparsemx.cpp:87-113).
+    rdrp256: real data (first 256 records of the reference's test_data/rdrp), ~7 stored cells per row: records of tens of KB,
+    the 160 KB single-buffer relax geometry with the 4x1 / 2x1 tile mix the 1000-record bench run uses."""
     import _bigdigest as D
     if D.fixture_for(*D.BIG_SETS[name]) is None:
         pytest.skip("fixture tests/golden/mpcbig_%s.npz not generated" % name)
     z = D.load(name)
-    n, length, seed = D.BIG_SETS[name]
-    seqs = make_family(n, length, seed=seed)
+    seqs = D.seqs_of(name)
     import hashlib
     assert hashlib.sha256("\n".join(seqs).encode()).hexdigest() == str(z["seqs_sha"])
     s, t, m, i, thr = G.hmm_tables()
@@ -501,3 +502,11 @@ def test_post_candidate_lists_with_gaps():
     """Both finishing kernels (and the multi-pass EA path) on synthetic candidate lists against the dense CalcAlnScoreFlat /
     FromPost: rows whose first cell lies beyond the EA frontier, empty rows, rows of > 64 cells (round-2 advisor finding)."""
     P.check_post_scores(None, trials=120)
+
+
+@pytest.mark.parametrize("name", P.BP_SETS)
+def test_buildpost_vs_reference_golden(name):
+    """Device BuildPost (mpcgpu_build_post: the matrix itself), AlignAlns and the PProg join against the compiled reference's
+    own matrices / paths / scores for the same joins (tests/golden/bp_*.npz: plain, weighted, transposed access of
+    buildpostflat.cpp:78-100, explicit pair lists of buildposterior3flat.cpp:19-85)."""
+    P.check_buildpost_golden(name)

@@ -122,3 +122,27 @@ def test_oracle_vs_config2_block0(hmm):
             h.update(np.ascontiguousarray(val, np.uint32).tobytes())
         assert h.digest() == z["blocks0"][b].tobytes(), "block %d" % b
         assert hashlib.sha256(np.ascontiguousarray(ea[b * block:(b + 1) * block], np.float32).tobytes()).digest() == z["ea_blocks"][b].tobytes()
+
+
+@pytest.mark.parametrize("name", ["bp_n9_L40"])
+def test_buildpost_restatement_vs_reference_golden(name):
+    """tests/_buildpost.py (numpy restatement of buildpostflat.cpp:18-106 the older device tests compare with) on the ORACLE's
+    store after two relax iterations reproduces the compiled reference's matrices bit for bit: pins the oracle's relax and the
+    restatement together."""
+    import _buildpost as BP
+    import _parity as P
+    z = G.load(name)
+    seqs = [str(x) for x in z["seqs"]]
+    stages, _ea = P.run_oracle(seqs)
+    n = len(seqs)
+    pidx = {p: k for k, p in enumerate((a, b) for a in range(n) for b in range(a + 1, n))}
+    for j in range(int(z["njoins"])):
+        k = "j%d_" % j
+        grp1, grp2 = [int(x) for x in z[k + "idx1"]], [int(x) for x in z[k + "idx2"]]
+        rows1, rows2 = [str(x) for x in z[k + "rows1"]], [str(x) for x in z[k + "rows2"]]
+        m1, m2 = [BP.pos_to_col(r) for r in rows1], [BP.pos_to_col(r) for r in rows2]
+        got = BP.build_post(stages[2], pidx, grp1, grp2, m1, m2, len(rows1[0]), len(rows2[0]))
+        assert np.array_equal(P.bits(got), P.bits(z[k + "post"])), j
+        w = z[k + "w"]
+        gotw = BP.build_post(stages[2], pidx, grp1, grp2, m1, m2, len(rows1[0]), len(rows2[0]), w[:len(grp1)], w[:len(grp2)])
+        assert np.array_equal(P.bits(gotw), P.bits(z[k + "postw"])), ("weighted", j)
