@@ -194,6 +194,7 @@ def main():
     for _ in range(a.warmup):
         run_stage(g, lens, exchange, torch_mod=torch)
     g.timers_reset()
+    g._exchange_seconds = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -303,6 +304,9 @@ def main():
                        "n_seqs": a.n, "mean_len": float(np.mean(lens)), "pairs": npairs,
                        "stored_posteriors": int(nnz.sum()), "parallelism": "pair-shard x%d" % world},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in timers.items()},
+            # host time of rank 0 inside the two exchanges of a step (all-gather of the packed shards, all-gather of the values per
+            # relax iteration), waits included; 0 on one GPU
+            "exchange_ms": 1000.0 * getattr(g, "_exchange_seconds", 0.0) / a.steps,
             "relax_geometry": dict(zip(("layout", "fallback"), g.relax_info())),
             "roofline": roof,
             "roofline_stage_a" if roof["kernel"].startswith("relax") else "roofline_relax": roof_other,

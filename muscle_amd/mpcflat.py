@@ -53,6 +53,30 @@ class TorchExchange:
         self.dist.all_gather_into_tensor(out, t)
         return [int(x) for x in out.cpu()]
 
+    def buffer(self, key, count, dtype):
+        """a persistent 1-D device buffer of at least `count` elements (grown geometrically, reused by every step: the gathered
+        shards are gigabytes and must not be allocated inside the timed loop)"""
+        import torch
+        bufs = self.__dict__.setdefault("_bufs", {})
+        b = bufs.get(key)
+        if b is None or b.numel() < count or b.dtype != dtype:
+            b = torch.empty(max(int(count + count // 16), 1), dtype=dtype, device=self.device)
+            bufs[key] = b
+        return b
+
+    def all_gather_segments(self, full, sizes):
+        """full: 1-D tensor that already holds THIS rank's segment at its final place (offset = sum of the sizes before it);
+        every other rank's segment is received straight into its own place: `world` broadcasts of exact sizes, queued
+        together and waited for once — no padding to the largest shard, no staging copy."""
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + int(sz))
+        works = [self.dist.broadcast(full[offs[r]:offs[r + 1]], src=r, async_op=True) for r in range(self.world) if sizes[r]]
+        for w in works:
+            if w is not None:
+                w.wait()
+        return full[:offs[-1]]
+
     def all_gather_var(self, mine, sizes, dtype):
         """mine: 1-D tensor of sizes[rank] elements. Returns a 1-D tensor = concatenation over ranks."""
         import torch
@@ -62,11 +86,7 @@ class TorchExchange:
         full = torch.empty(max(offs[-1], 1), dtype=dtype, device=self.device)
         if sizes[self.rank]:
             full[offs[self.rank]:offs[self.rank + 1]].copy_(mine)
-        works = [self.dist.broadcast(full[offs[r]:offs[r + 1]], src=r, async_op=True) for r in range(self.world) if sizes[r]]
-        for w in works:
-            if w is not None:
-                w.wait()
-        return full[:offs[-1]]
+        return self.all_gather_segments(full, sizes)
 
 
 def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=None):
@@ -83,32 +103,42 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
                 engine.cons_commit()
         engine.synchronize()
         return 0, npairs
+    import time
     torch = torch_mod
     cuts = shard_bounds(lens, exchange.world)
     k0, k1 = cuts[exchange.rank], cuts[exchange.rank + 1]
-    # ---- stage A on my shard, then all-gather the packed shards
+    t_x = 0.0  # host seconds inside the two exchanges (incl. the waits for them): reported by bench.py as exchange_ms
+    # ---- stage A on my shard, then all-gather the packed shards: my shard is written once, at its final place in the
+    # persistent gather buffer, and the peers' shards arrive at theirs
     engine.calc_posteriors(k0, k1)
     nbytes, _ = engine.shard_info()
+    t0 = time.perf_counter()
     sizes = exchange.all_sizes(nbytes)
-    mine = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=exchange.device)
-    engine.shard_export(mine.data_ptr())
-    full = exchange.all_gather_var(mine[:nbytes], sizes, torch.uint8)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    full = exchange.buffer("shards", int(offs[-1]), torch.uint8)
+    engine.shard_export(full.data_ptr() + int(offs[exchange.rank]))
+    full = exchange.all_gather_segments(full, sizes)
     _sync(torch, exchange.device)
+    t_x += time.perf_counter() - t0
     engine.store_import(cuts[:-1], cuts[1:], sizes, full.data_ptr())
     engine._keepalive = full  # dev_all must outlive the store
-    # ---- relax on my shard, all-gather the values, commit everywhere
+    # ---- relax on my shard, all-gather the values (each rank's slice straight into its place), commit everywhere
     if n >= 3:
         first, count = engine.values_slice(k0, k1)
         counts = exchange.all_sizes(count)
+        voffs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        allv = exchange.buffer("values", int(voffs[-1]), torch.float32)
         for _ in range(iters):
             engine.cons_iter(k0, k1)
-            v = torch.empty(max(count, 1), dtype=torch.float32, device=exchange.device)
-            engine.values_export(first, count, v.data_ptr())
-            allv = exchange.all_gather_var(v[:count], counts, torch.float32)
+            t0 = time.perf_counter()
+            engine.values_export(first, count, allv.data_ptr() + 4 * int(voffs[exchange.rank]))
+            got = exchange.all_gather_segments(allv, counts)
             _sync(torch, exchange.device)
-            engine.values_import(0, int(allv.numel()), allv.data_ptr())
+            t_x += time.perf_counter() - t0
+            engine.values_import(0, int(got.numel()), got.data_ptr())
             engine.cons_commit()
     engine.synchronize()
+    engine._exchange_seconds = getattr(engine, "_exchange_seconds", 0.0) + t_x
     return k0, k1
 
 

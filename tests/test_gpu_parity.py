@@ -510,3 +510,49 @@ def test_buildpost_vs_reference_golden(name):
     own matrices / paths / scores for the same joins (tests/golden/bp_*.npz: plain, weighted, transposed access of
     buildpostflat.cpp:78-100, explicit pair lists of buildposterior3flat.cpp:19-85)."""
     P.check_buildpost_golden(name)
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_two_gpus_rccl_group_and_torchrun_bench():
+    """Self-arming: runs wherever the box has >= 2 GPUs (the build boxes have one: skipped there, so the first multi-GPU box
+    exercises it). (1) the product's one-process group (mpcgpu_group_*, RCCL point-to-point sends / receives over xGMI) on
+    devices 0 and 1: every rank's store equals the reference's digests for BASELINE config 2 after every stage; (2) the driver's
+    launch of bench.py on 2 ranks (torch.distributed.run, backend nccl = RCCL): parity_digest must say match."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    import subprocess
+    import sys
+    import _bigdigest as D
+    from muscle_amd._lib import MpcGroup
+    name = "n256_L300"
+    z = D.load(name)
+    seqs = D.seqs_of(name)
+    s, t, m, i, thr = G.hmm_tables()
+    grp = MpcGroup([0, 1])
+    assert grp.transport() == "rccl"
+    grp.set_hmm(s, t, m, i, thr)
+    grp.set_seqs(seqs)
+    grp.calc_posteriors()
+    for r in range(2):
+        assert D.compare_ea(z, grp.ctx(r).get_ea()) is None, r
+        assert D.compare_stage(z, 0, grp.ctx(r)) is None, r
+    for it in range(2):
+        grp.cons_iter()
+        for r in range(2):
+            assert D.compare_stage(z, it + 1, grp.ctx(r)) is None, (it, r)
+    grp.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--nseqs", "256", "--seqlen", "300", "--steps", "1",
+                          "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert out.returncode == 0 and lines, out.stdout[-2000:] + out.stderr[-2000:]
+    rec = json.loads(lines[-1])
+    assert rec["n_gpus"] == 2 and rec["parity_digest"] == "match", rec
+    assert rec["exchange_ms"] > 0
