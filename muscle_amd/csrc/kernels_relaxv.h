@@ -56,40 +56,63 @@ struct RelaxVarParams {
 		sum += __uint_as_float((va).y) * pb1_;                                                                          \
 	} while (0)
 
-// The merge of one (cell, Z) in C++: the statement of what MpcRvBlocksAsm (mpc_platform.h) does with hand-scheduled
-// instructions. The emulator runs this one; on the device it is the MPCGPU_RELAX_MERGE=cxx instantiation (A/B).
+// The merge of one (cell, Z) in C++: the statement of what MpcRvBlocksAsm / MpcRvBlocksAsm2 (mpc_platform.h) do with
+// hand-scheduled instructions. The emulator runs these; on the device they are the MPCGPU_RELAX_MERGE=cxx instantiations (A/B).
+__device__ __forceinline__ void mpc_rv_merge_cxx(float &sum, MpcQuad va, MpcQuad vb, u32 ia, u32 ib)
+{
+	MPC_RV_TERMS(sum, va, vb);
+	// The row whose last column is not larger moves to its next block (the distance in bytes rides in the upper half of
+	// the block's first column word; 0: the row ends here); when that row has none the merge is over. Most lanes stop
+	// after the first step.
+	bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
+	u32 da = va.z >> 16, db = vb.z >> 16;
+	bool more = !((adv_a && da == 0u) || (adv_b && db == 0u));
+	while (more) {
+		ia += adv_a ? da : 0u;
+		ib += adv_b ? db : 0u;
+		va = mpc_lds_load16(ia); vb = mpc_lds_load16(ib);
+		MPC_RV_TERMS(sum, va, vb);
+		adv_a = va.w <= vb.w; adv_b = vb.w <= va.w;
+		da = va.z >> 16; db = vb.z >> 16;
+		more = !((adv_a && da == 0u) || (adv_b && db == 0u));
+	}
+}
+// one slot at a time, the next slot's first blocks in flight
 struct MpcRvBlocksCxx {
+	static constexpr bool dual = false;
 	MpcQuad a[2], b[2];
 	__device__ __forceinline__ void load(int set, u32 ia, u32 ib) { a[set] = mpc_lds_load16(ia); b[set] = mpc_lds_load16(ib); }
 	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32 ib, u32 nia, u32 nib)
 	{
-		MpcQuad va = a[SET], vb = b[SET];
+		const MpcQuad va = a[SET], vb = b[SET];
 		load(SET ^ 1, nia, nib); // the next slot's first blocks: in flight during this slot's arithmetic
-		MPC_RV_TERMS(sum, va, vb);
-		// The row whose last column is not larger moves to its next block (the distance in bytes rides in the upper half of
-		// the block's first column word; 0: the row ends here); when that row has none the merge is over. Most lanes stop
-		// after the first step.
-		bool adv_a = va.w <= vb.w, adv_b = vb.w <= va.w;
-		u32 da = va.z >> 16, db = vb.z >> 16;
-		bool more = !((adv_a && da == 0u) || (adv_b && db == 0u));
-		while (more) {
-			ia += adv_a ? da : 0u;
-			ib += adv_b ? db : 0u;
-			va = mpc_lds_load16(ia); vb = mpc_lds_load16(ib);
-			MPC_RV_TERMS(sum, va, vb);
-			adv_a = va.w <= vb.w; adv_b = vb.w <= va.w;
-			da = va.z >> 16; db = vb.z >> 16;
-			more = !((adv_a && da == 0u) || (adv_b && db == 0u));
-		}
+		mpc_rv_merge_cxx(sum, va, vb, ia, ib);
 	}
 };
+// two slots at a time (sets 2 PAR and 2 PAR + 1), the next two slots' first blocks in flight
+struct MpcRvBlocksCxx2 {
+	static constexpr bool dual = true;
+	MpcQuad a[4], b[4];
+	__device__ __forceinline__ void load(int set, u32 ia, u32 ib) { a[set] = mpc_lds_load16(ia); b[set] = mpc_lds_load16(ib); }
+	template <int PAR> __device__ __forceinline__ void merge2(float &sum0, float &sum1, u32 ia0, u32 ib0, u32 ia1, u32 ib1,
+		u32 nia0, u32 nib0, u32 nia1, u32 nib1)
+	{
+		const MpcQuad va0 = a[2 * PAR], vb0 = b[2 * PAR], va1 = a[2 * PAR + 1], vb1 = b[2 * PAR + 1];
+		load(2 * (PAR ^ 1), nia0, nib0);
+		load(2 * (PAR ^ 1) + 1, nia1, nib1);
+		mpc_rv_merge_cxx(sum0, va0, vb0, ia0, ib0);
+		mpc_rv_merge_cxx(sum1, va1, vb1, ia1, ib1);
+	}
+	template <int PAR> __device__ __forceinline__ void merge1(float &sum, u32 ia, u32 ib) { mpc_rv_merge_cxx(sum, a[2 * PAR], b[2 * PAR], ia, ib); }
+};
 #ifndef MPC_RV_HAVE_ASM
-typedef MpcRvBlocksCxx MpcRvBlocksAsm; // the emulator has one implementation
+typedef MpcRvBlocksCxx MpcRvBlocksAsm; // the emulator has the C++ statements only
+typedef MpcRvBlocksCxx2 MpcRvBlocksAsm2;
 #endif
 
 // THREADS: workgroup size; MAXSLOTS: cells per lane (the host splits any tile whose wave-aligned cells need more);
 // DIAG (measurement only, results wrong): 1 = staging and barriers only, 2 = merges only (step 0's records for every step,
-// no further staging, no barriers).
+// no further staging, no barriers), 3 = as 2 with the two barriers per step.
 // WGS: workgroups per CU the register allocation has to allow (waves per SIMD = WGS * THREADS / 256).
 // BLOCKS: MpcRvBlocksAsm (hand-scheduled merge, the default) or MpcRvBlocksCxx.
 template <int THREADS, int MAXSLOTS, int WGS, int DIAG = 0, class BLOCKS = MpcRvBlocksAsm>
@@ -234,6 +257,11 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 		for (u32 Z = 0; Z < n; ++Z) {
 			if (DIAG == 2 && Z > 0) {
 				// measurement only: every step merges step 0's records
+			} else if (DIAG == 3 && Z > 0) {
+				// measurement only: step 0's records, but the two barriers of a step are kept (what the waves of a workgroup lose by
+				// waiting for each other, without the staging)
+				__syncthreads();
+				__syncthreads();
 			} else if (p.nbuf == 2) {
 				__syncthreads(); // step Z's records have landed (every wave waited for its own DMA) and step Z-1's readers are done
 				if (DIAG != 2 && Z + 1 < n) {
@@ -251,34 +279,52 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 				// lane q of base_a / base_b: LDS address of slot q's two records at this step (one cross-lane gather each per step;
 				// a slot then takes its bases with two v_readlane of a constant lane)
 				const u32 base_a = mpc_lane_gather(vbase_cur, vsel_a), base_b = mpc_lane_gather(vbase_cur, vsel_b);
-				// first blocks of slot 0; from then on slot q+1's are read while slot q is merged
 				BLOCKS blk;
-				u32 nia, nib;
-				{
-					const u32 c = xy[0]; // one register per slot: the two row offsets are unpacked per step
-					nia = mpc_read_lane(base_a, 0u) + (c & 0xffffu); nib = mpc_read_lane(base_b, 0u) + (c >> 16);
+				auto addr_a = [&](int q) -> u32 { return mpc_read_lane(base_a, (u32)q) + (xy[q] & 0xffffu); }; // one register per slot:
+				auto addr_b = [&](int q) -> u32 { return mpc_read_lane(base_b, (u32)q) + (xy[q] >> 16); };     // the row offsets are unpacked per step
+				if constexpr (!BLOCKS::dual) {
+					// first blocks of slot 0; from then on slot q+1's are read while slot q is merged
+					u32 nia = addr_a(0), nib = addr_b(0);
 					blk.load(0, nia, nib);
-				}
-				// slots 0 .. nact-1, unrolled by recursion over the slot number (a loop with an early exit is not unrolled, and
-				// acc[] / xy[] must stay registers)
-				auto slot = [&](auto &&self, auto qc) __attribute__((always_inline)) {
-					constexpr int q = decltype(qc)::value;
-					if constexpr (q < MAXSLOTS) {
-						if ((u32)q >= nact) return; // wave-uniform: the slots a wave holds cells of are the first nact
-						const u32 ia = nia, ib = nib;
-						{
-							// slot q+1's first blocks, unconditionally (a slot without cells has sel 0 and offsets 0: row 0 of record 0)
+					// slots 0 .. nact-1, unrolled by recursion over the slot number (a loop with an early exit is not unrolled, and
+					// acc[] / xy[] must stay registers)
+					auto slot = [&](auto &&self, auto qc) __attribute__((always_inline)) {
+						constexpr int q = decltype(qc)::value;
+						if constexpr (q < MAXSLOTS) {
+							if ((u32)q >= nact) return; // wave-uniform: the slots a wave holds cells of are the first nact
+							const u32 ia = nia, ib = nib;
+							// slot q+1's first blocks, unconditionally (a slot without cells has base lane 0 and offsets 0: row 0 of record 0)
 							constexpr int qn = q + 1 < MAXSLOTS ? q + 1 : q;
-							const u32 c = xy[qn];
-							nia = mpc_read_lane(base_a, (u32)qn) + (c & 0xffffu); nib = mpc_read_lane(base_b, (u32)qn) + (c >> 16);
+							nia = addr_a(qn); nib = addr_b(qn);
+							float sum = acc[q];
+							blk.template merge<q & 1>(sum, ia, ib, nia, nib);
+							acc[q] = sum;
+							self(self, std::integral_constant<int, q + 1>{});
 						}
-						float sum = acc[q];
-						blk.template merge<q & 1>(sum, ia, ib, nia, nib);
-						acc[q] = sum;
-						self(self, std::integral_constant<int, q + 1>{});
-					}
-				};
-				slot(slot, std::integral_constant<int, 0>{});
+					};
+					slot(slot, std::integral_constant<int, 0>{});
+				} else {
+					// two slots per step of the recursion (MAXSLOTS is even). A wave with an odd number of slots merges one slot without
+					// cells along with its last one (base lane 0, offsets 0: row 0 of record 0 against itself; its sum is never written)
+					// — straight-line control flow between the merges keeps the block registers where the asm wants them
+					u32 n0a = addr_a(0), n0b = addr_b(0), n1a = addr_a(1), n1b = addr_b(1);
+					blk.load(0, n0a, n0b);
+					blk.load(1, n1a, n1b);
+					auto slot2 = [&](auto &&self, auto qc) __attribute__((always_inline)) {
+						constexpr int q = decltype(qc)::value;
+						if constexpr (q + 1 < MAXSLOTS) {
+							if ((u32)q >= nact) return;
+							const u32 ia0 = n0a, ib0 = n0b, ia1 = n1a, ib1 = n1b;
+							constexpr int q2 = q + 2 < MAXSLOTS ? q + 2 : q, q3 = q + 3 < MAXSLOTS ? q + 3 : q + 1;
+							n0a = addr_a(q2); n0b = addr_b(q2); n1a = addr_a(q3); n1b = addr_b(q3);
+							float s0 = acc[q], s1 = acc[q + 1];
+							blk.template merge2<(q / 2) & 1>(s0, s1, ia0, ib0, ia1, ib1, n0a, n0b, n1a, n1b);
+							acc[q] = s0; acc[q + 1] = s1;
+							self(self, std::integral_constant<int, q + 2>{});
+						}
+					};
+					slot2(slot2, std::integral_constant<int, 0>{});
+				}
 			}
 			if (p.nbuf == 2 && DIAG != 2) {
 				mpc_dma_wait(); // my part of step Z+1's records is in LDS
