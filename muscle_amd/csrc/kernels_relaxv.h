@@ -56,8 +56,8 @@ struct RelaxVarParams {
 		sum += __uint_as_float((va).y) * pb1_;                                                                          \
 	} while (0)
 
-// The merge of one (cell, Z) in C++: the statement of what MpcRvBlocksAsm / MpcRvBlocksAsm2 (mpc_platform.h) do with
-// hand-scheduled instructions. The emulator runs these; on the device they are the MPCGPU_RELAX_MERGE=cxx instantiations (A/B).
+// The merge of one (cell, Z) in C++: the statement of what MpcRvBlocksAsm (mpc_platform.h) does with hand-scheduled
+// instructions. The emulator runs this one; on the device it is the MPCGPU_RELAX_MERGE=cxx instantiation (A/B).
 __device__ __forceinline__ void mpc_rv_merge_cxx(float &sum, MpcQuad va, MpcQuad vb, u32 ia, u32 ib)
 {
 	MPC_RV_TERMS(sum, va, vb);
@@ -79,7 +79,6 @@ __device__ __forceinline__ void mpc_rv_merge_cxx(float &sum, MpcQuad va, MpcQuad
 }
 // one slot at a time, the next slot's first blocks in flight
 struct MpcRvBlocksCxx {
-	static constexpr bool dual = false;
 	MpcQuad a[2], b[2];
 	__device__ __forceinline__ void load(int set, u32 ia, u32 ib) { a[set] = mpc_lds_load16(ia); b[set] = mpc_lds_load16(ib); }
 	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32 ib, u32 nia, u32 nib)
@@ -89,25 +88,8 @@ struct MpcRvBlocksCxx {
 		mpc_rv_merge_cxx(sum, va, vb, ia, ib);
 	}
 };
-// two slots at a time (sets 2 PAR and 2 PAR + 1), the next two slots' first blocks in flight
-struct MpcRvBlocksCxx2 {
-	static constexpr bool dual = true;
-	MpcQuad a[4], b[4];
-	__device__ __forceinline__ void load(int set, u32 ia, u32 ib) { a[set] = mpc_lds_load16(ia); b[set] = mpc_lds_load16(ib); }
-	template <int PAR> __device__ __forceinline__ void merge2(float &sum0, float &sum1, u32 ia0, u32 ib0, u32 ia1, u32 ib1,
-		u32 nia0, u32 nib0, u32 nia1, u32 nib1)
-	{
-		const MpcQuad va0 = a[2 * PAR], vb0 = b[2 * PAR], va1 = a[2 * PAR + 1], vb1 = b[2 * PAR + 1];
-		load(2 * (PAR ^ 1), nia0, nib0);
-		load(2 * (PAR ^ 1) + 1, nia1, nib1);
-		mpc_rv_merge_cxx(sum0, va0, vb0, ia0, ib0);
-		mpc_rv_merge_cxx(sum1, va1, vb1, ia1, ib1);
-	}
-	template <int PAR> __device__ __forceinline__ void merge1(float &sum, u32 ia, u32 ib) { mpc_rv_merge_cxx(sum, a[2 * PAR], b[2 * PAR], ia, ib); }
-};
 #ifndef MPC_RV_HAVE_ASM
-typedef MpcRvBlocksCxx MpcRvBlocksAsm; // the emulator has the C++ statements only
-typedef MpcRvBlocksCxx2 MpcRvBlocksAsm2;
+typedef MpcRvBlocksCxx MpcRvBlocksAsm; // the emulator has the C++ statement only
 #endif
 
 // THREADS: workgroup size; MAXSLOTS: cells per lane (the host splits any tile whose wave-aligned cells need more);
@@ -282,49 +264,26 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 				BLOCKS blk;
 				auto addr_a = [&](int q) -> u32 { return mpc_read_lane(base_a, (u32)q) + (xy[q] & 0xffffu); }; // one register per slot:
 				auto addr_b = [&](int q) -> u32 { return mpc_read_lane(base_b, (u32)q) + (xy[q] >> 16); };     // the row offsets are unpacked per step
-				if constexpr (!BLOCKS::dual) {
-					// first blocks of slot 0; from then on slot q+1's are read while slot q is merged
-					u32 nia = addr_a(0), nib = addr_b(0);
-					blk.load(0, nia, nib);
-					// slots 0 .. nact-1, unrolled by recursion over the slot number (a loop with an early exit is not unrolled, and
-					// acc[] / xy[] must stay registers)
-					auto slot = [&](auto &&self, auto qc) __attribute__((always_inline)) {
-						constexpr int q = decltype(qc)::value;
-						if constexpr (q < MAXSLOTS) {
-							if ((u32)q >= nact) return; // wave-uniform: the slots a wave holds cells of are the first nact
-							const u32 ia = nia, ib = nib;
-							// slot q+1's first blocks, unconditionally (a slot without cells has base lane 0 and offsets 0: row 0 of record 0)
-							constexpr int qn = q + 1 < MAXSLOTS ? q + 1 : q;
-							nia = addr_a(qn); nib = addr_b(qn);
-							float sum = acc[q];
-							blk.template merge<q & 1>(sum, ia, ib, nia, nib);
-							acc[q] = sum;
-							self(self, std::integral_constant<int, q + 1>{});
-						}
-					};
-					slot(slot, std::integral_constant<int, 0>{});
-				} else {
-					// two slots per step of the recursion (MAXSLOTS is even). A wave with an odd number of slots merges one slot without
-					// cells along with its last one (base lane 0, offsets 0: row 0 of record 0 against itself; its sum is never written)
-					// — straight-line control flow between the merges keeps the block registers where the asm wants them
-					u32 n0a = addr_a(0), n0b = addr_b(0), n1a = addr_a(1), n1b = addr_b(1);
-					blk.load(0, n0a, n0b);
-					blk.load(1, n1a, n1b);
-					auto slot2 = [&](auto &&self, auto qc) __attribute__((always_inline)) {
-						constexpr int q = decltype(qc)::value;
-						if constexpr (q + 1 < MAXSLOTS) {
-							if ((u32)q >= nact) return;
-							const u32 ia0 = n0a, ib0 = n0b, ia1 = n1a, ib1 = n1b;
-							constexpr int q2 = q + 2 < MAXSLOTS ? q + 2 : q, q3 = q + 3 < MAXSLOTS ? q + 3 : q + 1;
-							n0a = addr_a(q2); n0b = addr_b(q2); n1a = addr_a(q3); n1b = addr_b(q3);
-							float s0 = acc[q], s1 = acc[q + 1];
-							blk.template merge2<(q / 2) & 1>(s0, s1, ia0, ib0, ia1, ib1, n0a, n0b, n1a, n1b);
-							acc[q] = s0; acc[q + 1] = s1;
-							self(self, std::integral_constant<int, q + 2>{});
-						}
-					};
-					slot2(slot2, std::integral_constant<int, 0>{});
-				}
+				// first blocks of slot 0; from then on slot q+1's are read while slot q is merged
+				u32 nia = addr_a(0), nib = addr_b(0);
+				blk.load(0, nia, nib);
+				// slots 0 .. nact-1, unrolled by recursion over the slot number (a loop with an early exit is not unrolled, and
+				// acc[] / xy[] must stay registers)
+				auto slot = [&](auto &&self, auto qc) __attribute__((always_inline)) {
+					constexpr int q = decltype(qc)::value;
+					if constexpr (q < MAXSLOTS) {
+						if ((u32)q >= nact) return; // wave-uniform: the slots a wave holds cells of are the first nact
+						const u32 ia = nia, ib = nib;
+						// slot q+1's first blocks, unconditionally (a slot without cells has base lane 0 and offsets 0: row 0 of record 0)
+						constexpr int qn = q + 1 < MAXSLOTS ? q + 1 : q;
+						nia = addr_a(qn); nib = addr_b(qn);
+						float sum = acc[q];
+						blk.template merge<q & 1>(sum, ia, ib, nia, nib);
+						acc[q] = sum;
+						self(self, std::integral_constant<int, q + 1>{});
+					}
+				};
+				slot(slot, std::integral_constant<int, 0>{});
 			}
 			if (p.nbuf == 2 && DIAG != 2) {
 				mpc_dma_wait(); // my part of step Z+1's records is in LDS

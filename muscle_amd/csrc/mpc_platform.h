@@ -125,7 +125,6 @@ __device__ __forceinline__ MpcQuad mpc_lds_load16(unsigned addr)
 // selects and a shift for the advance). "s_orn2 nl, nl, adv" is "the row has a next block, or it is not the row that advances".
 typedef unsigned long long mpc_u64s;
 struct MpcRvBlocksAsm {
-	static constexpr bool dual = false;
 	mpc_uint4v a0, b0, a1, b1; // set 0: v[24:27], v[28:31]; set 1: v[32:35], v[36:39]
 	__device__ __forceinline__ void load(int set, unsigned ia, unsigned ib)
 	{
@@ -192,310 +191,8 @@ struct MpcRvBlocksAsm {
 				: [nia] "v"(nia), [nib] "v"(nib), [kf] "s"(kf)
 				: "vcc", "scc", "memory");
 	}
-};
-// Two slots merged at once (the default with the 1 x 1024 geometry): the first steps of slots q and q+1 are interleaved
-// instruction by instruction, and in the loop for the further steps both slots' block reads are in flight before the one
-// s_waitcnt — a wave waits for LDS max(steps_q, steps_q+1) times instead of steps_q + steps_q+1 times, so the few waves of
-// one workgroup per CU (4 per SIMD) keep the VALU as busy as 6-8 single-slot waves. Four sets of 2 x 4 VGPRs: v[24:55]
-// (two being merged, two receiving the next two slots' first blocks). Generated text (scripts/gen_rv_merge2.py).
-struct MpcRvBlocksAsm2 {
-	static constexpr bool dual = true;
-	mpc_uint4v a[4], b[4]; // set s: a = v[24 + 8 s : +3], b = v[28 + 8 s : +3]
-	__device__ __forceinline__ void load(int set, unsigned ia, unsigned ib)
-	{
-		if (set == 0) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "={v[24:27]}"(a[0]), "={v[28:31]}"(b[0]) : "v"(ia), "v"(ib) : "memory");
-		else asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "={v[32:35]}"(a[1]), "={v[36:39]}"(b[1]) : "v"(ia), "v"(ib) : "memory");
-	}
-	// merges slots q (first blocks in set 2*PAR, addresses ia0 / ib0) and q+1 (set 2*PAR+1, ia1 / ib1) onto sum0 / sum1 and reads
-	// the first blocks of the next two slots (nia0 / nib0, nia1 / nib1) into the other two sets
-	template <int PAR> __device__ __forceinline__ void merge2(float &sum0, float &sum1, unsigned ia0, unsigned ib0, unsigned ia1, unsigned ib1,
-		unsigned nia0, unsigned nib0, unsigned nia1, unsigned nib1)
-	{
-		mpc_u64s sv, more0, more1, e000, e010, e100, e110, ada0, adb0, nla0, nlb0, e001, e011, e101, e111, ada1, adb1, nla1, nlb1;
-		float t0, t1, t2, t3;
-		const unsigned kf = 0xffffu;
-		if (PAR == 0)
-			asm volatile(
-			"\ts_waitcnt lgkmcnt(0)\n"
-			"\tds_read_b128 v[40:43], %[nia0]\n"
-			"\tds_read_b128 v[44:47], %[nib0]\n"
-			"\tds_read_b128 v[48:51], %[nia1]\n"
-			"\tds_read_b128 v[52:55], %[nib1]\n"
-			"\ts_mov_b64 %[sv], exec\n"
-			"\tv_cmp_eq_u32_sdwa %[e010], v26, v31 src0_sel:WORD_0 src1_sel:DWORD\n"
-			"\tv_cmp_eq_u32_sdwa %[e000], v26, v30 src0_sel:WORD_0 src1_sel:WORD_0\n"
-			"\tv_cmp_eq_u32_e64 %[e110], v27, v31\n"
-			"\tv_cmp_eq_u32_sdwa %[e100], v27, v30 src0_sel:DWORD src1_sel:WORD_0\n"
-			"\tv_cmp_le_u32_e64 %[ada0], v27, v31\n"
-			"\tv_cmp_le_u32_e64 %[adb0], v31, v27\n"
-			"\tv_cmp_lt_u32_e64 %[nla0], %[kf], v26\n"
-			"\tv_cmp_lt_u32_e64 %[nlb0], %[kf], v30\n"
-			"\tv_cmp_eq_u32_sdwa %[e011], v34, v39 src0_sel:WORD_0 src1_sel:DWORD\n"
-			"\tv_cmp_eq_u32_sdwa %[e001], v34, v38 src0_sel:WORD_0 src1_sel:WORD_0\n"
-			"\tv_cmp_eq_u32_e64 %[e111], v35, v39\n"
-			"\tv_cmp_eq_u32_sdwa %[e101], v35, v38 src0_sel:DWORD src1_sel:WORD_0\n"
-			"\tv_cmp_le_u32_e64 %[ada1], v35, v39\n"
-			"\tv_cmp_le_u32_e64 %[adb1], v39, v35\n"
-			"\tv_cmp_lt_u32_e64 %[nla1], %[kf], v34\n"
-			"\tv_cmp_lt_u32_e64 %[nlb1], %[kf], v38\n"
-			"\tv_cndmask_b32_e64 %[t0], 0, v29, %[e010]\n"
-			"\tv_cndmask_b32_e64 %[t1], 0, v29, %[e110]\n"
-			"\tv_cndmask_b32_e64 %[t2], 0, v37, %[e011]\n"
-			"\tv_cndmask_b32_e64 %[t3], 0, v37, %[e111]\n"
-			"\tv_cndmask_b32_e64 %[t0], %[t0], v28, %[e000]\n"
-			"\tv_cndmask_b32_e64 %[t1], %[t1], v28, %[e100]\n"
-			"\tv_cndmask_b32_e64 %[t2], %[t2], v36, %[e001]\n"
-			"\tv_cndmask_b32_e64 %[t3], %[t3], v36, %[e101]\n"
-			"\tv_mul_f32_e32 %[t0], v24, %[t0]\n"
-			"\tv_mul_f32_e32 %[t1], v25, %[t1]\n"
-			"\tv_mul_f32_e32 %[t2], v32, %[t2]\n"
-			"\tv_mul_f32_e32 %[t3], v33, %[t3]\n"
-			"\tv_add_f32_e32 %[sum0], %[sum0], %[t0]\n"
-			"\tv_add_f32_e32 %[sum1], %[sum1], %[t2]\n"
-			"\tv_add_f32_e32 %[sum0], %[sum0], %[t1]\n"
-			"\tv_add_f32_e32 %[sum1], %[sum1], %[t3]\n"
-			"\ts_orn2_b64 %[nla0], %[nla0], %[ada0]\n"
-			"\ts_orn2_b64 %[nlb0], %[nlb0], %[adb0]\n"
-			"\ts_and_b64 %[nla0], %[nla0], %[nlb0]\n"
-			"\ts_and_b64 %[more0], exec, %[nla0]\n"
-			"\ts_orn2_b64 %[nla1], %[nla1], %[ada1]\n"
-			"\ts_orn2_b64 %[nlb1], %[nlb1], %[adb1]\n"
-			"\ts_and_b64 %[nla1], %[nla1], %[nlb1]\n"
-			"\ts_and_b64 %[more1], exec, %[nla1]\n"
-			"\ts_or_b64 %[e000], %[more0], %[more1]\n"
-			"\ts_cbranch_scc0 .Lrv2_done_%=\n"
-			".Lrv2_loop_%=:\n"
-			"\ts_mov_b64 exec, %[more0]\n"
-			"\ts_cbranch_execz .Lrv2_ld0_%=\n"
-			"\ts_and_b64 exec, %[more0], %[ada0]\n"
-			"\tv_add_u32_sdwa %[ia0], %[ia0], v26 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-			"\ts_and_b64 exec, %[more0], %[adb0]\n"
-			"\tv_add_u32_sdwa %[ib0], %[ib0], v30 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-			"\ts_mov_b64 exec, %[more0]\n"
-			"\tds_read_b128 v[24:27], %[ia0]\n"
-			"\tds_read_b128 v[28:31], %[ib0]\n"
-			".Lrv2_ld0_%=:\n"
-			"\ts_mov_b64 exec, %[more1]\n"
-			"\ts_cbranch_execz .Lrv2_ld1_%=\n"
-			"\ts_and_b64 exec, %[more1], %[ada1]\n"
-			"\tv_add_u32_sdwa %[ia1], %[ia1], v34 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-			"\ts_and_b64 exec, %[more1], %[adb1]\n"
-			"\tv_add_u32_sdwa %[ib1], %[ib1], v38 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-			"\ts_mov_b64 exec, %[more1]\n"
-			"\tds_read_b128 v[32:35], %[ia1]\n"
-			"\tds_read_b128 v[36:39], %[ib1]\n"
-			".Lrv2_ld1_%=:\n"
-			"\ts_waitcnt lgkmcnt(0)\n"
-			"\ts_mov_b64 exec, %[more0]\n"
-			"\ts_cbranch_execz .Lrv2_tr0_%=\n"
-			"\tv_cmp_eq_u32_sdwa %[e010], v26, v31 src0_sel:WORD_0 src1_sel:DWORD\n"
-			"\tv_cmp_eq_u32_sdwa %[e000], v26, v30 src0_sel:WORD_0 src1_sel:WORD_0\n"
-			"\tv_cmp_eq_u32_e64 %[e110], v27, v31\n"
-			"\tv_cmp_eq_u32_sdwa %[e100], v27, v30 src0_sel:DWORD src1_sel:WORD_0\n"
-			"\tv_cmp_le_u32_e64 %[ada0], v27, v31\n"
-			"\tv_cmp_le_u32_e64 %[adb0], v31, v27\n"
-			"\tv_cmp_lt_u32_e64 %[nla0], %[kf], v26\n"
-			"\tv_cmp_lt_u32_e64 %[nlb0], %[kf], v30\n"
-			"\tv_cndmask_b32_e64 %[t0], 0, v29, %[e010]\n"
-			"\tv_cndmask_b32_e64 %[t1], 0, v29, %[e110]\n"
-			"\tv_cndmask_b32_e64 %[t0], %[t0], v28, %[e000]\n"
-			"\tv_cndmask_b32_e64 %[t1], %[t1], v28, %[e100]\n"
-			"\tv_mul_f32_e32 %[t0], v24, %[t0]\n"
-			"\tv_mul_f32_e32 %[t1], v25, %[t1]\n"
-			"\tv_add_f32_e32 %[sum0], %[sum0], %[t0]\n"
-			"\tv_add_f32_e32 %[sum0], %[sum0], %[t1]\n"
-			"\ts_orn2_b64 %[nla0], %[nla0], %[ada0]\n"
-			"\ts_orn2_b64 %[nlb0], %[nlb0], %[adb0]\n"
-			"\ts_and_b64 %[nla0], %[nla0], %[nlb0]\n"
-			"\ts_and_b64 %[more0], exec, %[nla0]\n"
-			".Lrv2_tr0_%=:\n"
-			"\ts_mov_b64 exec, %[more1]\n"
-			"\ts_cbranch_execz .Lrv2_tr1_%=\n"
-			"\tv_cmp_eq_u32_sdwa %[e011], v34, v39 src0_sel:WORD_0 src1_sel:DWORD\n"
-			"\tv_cmp_eq_u32_sdwa %[e001], v34, v38 src0_sel:WORD_0 src1_sel:WORD_0\n"
-			"\tv_cmp_eq_u32_e64 %[e111], v35, v39\n"
-			"\tv_cmp_eq_u32_sdwa %[e101], v35, v38 src0_sel:DWORD src1_sel:WORD_0\n"
-			"\tv_cmp_le_u32_e64 %[ada1], v35, v39\n"
-			"\tv_cmp_le_u32_e64 %[adb1], v39, v35\n"
-			"\tv_cmp_lt_u32_e64 %[nla1], %[kf], v34\n"
-			"\tv_cmp_lt_u32_e64 %[nlb1], %[kf], v38\n"
-			"\tv_cndmask_b32_e64 %[t2], 0, v37, %[e011]\n"
-			"\tv_cndmask_b32_e64 %[t3], 0, v37, %[e111]\n"
-			"\tv_cndmask_b32_e64 %[t2], %[t2], v36, %[e001]\n"
-			"\tv_cndmask_b32_e64 %[t3], %[t3], v36, %[e101]\n"
-			"\tv_mul_f32_e32 %[t2], v32, %[t2]\n"
-			"\tv_mul_f32_e32 %[t3], v33, %[t3]\n"
-			"\tv_add_f32_e32 %[sum1], %[sum1], %[t2]\n"
-			"\tv_add_f32_e32 %[sum1], %[sum1], %[t3]\n"
-			"\ts_orn2_b64 %[nla1], %[nla1], %[ada1]\n"
-			"\ts_orn2_b64 %[nlb1], %[nlb1], %[adb1]\n"
-			"\ts_and_b64 %[nla1], %[nla1], %[nlb1]\n"
-			"\ts_and_b64 %[more1], exec, %[nla1]\n"
-			".Lrv2_tr1_%=:\n"
-			"\ts_or_b64 %[e000], %[more0], %[more1]\n"
-			"\ts_cbranch_scc1 .Lrv2_loop_%=\n"
-			".Lrv2_done_%=:\n"
-			"\ts_mov_b64 exec, %[sv]\n"
-				: [sum0] "+v"(sum0), [sum1] "+v"(sum1), [ia0] "+v"(ia0), [ib0] "+v"(ib0), [ia1] "+v"(ia1), [ib1] "+v"(ib1),
-				  "+{v[24:27]}"(a[0]), "+{v[28:31]}"(b[0]), "+{v[32:35]}"(a[1]), "+{v[36:39]}"(b[1]), "=&{v[40:43]}"(a[2]), "=&{v[44:47]}"(b[2]), "=&{v[48:51]}"(a[3]), "=&{v[52:55]}"(b[3]),
-				  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv), [more0] "=&s"(more0), [more1] "=&s"(more1),
-				  [e000] "=&s"(e000), [e010] "=&s"(e010), [e100] "=&s"(e100), [e110] "=&s"(e110), [ada0] "=&s"(ada0), [adb0] "=&s"(adb0), [nla0] "=&s"(nla0), [nlb0] "=&s"(nlb0),
-				  [e001] "=&s"(e001), [e011] "=&s"(e011), [e101] "=&s"(e101), [e111] "=&s"(e111), [ada1] "=&s"(ada1), [adb1] "=&s"(adb1), [nla1] "=&s"(nla1), [nlb1] "=&s"(nlb1)
-				: [nia0] "v"(nia0), [nib0] "v"(nib0), [nia1] "v"(nia1), [nib1] "v"(nib1), [kf] "s"(kf)
-				: "vcc", "scc", "memory");
-		if (PAR == 1)
-			asm volatile(
-			"\ts_waitcnt lgkmcnt(0)\n"
-			"\tds_read_b128 v[24:27], %[nia0]\n"
-			"\tds_read_b128 v[28:31], %[nib0]\n"
-			"\tds_read_b128 v[32:35], %[nia1]\n"
-			"\tds_read_b128 v[36:39], %[nib1]\n"
-			"\ts_mov_b64 %[sv], exec\n"
-			"\tv_cmp_eq_u32_sdwa %[e010], v42, v47 src0_sel:WORD_0 src1_sel:DWORD\n"
-			"\tv_cmp_eq_u32_sdwa %[e000], v42, v46 src0_sel:WORD_0 src1_sel:WORD_0\n"
-			"\tv_cmp_eq_u32_e64 %[e110], v43, v47\n"
-			"\tv_cmp_eq_u32_sdwa %[e100], v43, v46 src0_sel:DWORD src1_sel:WORD_0\n"
-			"\tv_cmp_le_u32_e64 %[ada0], v43, v47\n"
-			"\tv_cmp_le_u32_e64 %[adb0], v47, v43\n"
-			"\tv_cmp_lt_u32_e64 %[nla0], %[kf], v42\n"
-			"\tv_cmp_lt_u32_e64 %[nlb0], %[kf], v46\n"
-			"\tv_cmp_eq_u32_sdwa %[e011], v50, v55 src0_sel:WORD_0 src1_sel:DWORD\n"
-			"\tv_cmp_eq_u32_sdwa %[e001], v50, v54 src0_sel:WORD_0 src1_sel:WORD_0\n"
-			"\tv_cmp_eq_u32_e64 %[e111], v51, v55\n"
-			"\tv_cmp_eq_u32_sdwa %[e101], v51, v54 src0_sel:DWORD src1_sel:WORD_0\n"
-			"\tv_cmp_le_u32_e64 %[ada1], v51, v55\n"
-			"\tv_cmp_le_u32_e64 %[adb1], v55, v51\n"
-			"\tv_cmp_lt_u32_e64 %[nla1], %[kf], v50\n"
-			"\tv_cmp_lt_u32_e64 %[nlb1], %[kf], v54\n"
-			"\tv_cndmask_b32_e64 %[t0], 0, v45, %[e010]\n"
-			"\tv_cndmask_b32_e64 %[t1], 0, v45, %[e110]\n"
-			"\tv_cndmask_b32_e64 %[t2], 0, v53, %[e011]\n"
-			"\tv_cndmask_b32_e64 %[t3], 0, v53, %[e111]\n"
-			"\tv_cndmask_b32_e64 %[t0], %[t0], v44, %[e000]\n"
-			"\tv_cndmask_b32_e64 %[t1], %[t1], v44, %[e100]\n"
-			"\tv_cndmask_b32_e64 %[t2], %[t2], v52, %[e001]\n"
-			"\tv_cndmask_b32_e64 %[t3], %[t3], v52, %[e101]\n"
-			"\tv_mul_f32_e32 %[t0], v40, %[t0]\n"
-			"\tv_mul_f32_e32 %[t1], v41, %[t1]\n"
-			"\tv_mul_f32_e32 %[t2], v48, %[t2]\n"
-			"\tv_mul_f32_e32 %[t3], v49, %[t3]\n"
-			"\tv_add_f32_e32 %[sum0], %[sum0], %[t0]\n"
-			"\tv_add_f32_e32 %[sum1], %[sum1], %[t2]\n"
-			"\tv_add_f32_e32 %[sum0], %[sum0], %[t1]\n"
-			"\tv_add_f32_e32 %[sum1], %[sum1], %[t3]\n"
-			"\ts_orn2_b64 %[nla0], %[nla0], %[ada0]\n"
-			"\ts_orn2_b64 %[nlb0], %[nlb0], %[adb0]\n"
-			"\ts_and_b64 %[nla0], %[nla0], %[nlb0]\n"
-			"\ts_and_b64 %[more0], exec, %[nla0]\n"
-			"\ts_orn2_b64 %[nla1], %[nla1], %[ada1]\n"
-			"\ts_orn2_b64 %[nlb1], %[nlb1], %[adb1]\n"
-			"\ts_and_b64 %[nla1], %[nla1], %[nlb1]\n"
-			"\ts_and_b64 %[more1], exec, %[nla1]\n"
-			"\ts_or_b64 %[e000], %[more0], %[more1]\n"
-			"\ts_cbranch_scc0 .Lrv2_done_%=\n"
-			".Lrv2_loop_%=:\n"
-			"\ts_mov_b64 exec, %[more0]\n"
-			"\ts_cbranch_execz .Lrv2_ld0_%=\n"
-			"\ts_and_b64 exec, %[more0], %[ada0]\n"
-			"\tv_add_u32_sdwa %[ia0], %[ia0], v42 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-			"\ts_and_b64 exec, %[more0], %[adb0]\n"
-			"\tv_add_u32_sdwa %[ib0], %[ib0], v46 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-			"\ts_mov_b64 exec, %[more0]\n"
-			"\tds_read_b128 v[40:43], %[ia0]\n"
-			"\tds_read_b128 v[44:47], %[ib0]\n"
-			".Lrv2_ld0_%=:\n"
-			"\ts_mov_b64 exec, %[more1]\n"
-			"\ts_cbranch_execz .Lrv2_ld1_%=\n"
-			"\ts_and_b64 exec, %[more1], %[ada1]\n"
-			"\tv_add_u32_sdwa %[ia1], %[ia1], v50 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-			"\ts_and_b64 exec, %[more1], %[adb1]\n"
-			"\tv_add_u32_sdwa %[ib1], %[ib1], v54 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
-			"\ts_mov_b64 exec, %[more1]\n"
-			"\tds_read_b128 v[48:51], %[ia1]\n"
-			"\tds_read_b128 v[52:55], %[ib1]\n"
-			".Lrv2_ld1_%=:\n"
-			"\ts_waitcnt lgkmcnt(0)\n"
-			"\ts_mov_b64 exec, %[more0]\n"
-			"\ts_cbranch_execz .Lrv2_tr0_%=\n"
-			"\tv_cmp_eq_u32_sdwa %[e010], v42, v47 src0_sel:WORD_0 src1_sel:DWORD\n"
-			"\tv_cmp_eq_u32_sdwa %[e000], v42, v46 src0_sel:WORD_0 src1_sel:WORD_0\n"
-			"\tv_cmp_eq_u32_e64 %[e110], v43, v47\n"
-			"\tv_cmp_eq_u32_sdwa %[e100], v43, v46 src0_sel:DWORD src1_sel:WORD_0\n"
-			"\tv_cmp_le_u32_e64 %[ada0], v43, v47\n"
-			"\tv_cmp_le_u32_e64 %[adb0], v47, v43\n"
-			"\tv_cmp_lt_u32_e64 %[nla0], %[kf], v42\n"
-			"\tv_cmp_lt_u32_e64 %[nlb0], %[kf], v46\n"
-			"\tv_cndmask_b32_e64 %[t0], 0, v45, %[e010]\n"
-			"\tv_cndmask_b32_e64 %[t1], 0, v45, %[e110]\n"
-			"\tv_cndmask_b32_e64 %[t0], %[t0], v44, %[e000]\n"
-			"\tv_cndmask_b32_e64 %[t1], %[t1], v44, %[e100]\n"
-			"\tv_mul_f32_e32 %[t0], v40, %[t0]\n"
-			"\tv_mul_f32_e32 %[t1], v41, %[t1]\n"
-			"\tv_add_f32_e32 %[sum0], %[sum0], %[t0]\n"
-			"\tv_add_f32_e32 %[sum0], %[sum0], %[t1]\n"
-			"\ts_orn2_b64 %[nla0], %[nla0], %[ada0]\n"
-			"\ts_orn2_b64 %[nlb0], %[nlb0], %[adb0]\n"
-			"\ts_and_b64 %[nla0], %[nla0], %[nlb0]\n"
-			"\ts_and_b64 %[more0], exec, %[nla0]\n"
-			".Lrv2_tr0_%=:\n"
-			"\ts_mov_b64 exec, %[more1]\n"
-			"\ts_cbranch_execz .Lrv2_tr1_%=\n"
-			"\tv_cmp_eq_u32_sdwa %[e011], v50, v55 src0_sel:WORD_0 src1_sel:DWORD\n"
-			"\tv_cmp_eq_u32_sdwa %[e001], v50, v54 src0_sel:WORD_0 src1_sel:WORD_0\n"
-			"\tv_cmp_eq_u32_e64 %[e111], v51, v55\n"
-			"\tv_cmp_eq_u32_sdwa %[e101], v51, v54 src0_sel:DWORD src1_sel:WORD_0\n"
-			"\tv_cmp_le_u32_e64 %[ada1], v51, v55\n"
-			"\tv_cmp_le_u32_e64 %[adb1], v55, v51\n"
-			"\tv_cmp_lt_u32_e64 %[nla1], %[kf], v50\n"
-			"\tv_cmp_lt_u32_e64 %[nlb1], %[kf], v54\n"
-			"\tv_cndmask_b32_e64 %[t2], 0, v53, %[e011]\n"
-			"\tv_cndmask_b32_e64 %[t3], 0, v53, %[e111]\n"
-			"\tv_cndmask_b32_e64 %[t2], %[t2], v52, %[e001]\n"
-			"\tv_cndmask_b32_e64 %[t3], %[t3], v52, %[e101]\n"
-			"\tv_mul_f32_e32 %[t2], v48, %[t2]\n"
-			"\tv_mul_f32_e32 %[t3], v49, %[t3]\n"
-			"\tv_add_f32_e32 %[sum1], %[sum1], %[t2]\n"
-			"\tv_add_f32_e32 %[sum1], %[sum1], %[t3]\n"
-			"\ts_orn2_b64 %[nla1], %[nla1], %[ada1]\n"
-			"\ts_orn2_b64 %[nlb1], %[nlb1], %[adb1]\n"
-			"\ts_and_b64 %[nla1], %[nla1], %[nlb1]\n"
-			"\ts_and_b64 %[more1], exec, %[nla1]\n"
-			".Lrv2_tr1_%=:\n"
-			"\ts_or_b64 %[e000], %[more0], %[more1]\n"
-			"\ts_cbranch_scc1 .Lrv2_loop_%=\n"
-			".Lrv2_done_%=:\n"
-			"\ts_mov_b64 exec, %[sv]\n"
-				: [sum0] "+v"(sum0), [sum1] "+v"(sum1), [ia0] "+v"(ia0), [ib0] "+v"(ib0), [ia1] "+v"(ia1), [ib1] "+v"(ib1),
-				  "+{v[40:43]}"(a[2]), "+{v[44:47]}"(b[2]), "+{v[48:51]}"(a[3]), "+{v[52:55]}"(b[3]), "=&{v[24:27]}"(a[0]), "=&{v[28:31]}"(b[0]), "=&{v[32:35]}"(a[1]), "=&{v[36:39]}"(b[1]),
-				  [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv), [more0] "=&s"(more0), [more1] "=&s"(more1),
-				  [e000] "=&s"(e000), [e010] "=&s"(e010), [e100] "=&s"(e100), [e110] "=&s"(e110), [ada0] "=&s"(ada0), [adb0] "=&s"(adb0), [nla0] "=&s"(nla0), [nlb0] "=&s"(nlb0),
-				  [e001] "=&s"(e001), [e011] "=&s"(e011), [e101] "=&s"(e101), [e111] "=&s"(e111), [ada1] "=&s"(ada1), [adb1] "=&s"(adb1), [nla1] "=&s"(nla1), [nlb1] "=&s"(nlb1)
-				: [nia0] "v"(nia0), [nib0] "v"(nib0), [nia1] "v"(nia1), [nib1] "v"(nib1), [kf] "s"(kf)
-				: "vcc", "scc", "memory");
-	}
-	// the last slot of a wave with an odd number of slots, alone: first blocks in set 2*PAR
-	template <int PAR> __device__ __forceinline__ void merge1(float &sum, unsigned ia, unsigned ib)
-	{
-		mpc_u64s sv, e00, e01, e10, e11, ada, adb, nla, nlb;
-		float t0, t1;
-		const unsigned kf = 0xffffu;
-		if (PAR == 0)
-			asm volatile(MPC_RV_MERGE_ASM("v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v[24:27]", "v[28:31]", "v[40:43]", "v[44:47]")
-				: [sum] "+v"(sum), [ia] "+v"(ia), [ib] "+v"(ib), "+{v[24:27]}"(a[0]), "+{v[28:31]}"(b[0]), "=&{v[40:43]}"(a[2]), "=&{v[44:47]}"(b[2]),
-				  [t0] "=&v"(t0), [t1] "=&v"(t1), [sv] "=&s"(sv), [e00] "=&s"(e00), [e01] "=&s"(e01), [e10] "=&s"(e10), [e11] "=&s"(e11),
-				  [ada] "=&s"(ada), [adb] "=&s"(adb), [nla] "=&s"(nla), [nlb] "=&s"(nlb)
-				: [nia] "v"(ia), [nib] "v"(ib), [kf] "s"(kf)
-				: "vcc", "scc", "memory");
-		else
-			asm volatile(MPC_RV_MERGE_ASM("v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v[40:43]", "v[44:47]", "v[24:27]", "v[28:31]")
-				: [sum] "+v"(sum), [ia] "+v"(ia), [ib] "+v"(ib), "+{v[40:43]}"(a[2]), "+{v[44:47]}"(b[2]), "=&{v[24:27]}"(a[0]), "=&{v[28:31]}"(b[0]),
-				  [t0] "=&v"(t0), [t1] "=&v"(t1), [sv] "=&s"(sv), [e00] "=&s"(e00), [e01] "=&s"(e01), [e10] "=&s"(e10), [e11] "=&s"(e11),
-				  [ada] "=&s"(ada), [adb] "=&s"(adb), [nla] "=&s"(nla), [nlb] "=&s"(nlb)
-				: [nia] "v"(ia), [nib] "v"(ib), [kf] "s"(kf)
-				: "vcc", "scc", "memory");
-	}
-};
 #undef MPC_RV_MERGE_ASM
+};
 #define MPC_RV_HAVE_ASM 1
 // A pointer through which wave-uniform reads of memory that this kernel never writes become scalar loads (s_load_dword*:
 // SGPR results, no VGPRs, no vmcnt): the constant address space. (Through a plain global pointer the compiler has to assume

@@ -483,7 +483,7 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only (results wrong): 1 = staging only, 2 = merges only
 	const char *merge_env = getenv("MPCGPU_RELAX_MERGE"); // "cxx": the compiler's code for the merge instead of the hand-scheduled one (A/B, 768 geometry)
 	const bool merge_cxx = merge_env && !strcmp(merge_env, "cxx");
-	const void *fn = geo == 1024 ? (const void *)relax_var_kernel<1024, 16, 1, 0, MpcRvBlocksAsm2>
+	const void *fn = geo == 1024 ? (const void *)relax_var_kernel<1024, 16, 1>
 	               : geo == 2048 ? (const void *)relax_var_kernel<1024, 14, 2>
 	               : geo == 768 ? (diag == 1 ? (const void *)relax_var_kernel<768, 18, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<768, 18, 2, 2> : diag == 3 ? (const void *)relax_var_kernel<768, 18, 2, 3>
 	                               : merge_cxx ? (const void *)relax_var_kernel<768, 18, 2, 0, MpcRvBlocksCxx> : (const void *)relax_var_kernel<768, 18, 2>)
@@ -492,7 +492,7 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	{
 		char kn[128];
 		snprintf(kn, sizeof(kn), "relax_var_kernel<%u, %u, %d, %d, %s>", threads, geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : 26u,
-			geo == 1024 ? 1 : 2, geo == 768 ? diag : 0, (geo == 768 && merge_cxx && !diag) ? "MpcRvBlocksCxx" : geo == 1024 ? "MpcRvBlocksAsm2" : "MpcRvBlocksAsm");
+			geo == 1024 ? 1 : 2, geo == 768 ? diag : 0, (geo == 768 && merge_cxx && !diag) ? "MpcRvBlocksCxx" : "MpcRvBlocksAsm");
 		c->relax_kernel_name = kn;
 	}
 	int occ = 0;
@@ -504,7 +504,7 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
-	if (geo == 1024) launch_relax_var<1024, 16, 1, 0, MpcRvBlocksAsm2>(rp, grid, smem, c->stream);
+	if (geo == 1024) launch_relax_var<1024, 16, 1>(rp, grid, smem, c->stream);
 	else if (geo == 2048) launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
 	else if (geo == 768) {
 		if (diag == 1) launch_relax_var<768, 18, 2, 1>(rp, grid, smem, c->stream);
