@@ -199,3 +199,120 @@ __global__ void __launch_bounds__(64) build_post_list_gen_kernel(BuildPostListPa
 		}
 	}
 }
+
+// ---- small joins: BuildPost by rows, ONE launch ------------------------------------------------------------------------
+// The joins inside a shrub of <= 32 sequences (progressive joins + the 100 refinement rounds of MPCFlat::Run: 131 per shrub,
+// 50 788 in a 10 000-sequence -super7 run) carry microseconds of work each, and the record / sort / run-list / reduce
+// pipeline above costs them ~8 launches apiece: what a join then takes is launch throughput, not arithmetic
+// (profiles/r02q_join_overhead.log: 0.9 ms per join on 8 worker contexts). For joins of few pairs this kernel builds the whole
+// matrix in one launch, from inputs it reads in page-locked host memory (no upload): one wave per output row col1.
+//   * Which entries feed row col1: for every (a, b) of MSA1 x MSA2, the position pos of sequence S = seq1[a] that stands in
+//     column col1 (none if S has a gap there), and row pos of the ORDERED matrix M(S,T), T = seq2[b] — the variable-size
+//     record store of the relax (kernels_store.h) holds every ordered pair by row, so both stored orientations of
+//     buildpostflat.cpp:56-100 are one access. A lane takes one (a, b); 64 pairs at a time, in (a, b) order.
+//   * Order of addition (buildpostflat.cpp: s outer, t inner; float addition is not associative): the lanes' entries are laid
+//     into an LDS list in lane order (a wave scan of the counts) — that IS (s, t) order — and added one after the other, the
+//     lane that owns column col2 % 64 adding into its register for chunk col2 / 64. One pair touches a cell at most once.
+#define MPC_BPR_CAP 1024u   // LDS list: entries of one chunk of 64 pairs
+#define MPC_BPR_GAP 0xffffffffu
+
+struct BuildPostRowsParams {
+	StoreParams s;
+	const u32 *seq1, *seq2; // sequence index of every row of MSA1 / MSA2
+	u32 n1, n2;
+	const u32 *c2p1; // n1 x C1: position of MSA1's row a that stands in column col1, MPC_BPR_GAP if none
+	const u32 *p2c2; // position -> column maps of MSA2's rows, concatenated
+	const u32 *off2; // n2 + 1: start of each row's map
+	u32 C1, C2;
+	const float *w1, *w2; // nullptr = all 1.0f
+	float *post;          // C1 x C2
+	u32 *err;             // set to 1 when a chunk's entries exceed the list (the host then takes the general path)
+};
+
+template <int CH> // 64 * CH >= C2: columns a lane accumulates in registers
+__global__ void __launch_bounds__(64) build_post_rows_kernel(BuildPostRowsParams p)
+{
+	MPC_DYN_SMEM(smem_raw); // 8 * MPC_BPR_CAP bytes: the list of one chunk of pairs
+	u32 *lkey = (u32 *)smem_raw;
+	float *lval = (float *)(smem_raw + 4 * MPC_BPR_CAP);
+	const u32 lane = threadIdx.x;
+	const u32 n = p.s.n;
+	const u32 npairs = p.n1 * p.n2;
+	const unsigned char *padb = (const unsigned char *)p.s.pad;
+	for (u32 col1 = blockIdx.x; col1 < p.C1; col1 += gridDim.x) {
+		float acc[CH];
+#pragma unroll
+		for (int c = 0; c < CH; ++c) acc[c] = 0.0f; // buildpostflat.cpp:27-30
+		for (u32 ab0 = 0; ab0 < npairs; ab0 += 64u) {
+			const u32 ab = ab0 + lane;
+			const bool valid = ab < npairs;
+			const u32 a = valid ? ab / p.n2 : 0u, b = valid ? ab % p.n2 : 0u;
+			const u32 pos = valid ? p.c2p1[(u64)a * p.C1 + col1] : MPC_BPR_GAP;
+			const bool have = pos != MPC_BPR_GAP;
+			const u32 S = p.seq1[a], T = p.seq2[b];
+			const unsigned char *row0 = padb + 16 * ((u64)p.s.rec_off[mpc_rec_index(n, S, T)] + (have ? pos : 0u));
+			// pass 1: stored entries of the row (a block's second entry is real unless it repeats the first column or is the
+			// empty-row sentinel; a block's first entry is real unless the row is empty)
+			u32 cnt = 0;
+			if (have) {
+				const unsigned char *blk = row0;
+				for (;;) {
+					const MpcQuad v = *(const MpcQuad *)blk;
+					const u32 c0 = v.z & 0xffffu, dist = v.z >> 16;
+					cnt += (c0 != MPC_PAD_SENTINEL ? 1u : 0u) + ((v.w != c0 && v.w != MPC_PAD_SENTINEL) ? 1u : 0u);
+					if (dist == 0u) break;
+					blk += dist;
+				}
+			}
+			u32 incl = cnt;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d);
+				if (lane >= (u32)d) incl += o;
+			}
+			const u32 total = mpc_wave_first(__shfl(incl, 63));
+			if (total > MPC_BPR_CAP) { // not expected for the joins the host sends here; reported, not guessed
+				if (lane == 0) *p.err = 1u;
+				continue;
+			}
+			// pass 2: the entries, in lane order = (a, b) order, rows' entries in column order
+			if (have && cnt) {
+				u32 at = incl - cnt;
+				const u32 *m2 = p.p2c2 + p.off2[b];
+				const float w12 = p.w1 ? p.w1[a] * p.w2[b] : 1.0f; // w1*w2 rounded first: buildpostflat.cpp:74 / :96
+				const unsigned char *blk = row0;
+				for (;;) {
+					const MpcQuad v = *(const MpcQuad *)blk;
+					const u32 c0 = v.z & 0xffffu, dist = v.z >> 16;
+					if (c0 != MPC_PAD_SENTINEL) {
+						lkey[at] = m2[c0];
+						lval[at] = p.w1 ? w12 * __uint_as_float(v.x) : __uint_as_float(v.x);
+						++at;
+					}
+					if (v.w != c0 && v.w != MPC_PAD_SENTINEL) {
+						lkey[at] = m2[v.w];
+						lval[at] = p.w1 ? w12 * __uint_as_float(v.y) : __uint_as_float(v.y);
+						++at;
+					}
+					if (dist == 0u) break;
+					blk += dist;
+				}
+			}
+			MPC_WAVE_LDS_ORDER();
+			// the additions, strictly in list order
+			for (u32 e = 0; e < total; ++e) {
+				const u32 k = mpc_wave_first(lkey[e]);
+				const float v = lval[e];
+				const u32 ch = k >> 6;
+				const bool mine = (k & 63u) == lane;
+#pragma unroll
+				for (int c = 0; c < CH; ++c)
+					if (ch == (u32)c) acc[c] = mine ? acc[c] + v : acc[c]; // ch is wave-uniform: scalar branches
+			}
+			MPC_WAVE_LDS_ORDER();
+		}
+		float *out = p.post + (u64)col1 * p.C2;
+#pragma unroll
+		for (int c = 0; c < CH; ++c)
+			if ((u32)c * 64u + lane < p.C2) out[(u32)c * 64u + lane] = acc[c];
+	}
+}

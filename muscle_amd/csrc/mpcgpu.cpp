@@ -1512,12 +1512,12 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	HIPCHK(c, c->d_aln_rev.ensure_grow((u64)LX + LY));
 	// one result record {path length, score, path}: one copy back, one wait
 	const u64 res_bytes = 8 + (u64)LX + LY;
-	HIPCHK(c, c->d_aln_res.ensure_grow(res_bytes));
 	HIPCHK(c, c->h_aln_res.ensure(res_bytes));
 	AlnParams ap;
 	ap.post = d_post; ap.LX = LX; ap.LY = LY;
 	ap.tb = c->d_aln_tb.as<char>(); ap.rev = c->d_aln_rev.as<char>();
-	ap.pathlen = c->d_aln_res.as<u32>(); ap.score = c->d_aln_res.as<float>() + 1; ap.path = c->d_aln_res.as<char>() + 8;
+	// the record is written straight into page-locked host memory (device-visible: hipHostMalloc): no copy back, one wait
+	ap.pathlen = c->h_aln_res.as<u32>(); ap.score = c->h_aln_res.as<float>() + 1; ap.path = c->h_aln_res.as<char>() + 8;
 	const int which = wave ? 0 : quad ? 1 : 2;
 	if (smem > c->aln_smem_set[which]) { // raise the kernel's dynamic-LDS limit only when this call needs more than any before
 		(void)hipFuncSetAttribute(wave ? (const void *)calc_aln_wave_kernel : quad ? (const void *)calc_aln_quad_kernel : (const void *)calc_aln_kernel,
@@ -1532,7 +1532,6 @@ static int run_calc_aln(mpcgpu_ctx *c, const float *d_post, uint32_t LX, uint32_
 	else MPC_LAUNCH(calc_aln_kernel, 1, MPC_ALN_THREADS, smem, c->stream, ap);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts_aln)) return 1;
-	HIPCHK(c, hipMemcpyAsync(c->h_aln_res.p, c->d_aln_res.p, res_bytes, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	const u32 n_path = c->h_aln_res.as<u32>()[0];
 	if (n_path > LX + LY) return fail(c, "mpcgpu_calc_aln: path length %u out of range (internal error)", n_path);
@@ -1710,6 +1709,70 @@ static int build_post_impl(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uin
 		for (u32 b = 0; b < n2; ++b) weighted = weighted || w2[b] != 1.0f;
 	}
 	const u64 npairs12 = (u64)n1 * n2;
+	// ---- small joins: the whole matrix in one launch, inputs read from page-locked host memory (kernels_prog.h:
+	// build_post_rows_kernel). Needs the variable-size record store (every ordered pair by row).
+	{
+		const char *bp_mode = getenv("MPCGPU_BP"); // "sort": always the general path; "rows": the row kernel whenever its limits allow
+		const bool want_rows = !(bp_mode && !strcmp(bp_mode, "sort"));
+		const u64 pair_limit = (bp_mode && !strcmp(bp_mode, "rows")) ? ~0ull : (u64)std::max(env_int("MPCGPU_BP_ROWS_PAIRS", 2048), 1);
+		if (want_rows && c->have_pad && npairs12 <= pair_limit && C2 <= 1024u && (u64)n1 * C1 <= (1u << 26)) {
+			const u64 r_seqs = 0, r_c2p = r_seqs + 4 * ((u64)n1 + n2), r_off2 = r_c2p + 4 * (u64)n1 * C1, r_maps = r_off2 + 4 * ((u64)n2 + 1),
+				r_w = r_maps + 4 * len2, r_err = r_w + (weighted ? 4 * ((u64)n1 + n2) : 0), r_bytes = r_err + 4;
+			HIPCHK(c, c->h_bp_in.ensure(r_bytes));
+			char *hin = c->h_bp_in.as<char>();
+			u32 *seqs = (u32 *)(hin + r_seqs), *c2p = (u32 *)(hin + r_c2p), *off2 = (u32 *)(hin + r_off2), *maps2 = (u32 *)(hin + r_maps);
+			memcpy(seqs, seq1, 4 * (size_t)n1);
+			memcpy(seqs + n1, seq2, 4 * (size_t)n2);
+			for (u64 q = 0; q < (u64)n1 * C1; ++q) c2p[q] = MPC_BPR_GAP;
+			u64 at = 0;
+			for (u32 a = 0; a < n1; ++a) {
+				const u32 L = c->len[seq1[a]];
+				for (u32 pos = 0; pos < L; ++pos) {
+					const u32 col = pos2col1[at + pos];
+					if (col >= C1) return fail(c, "mpcgpu_align_alns: column map of MSA1 out of range");
+					c2p[(u64)a * C1 + col] = pos;
+				}
+				at += L;
+			}
+			off2[0] = 0;
+			for (u32 b = 0; b < n2; ++b) off2[b + 1] = off2[b] + c->len[seq2[b]];
+			memcpy(maps2, pos2col2, 4 * len2);
+			for (u64 q = 0; q < len2; ++q) if (maps2[q] >= C2) return fail(c, "mpcgpu_align_alns: column map of MSA2 out of range");
+			for (u32 a = 0; a < n1; ++a)
+				for (u32 b = 0; b < n2; ++b) if (seq1[a] == seq2[b]) return fail(c, "mpcgpu_align_alns: sequence %u is in both alignments", seq1[a]);
+			if (weighted) {
+				float *w = (float *)(hin + r_w);
+				memcpy(w, w1, 4 * (size_t)n1);
+				memcpy(w + n1, w2, 4 * (size_t)n2);
+			}
+			*(u32 *)(hin + r_err) = 0u;
+			lap(0);
+			const u64 cells = (u64)C1 * C2;
+			HIPCHK(c, c->d_aln_post.ensure_grow(cells * 4));
+			BuildPostRowsParams rp;
+			fill_store_params(c, rp.s);
+			rp.seq1 = seqs; rp.seq2 = seqs + n1; rp.n1 = n1; rp.n2 = n2;
+			rp.c2p1 = c2p; rp.p2c2 = maps2; rp.off2 = off2; rp.C1 = C1; rp.C2 = C2;
+			rp.w1 = weighted ? (const float *)(hin + r_w) : nullptr; rp.w2 = weighted ? rp.w1 + n1 : nullptr;
+			rp.post = c->d_aln_post.as<float>(); rp.err = (u32 *)(hin + r_err);
+			const u32 grid = std::min<u32>(C1, (u32)c->prop.multiProcessorCount * 8u);
+			if (trace_on()) { fprintf(stderr, "[mpcgpu] build_post %u x %u rows, %u x %u columns: row kernel, grid %u\n", n1, n2, C1, C2, grid); fflush(stderr); }
+			TimedSpan ts_rows;
+			if (span_begin(c, 5, &ts_rows)) return 1;
+			if (C2 <= 512u) MPC_LAUNCH(build_post_rows_kernel<8>, grid, 64, 8 * MPC_BPR_CAP, c->stream, rp);
+			else MPC_LAUNCH(build_post_rows_kernel<16>, grid, 64, 8 * MPC_BPR_CAP, c->stream, rp);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &ts_rows)) return 1;
+			lap(2);
+			c->last_post_cells = cells;
+			int rc_rows = 0;
+			if (!path) HIPCHK(c, hipStreamSynchronize(c->stream));
+			else rc_rows = run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // ends with a wait for the stream
+			lap(3);
+			if (*(volatile u32 *)(hin + r_err) == 0u) return rc_rows;
+			// a chunk of pairs overflowed the row kernel's list (very wide posterior rows): the general path below redoes the join
+		}
+	}
 	const u64 o_off = 0, o_coff = o_off + 8 * ((u64)n1 + n2 + 1), o_seqs = o_coff + 8 * (npairs12 + 1), o_maps = o_seqs + 4 * ((u64)n1 + n2),
 		o_w = o_maps + 4 * (len1 + len2), in_bytes = o_w + (weighted ? 4 * ((u64)n1 + n2) : 0);
 	HIPCHK(c, c->h_bp_in.ensure(in_bytes));

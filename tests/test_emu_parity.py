@@ -458,7 +458,9 @@ def test_emu_post_candidate_lists_with_gaps(emu):
     P.check_post_scores(emu, trials=36)
 
 
+@pytest.mark.parametrize("mode", ["rows", "sort"])
 @pytest.mark.parametrize("name", P.BP_SETS)
-def test_emu_buildpost_vs_reference_golden(emu, name):
-    """mpcgpu_build_post / align_alns / align_msas against matrices, paths and scores generated by the compiled reference."""
-    P.check_buildpost_golden(name, emu)
+def test_emu_buildpost_vs_reference_golden(emu, name, mode):
+    """mpcgpu_build_post / align_alns / align_msas against matrices, paths and scores generated by the compiled reference; both
+    forms of the device BuildPost (one launch by rows for joins of few pairs / records, stable sort, in-order run sums)."""
+    _with_env({"MPCGPU_BP": mode}, lambda: P.check_buildpost_golden(name, emu))

@@ -504,11 +504,13 @@ def test_post_candidate_lists_with_gaps():
     P.check_post_scores(None, trials=120)
 
 
+@pytest.mark.parametrize("mode", ["rows", "sort"])
 @pytest.mark.parametrize("name", P.BP_SETS)
-def test_buildpost_vs_reference_golden(name):
+def test_buildpost_vs_reference_golden(name, mode, monkeypatch):
     """Device BuildPost (mpcgpu_build_post: the matrix itself), AlignAlns and the PProg join against the compiled reference's
     own matrices / paths / scores for the same joins (tests/golden/bp_*.npz: plain, weighted, transposed access of
-    buildpostflat.cpp:78-100, explicit pair lists of buildposterior3flat.cpp:19-85)."""
+    buildpostflat.cpp:78-100, explicit pair lists of buildposterior3flat.cpp:19-85); both forms of the device BuildPost."""
+    monkeypatch.setenv("MPCGPU_BP", mode)
     P.check_buildpost_golden(name)
 
 
