@@ -88,7 +88,7 @@ def cpu_baseline(seqs, n_full, budget_s=20.0):
     ("port") if the compiled reference is not shipped."""
     from muscle_amd.hostinfo import usable_cores
     cores = usable_cores()
-    n_s = min(len(seqs), 128)  # ~170 core-seconds of stage A at L~400: 10-30 s on a 8-16 core quota
+    n_s = min(len(seqs), 192)  # stage A ~19 s + 2 relax iterations ~6 s of the compiled reference on the box's 16-core quota (128: 8.4 + 1.6 s measured)
     sample = seqs[:n_s]
     np_s = n_s * (n_s - 1) // 2
     try:
@@ -115,13 +115,25 @@ def cpu_baseline(seqs, n_full, budget_s=20.0):
     per_pair_a = tA / np_s
     per_triple = tB / (2.0 * np_s * (n_s - 2))
     per_pair_full = per_pair_a + 2.0 * (n_full - 2) * per_triple
-    return {"value": 1.0 / per_pair_full, "unit": "pairs/s", "cores": cores, "kind": kind,
-            "extrapolated": n_s < n_full,
-            "sample": "%s on the first %d sequences of the same family (%d pairs) on this box: stage A %.2f s, 2 relax iterations %.2f s; "
-                      "EXTRAPOLATED to N=%d as t_pair = tA/pairs + 2*(N-2)*t_triple (stage A scales per pair, relax per (pair,Z) triple) — "
-                      "not a timed N=%d run (the one full reference run of 1000 x L~400, 81 min on 6 threads, was made in the build "
-                      "container: profiles/r01i_ref1000.log)" % ("compiled reference (MPCFlat::CalcPosteriors + ConsIter, OpenMP)" if kind == "reference"
-                                                                  else "C restatement (oracle/, reference binary not shipped)", n_s, np_s, tA, tB, n_full, n_full)}
+    out = {"value": 1.0 / per_pair_full, "unit": "pairs/s", "cores": cores, "kind": kind,
+           "extrapolated": n_s < n_full,
+           "sample": "%s on the first %d sequences of the same family (%d pairs) on this box: stage A %.2f s, 2 relax iterations %.2f s; "
+                     "EXTRAPOLATED to N=%d as t_pair = tA/pairs + 2*(N-2)*t_triple (stage A scales per pair, relax per (pair,Z) triple) — "
+                     "not a timed N=%d run" % ("compiled reference (MPCFlat::CalcPosteriors + ConsIter, OpenMP)" if kind == "reference"
+                                               else "C restatement (oracle/, reference binary not shipped)", n_s, np_s, tA, tB, n_full, n_full)}
+    # the same reference TIMED (nothing extrapolated) on a GPU box's host cores, and what this formula predicted for that size
+    # from a 128-sequence sample in the same run: committed by diag/ref_time.py (scripts/gpu.sh ... sh:python diag/ref_time.py)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03i_ref_time_512.json")) as f:
+            m = json.load(f)
+        out["measured_reference_run"] = {
+            "n": m["timed"]["n"], "pairs": m["timed"]["pairs"], "pairs_per_s": m["timed"]["pairs_per_s"], "cores": m["cores"], "cpu": m.get("cpu"),
+            "stage_a_s": m["timed"]["stage_a_s"], "relax_2it_s": m["timed"]["relax_2it_s"], "extrapolated": False,
+            "extrapolation_formula_error_at_this_size": m["extrapolation_error"],
+            "source": "profiles/r03i_ref_time_512.json (diag/ref_time.py on an MI355X box: EPYC 9575F, 16-core quota)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
 
 
 def main():
