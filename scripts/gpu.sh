@@ -20,7 +20,7 @@ OUT=$R/gpurun_out; mkdir -p $OUT; LOG=$OUT/$TAG.log; : > $LOG
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 LABEL=""
 step() { echo "=== $* (t=$SECONDS)" | tee -a $LOG; "$@" 2>&1 | tee -a $LOG | tail -${TAILN:-12}; rc=${PIPESTATUS[0]}; echo "=== rc=$rc (t=$SECONDS)" | tee -a $LOG; return $rc; }
-RDRP=tests/golden/rdrp_first1000.fa.gz
+RDRP=$R/tests/golden/rdrp_first1000.fa.gz
 prof() { # prof <dir> <rocprof args...> -- <bench args...>
 	local d=$1; shift; rm -rf $OUT/$d
 	local pa=(); while [ "$1" != "--" ]; do pa+=("$1"); shift; done; shift
