@@ -5,8 +5,8 @@
 # of the reference is copied into the repo, and the combined (GPL-3.0) binary is git-ignored; it
 # travels to the GPU box as a built artefact.
 #
-#   reference objects  - consflat.o, alnalnsflat.o, alnmsasflat.o, buildpostflat.o  (MPCFlat::ConsIter, MPCFlat::AlignAlns,
-#                        PProg::AlignMSAsFlat and MPCFlat::BuildPost are ours)
+#   reference objects  - consflat.o, alnalnsflat.o, alnmsasflat.o, buildpostflat.o, alignpairflat.o  (MPCFlat::ConsIter,
+#                        MPCFlat::AlignAlns, PProg::AlignMSAsFlat, MPCFlat::BuildPost and AlignPairFlat(_SparsePost) are ours)
 #                      - calcposteriorflat.o's CalcPosterior symbol, weakened with objcopy so that
 #                        hostcxx/mpcflat_gpu.cpp's strong definition wins while CalcPostFlat and the
 #                        two vestigial virtuals in the same object stay available
@@ -31,7 +31,10 @@ objcopy --weaken-symbol=_ZN7MPCFlat13CalcPosteriorEj "$REFOBJ/calcposteriorflat.
 rm -f "$OUT/buildpostflat_ref.o"
 # Super7::IntraAlignShrubs: ours (parallel over device contexts); the rest of super7.o stays
 objcopy --weaken-symbol=_ZN6Super716IntraAlignShrubsEv "$REFOBJ/super7.o" "$OUT/super7_weak.o"
-OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$')
+# UClust::Search: ours (all word-count hits aligned in one library call); AlignPairFlat / AlignPairFlat_SparsePost: ours
+# (alignpairflat.o is not linked)
+objcopy --weaken-symbol=_ZN6UClust6SearchEjRNSt7__cxx1112basic_stringIcSt11char_traitsIcESaIcEEE "$REFOBJ/uclust.o" "$OUT/uclust_weak.o"
+OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' -e '/uclust\.o$' -e '/alignpairflat\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$')
 # The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
 # MPCGPU_LIBDIR/MPCGPU_LIBNAME pointing at the SIMT-emulator build of the same library sources
 # (tests/emu, test infrastructure) to check the host-side plumbing of this file without a GPU.
@@ -40,6 +43,6 @@ LIBNAME="${MPCGPU_LIBNAME:-mpcgpu}"
 BIN="${MPCGPU_BIN:-muscle_gpu}"
 # --wrap=rand: the reference's rand() (refineflat.cpp:14) gets a private copy of glibc's default
 # stream; the HIP runtime in the same process otherwise consumes it (hostcxx/rand_isolate.cpp)
-g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/super7_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
+g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/super7_weak.o" "$OUT/uclust_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
   -L"$LIBDIR" -l"$LIBNAME" -Wl,-rpath,"$LIBDIR" -Wl,-rpath,'$ORIGIN/../../muscle_amd/csrc' -Wl,-rpath,/opt/rocm/lib -o "$OUT/$BIN"
 echo "built: $OUT/$BIN"

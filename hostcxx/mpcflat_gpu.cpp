@@ -37,6 +37,7 @@
 #include "pprog.h"
 #include "mega.h"
 #include "super7.h"
+#include "uclust.h"
 #include "mpcgpu.h"
 
 #include <atomic>
@@ -814,6 +815,128 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 	for (uint PairIndex = 0; PairIndex < PairCount; ++PairIndex)
 		SumEA += EA[PairIndex];
 	return SumEA/PairCount;
+	}
+
+// AlignPairFlat (alignpairflat.cpp:3-27) and its sequential caller in -super5, UClust::Search (uclust.cpp:26-56): the same
+// kernels as MPCFlat::CalcPosterior + CalcAlnFlat with a third caller. One pair on the device is one wavefront's work (a few
+// milliseconds of latency), so what pays is the LIST: UClust::Search tries up to MAX_REJECTS = 8 word-count hits one after the
+// other and stops at the first whose EA reaches the threshold — here all of them are aligned in one library call and the first
+// that qualifies, in the same order, is returned with its path: the same answer, 8 alignments of latency folded into one.
+namespace
+{
+void AlignPairsByLabel(const vector<string> &Labels1, const vector<string> &Labels2, vector<string> &Paths, vector<float> &EAs,
+  MySparseMx *SparsePost0)
+	{
+	const uint PairCount = SIZE(Labels1);
+	asserta(SIZE(Labels2) == PairCount && PairCount > 0);
+	std::map<const Sequence *, uint32_t> SeqToIndex;
+	vector<const uint8_t *> Ptrs;
+	vector<uint32_t> Lens;
+	vector<string> Labels;
+	auto Register = [&](const string &Label) -> uint32_t
+		{
+		const Sequence &Seq = GetGlobalInputSeqByLabel(Label); // calcpost.cpp:6-7,25-26 look the sequences up by global label
+		std::map<const Sequence *, uint32_t>::const_iterator p = SeqToIndex.find(&Seq);
+		if (p != SeqToIndex.end())
+			return p->second;
+		uint32_t Index = (uint32_t) Ptrs.size();
+		SeqToIndex[&Seq] = Index;
+		Ptrs.push_back(Seq.GetBytePtr());
+		Lens.push_back(Seq.GetLength());
+		Labels.push_back(Label);
+		return Index;
+		};
+	vector<uint32_t> Seqs1(PairCount), Seqs2(PairCount);
+	uint32_t Stride = 1;
+	for (uint i = 0; i < PairCount; ++i)
+		{
+		Seqs1[i] = Register(Labels1[i]);
+		Seqs2[i] = Register(Labels2[i]);
+		Stride = std::max(Stride, Lens[Seqs1[i]] + Lens[Seqs2[i]]);
+		}
+	vector<char> PathBuf(size_t(PairCount)*Stride);
+	vector<uint32_t> PathLens(PairCount);
+	EAs.assign(PairCount, 0.0f);
+	std::lock_guard<std::mutex> Guard(g_JoinMu);
+	if (g_CtxJoin == 0)
+		{
+		const int Device = DeviceList()[0];
+		if (mpcgpu_create(&g_CtxJoin, Device) != 0)
+			Die("GPU posterior stage: %s", mpcgpu_last_error(0));
+		}
+	mpcgpu_ctx *Ctx = g_CtxJoin;
+	GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
+	  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
+	GPUCHK(mpcgpu_set_seqs_registry(Ctx, (uint32_t) Ptrs.size(), Ptrs.data(), Lens.data()));
+	SetMega(Ctx, Labels, Lens);
+	GPUCHK(mpcgpu_align_pairs(Ctx, PairCount, Seqs1.data(), Seqs2.data(), Stride, PathBuf.data(), PathLens.data(), 0, EAs.data()));
+	Paths.resize(PairCount);
+	for (uint i = 0; i < PairCount; ++i)
+		Paths[i].assign(PathBuf.data() + size_t(i)*Stride, PathLens[i]);
+	if (SparsePost0 != 0)
+		{
+// AlignPairFlat_SparsePost: SparsePost->FromPost(Post, L1, L2) (alignpairflat.cpp:12-13)
+		uint32_t NNZ = 0;
+		GPUCHK(mpcgpu_get_list_sparse(Ctx, 0, &NNZ, 0, 0));
+		const uint LX = Lens[Seqs1[0]], LY = Lens[Seqs2[0]];
+		MySparseMx &Mx = *SparsePost0;
+		Mx.AllocLX(LX);
+		Mx.AllocVec(NNZ);
+		Mx.m_LX = LX;
+		Mx.m_LY = LY;
+		Mx.m_VecSize = NNZ;
+		vector<uint64_t> Vals(size_t(NNZ) + 1);
+		GPUCHK(mpcgpu_get_list_sparse(Ctx, 0, &NNZ, Mx.m_Offsets, Vals.data()));
+		memcpy(Mx.m_ValueVec, Vals.data(), 8*size_t(NNZ));
+		}
+	}
+}
+
+float AlignPairFlat_SparsePost(const string &Label1, const string &Label2, string &Path, MySparseMx *SparsePost)
+	{
+	vector<string> L1(1, Label1), L2(1, Label2), Paths;
+	vector<float> EAs;
+	AlignPairsByLabel(L1, L2, Paths, EAs, SparsePost);
+	Path = Paths[0];
+	return EAs[0];
+	}
+
+float AlignPairFlat(const string &Label1, const string &Label2, string &Path)
+	{
+	return AlignPairFlat_SparsePost(Label1, Label2, Path, 0);
+	}
+
+uint UClust::Search(uint SeqIndex, string &Path)
+	{
+// uclust.cpp:26-41
+	const Sequence *Seq = m_InputSeqs->GetSequence(SeqIndex);
+	const byte *ByteSeq = Seq->GetBytePtr();
+	const uint L = Seq->GetLength();
+	vector<uint> TopSeqIndexes;
+	vector<uint> TopWordCounts;
+	m_US.SearchSeq(ByteSeq, L, TopSeqIndexes, TopWordCounts);
+	uint TopCount = SIZE(TopSeqIndexes);
+	asserta(SIZE(TopWordCounts) == TopCount);
+	if (TopCount == 0)
+		return UINT_MAX;
+	if (TopCount > MAX_REJECTS)
+		TopCount = MAX_REJECTS;
+// uclust.cpp:44-54, all candidates at once
+	vector<string> L1, L2, Paths;
+	for (uint TopIndex = 0; TopIndex < TopCount; ++TopIndex)
+		{
+		L1.push_back(m_InputSeqs->GetSequence(SeqIndex)->m_Label);
+		L2.push_back(m_InputSeqs->GetSequence(TopSeqIndexes[TopIndex])->m_Label);
+		}
+	vector<float> EAs;
+	AlignPairsByLabel(L1, L2, Paths, EAs, 0);
+	for (uint TopIndex = 0; TopIndex < TopCount; ++TopIndex)
+		{
+		Path = Paths[TopIndex]; // the sequential loop leaves the last path it computed in Path
+		if (EAs[TopIndex] >= m_MinEA)
+			return TopSeqIndexes[TopIndex];
+		}
+	return UINT_MAX;
 	}
 
 // Super7::IntraAlignShrubs (super7.cpp:127-137): one MPCFlat::Run per shrub of <= shrub_size sequences. The reference runs

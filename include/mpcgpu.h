@@ -196,6 +196,17 @@ int mpcgpu_align_msas(mpcgpu_ctx *ctx, uint32_t npairs, const uint32_t *seq1, co
                       uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2, char *path, uint32_t *pathlen,
                       float *score, float *ea_out);
 
+/* AlignPairFlat (alignpairflat.cpp:3-27; callers uclust.cpp:14, transaln.cpp:787, eadistmx.cpp:54, eacluster.cpp:209) for a
+ * LIST of pairs of registered sequences: CalcPost (calcpost.cpp:4-36: fwd + bwd + CalcPostFlat), CalcAlnFlat + TraceBackFlat on the
+ * dense thresholded posterior. paths: npairs slots of path_stride bytes (>= LX+LY of every pair), B/X/Y strings of pathlens[q]
+ * characters; scores[q] = CalcAlnFlat's score, ea[q] = score / min(LX, LY) — what AlignPairFlat returns (either may be NULL).
+ * The sparse matrices of the same pairs (AlignPairFlat_SparsePost) are then available through mpcgpu_get_list_sparse. */
+int mpcgpu_align_pairs(mpcgpu_ctx *ctx, uint32_t npairs, const uint32_t *seq1, const uint32_t *seq2, uint32_t path_stride,
+                       char *paths, uint32_t *pathlens, float *scores, float *ea);
+/* MySparseMx::FromPost (mysparsemx.cpp:115-152) of pair q of the LAST list stage on this context (mpcgpu_align_pairs of at most 256
+ * pairs, mpcgpu_align_msas): nnz, offsets[LX+1], values (8 bytes per entry; capacity from a first call with values == NULL). */
+int mpcgpu_get_list_sparse(mpcgpu_ctx *ctx, uint32_t q, uint32_t *nnz, uint32_t *offsets, void *values);
+
 /* ---- several GPUs of one node inside ONE process (muscle_amd/csrc/mpcgpu_group.cpp) --------------------------
  * The drop-in binary is one process; it consumes the multi-GPU path through these calls. A group owns one context per
  * listed device (an ordinal may repeat: two contexts on one device is how the tests run this on a one-GPU box), shards

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mpcgpu_set_seqs", "mpcgpu_set_mega", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
-    "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
+    "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_align_pairs", "mpcgpu_get_list_sparse", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
@@ -75,6 +75,8 @@ def load(lib_path=None):
     L.mpcgpu_align_alns_w.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float)]
     L.mpcgpu_build_post.argtypes = [vp, u32, vp, u32, vp, u32, u32, vp, vp, vp, vp, vp]
     L.mpcgpu_get_last_post.argtypes = [vp, u32, u32, vp]
+    L.mpcgpu_align_pairs.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp]
+    L.mpcgpu_get_list_sparse.argtypes = [vp, u32, C.POINTER(u32), vp, vp]
     L.mpcgpu_set_seqs_registry.argtypes = [vp, u32, vp, vp]
     L.mpcgpu_align_msas.argtypes = [vp, u32, vp, vp, u32, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_float), vp]
     L.mpcgpu_timers_reset.argtypes = [vp]
@@ -377,6 +379,30 @@ class MpcGpu:
         self._ck(self.L.mpcgpu_align_alns(self.h, len(s1), s1.ctypes.data, len(s2), s2.ctypes.data, C1, C2,
                                            m1.ctypes.data, m2.ctypes.data, path.ctypes.data, C.byref(n), C.byref(sc)))
         return path[:n.value].tobytes().decode(), float(np.float32(sc.value))
+
+    def align_pairs(self, seq1, seq2, sparse=False):
+        """AlignPairFlat for a list of pairs of registered sequences -> [(path, score, ea)] (+ (off, val) per pair with sparse=True)"""
+        s1, s2 = np.ascontiguousarray(seq1, np.uint32), np.ascontiguousarray(seq2, np.uint32)
+        n = len(s1)
+        stride = int(max(int(self.lens[a]) + int(self.lens[b]) for a, b in zip(s1, s2))) if n else 1
+        paths = np.zeros(max(n, 1) * stride, np.uint8)
+        plen = np.zeros(max(n, 1), np.uint32)
+        sc = np.zeros(max(n, 1), np.float32)
+        ea = np.zeros(max(n, 1), np.float32)
+        self._ck(self.L.mpcgpu_align_pairs(self.h, n, s1.ctypes.data, s2.ctypes.data, stride, paths.ctypes.data, plen.ctypes.data,
+                                           sc.ctypes.data, ea.ctypes.data))
+        out = [(paths[q * stride:q * stride + int(plen[q])].tobytes().decode(), np.float32(sc[q]), np.float32(ea[q])) for q in range(n)]
+        if not sparse:
+            return out
+        sp = []
+        for q in range(n):
+            nz = C.c_uint32()
+            self._ck(self.L.mpcgpu_get_list_sparse(self.h, q, C.byref(nz), None, None))
+            off = np.empty(int(self.lens[s1[q]]) + 1, np.uint32)
+            val = np.empty(max(nz.value, 1) * 2, np.uint32)
+            self._ck(self.L.mpcgpu_get_list_sparse(self.h, q, C.byref(nz), off.ctypes.data, val.ctypes.data))
+            sp.append((off, val[:2 * nz.value].copy()))
+        return out, sp
 
     def build_post(self, seq1, seq2, p2c1, p2c2, C1, C2, w1=None, w2=None):
         """MPCFlat::BuildPost on the device store -> (C1, C2) float32 matrix (include/mpcgpu.h: mpcgpu_build_post)"""

@@ -15,6 +15,7 @@
 // the whole workgroup. This is a latency-bound kernel (2 barriers per row): it exists so that the
 // progressive stage can stay on the device, not because one call beats a CPU.
 #pragma once
+#include "kernels_fb.h" // candidate key layout (dense_post_kernel)
 #include "device_math.h"
 
 
@@ -107,9 +108,8 @@ __global__ void __launch_bounds__(MPC_ALN_THREADS) calc_aln_kernel(AlnParams p)
 #define MPC_ALNW_ROWBYTES (MPC_ALNW_MAXW / 2)
 #define MPC_ALNW_PF 4                      // rows of Post in flight
 
-__global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
+__device__ __forceinline__ void calc_aln_wave_body(const AlnParams &p, unsigned char *smem_raw) // smem_raw: (LX+1) rows of MPC_ALNW_ROWBYTES traceback nibbles
 {
-	MPC_DYN_SMEM(smem_raw); // (LX+1) rows of MPC_ALNW_ROWBYTES traceback nibbles
 	const u32 LX = p.LX, LY = p.LY, W = LY + 1;
 	const u32 lane = threadIdx.x & 63u;
 	const u32 j0 = lane * MPC_ALNW_C; // my columns [j0, j0 + C)
@@ -213,6 +213,54 @@ __global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
 	const u32 n = *s_n;
 	for (u32 k = lane; k < n; k += 64) p.path[k] = p.rev[n - 1 - k];
 	(void)W;
+}
+
+__global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)
+{
+	MPC_DYN_SMEM(smem_raw);
+	calc_aln_wave_body(p, smem_raw);
+}
+
+// the same, one workgroup (= one wavefront) per alignment of a batch (mpcgpu_align_pairs): dynamic LDS sized for the batch's
+// longest row sequence
+__global__ void __launch_bounds__(64) calc_aln_wave_batch_kernel(const AlnParams *batch)
+{
+	MPC_DYN_SMEM(smem_raw);
+	const AlnParams p = batch[blockIdx.x];
+	calc_aln_wave_body(p, smem_raw);
+}
+
+// The dense thresholded posterior of CalcPostFlat (calcposteriorflat.cpp:9-26) for the pairs of one stage-A batch, from the
+// candidate lists post_rows_kernel left behind (kernels_post.h: (cell key, P bits) of every cell with Score >= MIN_SPARSE_SCORE,
+// INCLUDING those MySparseMx::FromPost later drops for P < 0.01 — AlignPairFlat's CalcAlnFlat runs on the dense matrix,
+// alignpairflat.cpp:8-12). One workgroup per pair: zero, then scatter.
+struct DensePostParams {
+	const u32 *pair_x, *pair_y, *seq_len;
+	const u64 *cand;
+	u32 capc;
+	const u32 *cand_cnt;
+	u32 long_min;       // key layout: kernels_post.h mpc_key_shift
+	const u64 *out_off; // floats: start of pair q's LX x LY matrix
+	float *out;
+};
+
+__global__ void __launch_bounds__(256) dense_post_kernel(DensePostParams p)
+{
+	const u32 q = blockIdx.x;
+	const u32 LX = p.seq_len[p.pair_x[q]], LY = p.seq_len[p.pair_y[q]];
+	float *M = p.out + p.out_off[q];
+	const u64 cells = (u64)LX * LY;
+	for (u64 e = threadIdx.x; e < cells; e += blockDim.x) M[e] = 0.0f;
+	__syncthreads();
+	const u32 kshift = LX >= p.long_min ? MPC_KEY_ROW_SHIFT_LONG : MPC_KEY_ROW_SHIFT;
+	const u32 c = p.cand_cnt[q];
+	const u64 *cand = p.cand + (u64)q * p.capc;
+	for (u32 e = threadIdx.x; e < c; e += blockDim.x) {
+		const u64 v = cand[e];
+		const u32 key = (u32)(v >> 32);
+		const u32 row = key >> kshift, col = key & ((1u << kshift) - 1u);
+		M[(u64)row * LY + col] = __uint_as_float((u32)v);
+	}
 }
 
 // ---- several wavefronts, previous row in registers (matrices wider than one wave holds: the joins near the root) ---------

@@ -136,7 +136,7 @@ struct mpcgpu_ctx {
 	u64 total_entries = 0;
 	u32 max_nnz = 0, max_len = 0;
 	HostBuf h_bp_in, h_aln_res;
-	size_t aln_smem_set[3] = {0, 0, 0}; // largest dynamic LDS each CalcAlnFlat kernel has been allowed so far
+	size_t aln_smem_set[4] = {0, 0, 0, 0}; // largest dynamic LDS each CalcAlnFlat kernel has been allowed so far
 	DevBuf d_tile_next, d_bp_in, d_aln_res, d_post_prof, d_bp_seq, d_bp_map, d_bp_off, d_bp_coff, d_bp_keys, d_bp_vals, d_bp_tmp, d_bp_runs;
 	DevBuf d_tiles, d_pad, d_pos, d_aln_post, d_aln_tb, d_aln_rev;
 	bool have_pad = false;       // variable-size dense records + relax_var_kernel (else: slabs + gather relax)
@@ -164,6 +164,12 @@ struct mpcgpu_ctx {
 	u64 launches[MPCGPU_NKERNELS] = {0};
 	u64 work_cells = 0, work_entry_z = 0;
 	u64 last_post_cells = 0; // cells of the dense matrix in d_aln_post (mpcgpu_get_last_post)
+	u64 sa_b0 = 0, sa_B = 0;  // the last stage-A batch: first pair, pairs; candidate capacity, finishing kernel, key layout
+	u32 sa_capc = 0, sa_long_min = 0;
+	bool sa_post_rows = false;
+	std::vector<u32> list_x, list_y; // the pairs of the last list stage
+	HostBuf h_ap;             // mpcgpu_align_pairs: kernel parameters and results, page-locked
+	DevBuf d_ap_off;
 	double aa_trace_t[5] = {0, 0, 0, 0, 0}; // MPCGPU_TRACE_HOST: host seconds of mpcgpu_align_alns' phases
 	u64 aa_trace_n = 0;
 };
@@ -646,6 +652,8 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 	for (DevBuf *b : all) b->release();
 	c->h_bp_in.release();
 	c->h_aln_res.release();
+	c->h_ap.release();
+	c->d_ap_off.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -844,6 +852,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	HIPCHK(c, hipSetDevice(c->device));
 	c->have_shard = c->have_store = false;
 	c->shard_is_list = true;
+	c->list_x.assign(px, px + np); c->list_y.assign(py, py + np); // mpcgpu_get_list_sparse
 	c->sh_k0 = 0; c->sh_k1 = np;
 	c->sh_nnz.assign(np, 0);
 	c->sh_ea.assign(np, 0.0f);
@@ -1172,6 +1181,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		if (span_end(c, &sp)) return 1;
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		words_done = w;
+		// what the LAST batch left in the scratch buffers (mpcgpu_align_pairs reads the candidate lists of a one-batch stage)
+		c->sa_b0 = done; c->sa_B = B; c->sa_capc = capc; c->sa_post_rows = post_rows; c->sa_long_min = long_min;
 		done += B;
 		std::swap(cur, nxt);
 		lap(4);
@@ -1957,6 +1968,120 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	if (reduce_runs(c, rb, keys_sorted, vals_sorted, M, cells)) return 1;
 	c->last_post_cells = cells;
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // syncs before the vectors above die
+}
+
+// AlignPairFlat (alignpairflat.cpp:3-27) for a list of pairs: CalcPost (fwd + bwd + CalcPostFlat, calcpost.cpp:4-36) -> CalcAlnFlat on
+// the DENSE thresholded posterior -> path; EA = Score / min(L1, L2). Stage A runs on the list (the kernels of
+// mpcgpu_calc_posteriors), the dense matrices are rebuilt from the candidate lists (every cell with Score >= MIN_SPARSE_SCORE, also
+// those FromPost drops), the alignments run one wavefront each in ONE launch when they fit (else one after the other).
+int mpcgpu_align_pairs(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, const uint32_t *seq2, uint32_t path_stride, char *paths,
+	uint32_t *pathlens, float *scores, float *ea)
+{
+	if (!c) return 1;
+	if (c->n == 0) return fail(c, "mpcgpu_align_pairs: call mpcgpu_set_seqs / mpcgpu_set_seqs_registry first");
+	if (!seq1 || !seq2 || !paths || !pathlens) return fail(c, "mpcgpu_align_pairs: NULL argument");
+	for (u32 q = 0; q < npairs; ++q) {
+		if (seq1[q] >= c->n || seq2[q] >= c->n) return fail(c, "mpcgpu_align_pairs: sequence index out of range in pair %u", q);
+		if ((u64)c->len[seq1[q]] + c->len[seq2[q]] > path_stride) return fail(c, "mpcgpu_align_pairs: path_stride %u too small for pair %u", path_stride, q);
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	const u32 CHUNK = 256; // pairs per stage-A call: their dense matrices (LX*LY floats each) live together
+	for (u32 q0 = 0; q0 < npairs; q0 += CHUNK) {
+		const u32 nq = std::min<u32>(CHUNK, npairs - q0);
+		if (stage_a(c, nq, seq1 + q0, seq2 + q0)) return 1;
+		if (c->sa_b0 != 0 || c->sa_B != nq || !c->sa_post_rows)
+			return fail(c, "mpcgpu_align_pairs: the pairs did not fit one stage-A batch of the row-list finishing kernel (sequences too long for this entry point)");
+		// dense matrices
+		std::vector<u64> off(nq + 1, 0);
+		u32 Lsum_max = 0, LXmax = 0;
+		bool all_wave = true;
+		for (u32 q = 0; q < nq; ++q) {
+			const u32 LX = c->len[seq1[q0 + q]], LY = c->len[seq2[q0 + q]];
+			off[q + 1] = off[q] + (u64)LX * LY;
+			Lsum_max = std::max(Lsum_max, LX + LY);
+			LXmax = std::max(LXmax, LX);
+			all_wave = all_wave && (u64)LY + 1 <= MPC_ALNW_MAXW && (size_t)(LX + 1) * MPC_ALNW_ROWBYTES + 16 <= 160u * 1024u;
+		}
+		HIPCHK(c, c->d_aln_post.ensure_grow(off[nq] * 4));
+		if (upload(c, c->d_ap_off, off)) return 1;
+		DensePostParams dp;
+		dp.pair_x = c->d_bx.as<u32>(); dp.pair_y = c->d_by.as<u32>(); dp.seq_len = c->d_seq_len.as<u32>();
+		dp.cand = c->d_cand.as<u64>(); dp.capc = c->sa_capc; dp.cand_cnt = c->d_cand_cnt.as<u32>(); dp.long_min = c->sa_long_min;
+		dp.out_off = c->d_ap_off.as<u64>(); dp.out = c->d_aln_post.as<float>();
+		MPC_LAUNCH(dense_post_kernel, nq, 256, 0, c->stream, dp);
+		HIPCHK(c, hipGetLastError());
+		c->last_post_cells = 0; // several matrices: not what mpcgpu_get_last_post hands out
+		if (all_wave) {
+			// one launch: parameters in, {length, score, path} out through page-locked memory
+			const u64 rstride = ((u64)8 + Lsum_max + 7) & ~7ull;
+			const u64 o_par = 0, o_res = o_par + (u64)nq * sizeof(AlnParams), bytes = o_res + (u64)nq * rstride;
+			HIPCHK(c, c->h_ap.ensure(bytes));
+			HIPCHK(c, c->d_aln_rev.ensure_grow((u64)nq * Lsum_max + 16));
+			char *h = c->h_ap.as<char>();
+			AlnParams *ap = (AlnParams *)(h + o_par);
+			for (u32 q = 0; q < nq; ++q) {
+				char *r = h + o_res + (u64)q * rstride;
+				ap[q].post = c->d_aln_post.as<float>() + off[q];
+				ap[q].LX = c->len[seq1[q0 + q]]; ap[q].LY = c->len[seq2[q0 + q]];
+				ap[q].tb = nullptr; ap[q].rev = c->d_aln_rev.as<char>() + (u64)q * Lsum_max;
+				ap[q].pathlen = (u32 *)r; ap[q].score = (float *)(r + 4); ap[q].path = r + 8;
+			}
+			const size_t smem = (size_t)(LXmax + 1) * MPC_ALNW_ROWBYTES + 16;
+			if (smem > c->aln_smem_set[3]) {
+				(void)hipFuncSetAttribute((const void *)calc_aln_wave_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+				c->aln_smem_set[3] = smem;
+			}
+			TimedSpan ts;
+			if (span_begin(c, 8, &ts)) return 1;
+			MPC_LAUNCH(calc_aln_wave_batch_kernel, nq, 64, smem, c->stream, (const AlnParams *)ap);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &ts)) return 1;
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			for (u32 q = 0; q < nq; ++q) {
+				const char *r = h + o_res + (u64)q * rstride;
+				u32 n_path;
+				memcpy(&n_path, r, 4);
+				if (n_path > ap[q].LX + ap[q].LY) return fail(c, "mpcgpu_align_pairs: path length %u out of range (internal error)", n_path);
+				pathlens[q0 + q] = n_path;
+				float sc;
+				memcpy(&sc, r + 4, 4);
+				if (scores) scores[q0 + q] = sc;
+				if (ea) ea[q0 + q] = sc / (float)std::min(ap[q].LX, ap[q].LY); // alignpairflat.cpp:18 (uint -> float, IEEE divide)
+				memcpy(paths + (u64)(q0 + q) * path_stride, r + 8, n_path);
+			}
+		} else {
+			for (u32 q = 0; q < nq; ++q) {
+				const u32 LX = c->len[seq1[q0 + q]], LY = c->len[seq2[q0 + q]];
+				float sc = 0;
+				if (run_calc_aln(c, c->d_aln_post.as<float>() + off[q], LX, LY, paths + (u64)(q0 + q) * path_stride, &pathlens[q0 + q], &sc)) return 1;
+				if (scores) scores[q0 + q] = sc;
+				if (ea) ea[q0 + q] = sc / (float)std::min(LX, LY);
+			}
+		}
+	}
+	return 0;
+}
+
+int mpcgpu_get_list_sparse(mpcgpu_ctx *c, uint32_t q, uint32_t *nnz, uint32_t *offsets, void *values)
+{
+	if (!c) return 1;
+	if (!c->have_shard || !c->shard_is_list || q >= c->list_x.size()) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
+	HIPCHK(c, hipSetDevice(c->device));
+	const u64 np = c->list_x.size();
+	u64 w = shard_header_bytes(np) / 4;
+	for (u32 k = 0; k < q; ++k) w += rec_words(c->len[c->list_x[k]], c->len[c->list_y[k]], c->sh_nnz[k]);
+	const u32 LX = c->len[c->list_x[q]], LY = c->len[c->list_y[q]], nz = c->sh_nnz[q];
+	if (nnz) *nnz = nz;
+	if (!offsets || !values) return 0;
+	std::vector<u32> rowcnt(LX);
+	HIPCHK(c, hipMemcpyAsync(rowcnt.data(), c->d_shard.as<u32>() + w, (size_t)LX * 4, hipMemcpyDeviceToHost, c->stream));
+	if (nz) HIPCHK(c, hipMemcpyAsync(values, c->d_shard.as<u32>() + w + LX + LY, (size_t)nz * 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	u32 acc = 0;
+	for (u32 i = 0; i < LX; ++i) { offsets[i] = acc; acc += rowcnt[i]; }
+	offsets[LX] = acc;
+	if (acc != nz) return fail(c, "mpcgpu_get_list_sparse: record of pair %u is inconsistent (internal error)", q);
+	return 0;
 }
 
 int mpcgpu_relax_info(mpcgpu_ctx *c, char *buf, uint32_t buflen, int *is_fallback)

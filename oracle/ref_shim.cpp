@@ -21,6 +21,10 @@ void CalcPostFlat(const float *FlatFwd, const float *FlatBwd, uint LX, uint LY, 
 void CalcPosteriorFlat3(const MultiSequence &MSA1, const MultiSequence &MSA2, const vector<uint> &SeqIndexes1,
   const vector<uint> &SeqIndexes2, const vector<MySparseMx *> &SparseMxs, float *Flat); // buildposterior3flat.cpp:19
 
+// AlignPairFlat_SparsePost (alignpairflat.cpp:3-21) on sequences i, j of the global input of ref_mpc_begin (labels s<i>): the
+// path of CalcAlnFlat on the dense posterior, EA = Score / min(L1, L2), and the FromPost matrix.
+float AlignPairFlat_SparsePost(const string &Label1, const string &Label2, string &Path, MySparseMx *SparsePost);
+
 extern "C" {
 
 // HMMParams::FromDefaults/PerturbProbs/ToPairHMM (hmmparams.cpp:273,298; perturbhmm.cpp:15)
@@ -297,6 +301,28 @@ int ref_align_msas(uint n1, const char **rows1, const uint *idx1, uint n2, const
 	myfree(DPRows); myfree(TB);
 	delete MSA1;
 	delete MSA2;
+	return 0;
+	}
+
+
+int ref_align_pair(uint i, uint j, char *path, uint *pathlen, float *ea, uint *nnz, uint *offsets, byte *values, uint values_cap)
+	{
+	if (g_MS == 0)
+		return -1;
+	char l1[32], l2[32];
+	snprintf(l1, sizeof(l1), "s%u", i);
+	snprintf(l2, sizeof(l2), "s%u", j);
+	string Path;
+	MySparseMx S;
+	*ea = AlignPairFlat_SparsePost(l1, l2, Path, &S);
+	memcpy(path, Path.data(), Path.size());
+	*pathlen = (uint) Path.size();
+	const uint n = S.m_Offsets[S.m_LX];
+	*nnz = n;
+	if (offsets != 0)
+		memcpy(offsets, S.m_Offsets, sizeof(uint)*(S.m_LX+1));
+	if (values != 0 && n <= values_cap)
+		memcpy(values, S.m_ValueVec, 8*(size_t)n);
 	return 0;
 	}
 

@@ -193,3 +193,27 @@ def check_buildpost_golden(name, lib_path=None):
             tot = np.float32(tot + np.float32(e))
         assert bits(np.float32(tot / np.float32(len(ea)))) == bits(z[k + "ea_avg"]), (name, j, "msas mean EA")
     g.close()
+
+
+def check_align_pairs_golden(name="ap_ragged", lib_path=None):
+    """mpcgpu_align_pairs (AlignPairFlat on the device: stage A on the pair list, dense thresholded posterior from the candidate
+    lists, CalcAlnFlat + traceback, one launch for the batch) and mpcgpu_get_list_sparse against what the compiled reference's
+    AlignPairFlat_SparsePost returns (tests/golden/ap_*.npz): path, EA bits, FromPost matrix — lengths 1..300, identical
+    sequences, both index orders."""
+    z = G.load(name)
+    seqs = [str(x) for x in z["seqs"]]
+    pairs = [(int(a), int(b)) for a, b in z["pairs"]]
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, lib_path)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs_registry(seqs)
+    res, sp = g.align_pairs([a for a, b in pairs], [b for a, b in pairs], sparse=True)
+    for q, ((path, sc, ea), (off, val)) in enumerate(zip(res, sp)):
+        assert path == str(z["p%d_path" % q]), (q, pairs[q])
+        assert bits(ea) == bits(z["p%d_ea" % q]), (q, pairs[q])
+        assert np.array_equal(off, z["p%d_off" % q]) and np.array_equal(val, z["p%d_val" % q]), (q, pairs[q])
+    # one pair at a time gives the same answers (the drop-in's AlignPairFlat makes such calls)
+    for q in (0, 3, 7):
+        (path, sc, ea), = g.align_pairs([pairs[q][0]], [pairs[q][1]])
+        assert path == str(z["p%d_path" % q]) and bits(ea) == bits(z["p%d_ea" % q])
+    g.close()

@@ -384,7 +384,47 @@ def gen_bp():
             print(pool.map(_bp_worker, [(name, n, length, seed)])[0], flush=True)
 
 
+# ---- AlignPairFlat (alignpairflat.cpp:3-27): path, EA and FromPost matrix of single pairs, from the reference ----------
+def _ap_worker(args):
+    name, seqs, pairs = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import _ref as R
+    R.init_hmm(False, 0)
+    L = R.lib()
+    n = len(seqs)
+    arr = (C.c_char_p * n)(*[s.encode() for s in seqs])
+    assert L.ref_mpc_begin(n, arr, 1) == 0
+    u32p = C.POINTER(C.c_uint)
+    d = {"seqs": np.array(seqs), "pairs": np.array(pairs, np.uint32)}
+    for q, (i, j) in enumerate(pairs):
+        LX, LY = len(seqs[i]), len(seqs[j])
+        buf = C.create_string_buffer(LX + LY + 8)
+        plen, ea, nnz = C.c_uint(0), C.c_float(0), C.c_uint(0)
+        off = np.empty(LX + 1, np.uint32)
+        val = np.empty(max(LX * LY, 1) * 2, np.uint32)
+        assert L.ref_align_pair(i, j, buf, C.byref(plen), C.byref(ea), C.byref(nnz), off.ctypes.data_as(u32p),
+                                val.ctypes.data_as(R.u8p), LX * LY) == 0
+        d["p%d_path" % q], d["p%d_ea" % q] = np.array(buf.raw[:plen.value].decode()), np.float32(ea.value)
+        d["p%d_off" % q], d["p%d_val" % q] = off, val[:2 * nnz.value].copy()
+    np.savez_compressed(os.path.join(HERE, "%s.npz" % name), **d)
+    return name, len(pairs)
+
+
+def gen_ap():
+    from muscle_amd.synth import make_family
+    fam = make_family(6, 90, seed=17)
+    seqs = fam + ["M", "MKVLA", make_family(1, 300, seed=9)[0], fam[2], "ACDEFGHIKLMNPQRSTVWY" * 3, "WWWWWWWW"]
+    pairs = [(0, 1), (1, 0), (2, 5), (6, 7), (7, 8), (8, 0), (3, 9), (9, 3), (10, 4), (11, 6), (8, 10), (4, 4 + 1)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        print(pool.map(_ap_worker, [("ap_ragged", seqs, pairs)])[0], flush=True)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["ap"]:
+        gen_ap()
+        sys.exit(0)
     if sys.argv[1:] == ["bp"]:
         gen_bp()
         sys.exit(0)

@@ -464,3 +464,8 @@ def test_emu_buildpost_vs_reference_golden(emu, name, mode):
     """mpcgpu_build_post / align_alns / align_msas against matrices, paths and scores generated by the compiled reference; both
     forms of the device BuildPost (one launch by rows for joins of few pairs / records, stable sort, in-order run sums)."""
     _with_env({"MPCGPU_BP": mode}, lambda: P.check_buildpost_golden(name, emu))
+
+
+def test_emu_align_pairs_vs_reference_golden(emu):
+    """AlignPairFlat on the device against the compiled reference's AlignPairFlat_SparsePost (alignpairflat.cpp:3-27)."""
+    P.check_align_pairs_golden("ap_ragged", emu)

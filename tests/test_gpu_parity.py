@@ -558,3 +558,9 @@ def test_two_gpus_rccl_group_and_torchrun_bench():
     rec = json.loads(lines[-1])
     assert rec["n_gpus"] == 2 and rec["parity_digest"] == "match", rec
     assert rec["exchange_ms"] > 0
+
+
+def test_align_pairs_vs_reference_golden():
+    """mpcgpu_align_pairs / mpcgpu_get_list_sparse against the compiled reference's AlignPairFlat_SparsePost
+    (alignpairflat.cpp:3-27; callers uclust.cpp:14, transaln.cpp:787, eadistmx.cpp:54): path, EA bits, FromPost matrix."""
+    P.check_align_pairs_golden("ap_ragged")
