@@ -42,6 +42,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -824,11 +825,20 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 // that qualifies, in the same order, is returned with its path: the same answer, 8 alignments of latency folded into one.
 namespace
 {
-void AlignPairsByLabel(const vector<string> &Labels1, const vector<string> &Labels2, vector<string> &Paths, vector<float> &EAs,
-  MySparseMx *SparsePost0)
+// One caller's request: a list of (Label1, Label2), answered with paths and EAs (+ the FromPost matrix of its first pair).
+struct PairReq
 	{
-	const uint PairCount = SIZE(Labels1);
-	asserta(SIZE(Labels2) == PairCount && PairCount > 0);
+	const vector<string> *m_Labels1 = 0;
+	const vector<string> *m_Labels2 = 0;
+	vector<string> m_Paths;
+	vector<float> m_EAs;
+	MySparseMx *m_SparsePost0 = 0;
+	bool m_Done = false;
+	};
+
+// Runs the requests of one batch as ONE library call (under g_JoinMu).
+void RunPairBatch(const vector<PairReq *> &Batch)
+	{
 	std::map<const Sequence *, uint32_t> SeqToIndex;
 	vector<const uint8_t *> Ptrs;
 	vector<uint32_t> Lens;
@@ -846,18 +856,25 @@ void AlignPairsByLabel(const vector<string> &Labels1, const vector<string> &Labe
 		Labels.push_back(Label);
 		return Index;
 		};
-	vector<uint32_t> Seqs1(PairCount), Seqs2(PairCount);
+	vector<uint32_t> Seqs1, Seqs2;
+	vector<uint> First; // first pair of every request in the batch's list
 	uint32_t Stride = 1;
-	for (uint i = 0; i < PairCount; ++i)
+	for (size_t r = 0; r < Batch.size(); ++r)
 		{
-		Seqs1[i] = Register(Labels1[i]);
-		Seqs2[i] = Register(Labels2[i]);
-		Stride = std::max(Stride, Lens[Seqs1[i]] + Lens[Seqs2[i]]);
+		const PairReq &R = *Batch[r];
+		First.push_back(SIZE(Seqs1));
+		for (uint i = 0; i < SIZE(*R.m_Labels1); ++i)
+			{
+			Seqs1.push_back(Register((*R.m_Labels1)[i]));
+			Seqs2.push_back(Register((*R.m_Labels2)[i]));
+			Stride = std::max(Stride, Lens[Seqs1.back()] + Lens[Seqs2.back()]);
+			}
 		}
+	const uint PairCount = SIZE(Seqs1);
+	asserta(PairCount > 0);
 	vector<char> PathBuf(size_t(PairCount)*Stride);
 	vector<uint32_t> PathLens(PairCount);
-	EAs.assign(PairCount, 0.0f);
-	std::lock_guard<std::mutex> Guard(g_JoinMu);
+	vector<float> EAs(PairCount);
 	if (g_CtxJoin == 0)
 		{
 		const int Device = DeviceList()[0];
@@ -870,25 +887,96 @@ void AlignPairsByLabel(const vector<string> &Labels1, const vector<string> &Labe
 	GPUCHK(mpcgpu_set_seqs_registry(Ctx, (uint32_t) Ptrs.size(), Ptrs.data(), Lens.data()));
 	SetMega(Ctx, Labels, Lens);
 	GPUCHK(mpcgpu_align_pairs(Ctx, PairCount, Seqs1.data(), Seqs2.data(), Stride, PathBuf.data(), PathLens.data(), 0, EAs.data()));
-	Paths.resize(PairCount);
-	for (uint i = 0; i < PairCount; ++i)
-		Paths[i].assign(PathBuf.data() + size_t(i)*Stride, PathLens[i]);
-	if (SparsePost0 != 0)
+	for (size_t r = 0; r < Batch.size(); ++r)
 		{
+		PairReq &R = *Batch[r];
+		const uint n = SIZE(*R.m_Labels1);
+		R.m_Paths.resize(n);
+		R.m_EAs.resize(n);
+		for (uint i = 0; i < n; ++i)
+			{
+			const uint q = First[r] + i;
+			R.m_Paths[i].assign(PathBuf.data() + size_t(q)*Stride, PathLens[q]);
+			R.m_EAs[i] = EAs[q];
+			}
+		if (R.m_SparsePost0 != 0)
+			{
 // AlignPairFlat_SparsePost: SparsePost->FromPost(Post, L1, L2) (alignpairflat.cpp:12-13)
-		uint32_t NNZ = 0;
-		GPUCHK(mpcgpu_get_list_sparse(Ctx, 0, &NNZ, 0, 0));
-		const uint LX = Lens[Seqs1[0]], LY = Lens[Seqs2[0]];
-		MySparseMx &Mx = *SparsePost0;
-		Mx.AllocLX(LX);
-		Mx.AllocVec(NNZ);
-		Mx.m_LX = LX;
-		Mx.m_LY = LY;
-		Mx.m_VecSize = NNZ;
-		vector<uint64_t> Vals(size_t(NNZ) + 1);
-		GPUCHK(mpcgpu_get_list_sparse(Ctx, 0, &NNZ, Mx.m_Offsets, Vals.data()));
-		memcpy(Mx.m_ValueVec, Vals.data(), 8*size_t(NNZ));
+			const uint q = First[r];
+			asserta(PairCount <= 256); // mpcgpu_get_list_sparse addresses the pairs of ONE stage of the library
+			uint32_t NNZ = 0;
+			GPUCHK(mpcgpu_get_list_sparse(Ctx, q, &NNZ, 0, 0));
+			const uint LX = Lens[Seqs1[q]], LY = Lens[Seqs2[q]];
+			MySparseMx &Mx = *R.m_SparsePost0;
+			Mx.AllocLX(LX);
+			Mx.AllocVec(NNZ);
+			Mx.m_LX = LX;
+			Mx.m_LY = LY;
+			Mx.m_VecSize = NNZ;
+			vector<uint64_t> Vals(size_t(NNZ) + 1);
+			GPUCHK(mpcgpu_get_list_sparse(Ctx, q, &NNZ, Mx.m_Offsets, Vals.data()));
+			memcpy(Mx.m_ValueVec, Vals.data(), 8*size_t(NNZ));
+			}
 		}
+	}
+
+// The callers of AlignPairFlat inside OpenMP loops (eadistmx.cpp:32-66, eacluster.cpp:114, eesort.cpp:37) ask for one pair each
+// from many threads at once. One pair is one wavefront of work, so the requests are COMBINED: a thread that finds nobody
+// serving becomes the server, takes everything queued (its own request included) as one library call, and goes on until the
+// queue is empty; the others wait for their answers. A lone caller (uclust.cpp's sequential loop) is served at once.
+std::mutex g_PairQueueMu;
+std::condition_variable g_PairQueueCv;
+vector<PairReq *> g_PairQueue;
+bool g_PairServing = false;
+
+void AlignPairsByLabel(const vector<string> &Labels1, const vector<string> &Labels2, vector<string> &Paths, vector<float> &EAs,
+  MySparseMx *SparsePost0)
+	{
+	asserta(SIZE(Labels2) == SIZE(Labels1) && !Labels1.empty());
+	PairReq Mine;
+	Mine.m_Labels1 = &Labels1;
+	Mine.m_Labels2 = &Labels2;
+	Mine.m_SparsePost0 = SparsePost0;
+	std::unique_lock<std::mutex> Lock(g_PairQueueMu);
+	g_PairQueue.push_back(&Mine);
+	while (!Mine.m_Done)
+		{
+		if (g_PairServing)
+			{
+			g_PairQueueCv.wait(Lock);
+			continue;
+			}
+		g_PairServing = true;
+		while (!g_PairQueue.empty())
+			{
+			vector<PairReq *> Batch;
+			uint Pairs = 0;
+			while (!g_PairQueue.empty() && Pairs + SIZE(*g_PairQueue.front()->m_Labels1) <= 256)
+				{
+				Pairs += SIZE(*g_PairQueue.front()->m_Labels1);
+				Batch.push_back(g_PairQueue.front());
+				g_PairQueue.erase(g_PairQueue.begin());
+				}
+			if (Batch.empty()) // one request of more than 256 pairs: alone (the library cuts it into stages itself)
+				{
+				Batch.push_back(g_PairQueue.front());
+				g_PairQueue.erase(g_PairQueue.begin());
+				}
+			Lock.unlock();
+				{
+				std::lock_guard<std::mutex> Guard(g_JoinMu);
+				RunPairBatch(Batch);
+				}
+			Lock.lock();
+			for (size_t r = 0; r < Batch.size(); ++r)
+				Batch[r]->m_Done = true;
+			g_PairQueueCv.notify_all();
+			}
+		g_PairServing = false;
+		g_PairQueueCv.notify_all();
+		}
+	Paths.swap(Mine.m_Paths);
+	EAs.swap(Mine.m_EAs);
 	}
 }
 
