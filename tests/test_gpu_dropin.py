@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "bb11001", "bb11005", "n32_L150", "dupes", "consiters0", "perturb",
         "synth_64x200_s1", "synth_128x300_s1", "super7_200x120_b32", "super7_8x18_b4", "super5_14x20", "super5_120x80",
+        "super5_600x150",  # UCLUST (UClust::Search: all word-count hits of a sequence aligned in one call) + 214 PProg joins; reference: 12.5 min on one thread
         "synth_5x1300_s3",  # sequences longer than 1024: row-block fb kernel, gather relax
         # .mega inputs (structure profiles): CalcPost's profile branch in -align and in the -super7 joins
         "mega_bb11001", "mega_synth_6x40_s2", "mega_super7_12x30_b4"]
