@@ -13,7 +13,6 @@ pytestmark = pytest.mark.gpu
 
 SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "bb11001", "bb11005", "n32_L150", "dupes", "consiters0", "perturb",
         "synth_64x200_s1", "synth_128x300_s1", "super7_200x120_b32", "super7_8x18_b4", "super5_14x20", "super5_120x80",
-        "super5_600x150",  # UCLUST (UClust::Search: all word-count hits of a sequence aligned in one call) + 214 PProg joins; reference: 12.5 min on one thread
         "synth_5x1300_s3",  # sequences longer than 1024: row-block fb kernel, gather relax
         # .mega inputs (structure profiles): CalcPost's profile branch in -align and in the -super7 joins
         "mega_bb11001", "mega_synth_6x40_s2", "mega_super7_12x30_b4"]
@@ -85,3 +84,11 @@ def test_profseq_drives_buildpost_on_the_device(gpu_muscle, fixture):
     assert got == want
     syms = subprocess.run(["nm", gpu_muscle], capture_output=True, text=True).stdout
     assert "MPCFlat_BuildPost_ref" not in syms
+
+
+def test_super5_uclust_on_the_device(gpu_muscle):
+    """-super5 on 600 x L~150: UCLUST (uclust.cpp:26-56; the drop-in's UClust::Search aligns all <= 8 word-count hits of a sequence
+    in one mpcgpu_align_pairs call), then 214 PProg joins. Final MSA = the reference's (MD5 from a single-thread run of the compiled
+    reference, 12.5 CPU-minutes — not repeated here)."""
+    md5, _ = _msa.run_muscle(gpu_muscle, "super5_600x150", threads=1)
+    assert md5 == _msa.golden_md5()["super5_600x150"]
