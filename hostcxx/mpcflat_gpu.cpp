@@ -240,7 +240,7 @@ bool DebugOn()
 
 // MUSCLE_GPU_TIMING=1: wall time spent inside the replaced functions, printed at exit (where does an
 // end-to-end run spend its time once the stage itself takes a few seconds).
-enum { T_STAGE_A, T_CONS_ITER, T_ALN_PREP, T_ALN_LIB, T_ALN_POST, T_JOIN_PREP, T_JOIN_LIB, T_COUNT };
+enum { T_STAGE_A, T_CONS_ITER, T_ALN_PREP, T_ALN_LIB, T_ALN_POST, T_JOIN_PREP, T_JOIN_LIB, T_PAIRS_PREP, T_PAIRS_LIB, T_COUNT };
 double g_Seconds[T_COUNT];
 unsigned long long g_Calls[T_COUNT];
 bool TimingOn()
@@ -254,7 +254,8 @@ bool TimingOn()
 			atexit([]()
 				{
 				static const char *Names[T_COUNT] = { "stage A (all pairs)", "ConsIter", "AlignAlns: maps",
-				  "AlignAlns: library", "AlignAlns: result MSA", "AlignMSAsFlat: pairs+maps", "AlignMSAsFlat: library" };
+				  "AlignAlns: library", "AlignAlns: result MSA", "AlignMSAsFlat: pairs+maps", "AlignMSAsFlat: library",
+				  "AlignPairFlat lists: registry", "AlignPairFlat lists: library" };
 				fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  (static initialisation to exit handlers; the rows below are parts of it)\n",
 				  "process", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count());
 				fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  (inside the first call below that needed it)\n", "context creation, HIP init", g_CtxSeconds);
@@ -882,10 +883,12 @@ void RunPairBatch(const vector<PairReq *> &Batch)
 			Die("GPU posterior stage: %s", mpcgpu_last_error(0));
 		}
 	mpcgpu_ctx *Ctx = g_CtxJoin;
+	Stopwatch SW(T_PAIRS_PREP);
 	GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
 	  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
 	GPUCHK(mpcgpu_set_seqs_registry(Ctx, (uint32_t) Ptrs.size(), Ptrs.data(), Lens.data()));
 	SetMega(Ctx, Labels, Lens);
+	SW.Next(T_PAIRS_LIB);
 	GPUCHK(mpcgpu_align_pairs(Ctx, PairCount, Seqs1.data(), Seqs2.data(), Stride, PathBuf.data(), PathLens.data(), 0, EAs.data()));
 	for (size_t r = 0; r < Batch.size(); ++r)
 		{

@@ -845,6 +845,25 @@ int mpcgpu_set_mega(mpcgpu_ctx *c, uint32_t nfeat, const uint32_t *alpha, const 
 
 uint64_t mpcgpu_pair_count(const mpcgpu_ctx *c) { return c ? c->npairs : 0; }
 
+// the constant part of a forward/backward launch: sequences, PairHMM scores, tables, candidate buffers (the work list, queue and
+// forward-plane scratch are set per launch)
+static void fill_fb_params(mpcgpu_ctx *c, FbParams &fp, const u32 *pair_x, const u32 *pair_y, u32 capc, bool mega)
+{
+	fp.seq_code = c->d_seq_code.as<u8>(); fp.seq_off = c->d_seq_off.as<u64>(); fp.seq_len = c->d_seq_len.as<u32>();
+	fp.tSM = c->start[0]; fp.tSI = c->start[1]; fp.tSJ = c->start[3]; // pairhmm.h:11-19: M,IX,IY,JX,JY
+	fp.tMM = c->trans[0 * 5 + 0]; fp.tMI = c->trans[0 * 5 + 1]; fp.tMJ = c->trans[0 * 5 + 3];
+	fp.tII = c->trans[1 * 5 + 1]; fp.tIM = c->trans[1 * 5 + 0];
+	fp.tJJ = c->trans[3 * 5 + 3]; fp.tJM = c->trans[3 * 5 + 0];
+	fp.thr = c->thr; fp.A = c->A; fp.match = c->d_match.as<float>(); fp.ins = c->d_ins.as<float>();
+	fp.pair_x = pair_x; fp.pair_y = pair_y;
+	fp.cand = c->d_cand.as<u64>(); fp.capc = capc; fp.cand_cnt = c->d_cand_cnt.as<u32>();
+	fp.total = c->d_total.as<float>();
+	fp.mg_prof = mega ? c->d_mg_prof.as<u64>() : nullptr; fp.mg_ins = mega ? c->d_mg_ins.as<float>() : nullptr;
+	fp.mg_tab = mega ? c->d_mg_tab.as<float>() : nullptr; fp.mg_tab_floats = mega ? c->mg_tab_floats : 0;
+	for (u32 f = 0; f < MPC_MEGA_FMAX; ++f) { fp.mg_base[f] = mega ? c->mg_base[f] : 0; fp.mg_alpha[f] = mega ? c->mg_alpha[f] : 0; }
+	fp.bnd = nullptr; fp.bnd_stride = 0; fp.bnd_ld = 0; fp.fm_block = 0;
+}
+
 // Stage A over an explicit list of (x,y) sequence-index pairs (host arrays of np entries): the packed
 // shard of those pairs, in list order, ends up in c->d_shard with sh_nnz / sh_ea.
 static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
@@ -963,19 +982,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (MPC_HMAX + 2), c->stream));
 
 		FbParams fp;
-		fp.seq_code = c->d_seq_code.as<u8>(); fp.seq_off = c->d_seq_off.as<u64>(); fp.seq_len = c->d_seq_len.as<u32>();
-		fp.tSM = c->start[0]; fp.tSI = c->start[1]; fp.tSJ = c->start[3]; // pairhmm.h:11-19: M,IX,IY,JX,JY
-		fp.tMM = c->trans[0 * 5 + 0]; fp.tMI = c->trans[0 * 5 + 1]; fp.tMJ = c->trans[0 * 5 + 3];
-		fp.tII = c->trans[1 * 5 + 1]; fp.tIM = c->trans[1 * 5 + 0];
-		fp.tJJ = c->trans[3 * 5 + 3]; fp.tJM = c->trans[3 * 5 + 0];
-		fp.thr = c->thr; fp.A = c->A; fp.match = c->d_match.as<float>(); fp.ins = c->d_ins.as<float>();
-		fp.pair_x = c->d_bx.as<u32>(); fp.pair_y = c->d_by.as<u32>();
-		fp.cand = c->d_cand.as<u64>(); fp.capc = capc; fp.cand_cnt = c->d_cand_cnt.as<u32>();
-		fp.total = c->d_total.as<float>();
-		fp.mg_prof = mega ? c->d_mg_prof.as<u64>() : nullptr; fp.mg_ins = mega ? c->d_mg_ins.as<float>() : nullptr;
-		fp.mg_tab = mega ? c->d_mg_tab.as<float>() : nullptr; fp.mg_tab_floats = mega ? c->mg_tab_floats : 0;
-		for (u32 f = 0; f < MPC_MEGA_FMAX; ++f) { fp.mg_base[f] = mega ? c->mg_base[f] : 0; fp.mg_alpha[f] = mega ? c->mg_alpha[f] : 0; }
-		fp.bnd = nullptr; fp.bnd_stride = 0; fp.bnd_ld = 0; fp.fm_block = 0;
+		fill_fb_params(c, fp, c->d_bx.as<u32>(), c->d_by.as<u32>(), capc, mega);
 		// row-list post kernel (no sorts, 3 LDS trips per EA row) when LY fits its LDS arrays; MPCGPU_POST=sort forces the general one
 		const char *post_mode = getenv("MPCGPU_POST");
 		// (up to ~12 000 positions: three arrays of one word per position + the sorted-list buffer in the CU's LDS)
@@ -1970,6 +1977,147 @@ int mpcgpu_align_msas(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, cons
 	return run_calc_aln(c, c->d_aln_post.as<float>(), C1, C2, path, pathlen, score); // syncs before the vectors above die
 }
 
+// mpcgpu_align_pairs for a SHORT list (what UClust::Search and single AlignPairFlat calls send: 1..8 pairs): the kernels of the
+// general path, driven with one wait. Everything the kernels read from the host (pair list, launch order, alignment parameters)
+// and everything the host reads back (candidate-overflow flags, path records) lives in ONE page-locked record that the device
+// addresses directly; nothing is packed into a shard (mpcgpu_get_list_sparse re-runs the general stage when somebody asks).
+// 0 = done, 1 = error, 2 = not applicable (the caller takes the general path).
+static int align_pairs_small(mpcgpu_ctx *c, u32 np, const u32 *px, const u32 *py, u32 path_stride, char *paths, u32 *pathlens,
+	float *scores, float *ea)
+{
+	const u32 long_min = (u32)std::min(std::max(env_int("MPCGPU_FB_LONG_MIN", 64 * 12 + 1), 2), 64 * MPC_HMAX + 1);
+	u32 LXmax = 0, LYmax = 0, Lsum_max = 0;
+	for (u32 q = 0; q < np; ++q) {
+		const u32 LX = c->len[px[q]], LY = c->len[py[q]];
+		if (LX >= long_min) return 2; // row-block pairs: general path
+		if ((u64)LY + 1 > MPC_ALNW_MAXW || (size_t)(LX + 1) * MPC_ALNW_ROWBYTES + 16 > 160u * 1024u) return 2; // not a one-wave alignment
+		LXmax = std::max(LXmax, LX); LYmax = std::max(LYmax, LY); Lsum_max = std::max(Lsum_max, LX + LY);
+	}
+	if (((size_t)LXmax + 2 + 2 * ((size_t)LYmax + 2)) * 4 + 8 + 8 * 1024 > 150 * 1024) return 2;
+	const u32 Lmax = std::max(LXmax, LYmax);
+	const u32 capc = std::max((u32)std::max(env_int("MPCGPU_CAND_PER_ROW", 12), 1) * Lmax, 1024u);
+	const bool mega = c->have_mega;
+	c->have_shard = c->have_store = false;
+	c->shard_is_list = true;
+	c->list_x.assign(px, px + np); c->list_y.assign(py, py + np);
+	c->sh_k0 = 0; c->sh_k1 = np;
+	// ---- the page-locked record
+	std::vector<u64> off(np + 1, 0);
+	for (u32 q = 0; q < np; ++q) off[q + 1] = off[q] + (u64)c->len[px[q]] * c->len[py[q]];
+	const u64 rstride = ((u64)8 + Lsum_max + 7) & ~7ull;
+	const u64 o_bx = 0, o_by = o_bx + 4 * (u64)np, o_order = o_by + 4 * (u64)np, o_off = (o_order + 4 * (u64)np + 7) & ~7ull,
+		o_par = o_off + 8 * ((u64)np + 1), o_flags = o_par + (u64)np * sizeof(AlnParams), o_nnz = o_flags + 4 * (u64)np,
+		o_ea = o_nnz + 4 * (u64)np, o_res = (o_ea + 4 * (u64)np + 7) & ~7ull, bytes = o_res + (u64)np * rstride;
+	HIPCHK(c, c->h_ap.ensure(bytes));
+	char *h = c->h_ap.as<char>();
+	u32 *bx = (u32 *)(h + o_bx), *by = (u32 *)(h + o_by), *order = (u32 *)(h + o_order);
+	memcpy(bx, px, 4 * (size_t)np);
+	memcpy(by, py, 4 * (size_t)np);
+	memcpy(h + o_off, off.data(), 8 * ((size_t)np + 1));
+	u32 hcount[MPC_HMAX + 1] = {0};
+	{
+		std::vector<u32> keys(np);
+		for (u32 q = 0; q < np; ++q) { const u32 H = (c->len[px[q]] + 63) / 64; hcount[H]++; keys[q] = (H << 16) | q; }
+		std::sort(keys.begin(), keys.end());
+		for (u32 q = 0; q < np; ++q) order[q] = keys[q] & 0xffffu;
+	}
+	// ---- scratch
+	const u64 res_stride = (u64)LXmax + LYmax + 4 * (u64)capc;
+	const int waves_per_block = 4, block = 64 * waves_per_block;
+	const size_t fb_smem = (mega ? (size_t)c->mg_tab_floats : (size_t)c->A * c->A + c->A) * sizeof(float);
+	HIPCHK(c, c->d_cand.ensure((u64)np * capc * 8));
+	HIPCHK(c, c->d_cand_cnt.ensure((u64)np * 4));
+	HIPCHK(c, c->d_total.ensure((u64)np * 4));
+	HIPCHK(c, c->d_res.ensure((u64)np * res_stride * 4));
+	HIPCHK(c, c->d_queue.ensure(4 * (MPC_HMAX + 2)));
+	HIPCHK(c, c->d_aln_post.ensure_grow(off[np] * 4));
+	HIPCHK(c, c->d_aln_rev.ensure_grow((u64)np * Lsum_max + 16));
+	HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (MPC_HMAX + 2), c->stream));
+	// ---- forward / backward, one launch per rows-per-lane bin
+	FbParams fp;
+	fill_fb_params(c, fp, bx, by, capc, mega);
+	TimedSpan sp;
+	u32 pos = 0;
+	for (u32 H = 1; H <= MPC_HMAX; ++H) {
+		if (!hcount[H]) continue;
+		const u32 cnt = hcount[H];
+		const u32 grid = (cnt + waves_per_block - 1) / waves_per_block;
+		const u64 fm_stride = (u64)(LYmax + 64) * H * 64;
+		HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
+		fp.order = order + pos; fp.count = cnt;
+		fp.queue = c->d_queue.as<u32>() + H;
+		fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride;
+		if (span_begin(c, 0, &sp)) return 1;
+		launch_fb_h((int)H, mega, fp, grid, block, fb_smem, c->stream);
+		HIPCHK(c, hipGetLastError());
+		if (span_end(c, &sp)) return 1;
+		pos += cnt;
+	}
+	// ---- probabilities, EA, sparsify (the candidate lists keep the probabilities)
+	PostRowsParams pr;
+	pr.pair_x = bx; pr.pair_y = by; pr.seq_len = c->d_seq_len.as<u32>();
+	pr.cand = c->d_cand.as<u64>(); pr.capc = capc; pr.cand_cnt = c->d_cand_cnt.as<u32>();
+	pr.use_fma = c->use_fma;
+	pr.lx_cap = LXmax + 2; pr.ly_cap = LYmax + 2;
+	pr.sort_cap = std::min<u32>(capc, 1024u); pr.sort_stride = capc;
+	pr.batch = 64;
+	const size_t fixed_lds = ((((size_t)pr.lx_cap + 2 * (size_t)pr.ly_cap) * 4 + 7) & ~(size_t)7);
+	const size_t smem = fixed_lds + (size_t)pr.sort_cap * 8;
+	if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void *)post_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+	HIPCHK(c, c->d_sort_scratch.ensure(capc > pr.sort_cap ? (u64)np * pr.sort_stride * 8 : 8));
+	pr.sort_scratch = c->d_sort_scratch.as<u64>();
+	pr.res = c->d_res.as<u32>(); pr.res_stride = res_stride;
+	pr.nnz = (u32 *)(h + o_nnz); pr.ea = (float *)(h + o_ea); pr.flags = (u32 *)(h + o_flags);
+	pr.count = np; pr.long_min = long_min; pr.prof = nullptr;
+	if (span_begin(c, 1, &sp)) return 1;
+	MPC_LAUNCH(post_rows_kernel, np, 64, smem, c->stream, pr);
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &sp)) return 1;
+	// ---- dense thresholded posteriors, alignments
+	DensePostParams dp;
+	dp.pair_x = bx; dp.pair_y = by; dp.seq_len = c->d_seq_len.as<u32>();
+	dp.cand = c->d_cand.as<u64>(); dp.capc = capc; dp.cand_cnt = c->d_cand_cnt.as<u32>(); dp.long_min = long_min;
+	dp.out_off = (const u64 *)(h + o_off); dp.out = c->d_aln_post.as<float>();
+	MPC_LAUNCH(dense_post_kernel, np, 256, 0, c->stream, dp);
+	HIPCHK(c, hipGetLastError());
+	c->last_post_cells = 0;
+	AlnParams *ap = (AlnParams *)(h + o_par);
+	for (u32 q = 0; q < np; ++q) {
+		char *r = h + o_res + (u64)q * rstride;
+		ap[q].post = c->d_aln_post.as<float>() + off[q];
+		ap[q].LX = c->len[px[q]]; ap[q].LY = c->len[py[q]];
+		ap[q].tb = nullptr; ap[q].rev = c->d_aln_rev.as<char>() + (u64)q * Lsum_max;
+		ap[q].pathlen = (u32 *)r; ap[q].score = (float *)(r + 4); ap[q].path = r + 8;
+	}
+	const size_t asmem = (size_t)(LXmax + 1) * MPC_ALNW_ROWBYTES + 16;
+	if (asmem > c->aln_smem_set[3]) {
+		(void)hipFuncSetAttribute((const void *)calc_aln_wave_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)asmem);
+		c->aln_smem_set[3] = asmem;
+	}
+	if (span_begin(c, 8, &sp)) return 1;
+	MPC_LAUNCH(calc_aln_wave_batch_kernel, np, 64, asmem, c->stream, (const AlnParams *)ap);
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &sp)) return 1;
+	HIPCHK(c, hipStreamSynchronize(c->stream)); // the one wait
+	for (u32 q = 0; q < np; ++q)
+		if (((const u32 *)(h + o_flags))[q] & 1u) return 2; // a candidate list overflowed: the general path grows it and retries
+	c->sh_nnz.assign((const u32 *)(h + o_nnz), (const u32 *)(h + o_nnz) + np);
+	c->sh_ea.assign((const float *)(h + o_ea), (const float *)(h + o_ea) + np);
+	for (u32 q = 0; q < np; ++q) {
+		const char *r = h + o_res + (u64)q * rstride;
+		u32 n_path;
+		memcpy(&n_path, r, 4);
+		if (n_path > ap[q].LX + ap[q].LY) return fail(c, "mpcgpu_align_pairs: path length %u out of range (internal error)", n_path);
+		pathlens[q] = n_path;
+		float sc;
+		memcpy(&sc, r + 4, 4);
+		if (scores) scores[q] = sc;
+		if (ea) ea[q] = sc / (float)std::min(ap[q].LX, ap[q].LY); // alignpairflat.cpp:18 (uint -> float, IEEE divide)
+		memcpy(paths + (u64)q * path_stride, r + 8, n_path);
+	}
+	return 0;
+}
+
 // AlignPairFlat (alignpairflat.cpp:3-27) for a list of pairs: CalcPost (fwd + bwd + CalcPostFlat, calcpost.cpp:4-36) -> CalcAlnFlat on
 // the DENSE thresholded posterior -> path; EA = Score / min(L1, L2). Stage A runs on the list (the kernels of
 // mpcgpu_calc_posteriors), the dense matrices are rebuilt from the candidate lists (every cell with Score >= MIN_SPARSE_SCORE, also
@@ -1985,6 +2133,10 @@ int mpcgpu_align_pairs(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, con
 		if ((u64)c->len[seq1[q]] + c->len[seq2[q]] > path_stride) return fail(c, "mpcgpu_align_pairs: path_stride %u too small for pair %u", path_stride, q);
 	}
 	HIPCHK(c, hipSetDevice(c->device));
+	if (npairs >= 1 && npairs <= 64 && env_int("MPCGPU_PAIRS_SMALL", 1)) {
+		const int rc = align_pairs_small(c, npairs, seq1, seq2, path_stride, paths, pathlens, scores, ea);
+		if (rc != 2) return rc;
+	}
 	const u32 CHUNK = 256; // pairs per stage-A call: their dense matrices (LX*LY floats each) live together
 	for (u32 q0 = 0; q0 < npairs; q0 += CHUNK) {
 		const u32 nq = std::min<u32>(CHUNK, npairs - q0);
@@ -2065,8 +2217,14 @@ int mpcgpu_align_pairs(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, con
 int mpcgpu_get_list_sparse(mpcgpu_ctx *c, uint32_t q, uint32_t *nnz, uint32_t *offsets, void *values)
 {
 	if (!c) return 1;
-	if (!c->have_shard || !c->shard_is_list || q >= c->list_x.size()) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
+	if (!c->shard_is_list || q >= c->list_x.size()) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
 	HIPCHK(c, hipSetDevice(c->device));
+	if (q >= c->sh_nnz.size()) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
+	if (!c->have_shard && offsets && values) { // the short-list path of mpcgpu_align_pairs packs nothing: the general stage on the same list does
+		const std::vector<u32> lx = c->list_x, ly = c->list_y;
+		if (lx.size() > 256) return fail(c, "mpcgpu_get_list_sparse: the last list stage is gone");
+		if (stage_a(c, lx.size(), lx.data(), ly.data())) return 1;
+	}
 	const u64 np = c->list_x.size();
 	u64 w = shard_header_bytes(np) / 4;
 	for (u32 k = 0; k < q; ++k) w += rec_words(c->len[c->list_x[k]], c->len[c->list_y[k]], c->sh_nnz[k]);

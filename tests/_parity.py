@@ -216,4 +216,21 @@ def check_align_pairs_golden(name="ap_ragged", lib_path=None):
     for q in (0, 3, 7):
         (path, sc, ea), = g.align_pairs([pairs[q][0]], [pairs[q][1]])
         assert path == str(z["p%d_path" % q]) and bits(ea) == bits(z["p%d_ea" % q])
+    # lists of up to 64 pairs take the one-wait path of the library (nothing packed; the lists come from a second, general
+    # stage on demand), longer ones the general stage: both must agree with the reference
+    import os
+    old = os.environ.get("MPCGPU_PAIRS_SMALL")
+    try:
+        for small in ("0", "1"):
+            os.environ["MPCGPU_PAIRS_SMALL"] = small
+            sel = list(range(min(len(pairs), 8)))
+            res, sp = g.align_pairs([pairs[q][0] for q in sel], [pairs[q][1] for q in sel], sparse=True)
+            for q, (path, sc, ea), (off, val) in zip(sel, res, sp):
+                assert path == str(z["p%d_path" % q]) and bits(ea) == bits(z["p%d_ea" % q]), (small, q)
+                assert np.array_equal(off, z["p%d_off" % q]) and np.array_equal(val, z["p%d_val" % q]), (small, q)
+    finally:
+        if old is None:
+            os.environ.pop("MPCGPU_PAIRS_SMALL", None)
+        else:
+            os.environ["MPCGPU_PAIRS_SMALL"] = old
     g.close()
