@@ -249,6 +249,10 @@ int mpcgpu_timers_get(mpcgpu_ctx *ctx, float ms[MPCGPU_NKERNELS], uint64_t launc
 /* Algorithmic work of the last calc_posteriors call: DP cells summed over pairs
  * (sum (LX+1)(LY+1)) and of the last cons_iter: (pair,Z) triples and stored entries. */
 int mpcgpu_work_get(mpcgpu_ctx *ctx, uint64_t *dp_cells, uint64_t *relax_entry_z, uint64_t *store_entries);
+/* How the last stage A (mpcgpu_calc_posteriors / a pair-list call) ran its forward/backward sweeps: pairs in all, pairs that
+ * ran as members of chains (consecutive pairs with the same row sequence swept back to back by one wavefront, no systolic
+ * fill/drain in between: kernels_fbc.h), and the number of chains. Same cells, same results; MPCGPU_FB_CHAIN=0 turns chains off. */
+int mpcgpu_stage_a_info(mpcgpu_ctx *ctx, uint64_t *pairs, uint64_t *chained_pairs, uint64_t *chains);
 int mpcgpu_synchronize(mpcgpu_ctx *ctx);
 /* Which store layout and relax kernel the current store uses, in words (record sizes, workgroup geometry, the tile shapes
  * once a relax iteration has built them), and whether that is a FALLBACK this build chose because the run exceeds the default

@@ -19,7 +19,7 @@ SYMBOLS = [
     "mpcgpu_set_seqs", "mpcgpu_set_mega", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
-    "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_align_pairs", "mpcgpu_get_list_sparse", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
+    "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_align_pairs", "mpcgpu_get_list_sparse", "mpcgpu_stage_a_info", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
@@ -83,6 +83,7 @@ def load(lib_path=None):
     L.mpcgpu_timers_enable.argtypes = [vp, C.c_int]
     L.mpcgpu_timers_get.argtypes = [vp, vp, vp]
     L.mpcgpu_work_get.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.mpcgpu_stage_a_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mpcgpu_synchronize.argtypes = [vp]
     L.mpcgpu_relax_info.argtypes = [vp, C.c_char_p, u32, C.POINTER(i32)]
     L.mpcgpu_group_create.argtypes = [C.POINTER(vp), u32, vp]
@@ -428,6 +429,12 @@ class MpcGpu:
         fb = C.c_int(0)
         self._ck(self.L.mpcgpu_relax_info(self.h, buf, 1024, C.byref(fb)))
         return buf.value.decode(), bool(fb.value)
+
+    def stage_a_info(self):
+        """(pairs, pairs that ran in chains, chains) of the last stage A"""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.mpcgpu_stage_a_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def timers_reset(self):
         self._ck(self.L.mpcgpu_timers_reset(self.h))

@@ -8,6 +8,7 @@
 // hand-written.
 #include "../../include/mpcgpu.h"
 #include "kernels_fb.h"
+#include "kernels_fbc.h"
 #include "kernels_post.h"
 #include "kernels_store.h"
 #include "kernels_relaxv.h"
@@ -170,6 +171,8 @@ struct mpcgpu_ctx {
 	std::vector<u32> list_x, list_y; // the pairs of the last list stage
 	HostBuf h_ap;             // mpcgpu_align_pairs: kernel parameters and results, page-locked
 	DevBuf d_ap_off;
+	DevBuf d_chain_first, d_chain_cnt; // fb_chain_kernel's work list (kernels_fbc.h)
+	u64 sa_pairs = 0, sa_chained = 0, sa_chains = 0; // last stage A: pairs, pairs that ran in chains, chains
 	double aa_trace_t[5] = {0, 0, 0, 0, 0}; // MPCGPU_TRACE_HOST: host seconds of mpcgpu_align_alns' phases
 	u64 aa_trace_n = 0;
 };
@@ -327,6 +330,43 @@ void launch_fb_h(int H, bool mega, const FbParams &p, u32 grid, u32 block, size_
 {
 	switch (H) {
 #define MPC_CASE(h) case h: if (mega) launch_fb<h, true>(p, grid, block, smem, st); else launch_fb<h, false>(p, grid, block, smem, st); break;
+	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
+	MPC_CASE(9) MPC_CASE(10) MPC_CASE(11) MPC_CASE(12) MPC_CASE(13) MPC_CASE(14) MPC_CASE(15) MPC_CASE(16)
+#undef MPC_CASE
+	default: break;
+	}
+}
+
+// fb_chain_kernel (kernels_fbc.h): chains of pairs that share their row sequence
+template <int H> void launch_fbc(const FbChainParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+{
+	auto kern = fb_chain_kernel<H>;
+	MPC_LAUNCH(kern, grid, block, smem, st, p);
+}
+
+template <int H> int occ_fbc(u32 block, size_t smem)
+{
+	int nb = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_chain_kernel<H>, (int)block, smem) != hipSuccess || nb < 1)
+		nb = 1;
+	return nb;
+}
+
+int occ_fbc_h(int H, u32 block, size_t smem)
+{
+	switch (H) {
+#define MPC_CASE(h) case h: return occ_fbc<h>(block, smem);
+	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
+	MPC_CASE(9) MPC_CASE(10) MPC_CASE(11) MPC_CASE(12) MPC_CASE(13) MPC_CASE(14) MPC_CASE(15) MPC_CASE(16)
+#undef MPC_CASE
+	default: return 1;
+	}
+}
+
+void launch_fbc_h(int H, const FbChainParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
+{
+	switch (H) {
+#define MPC_CASE(h) case h: launch_fbc<h>(p, grid, block, smem, st); break;
 	MPC_CASE(1) MPC_CASE(2) MPC_CASE(3) MPC_CASE(4) MPC_CASE(5) MPC_CASE(6) MPC_CASE(7) MPC_CASE(8)
 	MPC_CASE(9) MPC_CASE(10) MPC_CASE(11) MPC_CASE(12) MPC_CASE(13) MPC_CASE(14) MPC_CASE(15) MPC_CASE(16)
 #undef MPC_CASE
@@ -654,6 +694,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 	c->h_aln_res.release();
 	c->h_ap.release();
 	c->d_ap_off.release();
+	c->d_chain_first.release(); c->d_chain_cnt.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -876,6 +917,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	c->sh_nnz.assign(np, 0);
 	c->sh_ea.assign(np, 0.0f);
 	c->work_cells = 0;
+	c->sa_pairs = np; c->sa_chained = c->sa_chains = 0;
 	const u64 hdr = shard_header_bytes(np);
 	if (np == 0) {
 		HIPCHK(c, c->d_shard.ensure(hdr));
@@ -923,7 +965,29 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		u32 capc = 0;
 		std::vector<u32> bx, by, order;
 		u32 hcount[MPC_HMAX + 2];
+		// chains of pairs with the same row sequence (fb_chain_kernel): members in `order` behind the single pairs
+		std::vector<u32> chain_first, chain_cnt;
+		u32 ccount[MPC_HMAX + 1];   // chains per rows-per-lane bin
+		u32 cvmax[MPC_HMAX + 1];    // longest virtual column axis of a bin's chains
 	};
+	// Chains: consecutive pairs of the list with the same row sequence (the all-pairs order is full of them), each with
+	// LY + 1 >= T (kernels_fbc.h), up to MPCGPU_FB_CHAIN_MAX (default 8) pairs and as many columns as the forward M planes of the
+	// resident waves may take (a quarter of the free memory, 32 GB at most). MPCGPU_FB_CHAIN=0: every pair on its own (fb_kernel).
+	const bool chain_on = !mega && env_int("MPCGPU_FB_CHAIN", 1) != 0;
+	const u32 chain_max = (u32)std::min(std::max(env_int("MPCGPU_FB_CHAIN_MAX", 8), 2), MPC_CHAIN_MAX);
+	const size_t fbc_smem = ((size_t)c->A * c->A + c->A) * sizeof(float) + (size_t)waves_per_block * MPC_CHAIN_TAB_BYTES;
+	u32 chain_vcap[MPC_HMAX + 1];
+	for (u32 H = 0; H <= MPC_HMAX; ++H) chain_vcap[H] = 0;
+	if (chain_on) {
+		size_t freeb = 0, totb = 0;
+		HIPCHK(c, hipMemGetInfo(&freeb, &totb));
+		const u64 fm_budget = std::min<u64>((u64)32 << 30, (u64)((freeb + c->d_fm.cap) * 0.25));
+		for (u32 H = 1; H <= MPC_HMAX; ++H) {
+			const u64 waves = (u64)cus * (u32)occ_fbc_h((int)H, block, fbc_smem) * waves_per_block;
+			const u64 steps = fm_budget / (waves * H * 64 * 4);
+			chain_vcap[H] = steps > 64 + 2 ? (u32)std::min<u64>(steps - 64, 1u << 24) : 0;
+		}
+	}
 	auto prepare = [&](u64 b0, BatchPrep &P) -> int {
 		// ---- batch sizing: candidates + fixed-stride records per pair
 		const u64 res_stride = (u64)LXmax + LYmax + 4 * (u64)capc;
@@ -940,19 +1004,59 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		// one 64-bit key per pair: bin (5 bits) | work, descending (37 bits) | index (22 bits) — a plain integer sort (with a
 		// three-array comparator it cost 9 ms per 125 000 pairs)
 		P.bx.resize(B); P.by.resize(B); P.order.resize(B);
-		std::vector<u64> keys(B);
+		std::vector<u64> keys;
+		keys.reserve(B);
 		for (u32 h = 0; h < MPC_HMAX + 2; ++h) P.hcount[h] = 0; // bin MPC_HMAX+1: the row-block (LONG) pairs
+		for (u32 h = 0; h <= MPC_HMAX; ++h) P.ccount[h] = P.cvmax[h] = 0;
+		P.chain_first.clear(); P.chain_cnt.clear();
+		for (u64 q = 0; q < B; ++q) { P.bx[q] = px[b0 + q]; P.by[q] = py[b0 + q]; }
+		// chains first: runs of consecutive pairs with the same row sequence
+		struct Chain { u32 q0, cnt, H; u64 work; };
+		std::vector<Chain> chains;
+		std::vector<unsigned char> chained(B, 0);
+		if (chain_on) {
+			u64 q = 0;
+			while (q < B) {
+				const u32 LX = c->len[P.bx[q]];
+				const u32 H = (LX + 63) / 64;
+				const u32 T = H ? (LX + H - 1) / H : 0;
+				u64 e = q;
+				u64 V = 0;
+				if (LX < long_min && H >= 1 && H <= MPC_HMAX)
+					while (e < B && P.bx[e] == P.bx[q] && e - q < chain_max) {
+						const u32 LY = c->len[P.by[e]];
+						if (LY + 1 < T || V + LY + 1 > chain_vcap[H]) break;
+						V += LY + 1;
+						++e;
+					}
+				if (e - q >= 2) {
+					chains.push_back({(u32)q, (u32)(e - q), H, (V + T) * H});
+					for (u64 k = q; k < e; ++k) chained[k] = 1;
+					P.cvmax[H] = std::max<u32>(P.cvmax[H], (u32)V);
+					q = e;
+				} else ++q;
+			}
+		}
 		for (u64 q = 0; q < B; ++q) {
-			P.bx[q] = px[b0 + q]; P.by[q] = py[b0 + q];
+			if (chained[q]) continue;
 			const u32 LX = c->len[P.bx[q]], LY = c->len[P.by[q]];
 			const bool lng = LX >= long_min;
 			const u32 H = lng ? MPC_HMAX + 1 : (LX + 63) / 64;
 			P.hcount[H]++;
 			const u64 wk = lng ? (u64)LX * LY : (u64)(LY + (LX + H - 1) / H) * H; // < 2^37 (lengths < 2^16 when LONG, < 2^22 otherwise with H <= 16)
-			keys[q] = ((u64)H << 59) | ((((u64)1 << 37) - 1 - wk) << 22) | q;
+			keys.push_back(((u64)H << 59) | ((((u64)1 << 37) - 1 - wk) << 22) | q);
 		}
 		std::sort(keys.begin(), keys.end());
-		for (u64 q = 0; q < B; ++q) P.order[q] = (u32)(keys[q] & (((u64)1 << 22) - 1));
+		u64 at = 0;
+		for (; at < keys.size(); ++at) P.order[at] = (u32)(keys[at] & (((u64)1 << 22) - 1));
+		// the chains: by bin, longest first; their members follow the single pairs in `order`
+		std::sort(chains.begin(), chains.end(), [](const Chain &a, const Chain &b) { return a.H != b.H ? a.H < b.H : a.work != b.work ? a.work > b.work : a.q0 < b.q0; });
+		for (const Chain &ch : chains) {
+			P.ccount[ch.H]++;
+			P.chain_first.push_back((u32)at);
+			P.chain_cnt.push_back(ch.cnt);
+			for (u32 k = 0; k < ch.cnt; ++k) P.order[at++] = ch.q0 + k;
+		}
 		P.valid = true;
 		return 0;
 	};
@@ -971,6 +1075,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		const u32 *hcount = cur.hcount;
 		lap(0);
 		if (upload(c, c->d_bx, bx) || upload(c, c->d_by, by) || upload(c, c->d_order, order)) return 1;
+		if (!cur.chain_first.empty() && (upload(c, c->d_chain_first, cur.chain_first) || upload(c, c->d_chain_cnt, cur.chain_cnt))) return 1;
 		HIPCHK(c, c->d_cand.ensure(B * capc * 8));
 		HIPCHK(c, c->d_cand_cnt.ensure(B * 4));
 		HIPCHK(c, c->d_total.ensure(B * 4));
@@ -978,8 +1083,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		HIPCHK(c, c->d_nnz.ensure(B * 4));
 		HIPCHK(c, c->d_ea.ensure(B * 4));
 		HIPCHK(c, c->d_flags.ensure(B * 4));
-		HIPCHK(c, c->d_queue.ensure(4 * (MPC_HMAX + 2)));
-		HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (MPC_HMAX + 2), c->stream));
+		HIPCHK(c, c->d_queue.ensure(4 * (2 * MPC_HMAX + 4))); // single pairs per bin, then chains per bin
+		HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (2 * MPC_HMAX + 4), c->stream));
 
 		FbParams fp;
 		fill_fb_params(c, fp, c->d_bx.as<u32>(), c->d_by.as<u32>(), capc, mega);
@@ -1063,6 +1168,33 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			HIPCHK(c, hipGetLastError());
 			if (span_end(c, &sp)) return 1;
 			pos += cnt;
+		}
+		u32 cpos = 0;
+		u64 batch_chains = 0, batch_chained = 0;
+		for (u32 c2 : cur.chain_cnt) { ++batch_chains; batch_chained += c2; }
+		for (u32 H = 1; H <= MPC_HMAX; ++H) { // chains (kernels_fbc.h)
+			if (!cur.ccount[H]) continue;
+			const u32 cnt = cur.ccount[H];
+			const u32 occ = (u32)occ_fbc_h((int)H, block, fbc_smem);
+			const u32 grid = std::max(std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ), 1u);
+			const u64 fm_stride = (u64)(cur.cvmax[H] + 64) * H * 64;
+			HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
+			if (trace_on()) {
+				fprintf(stderr, "[mpcgpu] fb chains H=%u chains=%u grid=%u occ=%u longest axis=%u fm=%.1f MB\n", H, cnt, grid, occ, cur.cvmax[H],
+					(double)grid * waves_per_block * fm_stride * 4 / 1048576.0);
+				fflush(stderr);
+			}
+			FbChainParams cp;
+			cp.f = fp;
+			cp.f.order = c->d_order.as<u32>(); cp.f.count = cnt;
+			cp.f.queue = c->d_queue.as<u32>() + (MPC_HMAX + 2) + H;
+			cp.f.fm_scratch = c->d_fm.as<float>(); cp.f.fm_stride = fm_stride;
+			cp.chain_first = c->d_chain_first.as<u32>() + cpos; cp.chain_cnt = c->d_chain_cnt.as<u32>() + cpos;
+			if (span_begin(c, 0, &sp)) return 1;
+			launch_fbc_h((int)H, cp, grid, block, fbc_smem, c->stream);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &sp)) return 1;
+			cpos += cnt;
 		}
 		// ---- finish: probabilities, sort, EA, sparsify
 		if (post_rows) {
@@ -1191,6 +1323,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		// what the LAST batch left in the scratch buffers (mpcgpu_align_pairs reads the candidate lists of a one-batch stage)
 		c->sa_b0 = done; c->sa_B = B; c->sa_capc = capc; c->sa_post_rows = post_rows; c->sa_long_min = long_min;
 		done += B;
+		c->sa_chains += batch_chains; c->sa_chained += batch_chained;
 		std::swap(cur, nxt);
 		lap(4);
 	}
@@ -2253,6 +2386,15 @@ int mpcgpu_relax_info(mpcgpu_ctx *c, char *buf, uint32_t buflen, int *is_fallbac
 		snprintf(buf, buflen, "%s", d.c_str());
 	}
 	if (is_fallback) *is_fallback = c->relax_fallback ? 1 : 0;
+	return 0;
+}
+
+int mpcgpu_stage_a_info(mpcgpu_ctx *c, uint64_t *pairs, uint64_t *chained_pairs, uint64_t *chains)
+{
+	if (!c) return 1;
+	if (pairs) *pairs = c->sa_pairs;
+	if (chained_pairs) *chained_pairs = c->sa_chained;
+	if (chains) *chains = c->sa_chains;
 	return 0;
 }
 

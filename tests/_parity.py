@@ -11,8 +11,9 @@ def bits(a):
     return np.asarray(a, np.float32).view(np.uint32)
 
 
-def run_lib(seqs, iters=2, lib_path=None, hmm_name="hmm_amino", expf_variant=-1, mega=None):
-    """mega = dict(alpha, weight, lp, mx, profs): stage A on structure profiles (mpcgpu_set_mega)"""
+def run_lib(seqs, iters=2, lib_path=None, hmm_name="hmm_amino", expf_variant=-1, mega=None, info=None):
+    """mega = dict(alpha, weight, lp, mx, profs): stage A on structure profiles (mpcgpu_set_mega); info: a dict that receives
+    stage_a_info"""
     s, t, m, i, thr = G.hmm_tables(hmm_name)
     g = MpcGpu(0, lib_path)
     g.set_hmm(s, t, m, i, thr, expf_variant)
@@ -20,6 +21,8 @@ def run_lib(seqs, iters=2, lib_path=None, hmm_name="hmm_amino", expf_variant=-1,
     if mega is not None:
         g.set_mega(mega["alpha"], mega["weight"], mega["lp"], mega["mx"], mega["profs"])
     g.calc_posteriors()
+    if info is not None:
+        info["stage_a_info"] = g.stage_a_info()
     ea = g.get_ea().copy()
     g.build_store()
     stages = [g.get_sparse_range()]
@@ -234,3 +237,32 @@ def check_align_pairs_golden(name="ap_ragged", lib_path=None):
         else:
             os.environ["MPCGPU_PAIRS_SMALL"] = old
     g.close()
+
+
+def check_fb_chains(lib_path=None):
+    """fb_chain_kernel (kernels_fbc.h: consecutive pairs with the same row sequence swept back to back) against fb_kernel
+    (MPCGPU_FB_CHAIN=0) and the oracle: lengths that give 1, 2 and 3 rows per lane, chains cut by the length rule (LY + 1 < T),
+    by the chain limit (2, 3, 8 pairs) and by the end of a row's run of pairs; every stage snapshot and EA bit for bit."""
+    import os
+    from muscle_amd.synth import make_family
+    fams = [make_family(7, 40, seed=21), make_family(6, 150, seed=22),
+            make_family(3, 90, seed=23) + make_family(2, 30, seed=24) + make_family(3, 140, seed=25) + ["MKV", "ACDEFGHIKLMNPQRSTVWY" * 5]]
+    old = {k: os.environ.get(k) for k in ("MPCGPU_FB_CHAIN", "MPCGPU_FB_CHAIN_MAX")}
+    try:
+        for seqs in fams:
+            want = run_oracle(seqs)
+            os.environ["MPCGPU_FB_CHAIN"] = "0"
+            assert_same(run_lib(seqs, lib_path=lib_path), want, "fb_kernel")
+            for cmax in ("2", "3", "8"):
+                os.environ["MPCGPU_FB_CHAIN"] = "1"
+                os.environ["MPCGPU_FB_CHAIN_MAX"] = cmax
+                info = {}
+                got = run_lib(seqs, lib_path=lib_path, info=info)
+                assert_same(got, want, "chains of up to %s" % cmax)
+                assert info["stage_a_info"][1] >= 2, info  # chains did form
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

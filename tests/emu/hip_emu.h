@@ -95,7 +95,7 @@ template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xch
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
 #define MPC_OPAQUE(v) ((void)0)
 #define MPC_SCHED_BARRIER() ((void)0)
-#define MPC_WAVE_LDS_ORDER() __syncthreads() // the emulator runs lanes one after the other between synchronisation points
+#define MPC_WAVE_LDS_ORDER() ((void)__shfl(0, 0)) // a rendezvous of the WAVE (any collective is one): the emulator runs lanes one after the other between synchronisation points
 #define MPC_WAVE_FENCE() ((void)0) // emulated lanes meet at every shuffle
 template <class T> static inline T mpc_read_lane(T v, unsigned l) { return __shfl(v, (int)l); }
 static inline unsigned mpc_lane_gather(unsigned v, unsigned byte_index) { return __shfl(v, (int)(byte_index / 4u)); }

@@ -469,3 +469,8 @@ def test_emu_buildpost_vs_reference_golden(emu, name, mode):
 def test_emu_align_pairs_vs_reference_golden(emu):
     """AlignPairFlat on the device against the compiled reference's AlignPairFlat_SparsePost (alignpairflat.cpp:3-27)."""
     P.check_align_pairs_golden("ap_ragged", emu)
+
+
+def test_emu_fb_chains(emu):
+    """pairs that share their row sequence swept back to back (kernels_fbc.h) == one pair per sweep == the oracle"""
+    P.check_fb_chains(emu)

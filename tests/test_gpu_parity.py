@@ -564,3 +564,9 @@ def test_align_pairs_vs_reference_golden():
     """mpcgpu_align_pairs / mpcgpu_get_list_sparse against the compiled reference's AlignPairFlat_SparsePost
     (alignpairflat.cpp:3-27; callers uclust.cpp:14, transaln.cpp:787, eadistmx.cpp:54): path, EA bits, FromPost matrix."""
     P.check_align_pairs_golden("ap_ragged")
+
+
+@pytest.mark.gpu
+def test_fb_chains():
+    """pairs that share their row sequence swept back to back (kernels_fbc.h) == one pair per sweep == the oracle"""
+    P.check_fb_chains()
