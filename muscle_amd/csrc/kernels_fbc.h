@@ -300,21 +300,42 @@ __global__ void __launch_bounds__(256, (H == 8) ? 4 : 1) fb_chain_kernel(FbChain
 			if (__ballot(anyhit)) {
 				u64 *candA = p.cand + (u64)pidA * p.capc, *candB = p.cand + (u64)pidB * p.capc;
 				const u64 below = (1ull << t) - 1ull;
+				if (vbB >= Vlead && vbB <= Vlead + (T - 1)) { // the boundary is inside the wave: two lists grow
 #pragma unroll
-				for (int r = 0; r < H; ++r) {
-					const int i = t * H + r + 1;
-					const bool hit = (i <= LX) && incol && (sc[r] >= p.thr);
-					const u64 bal = __ballot(hit);
-					if (bal) {
-						const u64 balB = __ballot(hit && lo), balA = bal & ~balB;
-						const u32 pos = lo ? ncB + (u32)__popcll(balB & below) : ncA + (u32)__popcll(balA & below);
-						if (hit && pos < p.capc) {
-							const u32 idx = ((u32)(i - 1) << MPC_KEY_ROW_SHIFT) | (u32)(j - 1);
-							(lo ? candB : candA)[pos] = ((u64)idx << 32) | (u64)__float_as_uint(sc[r]);
+					for (int r = 0; r < H; ++r) {
+						const int i = t * H + r + 1;
+						const bool hit = (i <= LX) && incol && (sc[r] >= p.thr);
+						const u64 bal = __ballot(hit);
+						if (bal) {
+							const u64 balB = __ballot(hit && lo), balA = bal & ~balB;
+							const u32 pos = lo ? ncB + (u32)__popcll(balB & below) : ncA + (u32)__popcll(balA & below);
+							if (hit && pos < p.capc) {
+								const u32 idx = ((u32)(i - 1) << MPC_KEY_ROW_SHIFT) | (u32)(j - 1);
+								(lo ? candB : candA)[pos] = ((u64)idx << 32) | (u64)__float_as_uint(sc[r]);
+							}
+							ncA += (u32)__popcll(balA);
+							ncB += (u32)__popcll(balB);
 						}
-						ncA += (u32)__popcll(balA);
-						ncB += (u32)__popcll(balB);
 					}
+				} else { // every lane is in the same pair: as in fb_kernel
+					const bool allB = Vlead + (T - 1) < vbB; // wave-uniform
+					u64 *cand1 = allB ? candB : candA;
+					u32 nc1 = allB ? ncB : ncA;
+#pragma unroll
+					for (int r = 0; r < H; ++r) {
+						const int i = t * H + r + 1;
+						const bool hit = (i <= LX) && incol && (sc[r] >= p.thr);
+						const u64 bal = __ballot(hit);
+						if (bal) {
+							const u32 pos = nc1 + (u32)__popcll(bal & below);
+							if (hit && pos < p.capc) {
+								const u32 idx = ((u32)(i - 1) << MPC_KEY_ROW_SHIFT) | (u32)(j - 1);
+								cand1[pos] = ((u64)idx << 32) | (u64)__float_as_uint(sc[r]);
+							}
+							nc1 += (u32)__popcll(bal);
+						}
+					}
+					if (allB) ncB = nc1; else ncA = nc1;
 				}
 			}
 			if (Vlead + (T - 1) == vbB) { // lane 0 has left pair A: its list is complete, B becomes A

@@ -975,6 +975,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	// resident waves may take (a quarter of the free memory, 32 GB at most). MPCGPU_FB_CHAIN=0: every pair on its own (fb_kernel).
 	const bool chain_on = !mega && env_int("MPCGPU_FB_CHAIN", 1) != 0;
 	const u32 chain_max = (u32)std::min(std::max(env_int("MPCGPU_FB_CHAIN_MAX", 8), 2), MPC_CHAIN_MAX);
+	const bool chain_grade = env_int("MPCGPU_FB_CHAIN_GRADE", 1) != 0; // 0: no shorter chains at the end of a launch (tests)
 	const size_t fbc_smem = ((size_t)c->A * c->A + c->A) * sizeof(float) + (size_t)waves_per_block * MPC_CHAIN_TAB_BYTES;
 	u32 chain_vcap[MPC_HMAX + 1];
 	for (u32 H = 0; H <= MPC_HMAX; ++H) chain_vcap[H] = 0;
@@ -1010,31 +1011,68 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		for (u32 h = 0; h <= MPC_HMAX; ++h) P.ccount[h] = P.cvmax[h] = 0;
 		P.chain_first.clear(); P.chain_cnt.clear();
 		for (u64 q = 0; q < B; ++q) { P.bx[q] = px[b0 + q]; P.by[q] = py[b0 + q]; }
-		// chains first: runs of consecutive pairs with the same row sequence
+		// chains first: runs of consecutive pairs with the same row sequence. Every pair the chain kernel can take goes to it (a
+		// pair on its own is a chain of one), so a bin is ONE launch; the chains of a launch are served longest first, and the
+		// last ones are cut shorter (4, 2, 1 pairs for about one round of the resident waves each) so that the waves finish together
 		struct Chain { u32 q0, cnt, H; u64 work; };
 		std::vector<Chain> chains;
 		std::vector<unsigned char> chained(B, 0);
 		if (chain_on) {
+			auto work_of = [&](u32 q0, u32 cnt, u32 H, u32 T) {
+				u64 V = 0;
+				for (u32 k = 0; k < cnt; ++k) V += c->len[P.by[q0 + k]] + 1;
+				return (V + T) * H;
+			};
 			u64 q = 0;
 			while (q < B) {
 				const u32 LX = c->len[P.bx[q]];
 				const u32 H = (LX + 63) / 64;
-				const u32 T = H ? (LX + H - 1) / H : 0;
+				if (LX >= long_min || H < 1 || H > MPC_HMAX || c->len[P.by[q]] + 1 > chain_vcap[H]) { ++q; continue; }
+				const u32 T = (LX + H - 1) / H;
 				u64 e = q;
 				u64 V = 0;
-				if (LX < long_min && H >= 1 && H <= MPC_HMAX)
-					while (e < B && P.bx[e] == P.bx[q] && e - q < chain_max) {
-						const u32 LY = c->len[P.by[e]];
-						if (LY + 1 < T || V + LY + 1 > chain_vcap[H]) break;
-						V += LY + 1;
-						++e;
+				while (e < B && P.bx[e] == P.bx[q] && e - q < chain_max) {
+					const u32 LY = c->len[P.by[e]];
+					if (LY + 1 < T || V + LY + 1 > chain_vcap[H]) break;
+					V += LY + 1;
+					++e;
+				}
+				if (e == q) e = q + 1; // a pair too short to chain: on its own
+				chains.push_back({(u32)q, (u32)(e - q), H, 0});
+				for (u64 k = q; k < e; ++k) chained[k] = 1;
+				q = e;
+			}
+			for (Chain &ch : chains) { const u32 LX = c->len[P.bx[ch.q0]]; ch.work = work_of(ch.q0, ch.cnt, ch.H, (LX + ch.H - 1) / ch.H); }
+			auto by_bin_and_work = [](const Chain &a, const Chain &b) { return a.H != b.H ? a.H < b.H : a.work != b.work ? a.work > b.work : a.q0 < b.q0; };
+			std::sort(chains.begin(), chains.end(), by_bin_and_work);
+			// the short end of every bin
+			std::vector<Chain> graded;
+			graded.reserve(chains.size() * 2);
+			size_t lo = 0;
+			while (lo < chains.size()) {
+				size_t hi = lo;
+				while (hi < chains.size() && chains[hi].H == chains[lo].H) ++hi;
+				const u32 H = chains[lo].H;
+				const u64 waves = (u64)cus * (u32)occ_fbc_h((int)H, block, fbc_smem) * waves_per_block;
+				u64 seen = 0; // pairs, counted from the end of the bin
+				for (size_t k = hi; k-- > lo;) {
+					const Chain &ch = chains[k];
+					const u32 piece = !chain_grade ? ch.cnt : seen < waves ? 1u : seen < 3 * waves ? 2u : seen < 7 * waves ? 4u : ch.cnt;
+					seen += ch.cnt;
+					const u32 LX = c->len[P.bx[ch.q0]];
+					for (u32 o = 0; o < ch.cnt; o += piece) {
+						const u32 n = std::min(piece, ch.cnt - o);
+						graded.push_back({ch.q0 + o, n, H, work_of(ch.q0 + o, n, H, (LX + H - 1) / H)});
 					}
-				if (e - q >= 2) {
-					chains.push_back({(u32)q, (u32)(e - q), H, (V + T) * H});
-					for (u64 k = q; k < e; ++k) chained[k] = 1;
-					P.cvmax[H] = std::max<u32>(P.cvmax[H], (u32)V);
-					q = e;
-				} else ++q;
+				}
+				lo = hi;
+			}
+			std::sort(graded.begin(), graded.end(), by_bin_and_work);
+			chains.swap(graded);
+			for (const Chain &ch : chains) {
+				u64 V = 0;
+				for (u32 k = 0; k < ch.cnt; ++k) V += c->len[P.by[ch.q0 + k]] + 1;
+				P.cvmax[ch.H] = std::max<u32>(P.cvmax[ch.H], (u32)V);
 			}
 		}
 		for (u64 q = 0; q < B; ++q) {
@@ -1049,8 +1087,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		std::sort(keys.begin(), keys.end());
 		u64 at = 0;
 		for (; at < keys.size(); ++at) P.order[at] = (u32)(keys[at] & (((u64)1 << 22) - 1));
-		// the chains: by bin, longest first; their members follow the single pairs in `order`
-		std::sort(chains.begin(), chains.end(), [](const Chain &a, const Chain &b) { return a.H != b.H ? a.H < b.H : a.work != b.work ? a.work > b.work : a.q0 < b.q0; });
+		// the chains: by bin, longest first; their members follow the other pairs in `order`
 		for (const Chain &ch : chains) {
 			P.ccount[ch.H]++;
 			P.chain_first.push_back((u32)at);
@@ -1171,7 +1208,7 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		}
 		u32 cpos = 0;
 		u64 batch_chains = 0, batch_chained = 0;
-		for (u32 c2 : cur.chain_cnt) { ++batch_chains; batch_chained += c2; }
+		for (u32 c2 : cur.chain_cnt) if (c2 >= 2) { ++batch_chains; batch_chained += c2; }
 		for (u32 H = 1; H <= MPC_HMAX; ++H) { // chains (kernels_fbc.h)
 			if (!cur.ccount[H]) continue;
 			const u32 cnt = cur.ccount[H];

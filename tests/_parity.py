@@ -247,19 +247,21 @@ def check_fb_chains(lib_path=None):
     from muscle_amd.synth import make_family
     fams = [make_family(7, 40, seed=21), make_family(6, 150, seed=22),
             make_family(3, 90, seed=23) + make_family(2, 30, seed=24) + make_family(3, 140, seed=25) + ["MKV", "ACDEFGHIKLMNPQRSTVWY" * 5]]
-    old = {k: os.environ.get(k) for k in ("MPCGPU_FB_CHAIN", "MPCGPU_FB_CHAIN_MAX")}
+    old = {k: os.environ.get(k) for k in ("MPCGPU_FB_CHAIN", "MPCGPU_FB_CHAIN_MAX", "MPCGPU_FB_CHAIN_GRADE")}
     try:
         for seqs in fams:
             want = run_oracle(seqs)
             os.environ["MPCGPU_FB_CHAIN"] = "0"
             assert_same(run_lib(seqs, lib_path=lib_path), want, "fb_kernel")
-            for cmax in ("2", "3", "8"):
+            for cmax, grade in (("2", "0"), ("3", "0"), ("8", "0"), ("8", "1")):
                 os.environ["MPCGPU_FB_CHAIN"] = "1"
                 os.environ["MPCGPU_FB_CHAIN_MAX"] = cmax
+                os.environ["MPCGPU_FB_CHAIN_GRADE"] = grade  # 1: shorter chains at the end of a launch (the default)
                 info = {}
                 got = run_lib(seqs, lib_path=lib_path, info=info)
                 assert_same(got, want, "chains of up to %s" % cmax)
-                assert info["stage_a_info"][1] >= 2, info  # chains did form
+                if grade == "0":
+                    assert info["stage_a_info"][1] >= 4 and info["stage_a_info"][2] >= 2, info  # chains did form
     finally:
         for k, v in old.items():
             if v is None:
