@@ -295,7 +295,12 @@ def main():
             avg_s = ms * 1e-3 / max(launches, 1)
             per_launch = stage_a_flops(lens) * my_frac * a.steps / max(launches, 1)  # all pairs of this rank per step, over launches/steps batches
             achieved = per_launch / avg_s / 1e12
-            r = {"kernel": "fb_kernel<H> (pair-HMM fwd+bwd+posterior threshold, one wave per pair)",
+            sa_pairs, sa_chained, sa_chains = g.stage_a_info()
+            chained = sa_chained > 0
+            fb_name = "fb_chain_kernel" if chained else "fb_kernel"
+            r = {"kernel": ("fb_chain_kernel<H> (pair-HMM fwd+bwd+posterior threshold; one wave sweeps a chain of pairs that share their row "
+                            "sequence, no systolic fill/drain in between: %d of %d pairs in %d chains of 2..16)" % (sa_chained, sa_pairs, sa_chains))
+                           if chained else "fb_kernel<H> (pair-HMM fwd+bwd+posterior threshold, one wave per pair)",
                  "launches": launches, "avg_launch_ms": ms / max(launches, 1),
                  "algorithmic_TFLOPs": achieved, "frac_of_fp32_vector_peak": achieved / FP32_PEAK_TFLOPS, "no_fma_add_mul_peak_TFLOPs": 63.0,
                  "note": "FP32 vector-ALU bound log-space recurrence: no contraction (parity), no MFMA shape. bound / frac as for the relax "
@@ -303,7 +308,7 @@ def main():
                          "the launch's pairs of 164(LX+1)(LY+1)+5LXLY flop (SURVEY.md 8d) / launch time; frac_of_fp32_vector_peak is against "
                          "157.3 TFLOP/s, which counts v_pk_fma_f32 — measured on this chip (diag/pkbench, profiles/r02b_pkbench.log) plain "
                          "add/mul issue at 63 Tlane-op/s and min/max/cvt/select at 0.6 of that, so 63 TFLOP/s is the ceiling of an FMA-free stream."}
-            return measured_roof(r, pmc_entry("fb_kernel", *fixture_shape), avg_s, 1.27, None)
+            return measured_roof(r, pmc_entry(fb_name, *fixture_shape), avg_s, 1.27, fb_name)
 
         roof = relax_roof() if timers["relax"][0] >= timers["fb"][0] else fb_roof()
         roof_other = fb_roof() if timers["relax"][0] >= timers["fb"][0] else relax_roof()

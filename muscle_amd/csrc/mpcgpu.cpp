@@ -971,10 +971,10 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		u32 cvmax[MPC_HMAX + 1];    // longest virtual column axis of a bin's chains
 	};
 	// Chains: consecutive pairs of the list with the same row sequence (the all-pairs order is full of them), each with
-	// LY + 1 >= T (kernels_fbc.h), up to MPCGPU_FB_CHAIN_MAX (default 8) pairs and as many columns as the forward M planes of the
+	// LY + 1 >= T (kernels_fbc.h), up to MPCGPU_FB_CHAIN_MAX (default 16) pairs and as many columns as the forward M planes of the
 	// resident waves may take (a quarter of the free memory, 32 GB at most). MPCGPU_FB_CHAIN=0: every pair on its own (fb_kernel).
 	const bool chain_on = !mega && env_int("MPCGPU_FB_CHAIN", 1) != 0;
-	const u32 chain_max = (u32)std::min(std::max(env_int("MPCGPU_FB_CHAIN_MAX", 8), 2), MPC_CHAIN_MAX);
+	const u32 chain_max = (u32)std::min(std::max(env_int("MPCGPU_FB_CHAIN_MAX", 16), 2), MPC_CHAIN_MAX);
 	const bool chain_grade = env_int("MPCGPU_FB_CHAIN_GRADE", 1) != 0; // 0: no shorter chains at the end of a launch (tests)
 	const size_t fbc_smem = ((size_t)c->A * c->A + c->A) * sizeof(float) + (size_t)waves_per_block * MPC_CHAIN_TAB_BYTES;
 	u32 chain_vcap[MPC_HMAX + 1];
