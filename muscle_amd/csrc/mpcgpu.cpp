@@ -150,6 +150,9 @@ struct mpcgpu_ctx {
 	bool relax_fallback = false;
 	// tile list of the LDS-tiled relax, cached per pair range (the sparsity pattern is frozen)
 	std::vector<u32> h_tiles;
+	std::vector<u32> h_tiles2; // tiles of the pairs that only fit the one-workgroup-per-CU geometry (var_mixed)
+	DevBuf d_tiles2;
+	bool var_mixed = false;    // two launches per relax: the configured geometry + 1 x 1024 threads / 160 KB for what does not fit it
 	u64 tiles_k0 = ~0ull, tiles_k1 = ~0ull;
 	u32 tiles_bx = 0, tiles_by = 0;
 
@@ -406,7 +409,8 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 // run two per CU.
 void var_lds_geometry(u32 geo, u32 nbuf, u32 *buf_bytes, size_t *smem)
 {
-	const u64 lds_cap = (u64)env_int("MPCGPU_RELAX_LDS_KB", geo == 1024 ? 160 : 80) * 1024;
+	// MPCGPU_RELAX_LDS_KB: tests shrink the budget to reach tile splitting with short sequences (_1024: the one-workgroup geometry alone)
+	const u64 lds_cap = (u64)(geo == 1024 ? env_int("MPCGPU_RELAX_LDS_KB_1024", env_int("MPCGPU_RELAX_LDS_KB", 160)) : env_int("MPCGPU_RELAX_LDS_KB", 80)) * 1024;
 	*buf_bytes = (u32)(((lds_cap - MPC_RV_TAB_BYTES) / nbuf) & ~15ull);
 	*smem = MPC_RV_TAB_BYTES + (size_t)nbuf * *buf_bytes;
 }
@@ -430,103 +434,19 @@ template <int TH, int SL, int WGS, int DG = 0, class BL = MpcRvBlocksAsm> void l
 	MPC_LAUNCH(kern, grid, TH, smem, st, rp);
 }
 
-int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
+// launches relax_var_kernel of geometry `geo` (see var_max_slots) over a tile list
+static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1, u32 geo, u32 nbuf, const DevBuf &d_tiles, u32 ntiles,
+	u32 counter_slot, bool primary)
 {
-	const u32 n = c->n;
-	const u32 geo = c->var_threads, nbuf = c->var_nbuf;
 	const u32 threads = geo == 2048 ? 1024u : geo;
 	u32 buf_bytes = 0;
 	size_t smem = 0;
 	var_lds_geometry(geo, nbuf, &buf_bytes, &smem);
-	const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)var_max_slots(geo)), 1), (int)var_max_slots(geo));
-	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
-	// slots a tile needs: the cells of its pairs in [k0,k1), every pair rounded up to whole waves, in chunks of `threads`
-	auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
-		u64 cells = 0;
-		for (u32 X = x0; X < x0 + nx; ++X)
-			for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
-				const u64 k = pidx(X, Y);
-				if (k >= k0 && k < k1) cells += ((u64)c->all_nnz[k] + 63) & ~63ull;
-			}
-		return (u32)((cells + threads - 1) / threads);
-	};
-	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != 4 || c->tiles_by != 4) {
-		std::vector<u32> tiles;
-		bool too_big = false;
-		std::function<void(u32, u32, u32, u32)> emit = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
-			const u32 slots = tile_slots(x0, nx, y0, ny);
-			if (slots == 0) return;
-			if (slots <= max_slots) { tiles.push_back(x0); tiles.push_back(nx); tiles.push_back(y0); tiles.push_back(ny); return; }
-			if (ny > 1) { emit(x0, nx, y0, ny / 2); emit(x0, nx, y0 + ny / 2, ny - ny / 2); }
-			else if (nx > 1) { emit(x0, nx / 2, y0, ny); emit(x0 + nx / 2, nx - nx / 2, y0, ny); }
-			else too_big = true;
-		};
-		// X blocks of 4, Y blocks of 4, walked in 8x8 super-tiles (the workgroups of an XCD read the same sequences' records)
-		const u32 nbx = (n + 3) / 4, nby = (n + 3) / 4;
-		for (u32 sx = 0; sx < nbx; sx += 8)
-			for (u32 sy = 0; sy < nby; sy += 8)
-				for (u32 xb = sx; xb < std::min(sx + 8, nbx); ++xb)
-					for (u32 yb = sy; yb < std::min(sy + 8, nby); ++yb) {
-						const u32 x0 = xb * 4, nx = std::min(4u, n - x0), y0 = yb * 4, ny = std::min(4u, n - y0);
-						if (y0 + ny <= x0 + 1) continue; // no pair X < Y in this block
-						emit(x0, nx, y0, ny);
-					}
-		c->tiles_k0 = c->tiles_k1 = ~0ull;
-		if (too_big) return fail(c, "mpcgpu_cons_iter: a pair has more than %u stored cells (tile slot budget)", max_slots * threads);
-		// LDS fit: a tile's records of one step, packed back to back, must fit one staging buffer at EVERY step. The worst
-		// step of every tile is measured on the device; the few tiles over the budget are split and measured again.
-		const u32 budget_blocks = buf_bytes / 16;
-		std::vector<u32> ok;
-		for (int round = 0; round < 8 && !tiles.empty(); ++round) {
-			const u32 nt = (u32)(tiles.size() / 4);
-			if (upload(c, c->d_tiles, tiles)) return 1;
-			HIPCHK(c, c->d_tilefit.ensure((size_t)nt * 4));
-			MPC_LAUNCH(var_tile_fit_kernel, std::min<u32>(nt, (u32)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_tiles.as<u32>(), nt,
-				c->d_tilefit.as<u32>());
-			HIPCHK(c, hipGetLastError());
-			std::vector<u32> fit(nt);
-			HIPCHK(c, hipMemcpyAsync(fit.data(), c->d_tilefit.p, (size_t)nt * 4, hipMemcpyDeviceToHost, c->stream));
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			std::vector<u32> next;
-			u32 nsplit = 0;
-			for (u32 t = 0; t < nt; ++t) {
-				const u32 x0 = tiles[4 * t], nx = tiles[4 * t + 1], y0 = tiles[4 * t + 2], ny = tiles[4 * t + 3];
-				if (fit[t] <= budget_blocks) { ok.insert(ok.end(), {x0, nx, y0, ny}); continue; }
-				++nsplit;
-				auto push = [&](u32 a, u32 b, u32 cc, u32 d) { if (tile_slots(a, b, cc, d)) next.insert(next.end(), {a, b, cc, d}); };
-				if (ny > 1) { push(x0, nx, y0, ny / 2); push(x0, nx, y0 + ny / 2, ny - ny / 2); }
-				else if (nx > 1) { push(x0, nx / 2, y0, ny); push(x0 + nx / 2, nx - nx / 2, y0, ny); }
-				else return fail(c, "mpcgpu_cons_iter: the two records of pair (%u,%u) need %u bytes of LDS at some step, one staging buffer holds %u",
-					x0, y0, fit[t] * 16, buf_bytes);
-			}
-			if (trace_on() && nsplit) { fprintf(stderr, "[mpcgpu] relax var: %u of %u tiles over the LDS budget (%u B), split\n", nsplit, nt, buf_bytes); fflush(stderr); }
-			tiles.swap(next);
-		}
-		if (!tiles.empty()) return fail(c, "mpcgpu_cons_iter: tile splitting did not converge");
-		{
-			u32 hist[5][5] = {{0}};
-			for (size_t t = 0; t + 3 < ok.size(); t += 4) hist[std::min(ok[t + 1], 4u)][std::min(ok[t + 3], 4u)]++;
-			char b[256];
-			int o = snprintf(b, sizeof(b), "%zu tiles:", ok.size() / 4);
-			for (u32 a = 4; a >= 1; --a)
-				for (u32 bb = 4; bb >= 1; --bb)
-					if (hist[a][bb] && o < (int)sizeof(b) - 24) o += snprintf(b + o, sizeof(b) - o, " %ux%u x %u", a, bb, hist[a][bb]);
-			c->tiles_desc = b;
-		}
-		c->h_tiles.swap(ok);
-		if (upload(c, c->d_tiles, c->h_tiles)) return 1;
-		HIPCHK(c, hipStreamSynchronize(c->stream)); // the source of the async copy lives in the context; drained before any rebuild
-		c->tiles_k0 = k0; c->tiles_k1 = k1; c->tiles_bx = 4; c->tiles_by = 4;
-	}
-	const std::vector<u32> &tiles = c->h_tiles;
-	if (tiles.empty()) return 0;
 	RelaxVarParams rp;
-	rp.s = sp; rp.tiles = c->d_tiles.as<u32>(); rp.ntiles = (u32)(tiles.size() / 4);
+	rp.s = sp; rp.tiles = d_tiles.as<u32>(); rp.ntiles = ntiles;
 	rp.k0 = k0; rp.k1 = k1; rp.nbuf = nbuf; rp.buf_bytes = buf_bytes;
-	HIPCHK(c, c->d_tile_next.ensure(8 * 4));
-	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 8 * 4, c->stream));
-	rp.tile_next = c->d_tile_next.as<u32>();
-	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only (results wrong): 1 = staging only, 2 = merges only
+	rp.tile_next = c->d_tile_next.as<u32>() + 8 * counter_slot;
+	const int diag = primary ? env_int("MPCGPU_RELAX_DIAG", 0) : 0; // measurement only (results wrong): 1 = staging only, 2 = merges only
 	const char *merge_env = getenv("MPCGPU_RELAX_MERGE"); // "cxx": the compiler's code for the merge instead of the hand-scheduled one (A/B, 768 geometry)
 	const bool merge_cxx = merge_env && !strcmp(merge_env, "cxx");
 	const void *fn = geo == 1024 ? (const void *)relax_var_kernel<1024, 16, 1>
@@ -535,7 +455,7 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	                               : merge_cxx ? (const void *)relax_var_kernel<768, 18, 2, 0, MpcRvBlocksCxx> : (const void *)relax_var_kernel<768, 18, 2>)
 	               : (const void *)relax_var_kernel<512, 26, 2>;
 	HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-	{
+	if (primary) {
 		char kn[128];
 		snprintf(kn, sizeof(kn), "relax_var_kernel<%u, %u, %d, %d, %s>", threads, geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : 26u,
 			geo == 1024 ? 1 : 2, geo == 768 ? diag : 0, (geo == 768 && merge_cxx && !diag) ? "MpcRvBlocksCxx" : "MpcRvBlocksAsm");
@@ -562,6 +482,116 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	else launch_relax_var<512, 26, 2>(rp, grid, smem, c->stream);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
+	return 0;
+}
+
+int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
+{
+	const u32 n = c->n;
+	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
+	// Tiles of geometry (geo, nbuf) out of a list of candidate tiles: a tile is kept when its cells fit the register slots and its
+	// records of one step, packed back to back, fit one staging buffer at EVERY step (the worst step of every tile is measured on
+	// the device); others are split (Y first, then X) and measured again. Single pairs that still do not fit go to `leftover`
+	// (when given: the second geometry takes them) or fail the call.
+	auto build_tiles = [&](u32 geo, u32 nbuf, std::vector<u32> cand, std::vector<u32> &ok, std::vector<u32> *leftover) -> int {
+		const u32 threads = geo == 2048 ? 1024u : geo;
+		u32 buf_bytes = 0;
+		size_t smem = 0;
+		var_lds_geometry(geo, nbuf, &buf_bytes, &smem);
+		const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)var_max_slots(geo)), 1), (int)var_max_slots(geo));
+		// slots a tile needs: the cells of its pairs in [k0,k1), every pair rounded up to whole waves, in chunks of `threads`
+		auto tile_slots = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
+			u64 cells = 0;
+			for (u32 X = x0; X < x0 + nx; ++X)
+				for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
+					const u64 k = pidx(X, Y);
+					if (k >= k0 && k < k1) cells += ((u64)c->all_nnz[k] + 63) & ~63ull;
+				}
+			return (u32)((cells + threads - 1) / threads);
+		};
+		std::vector<u32> tiles;
+		bool too_big = false;
+		std::function<void(u32, u32, u32, u32)> emit = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
+			const u32 slots = tile_slots(x0, nx, y0, ny);
+			if (slots == 0) return;
+			if (slots <= max_slots) { tiles.insert(tiles.end(), {x0, nx, y0, ny}); return; }
+			if (ny > 1) { emit(x0, nx, y0, ny / 2); emit(x0, nx, y0 + ny / 2, ny - ny / 2); }
+			else if (nx > 1) { emit(x0, nx / 2, y0, ny); emit(x0 + nx / 2, nx - nx / 2, y0, ny); }
+			else if (leftover) leftover->insert(leftover->end(), {x0, nx, y0, ny});
+			else too_big = true;
+		};
+		for (size_t t = 0; t + 3 < cand.size(); t += 4) emit(cand[t], cand[t + 1], cand[t + 2], cand[t + 3]);
+		if (too_big) return fail(c, "mpcgpu_cons_iter: a pair has more than %u stored cells (tile slot budget)", max_slots * threads);
+		const u32 budget_blocks = buf_bytes / 16;
+		for (int round = 0; round < 8 && !tiles.empty(); ++round) {
+			const u32 nt = (u32)(tiles.size() / 4);
+			if (upload(c, c->d_tiles, tiles)) return 1;
+			HIPCHK(c, c->d_tilefit.ensure((size_t)nt * 4));
+			MPC_LAUNCH(var_tile_fit_kernel, std::min<u32>(nt, (u32)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_tiles.as<u32>(), nt,
+				c->d_tilefit.as<u32>());
+			HIPCHK(c, hipGetLastError());
+			std::vector<u32> fit(nt);
+			HIPCHK(c, hipMemcpyAsync(fit.data(), c->d_tilefit.p, (size_t)nt * 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			std::vector<u32> next;
+			u32 nsplit = 0;
+			for (u32 t = 0; t < nt; ++t) {
+				const u32 x0 = tiles[4 * t], nx = tiles[4 * t + 1], y0 = tiles[4 * t + 2], ny = tiles[4 * t + 3];
+				if (fit[t] <= budget_blocks) { ok.insert(ok.end(), {x0, nx, y0, ny}); continue; }
+				++nsplit;
+				auto push = [&](u32 a, u32 b, u32 cc, u32 d) { if (tile_slots(a, b, cc, d)) next.insert(next.end(), {a, b, cc, d}); };
+				if (ny > 1) { push(x0, nx, y0, ny / 2); push(x0, nx, y0 + ny / 2, ny - ny / 2); }
+				else if (nx > 1) { push(x0, nx / 2, y0, ny); push(x0 + nx / 2, nx - nx / 2, y0, ny); }
+				else if (leftover) leftover->insert(leftover->end(), {x0, nx, y0, ny});
+				else return fail(c, "mpcgpu_cons_iter: the two records of pair (%u,%u) need %u bytes of LDS at some step, one staging buffer holds %u",
+					x0, y0, fit[t] * 16, buf_bytes);
+			}
+			if (trace_on() && nsplit) { fprintf(stderr, "[mpcgpu] relax var: %u of %u tiles over the LDS budget (%u B), split\n", nsplit, nt, buf_bytes); fflush(stderr); }
+			tiles.swap(next);
+		}
+		if (!tiles.empty()) return fail(c, "mpcgpu_cons_iter: tile splitting did not converge");
+		return 0;
+	};
+	auto describe = [](const std::vector<u32> &ok) {
+		u32 hist[5][5] = {{0}};
+		for (size_t t = 0; t + 3 < ok.size(); t += 4) hist[std::min(ok[t + 1], 4u)][std::min(ok[t + 3], 4u)]++;
+		char b[256];
+		int o = snprintf(b, sizeof(b), "%zu tiles:", ok.size() / 4);
+		for (u32 a = 4; a >= 1; --a)
+			for (u32 bb = 4; bb >= 1; --bb)
+				if (hist[a][bb] && o < (int)sizeof(b) - 24) o += snprintf(b + o, sizeof(b) - o, " %ux%u x %u", a, bb, hist[a][bb]);
+		return std::string(b);
+	};
+	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != 4 || c->tiles_by != 4) {
+		c->tiles_k0 = c->tiles_k1 = ~0ull;
+		// X blocks of 4, Y blocks of 4, walked in 8x8 super-tiles (the workgroups of an XCD read the same sequences' records)
+		std::vector<u32> cand;
+		const u32 nbx = (n + 3) / 4, nby = (n + 3) / 4;
+		for (u32 sx = 0; sx < nbx; sx += 8)
+			for (u32 sy = 0; sy < nby; sy += 8)
+				for (u32 xb = sx; xb < std::min(sx + 8, nbx); ++xb)
+					for (u32 yb = sy; yb < std::min(sy + 8, nby); ++yb) {
+						const u32 x0 = xb * 4, nx = std::min(4u, n - x0), y0 = yb * 4, ny = std::min(4u, n - y0);
+						if (y0 + ny <= x0 + 1) continue; // no pair X < Y in this block
+						cand.insert(cand.end(), {x0, nx, y0, ny});
+					}
+		std::vector<u32> ok, ok2, left;
+		if (build_tiles(c->var_threads, c->var_nbuf, cand, ok, c->var_mixed ? &left : nullptr)) return 1;
+		if (!left.empty() && build_tiles(1024, 1, left, ok2, nullptr)) return 1;
+		c->tiles_desc = describe(ok);
+		if (!ok2.empty()) c->tiles_desc += "; + 1 x 1024-thread workgroup per CU, 1 staging buffer of 160 KB for " + describe(ok2);
+		c->h_tiles.swap(ok);
+		c->h_tiles2.swap(ok2);
+		if (upload(c, c->d_tiles, c->h_tiles)) return 1;
+		if (!c->h_tiles2.empty() && upload(c, c->d_tiles2, c->h_tiles2)) return 1;
+		HIPCHK(c, hipStreamSynchronize(c->stream)); // the source of the async copy lives in the context; drained before any rebuild
+		c->tiles_k0 = k0; c->tiles_k1 = k1; c->tiles_bx = 4; c->tiles_by = 4;
+	}
+	if (c->h_tiles.empty() && c->h_tiles2.empty()) return 0;
+	HIPCHK(c, c->d_tile_next.ensure(16 * 4));
+	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 16 * 4, c->stream));
+	if (!c->h_tiles.empty() && relax_var_launch(c, sp, k0, k1, c->var_threads, c->var_nbuf, c->d_tiles, (u32)(c->h_tiles.size() / 4), 0, true)) return 1;
+	if (!c->h_tiles2.empty() && relax_var_launch(c, sp, k0, k1, 1024, 1, c->d_tiles2, (u32)(c->h_tiles2.size() / 4), 1, c->h_tiles.empty())) return 1;
 	return 0;
 }
 
@@ -600,10 +630,17 @@ int build_var_store(mpcgpu_ctx *c)
 	u32 buf_bytes = 0;
 	size_t smem = 0;
 	var_lds_geometry(threads, nbuf, &buf_bytes, &smem);
-	if (2ull * max_rec * 16 > buf_bytes || !slots_ok(threads)) { // any single pair (two records, its cells) must fit a tile
-		threads = 1024; nbuf = 1;
-		var_lds_geometry(threads, nbuf, &buf_bytes, &smem);
-		if (2ull * max_rec * 16 > buf_bytes || !slots_ok(threads)) return 2;
+	c->var_mixed = false;
+	if (2ull * max_rec * 16 > buf_bytes || !slots_ok(threads)) { // not every single pair (two records, its cells) fits a tile of this geometry
+		u32 bb1 = 0;
+		size_t sm1 = 0;
+		var_lds_geometry(1024, 1, &bb1, &sm1);
+		if (2ull * max_rec * 16 > bb1 || !slots_ok(1024)) return 2;
+		// MPCGPU_RELAX_MIXED (default 1): keep the configured geometry for the pairs that fit it (two workgroups per CU: one's
+		// staging overlaps the other's merges) and give the rest to a second launch of the one-workgroup geometry; 0: everything
+		// to the one-workgroup geometry
+		if (threads != 1024 && env_int("MPCGPU_RELAX_MIXED", 1)) c->var_mixed = true;
+		else { threads = 1024; nbuf = 1; buf_bytes = bb1; smem = sm1; }
 	}
 	const u64 pad_bytes = run * 16 + 4 * std::max<u64>(c->total_entries, 1);
 	size_t freeb = 0, totb = 0;
@@ -626,7 +663,9 @@ int build_var_store(mpcgpu_ctx *c)
 			threads == 2048 ? "2 x 1024-thread workgroups per CU" : threads == 1024 ? "1 x 1024-thread workgroup per CU" :
 			threads == 768 ? "2 x 768-thread workgroups per CU" : "2 x 512-thread workgroups per CU",
 			nbuf, nbuf == 1 ? "" : "s", buf_bytes);
-		c->store_desc = b; c->tiles_desc.clear(); c->relax_kernel_name.clear(); c->relax_fallback = false;
+		c->store_desc = b;
+		if (c->var_mixed) c->store_desc += " (pairs whose records do not fit it: 1 x 1024-thread workgroup per CU with 160 KB, second launch)";
+		c->tiles_desc.clear(); c->relax_kernel_name.clear(); c->relax_fallback = false;
 	}
 	StoreParams sp;
 	fill_store_params(c, sp);
@@ -695,6 +734,7 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 	c->h_ap.release();
 	c->d_ap_off.release();
 	c->d_chain_first.release(); c->d_chain_cnt.release();
+	c->d_tiles2.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }

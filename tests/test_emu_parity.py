@@ -10,6 +10,7 @@ import pytest
 
 import _golden as G
 import _parity as P
+from muscle_amd._lib import MpcGpu
 from muscle_amd.synth import make_family
 
 EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
@@ -474,3 +475,28 @@ def test_emu_align_pairs_vs_reference_golden(emu):
 def test_emu_fb_chains(emu):
     """pairs that share their row sequence swept back to back (kernels_fbc.h) == one pair per sweep == the oracle"""
     P.check_fb_chains(emu)
+
+
+def test_emu_relax_two_geometries(emu):
+    """pairs whose records do not fit the two-workgroups-per-CU geometry go to a second launch of the one-workgroup geometry
+    (real data: rdrp records of 24..43 KB): a 1 KB budget for the first and 8 KB for the second, sequences of 12..60 residues"""
+    seqs = make_family(4, 12, seed=31) + make_family(3, 60, seed=32) + make_family(3, 30, seed=33)
+    want = P.run_oracle(seqs)
+    info = {}
+
+    def run():
+        s, t, m, i, thr = G.hmm_tables()
+        g = MpcGpu(0, emu)
+        g.set_hmm(s, t, m, i, thr)
+        g.set_seqs(seqs)
+        g.calc_posteriors()
+        g.build_store()
+        g.cons_iter()
+        info["geo"] = g.relax_info()[0]
+        g.close()
+        return P.run_lib(seqs, lib_path=emu)
+    got = _with_env({"MPCGPU_RELAX_LDS_KB": "1", "MPCGPU_RELAX_LDS_KB_1024": "8"}, run)
+    assert "second launch" in info["geo"] and "+ 1 x 1024" in info["geo"], info["geo"]
+    P.assert_same(got, want, "two geometries")
+    got0 = _with_env({"MPCGPU_RELAX_LDS_KB": "1", "MPCGPU_RELAX_LDS_KB_1024": "8", "MPCGPU_RELAX_MIXED": "0"}, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got0, want, "one-workgroup geometry alone")
