@@ -639,7 +639,14 @@ int build_var_store(mpcgpu_ctx *c)
 		// MPCGPU_RELAX_MIXED (default 1): keep the configured geometry for the pairs that fit it (two workgroups per CU: one's
 		// staging overlaps the other's merges) and give the rest to a second launch of the one-workgroup geometry; 0: everything
 		// to the one-workgroup geometry
-		if (threads != 1024 && env_int("MPCGPU_RELAX_MIXED", 1)) c->var_mixed = true;
+		if (!(threads == 1024 && nbuf == 1) && env_int("MPCGPU_RELAX_MIXED", 1)) {
+			c->var_mixed = true;
+			// such runs end up with tiles of one pair (two records of 20..40 KB per step for ~3 slots of cells): two 1024-thread
+			// workgroups per CU (8 waves per SIMD) measured 4 % faster than two of 768 on the first 1000 rdrp records
+			// (profiles/r04a), unless the geometry was asked for
+			const char *wg_env = getenv("MPCGPU_RELAX_WG");
+			if (!(wg_env && *wg_env) && slots_ok(2048)) { threads = 2048; nbuf = 1; var_lds_geometry(threads, nbuf, &buf_bytes, &smem); }
+		}
 		else { threads = 1024; nbuf = 1; buf_bytes = bb1; smem = sm1; }
 	}
 	const u64 pad_bytes = run * 16 + 4 * std::max<u64>(c->total_entries, 1);
