@@ -161,11 +161,11 @@ struct MpcRvBlocksAsm {
 	"s_mov_b64 %[nlb], exec\n\t"                                                                                         \
 	"s_and_b64 exec, %[nlb], %[ada]\n\t"                                                                                 \
 	"v_add_u32_sdwa %[ia], %[ia], " A2_ " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"        \
+	"ds_read_b128 " CURA_ ", %[ia]\n\t" /* only the lanes whose row advanced read its next block: the others keep theirs */ \
 	"s_and_b64 exec, %[nlb], %[adb]\n\t"                                                                                 \
 	"v_add_u32_sdwa %[ib], %[ib], " B2_ " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"        \
-	"s_mov_b64 exec, %[nlb]\n\t"                                                                                         \
-	"ds_read_b128 " CURA_ ", %[ia]\n\t"                                                                                  \
 	"ds_read_b128 " CURB_ ", %[ib]\n\t"                                                                                  \
+	"s_mov_b64 exec, %[nlb]\n\t"                                                                                         \
 	"s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
 	"s_branch .Lrv_step_%=\n"                                                                                            \
 	".Lrv_done_%=:\n\t"                                                                                                  \

@@ -33,8 +33,17 @@ def main():
             d = json.load(f)
     except (OSError, ValueError):
         d = {}
-    for kname in sorted(set(fetch) | set(write)):
-        short = kname.split("(")[0].replace("void ", "").split("<")[0]
+    # several instantiations of one template in a run (relax_var_kernel's two geometries on real data): the entry describes the
+    # one that moved the most data
+    def short_of(kname):
+        return kname.split("(")[0].replace("void ", "").split("<")[0]
+    weight = {k: sum(fetch.get(k, [])) + sum(write.get(k, [])) for k in set(fetch) | set(write)}
+    dominant = {}
+    for k, w in weight.items():
+        if short_of(k) not in dominant or w > weight[dominant[short_of(k)]]:
+            dominant[short_of(k)] = k
+    for kname in sorted(dominant.values()):
+        short = short_of(kname)
         fv, wv = fetch.get(kname, []), write.get(kname, [])
         if not fv and not wv:
             continue
@@ -57,9 +66,9 @@ def main():
                 for row in csv.DictReader(f):
                     sq[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for kname, counters in sq.items():
-        short = kname.split("(")[0].replace("void ", "").split("<")[0]
+        short = short_of(kname)
         key = "%s@%dx%d" % (short, n, length)
-        if key in d:
+        if key in d and d[key]["kernel"] == kname:
             d[key]["sq_per_launch"] = {c: sum(v) / len(v) for c, v in sorted(counters.items())}
     with open(out, "w") as f:
         json.dump(d, f, indent=1, sort_keys=True)
