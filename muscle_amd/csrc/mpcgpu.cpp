@@ -175,10 +175,6 @@ struct mpcgpu_ctx {
 	HostBuf h_ap;             // mpcgpu_align_pairs: kernel parameters and results, page-locked
 	DevBuf d_ap_off;
 	DevBuf d_chain_first, d_chain_cnt; // fb_chain_kernel's work list (kernels_fbc.h)
-	DevBuf d_cand_b, d_cand_cnt_b, d_total_b, d_bx_b, d_by_b; // second set of a batch's buffers (stage A keeps two batches in flight)
-	hipStream_t stream2 = nullptr;   // finishing kernels of stage A
-	hipEvent_t ev_fb[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
-	HostBuf h_sizes;                 // nnz, EA bits, flags of a batch, page-locked
 	u64 sa_pairs = 0, sa_chained = 0, sa_chains = 0; // last stage A: pairs, pairs that ran in chains, chains
 	double aa_trace_t[5] = {0, 0, 0, 0, 0}; // MPCGPU_TRACE_HOST: host seconds of mpcgpu_align_alns' phases
 	u64 aa_trace_n = 0;
@@ -746,9 +742,6 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 	c->d_ap_off.release();
 	c->d_chain_first.release(); c->d_chain_cnt.release();
 	c->d_tiles2.release();
-	for (DevBuf *b : {&c->d_cand_b, &c->d_cand_cnt_b, &c->d_total_b, &c->d_bx_b, &c->d_by_b}) b->release();
-	c->h_sizes.release();
-	if (c->stream2) { for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(c->ev_fb[k]); (void)hipEventDestroy(c->ev_post[k]); } (void)hipStreamDestroy(c->stream2); }
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1151,357 +1144,273 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		P.valid = true;
 		return 0;
 	};
-	// Two batches in flight: the forward/backward launches of batch b+1 are queued (stream 1) before the host waits for the
-	// finishing kernel of batch b (stream 2: probabilities, EA, sparsify, sizes back, pack), so the finishing work and the
-	// host's bookkeeping run under the next batch's sweeps. The candidate lists, totals and the batch's pair arrays exist twice
-	// (set 0 / set 1: SetSwap puts the set a batch uses behind the usual names); the finishing kernel's outputs and the packed shard
-	// are touched by stream 2 alone. MPCGPU_SA_PIPELINE=0: one batch at a time (stream 1 alone does everything).
-	struct Flight { BatchPrep P; int set = 0; bool fb_launched = false; };
-	struct SetSwap {
-		mpcgpu_ctx *c; bool on;
-		void flip() { std::swap(c->d_cand, c->d_cand_b); std::swap(c->d_cand_cnt, c->d_cand_cnt_b); std::swap(c->d_total, c->d_total_b); std::swap(c->d_bx, c->d_bx_b); std::swap(c->d_by, c->d_by_b); }
-		SetSwap(mpcgpu_ctx *cc, int set) : c(cc), on(set != 0) { if (on) flip(); }
-		~SetSwap() { if (on) flip(); }
-	};
-	struct StreamSwap {
-		mpcgpu_ctx *c; hipStream_t old;
-		StreamSwap(mpcgpu_ctx *cc, hipStream_t s) : c(cc), old(cc->stream) { c->stream = s; }
-		~StreamSwap() { c->stream = old; }
-	};
-	const bool pipeline = env_int("MPCGPU_SA_PIPELINE", 1) != 0;
-	if (!c->stream2) {
-		HIPCHK(c, hipStreamCreate(&c->stream2));
-		for (int k = 0; k < 2; ++k) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_fb[k], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_post[k], hipEventDisableTiming)); }
-	}
-	hipStream_t const stream_post = pipeline ? c->stream2 : c->stream;
-	bool post_pending[2] = {false, false}; // a finishing kernel still reads this set's candidate lists
-	// row-list post kernel (no sorts, 3 LDS trips per EA row) when LY fits its LDS arrays; MPCGPU_POST=sort forces the general one
-	const char *post_mode = getenv("MPCGPU_POST");
-	// (up to ~12 000 positions: three arrays of one word per position + the sorted-list buffer in the CU's LDS)
-	const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) &&
-		((size_t)LXmax + 2 + 2 * ((size_t)LYmax + 2)) * 4 + 8 + 8 * (size_t)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2) <= 150 * 1024;
-
-
-	Flight fl_cur, fl_nxt;
+	BatchPrep cur, nxt;
 	const bool host_trace = env_int("MPCGPU_TRACE_HOST", 0) != 0; // diagnostics: host wall time between the device phases of a batch
 	auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 	double lap_t[6] = {0, 0, 0, 0, 0, 0}, t_prev = host_trace ? now() : 0.0;
 	auto lap = [&](int k) { if (host_trace) { const double t = now(); lap_t[k] += t - t_prev; t_prev = t; } };
 	u64 words_done = 0; // record words packed so far
 	u64 done = 0;
-#define MPC_SA_BATCH(F) \
-	BatchPrep &cur = (F).P; const u64 res_stride = (u64)LXmax + LYmax + 4 * (u64)capc; const u64 B = cur.B; \
-	const std::vector<u32> &bx = cur.bx, &by = cur.by, &order = cur.order; const u32 *hcount = cur.hcount; \
-	(void)res_stride; (void)B; (void)bx; (void)by; (void)order; (void)hcount
-	// uploads and forward/backward launches of a batch (stream 1)
-	auto launch_fb = [&](Flight &F) -> int {
-		MPC_SA_BATCH(F);
-		SetSwap sets(c, F.set);
-		if (post_pending[F.set]) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_post[F.set], 0)); // the batch before the last has let go of this set
-			if (upload(c, c->d_bx, bx) || upload(c, c->d_by, by) || upload(c, c->d_order, order)) return 1;
-			if (!cur.chain_first.empty() && (upload(c, c->d_chain_first, cur.chain_first) || upload(c, c->d_chain_cnt, cur.chain_cnt))) return 1;
-			HIPCHK(c, c->d_cand.ensure(B * capc * 8));
-			HIPCHK(c, c->d_cand_cnt.ensure(B * 4));
-			HIPCHK(c, c->d_total.ensure(B * 4));
-			HIPCHK(c, c->d_res.ensure(B * res_stride * 4));
-			HIPCHK(c, c->d_nnz.ensure(B * 4));
-			HIPCHK(c, c->d_ea.ensure(B * 4));
-			HIPCHK(c, c->d_flags.ensure(B * 4));
-			HIPCHK(c, c->d_queue.ensure(4 * (2 * MPC_HMAX + 4))); // single pairs per bin, then chains per bin
-			HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (2 * MPC_HMAX + 4), c->stream));
-
-			FbParams fp;
-			fill_fb_params(c, fp, c->d_bx.as<u32>(), c->d_by.as<u32>(), capc, mega);
-			TimedSpan sp;
-			u32 pos = 0;
-			if (hcount[MPC_HMAX + 1]) { // ---- row-block pairs (the order lists them last: bins ascend)
-				const u32 cnt = hcount[MPC_HMAX + 1];
-				u32 first = 0;
-				for (u32 H = 1; H <= MPC_HMAX; ++H) first += hcount[H];
-				const u32 ld = (LYlong + 2 + 63) & ~63u;
-				auto planes = [&](u32 h, u32 *nb, u64 *blk) { *nb = (LXlong + 64 * h - 1) / (64 * h); *blk = (u64)(LYlong + 64) * h * 64; return *blk * *nb; };
-				// resident waves are bounded by the forward M planes they keep (LX*LY floats each)
-				size_t freeb2 = 0, totb2 = 0;
-				HIPCHK(c, hipMemGetInfo(&freeb2, &totb2));
-				// (up to 45 % of what is free, counting the plane buffer already owned: 36 MB per 3000 x 3000 pair — with the 16 GB the
-				// other scratch is held to, 444 waves were resident where the chip takes 2048. The buffer stays allocated — hipMalloc and
-				// hipFree of ~100 GB take seconds — and is given back only when the store needs the room: mpcgpu_store_import)
-				const char *scratch_env = getenv("MPCGPU_SCRATCH_GB");
-				const u64 fm_budget = std::min<u64>((scratch_env && *scratch_env) ? (u64)atoi(scratch_env) << 30 : ~0ull, (u64)((freeb2 + c->d_fm.cap) * 0.45));
-				// rows per lane: 7 (217 VGPRs, 2 waves per SIMD), or 4 (166 VGPRs, 3 waves per SIMD; more blocks, more line-buffer
-				// traffic) when the pairs and the memory for their forward planes can keep more than 2 waves per SIMD busy
-				// (100 x L~3000: 517 -> 407 ms; 64 x L~6000, 875 waves fit: 1985 ms with 7 rows, 2190 with 4)
-				u32 long_h = long_h_env == 1 ? 1u : long_h_env == MPC_LONG_H_SMALL ? (u32)MPC_LONG_H_SMALL : (u32)MPC_LONG_H;
-				u32 nbmax = 0;
-				u64 fm_block = 0;
-				if (long_h_env == 0) {
-					const u64 stride_small = planes(MPC_LONG_H_SMALL, &nbmax, &fm_block);
-					const u64 waves_small = std::min<u64>(cnt, fm_budget / (stride_small * 4 + 16ull * ld * 4));
-					if (waves_small > (u64)cus * 4 * 2) long_h = MPC_LONG_H_SMALL;
-				}
-				const u64 fm_stride = planes(long_h, &nbmax, &fm_block);
-				const u64 max_waves = fm_budget / (fm_stride * 4 + 16ull * ld * 4);
-				if (max_waves < 1)
-					return fail(c, "mpcgpu_calc_posteriors: not enough device memory for the forward plane of a %u x %u pair", LXlong, LYlong);
-				const u32 occ = (u32)occ_fb_long((int)long_h, mega, block, fb_smem);
-				u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ);
-				grid = (u32)std::max<u64>(std::min<u64>(grid, max_waves / waves_per_block), 1);
-				const u32 wpb = max_waves < (u64)waves_per_block ? (u32)max_waves : (u32)waves_per_block; // fewer waves per workgroup when memory is that tight
-				HIPCHK(c, c->d_fm.ensure((u64)grid * wpb * fm_stride * 4));
-				HIPCHK(c, c->d_bnd.ensure((u64)grid * wpb * 16 * ld * 4));
-				if (trace_on()) {
-					fprintf(stderr, "[mpcgpu] fb row blocks: H=%u pairs=%u blocks<=%u grid=%u x %u waves occ=%u fm=%.1f MB\n", long_h, cnt, nbmax,
-						grid, wpb, occ, (double)grid * wpb * fm_stride * 4 / 1048576.0);
-					fflush(stderr);
-				}
-				fp.order = c->d_order.as<u32>() + first; fp.count = cnt;
-				fp.queue = c->d_queue.as<u32>() + MPC_HMAX + 1;
-				fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride; fp.fm_block = fm_block;
-				fp.bnd = c->d_bnd.as<float>(); fp.bnd_stride = 16ull * ld; fp.bnd_ld = ld;
-				if (span_begin(c, 0, &sp)) return 1;
-				launch_fb_long((int)long_h, mega, fp, grid, 64 * wpb, fb_smem, c->stream);
-				HIPCHK(c, hipGetLastError());
-				if (span_end(c, &sp)) return 1;
-				fp.bnd = nullptr; fp.bnd_stride = 0; fp.bnd_ld = 0; fp.fm_block = 0;
-			}
-			for (u32 H = 1; H <= MPC_HMAX; ++H) {
-				if (!hcount[H]) continue;
-				const u32 cnt = hcount[H];
-				// persistent waves: exactly as many workgroups as the chip keeps resident (VGPR-limited)
-				const u32 occ = (u32)occ_fb_h((int)H, mega, block, fb_smem);
-				u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ);
-				grid = std::max(grid, 1u);
-				const u64 fm_stride = (u64)(LYmax + 64) * H * 64;
-				HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
-				if (trace_on()) {
-					fprintf(stderr, "[mpcgpu] fb H=%u pairs=%u grid=%u block=%d occ=%u capc=%u batch=%llu fm=%.1f MB\n", H, cnt, grid,
-						block, occ, capc, B, (double)grid * waves_per_block * fm_stride * 4 / 1048576.0);
-					fflush(stderr);
-				}
-				fp.order = c->d_order.as<u32>() + pos; fp.count = cnt;
-				fp.queue = c->d_queue.as<u32>() + H;
-				fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride;
-				if (span_begin(c, 0, &sp)) return 1;
-				launch_fb_h((int)H, mega, fp, grid, block, fb_smem, c->stream);
-				HIPCHK(c, hipGetLastError());
-				if (span_end(c, &sp)) return 1;
-				pos += cnt;
-			}
-			u32 cpos = 0;
-			for (u32 H = 1; H <= MPC_HMAX; ++H) { // chains (kernels_fbc.h)
-				if (!cur.ccount[H]) continue;
-				const u32 cnt = cur.ccount[H];
-				const u32 occ = (u32)occ_fbc_h((int)H, block, fbc_smem);
-				const u32 grid = std::max(std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ), 1u);
-				const u64 fm_stride = (u64)(cur.cvmax[H] + 64) * H * 64;
-				HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
-				if (trace_on()) {
-					fprintf(stderr, "[mpcgpu] fb chains H=%u chains=%u grid=%u occ=%u longest axis=%u fm=%.1f MB\n", H, cnt, grid, occ, cur.cvmax[H],
-						(double)grid * waves_per_block * fm_stride * 4 / 1048576.0);
-					fflush(stderr);
-				}
-				FbChainParams cp;
-				cp.f = fp;
-				cp.f.order = c->d_order.as<u32>(); cp.f.count = cnt;
-				cp.f.queue = c->d_queue.as<u32>() + (MPC_HMAX + 2) + H;
-				cp.f.fm_scratch = c->d_fm.as<float>(); cp.f.fm_stride = fm_stride;
-				cp.chain_first = c->d_chain_first.as<u32>() + cpos; cp.chain_cnt = c->d_chain_cnt.as<u32>() + cpos;
-				if (span_begin(c, 0, &sp)) return 1;
-				launch_fbc_h((int)H, cp, grid, block, fbc_smem, c->stream);
-				HIPCHK(c, hipGetLastError());
-				if (span_end(c, &sp)) return 1;
-				cpos += cnt;
-			}
-		HIPCHK(c, hipEventRecord(c->ev_fb[F.set], c->stream));
-		F.fb_launched = true;
-		return 0;
-	};
-	// finishing kernel of a batch and its sizes back (stream 2, behind the batch's sweeps)
-	auto launch_post = [&](Flight &F) -> int {
-		MPC_SA_BATCH(F);
-		SetSwap sets(c, F.set);
-		StreamSwap str(c, stream_post);
-		if (pipeline) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fb[F.set], 0));
-		TimedSpan sp;
-			// ---- finish: probabilities, sort, EA, sparsify
-			if (post_rows) {
-				PostRowsParams pr;
-				pr.pair_x = c->d_bx.as<u32>(); pr.pair_y = c->d_by.as<u32>(); pr.seq_len = c->d_seq_len.as<u32>();
-				pr.cand = c->d_cand.as<u64>(); pr.capc = capc; pr.cand_cnt = c->d_cand_cnt.as<u32>();
-				pr.use_fma = c->use_fma;
-				pr.lx_cap = LXmax + 2; pr.ly_cap = LYmax + 2;
-				// LDS list of a pair's candidates (larger lists cost resident waves, pairs that exceed it sort through HBM scratch; per
-				// batch of 125 000 pairs at L~400: 512 entries 16.9 ms, 768: 12.3, 896: 11.9, 1024: 11.7, 1280: 12.7, 1408 (holds every
-				// pair): 14.0, 1664: 15.8)
-				const u32 sort_cap = (u32)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2);
-				pr.sort_cap = std::min<u32>(capc, sort_cap);
-				pr.sort_stride = capc;
-				pr.batch = (u32)std::min(std::max(env_int("MPCGPU_POST_BATCH", 64), 1), 64);
-				const size_t fixed_lds = ((((size_t)pr.lx_cap + 2 * (size_t)pr.ly_cap) * 4 + 7) & ~(size_t)7);
-				if (fixed_lds + (size_t)pr.sort_cap * 8 > 150 * 1024) pr.sort_cap = (u32)((150 * 1024 - fixed_lds) / 8); // long sequences: the arrays per position come first
-				const size_t smem = fixed_lds + (size_t)pr.sort_cap * 8;
-				if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void *)post_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-				int pocc = 0;
-				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_rows_kernel, 64, smem) != hipSuccess || pocc < 1) pocc = 1;
-				// The persistent grid must not be larger than what is really resident, or its last workgroups run as a second round
-				// (measured, per batch of 125 000 pairs: 15 248 B of LDS, 10 workgroups per CU reported: 12.7 ms; 15 760 B, still 10
-				// reported: 22.5 ms; 17 296 B, 9 reported: 14.1 ms — 64-thread workgroups stop fitting at ~152 KB per CU, not 160)
-				pocc = std::max(1, std::min(pocc, (int)((152 * 1024) / smem)));
-				const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
-				HIPCHK(c, c->d_sort_scratch.ensure(capc > pr.sort_cap ? (u64)pgrid * pr.sort_stride * 8 : 8));
-				pr.sort_scratch = c->d_sort_scratch.as<u64>();
-				pr.res = c->d_res.as<u32>(); pr.res_stride = res_stride;
-				pr.nnz = c->d_nnz.as<u32>(); pr.ea = c->d_ea.as<float>(); pr.flags = c->d_flags.as<u32>();
-				pr.count = (u32)B;
-				pr.long_min = long_min;
-				pr.prof = nullptr;
-				const bool post_prof = env_int("MPCGPU_POST_PROFILE", 0) != 0; // measurement only: phase clocks of workgroup 0
-				if (post_prof) {
-					HIPCHK(c, c->d_post_prof.ensure(8 * 8));
-					HIPCHK(c, hipMemsetAsync(c->d_post_prof.p, 0, 64, c->stream));
-					pr.prof = c->d_post_prof.as<u64>();
-				}
-				if (trace_on()) { fprintf(stderr, "[mpcgpu] post rows: list of %u candidates in LDS, lds=%zu B blocks/CU=%d grid=%u\n", pr.sort_cap, smem, pocc, pgrid); fflush(stderr); }
-				if (span_begin(c, 1, &sp)) return 1;
-				MPC_LAUNCH(post_rows_kernel, pgrid, 64, smem, c->stream, pr);
-				HIPCHK(c, hipGetLastError());
-				if (span_end(c, &sp)) return 1;
-				if (post_prof) {
-					u64 ticks[8];
-					HIPCHK(c, hipMemcpyAsync(ticks, pr.prof, 64, hipMemcpyDeviceToHost, c->stream));
-					HIPCHK(c, hipStreamSynchronize(c->stream));
-					const u64 npairs0 = (B + pgrid - 1) / pgrid; // pairs workgroup 0 handled
-					fprintf(stderr, "[mpcgpu] post_rows_kernel, workgroup 0, %llu pairs, us per pair (100 MHz clock): prob+histogram %.1f, scan+scatter %.1f, "
-						"row sort %.1f, EA %.1f, kept entries %.1f, column ranks %.1f\n", (u64)npairs0, ticks[0] / 100.0 / npairs0, ticks[1] / 100.0 / npairs0,
-						ticks[2] / 100.0 / npairs0, ticks[3] / 100.0 / npairs0, ticks[4] / 100.0 / npairs0, ticks[5] / 100.0 / npairs0);
-				}
-			} else {
-			PostParams pp;
-			pp.pair_x = c->d_bx.as<u32>(); pp.pair_y = c->d_by.as<u32>(); pp.seq_len = c->d_seq_len.as<u32>();
-			pp.cand = c->d_cand.as<u64>(); pp.capc = capc; pp.cand_cnt = c->d_cand_cnt.as<u32>();
-			pp.use_fma = c->use_fma;
-			// LDS sort buffer capacity (entries, power of two): pairs with more candidates sort in the
-			// global scratch. The kernel is latency-bound (one wave per pair), so LDS per workgroup trades
-			// against resident waves; MPCGPU_POST_SORT_CAP overrides for tuning.
-			pp.sort_cap = std::min<u32>(next_pow2(capc), next_pow2((u32)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2)));
-			pp.srow_cap = std::min<u32>(LYmax + 1, 2048u);
-			const size_t psmem0 = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
-			int pocc = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_kernel, 64, psmem0) != hipSuccess || pocc < 1) pocc = 8;
-			if (psmem0) pocc = std::max(1, std::min(pocc, (int)((152 * 1024) / psmem0))); // as for post_rows_kernel above
-			const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
-			if (trace_on()) { fprintf(stderr, "[mpcgpu] post: sort_cap=%u lds=%zu B blocks/CU=%d grid=%u\n", pp.sort_cap, psmem0, pocc, pgrid); fflush(stderr); }
-			pp.sort_stride = next_pow2(capc);
-			pp.srow_stride = 2 * ((u64)LYmax + 1);
-			const bool need_sort_scr = next_pow2(capc) > pp.sort_cap, need_srow_scr = LYmax + 1 > pp.srow_cap;
-			HIPCHK(c, c->d_sort_scratch.ensure(need_sort_scr ? (u64)pgrid * pp.sort_stride * 8 : 8));
-			HIPCHK(c, c->d_srow_scratch.ensure(need_srow_scr ? (u64)pgrid * pp.srow_stride * 4 : 8));
-			pp.sort_scratch = c->d_sort_scratch.as<u64>(); pp.srow_scratch = c->d_srow_scratch.as<float>();
-			pp.res = c->d_res.as<u32>(); pp.res_stride = res_stride;
-			pp.nnz = c->d_nnz.as<u32>(); pp.ea = c->d_ea.as<float>(); pp.flags = c->d_flags.as<u32>();
-			pp.count = (u32)B;
-			pp.long_min = long_min;
-			const size_t psmem = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
-			if (span_begin(c, 1, &sp)) return 1;
-			MPC_LAUNCH(post_kernel, pgrid, 64, psmem, c->stream, pp);
-			HIPCHK(c, hipGetLastError());
-			if (span_end(c, &sp)) return 1;
-			}
-		HIPCHK(c, c->h_sizes.ensure(3 * B * 4));
-		HIPCHK(c, hipMemcpyAsync(c->h_sizes.as<u32>(), c->d_nnz.p, B * 4, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipMemcpyAsync(c->h_sizes.as<u32>() + B, c->d_ea.p, B * 4, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipMemcpyAsync(c->h_sizes.as<u32>() + 2 * B, c->d_flags.p, B * 4, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipEventRecord(c->ev_post[F.set], c->stream));
-		post_pending[F.set] = true;
-		return 0;
-	};
-	// sizes, overflow check, pack (stream 2)
-	auto finish = [&](Flight &F, bool *overflow) -> int {
-		MPC_SA_BATCH(F);
-		SetSwap sets(c, F.set);
-		StreamSwap str(c, stream_post);
-		TimedSpan sp;
-		*overflow = false;
-			// ---- sizes back, overflow check, pack
-			// (the copies into page-locked memory were queued behind the finishing kernel: launch_post)
-			HIPCHK(c, hipEventSynchronize(c->ev_post[F.set]));
-			post_pending[F.set] = false;
-			const u32 *h_sz = c->h_sizes.as<u32>();
-			memcpy(&c->sh_nnz[done], h_sz, B * 4);
-			memcpy(&c->sh_ea[done], h_sz + B, B * 4);
-			const u32 *flags = h_sz + 2 * B;
-			lap(3);
-			bool any_overflow = false;
-			for (u64 q = 0; q < B; ++q) any_overflow = any_overflow || (flags[q] & 1u);
-			if (any_overflow) {
-				if (capc >= LXmax * (u64)LYmax)
-					return fail(c, "mpcgpu_calc_posteriors: candidate overflow at full capacity (internal error)");
-				*overflow = true; // the caller redoes this batch with a larger candidate capacity
-				return 0;
-			}
-			std::vector<u64> dstbase(B), recw(B);
-			u64 w = words_done;
-			for (u64 q = 0; q < B; ++q) {
-				recw[q] = rec_words(c->len[bx[q]], c->len[by[q]], c->sh_nnz[done + q]);
-				dstbase[q] = hdr / 4 + w;
-				w += recw[q];
-			}
-			// capacity estimate for the whole shard from the words seen so far
-			const double per = double(w) / double(done + B);
-			const u64 est = hdr + (u64)(per * 1.05 * double(np) + 1024) * 4;
-			HIPCHK(c, c->d_shard.ensure(std::max<u64>(est, hdr + w * 4), true, c->stream));
-			if (upload(c, c->d_dstbase, dstbase) || upload(c, c->d_recwords, recw)) return 1;
-			if (span_begin(c, 1, &sp)) return 1;
-			MPC_LAUNCH(pack_kernel, (u32)std::min<u64>(B, (u64)cus * 8), 256, 0, c->stream, c->d_res.as<u32>(), res_stride,
-				c->d_dstbase.as<u64>(), c->d_recwords.as<u64>(), c->d_shard.as<u32>(), (u32)B);
-			HIPCHK(c, hipGetLastError());
-			if (span_end(c, &sp)) return 1;
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			words_done = w;
-			// what the LAST batch left in the scratch buffers (mpcgpu_align_pairs reads the candidate lists of a one-batch stage)
-			c->sa_b0 = done; c->sa_B = B; c->sa_capc = capc; c->sa_post_rows = post_rows; c->sa_long_min = long_min;
-			for (u32 c2 : cur.chain_cnt) if (c2 >= 2) { c->sa_chains += 1; c->sa_chained += c2; }
-		return 0;
-	};
-#undef MPC_SA_BATCH
-	int last_set = 0;
 	while (done < np) {
-		if (!(fl_cur.P.valid && fl_cur.P.b0 == done && fl_cur.P.capc == capc)) {
-			if (prepare(done, fl_cur.P)) return 1;
-			fl_cur.fb_launched = false;
-		}
+		if (!(cur.valid && cur.b0 == done && cur.capc == capc) && prepare(done, cur)) return 1;
+		const u64 res_stride = (u64)LXmax + LYmax + 4 * (u64)capc;
+		const u64 B = cur.B;
+		const std::vector<u32> &bx = cur.bx, &by = cur.by, &order = cur.order;
+		const u32 *hcount = cur.hcount;
 		lap(0);
-		if (!fl_cur.fb_launched && launch_fb(fl_cur)) return 1;
-		if (launch_post(fl_cur)) return 1;
+		if (upload(c, c->d_bx, bx) || upload(c, c->d_by, by) || upload(c, c->d_order, order)) return 1;
+		if (!cur.chain_first.empty() && (upload(c, c->d_chain_first, cur.chain_first) || upload(c, c->d_chain_cnt, cur.chain_cnt))) return 1;
+		HIPCHK(c, c->d_cand.ensure(B * capc * 8));
+		HIPCHK(c, c->d_cand_cnt.ensure(B * 4));
+		HIPCHK(c, c->d_total.ensure(B * 4));
+		HIPCHK(c, c->d_res.ensure(B * res_stride * 4));
+		HIPCHK(c, c->d_nnz.ensure(B * 4));
+		HIPCHK(c, c->d_ea.ensure(B * 4));
+		HIPCHK(c, c->d_flags.ensure(B * 4));
+		HIPCHK(c, c->d_queue.ensure(4 * (2 * MPC_HMAX + 4))); // single pairs per bin, then chains per bin
+		HIPCHK(c, hipMemsetAsync(c->d_queue.p, 0, 4 * (2 * MPC_HMAX + 4), c->stream));
+
+		FbParams fp;
+		fill_fb_params(c, fp, c->d_bx.as<u32>(), c->d_by.as<u32>(), capc, mega);
+		// row-list post kernel (no sorts, 3 LDS trips per EA row) when LY fits its LDS arrays; MPCGPU_POST=sort forces the general one
+		const char *post_mode = getenv("MPCGPU_POST");
+		// (up to ~12 000 positions: three arrays of one word per position + the sorted-list buffer in the CU's LDS)
+		const bool post_rows = !(post_mode && !strcmp(post_mode, "sort")) &&
+			((size_t)LXmax + 2 + 2 * ((size_t)LYmax + 2)) * 4 + 8 + 8 * (size_t)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2) <= 150 * 1024;
+
+		TimedSpan sp;
+		u32 pos = 0;
+		if (hcount[MPC_HMAX + 1]) { // ---- row-block pairs (the order lists them last: bins ascend)
+			const u32 cnt = hcount[MPC_HMAX + 1];
+			u32 first = 0;
+			for (u32 H = 1; H <= MPC_HMAX; ++H) first += hcount[H];
+			const u32 ld = (LYlong + 2 + 63) & ~63u;
+			auto planes = [&](u32 h, u32 *nb, u64 *blk) { *nb = (LXlong + 64 * h - 1) / (64 * h); *blk = (u64)(LYlong + 64) * h * 64; return *blk * *nb; };
+			// resident waves are bounded by the forward M planes they keep (LX*LY floats each)
+			size_t freeb2 = 0, totb2 = 0;
+			HIPCHK(c, hipMemGetInfo(&freeb2, &totb2));
+			// (up to 45 % of what is free, counting the plane buffer already owned: 36 MB per 3000 x 3000 pair — with the 16 GB the
+			// other scratch is held to, 444 waves were resident where the chip takes 2048. The buffer stays allocated — hipMalloc and
+			// hipFree of ~100 GB take seconds — and is given back only when the store needs the room: mpcgpu_store_import)
+			const char *scratch_env = getenv("MPCGPU_SCRATCH_GB");
+			const u64 fm_budget = std::min<u64>((scratch_env && *scratch_env) ? (u64)atoi(scratch_env) << 30 : ~0ull, (u64)((freeb2 + c->d_fm.cap) * 0.45));
+			// rows per lane: 7 (217 VGPRs, 2 waves per SIMD), or 4 (166 VGPRs, 3 waves per SIMD; more blocks, more line-buffer
+			// traffic) when the pairs and the memory for their forward planes can keep more than 2 waves per SIMD busy
+			// (100 x L~3000: 517 -> 407 ms; 64 x L~6000, 875 waves fit: 1985 ms with 7 rows, 2190 with 4)
+			u32 long_h = long_h_env == 1 ? 1u : long_h_env == MPC_LONG_H_SMALL ? (u32)MPC_LONG_H_SMALL : (u32)MPC_LONG_H;
+			u32 nbmax = 0;
+			u64 fm_block = 0;
+			if (long_h_env == 0) {
+				const u64 stride_small = planes(MPC_LONG_H_SMALL, &nbmax, &fm_block);
+				const u64 waves_small = std::min<u64>(cnt, fm_budget / (stride_small * 4 + 16ull * ld * 4));
+				if (waves_small > (u64)cus * 4 * 2) long_h = MPC_LONG_H_SMALL;
+			}
+			const u64 fm_stride = planes(long_h, &nbmax, &fm_block);
+			const u64 max_waves = fm_budget / (fm_stride * 4 + 16ull * ld * 4);
+			if (max_waves < 1)
+				return fail(c, "mpcgpu_calc_posteriors: not enough device memory for the forward plane of a %u x %u pair", LXlong, LYlong);
+			const u32 occ = (u32)occ_fb_long((int)long_h, mega, block, fb_smem);
+			u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ);
+			grid = (u32)std::max<u64>(std::min<u64>(grid, max_waves / waves_per_block), 1);
+			const u32 wpb = max_waves < (u64)waves_per_block ? (u32)max_waves : (u32)waves_per_block; // fewer waves per workgroup when memory is that tight
+			HIPCHK(c, c->d_fm.ensure((u64)grid * wpb * fm_stride * 4));
+			HIPCHK(c, c->d_bnd.ensure((u64)grid * wpb * 16 * ld * 4));
+			if (trace_on()) {
+				fprintf(stderr, "[mpcgpu] fb row blocks: H=%u pairs=%u blocks<=%u grid=%u x %u waves occ=%u fm=%.1f MB\n", long_h, cnt, nbmax,
+					grid, wpb, occ, (double)grid * wpb * fm_stride * 4 / 1048576.0);
+				fflush(stderr);
+			}
+			fp.order = c->d_order.as<u32>() + first; fp.count = cnt;
+			fp.queue = c->d_queue.as<u32>() + MPC_HMAX + 1;
+			fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride; fp.fm_block = fm_block;
+			fp.bnd = c->d_bnd.as<float>(); fp.bnd_stride = 16ull * ld; fp.bnd_ld = ld;
+			if (span_begin(c, 0, &sp)) return 1;
+			launch_fb_long((int)long_h, mega, fp, grid, 64 * wpb, fb_smem, c->stream);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &sp)) return 1;
+			fp.bnd = nullptr; fp.bnd_stride = 0; fp.bnd_ld = 0; fp.fm_block = 0;
+		}
+		for (u32 H = 1; H <= MPC_HMAX; ++H) {
+			if (!hcount[H]) continue;
+			const u32 cnt = hcount[H];
+			// persistent waves: exactly as many workgroups as the chip keeps resident (VGPR-limited)
+			const u32 occ = (u32)occ_fb_h((int)H, mega, block, fb_smem);
+			u32 grid = std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ);
+			grid = std::max(grid, 1u);
+			const u64 fm_stride = (u64)(LYmax + 64) * H * 64;
+			HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
+			if (trace_on()) {
+				fprintf(stderr, "[mpcgpu] fb H=%u pairs=%u grid=%u block=%d occ=%u capc=%u batch=%llu fm=%.1f MB\n", H, cnt, grid,
+					block, occ, capc, B, (double)grid * waves_per_block * fm_stride * 4 / 1048576.0);
+				fflush(stderr);
+			}
+			fp.order = c->d_order.as<u32>() + pos; fp.count = cnt;
+			fp.queue = c->d_queue.as<u32>() + H;
+			fp.fm_scratch = c->d_fm.as<float>(); fp.fm_stride = fm_stride;
+			if (span_begin(c, 0, &sp)) return 1;
+			launch_fb_h((int)H, mega, fp, grid, block, fb_smem, c->stream);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &sp)) return 1;
+			pos += cnt;
+		}
+		u32 cpos = 0;
+		u64 batch_chains = 0, batch_chained = 0;
+		for (u32 c2 : cur.chain_cnt) if (c2 >= 2) { ++batch_chains; batch_chained += c2; }
+		for (u32 H = 1; H <= MPC_HMAX; ++H) { // chains (kernels_fbc.h)
+			if (!cur.ccount[H]) continue;
+			const u32 cnt = cur.ccount[H];
+			const u32 occ = (u32)occ_fbc_h((int)H, block, fbc_smem);
+			const u32 grid = std::max(std::min<u32>((cnt + waves_per_block - 1) / waves_per_block, cus * occ), 1u);
+			const u64 fm_stride = (u64)(cur.cvmax[H] + 64) * H * 64;
+			HIPCHK(c, c->d_fm.ensure((u64)grid * waves_per_block * fm_stride * 4));
+			if (trace_on()) {
+				fprintf(stderr, "[mpcgpu] fb chains H=%u chains=%u grid=%u occ=%u longest axis=%u fm=%.1f MB\n", H, cnt, grid, occ, cur.cvmax[H],
+					(double)grid * waves_per_block * fm_stride * 4 / 1048576.0);
+				fflush(stderr);
+			}
+			FbChainParams cp;
+			cp.f = fp;
+			cp.f.order = c->d_order.as<u32>(); cp.f.count = cnt;
+			cp.f.queue = c->d_queue.as<u32>() + (MPC_HMAX + 2) + H;
+			cp.f.fm_scratch = c->d_fm.as<float>(); cp.f.fm_stride = fm_stride;
+			cp.chain_first = c->d_chain_first.as<u32>() + cpos; cp.chain_cnt = c->d_chain_cnt.as<u32>() + cpos;
+			if (span_begin(c, 0, &sp)) return 1;
+			launch_fbc_h((int)H, cp, grid, block, fbc_smem, c->stream);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &sp)) return 1;
+			cpos += cnt;
+		}
+		// ---- finish: probabilities, sort, EA, sparsify
+		if (post_rows) {
+			PostRowsParams pr;
+			pr.pair_x = c->d_bx.as<u32>(); pr.pair_y = c->d_by.as<u32>(); pr.seq_len = c->d_seq_len.as<u32>();
+			pr.cand = c->d_cand.as<u64>(); pr.capc = capc; pr.cand_cnt = c->d_cand_cnt.as<u32>();
+			pr.use_fma = c->use_fma;
+			pr.lx_cap = LXmax + 2; pr.ly_cap = LYmax + 2;
+			// LDS list of a pair's candidates (larger lists cost resident waves, pairs that exceed it sort through HBM scratch; per
+			// batch of 125 000 pairs at L~400: 512 entries 16.9 ms, 768: 12.3, 896: 11.9, 1024: 11.7, 1280: 12.7, 1408 (holds every
+			// pair): 14.0, 1664: 15.8)
+			const u32 sort_cap = (u32)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2);
+			pr.sort_cap = std::min<u32>(capc, sort_cap);
+			pr.sort_stride = capc;
+			pr.batch = (u32)std::min(std::max(env_int("MPCGPU_POST_BATCH", 64), 1), 64);
+			const size_t fixed_lds = ((((size_t)pr.lx_cap + 2 * (size_t)pr.ly_cap) * 4 + 7) & ~(size_t)7);
+			if (fixed_lds + (size_t)pr.sort_cap * 8 > 150 * 1024) pr.sort_cap = (u32)((150 * 1024 - fixed_lds) / 8); // long sequences: the arrays per position come first
+			const size_t smem = fixed_lds + (size_t)pr.sort_cap * 8;
+			if (smem > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void *)post_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+			int pocc = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_rows_kernel, 64, smem) != hipSuccess || pocc < 1) pocc = 1;
+			// The persistent grid must not be larger than what is really resident, or its last workgroups run as a second round
+			// (measured, per batch of 125 000 pairs: 15 248 B of LDS, 10 workgroups per CU reported: 12.7 ms; 15 760 B, still 10
+			// reported: 22.5 ms; 17 296 B, 9 reported: 14.1 ms — 64-thread workgroups stop fitting at ~152 KB per CU, not 160)
+			pocc = std::max(1, std::min(pocc, (int)((152 * 1024) / smem)));
+			const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
+			HIPCHK(c, c->d_sort_scratch.ensure(capc > pr.sort_cap ? (u64)pgrid * pr.sort_stride * 8 : 8));
+			pr.sort_scratch = c->d_sort_scratch.as<u64>();
+			pr.res = c->d_res.as<u32>(); pr.res_stride = res_stride;
+			pr.nnz = c->d_nnz.as<u32>(); pr.ea = c->d_ea.as<float>(); pr.flags = c->d_flags.as<u32>();
+			pr.count = (u32)B;
+			pr.long_min = long_min;
+			pr.prof = nullptr;
+			const bool post_prof = env_int("MPCGPU_POST_PROFILE", 0) != 0; // measurement only: phase clocks of workgroup 0
+			if (post_prof) {
+				HIPCHK(c, c->d_post_prof.ensure(8 * 8));
+				HIPCHK(c, hipMemsetAsync(c->d_post_prof.p, 0, 64, c->stream));
+				pr.prof = c->d_post_prof.as<u64>();
+			}
+			if (trace_on()) { fprintf(stderr, "[mpcgpu] post rows: list of %u candidates in LDS, lds=%zu B blocks/CU=%d grid=%u\n", pr.sort_cap, smem, pocc, pgrid); fflush(stderr); }
+			if (span_begin(c, 1, &sp)) return 1;
+			MPC_LAUNCH(post_rows_kernel, pgrid, 64, smem, c->stream, pr);
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &sp)) return 1;
+			if (post_prof) {
+				u64 ticks[8];
+				HIPCHK(c, hipMemcpyAsync(ticks, pr.prof, 64, hipMemcpyDeviceToHost, c->stream));
+				HIPCHK(c, hipStreamSynchronize(c->stream));
+				const u64 npairs0 = (B + pgrid - 1) / pgrid; // pairs workgroup 0 handled
+				fprintf(stderr, "[mpcgpu] post_rows_kernel, workgroup 0, %llu pairs, us per pair (100 MHz clock): prob+histogram %.1f, scan+scatter %.1f, "
+					"row sort %.1f, EA %.1f, kept entries %.1f, column ranks %.1f\n", (u64)npairs0, ticks[0] / 100.0 / npairs0, ticks[1] / 100.0 / npairs0,
+					ticks[2] / 100.0 / npairs0, ticks[3] / 100.0 / npairs0, ticks[4] / 100.0 / npairs0, ticks[5] / 100.0 / npairs0);
+			}
+		} else {
+		PostParams pp;
+		pp.pair_x = c->d_bx.as<u32>(); pp.pair_y = c->d_by.as<u32>(); pp.seq_len = c->d_seq_len.as<u32>();
+		pp.cand = c->d_cand.as<u64>(); pp.capc = capc; pp.cand_cnt = c->d_cand_cnt.as<u32>();
+		pp.use_fma = c->use_fma;
+		// LDS sort buffer capacity (entries, power of two): pairs with more candidates sort in the
+		// global scratch. The kernel is latency-bound (one wave per pair), so LDS per workgroup trades
+		// against resident waves; MPCGPU_POST_SORT_CAP overrides for tuning.
+		pp.sort_cap = std::min<u32>(next_pow2(capc), next_pow2((u32)std::max(env_int("MPCGPU_POST_SORT_CAP", 1024), 2)));
+		pp.srow_cap = std::min<u32>(LYmax + 1, 2048u);
+		const size_t psmem0 = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
+		int pocc = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pocc, (const void *)post_kernel, 64, psmem0) != hipSuccess || pocc < 1) pocc = 8;
+		if (psmem0) pocc = std::max(1, std::min(pocc, (int)((152 * 1024) / psmem0))); // as for post_rows_kernel above
+		const u32 pgrid = (u32)std::min<u64>(B, (u64)cus * (u32)pocc);
+		if (trace_on()) { fprintf(stderr, "[mpcgpu] post: sort_cap=%u lds=%zu B blocks/CU=%d grid=%u\n", pp.sort_cap, psmem0, pocc, pgrid); fflush(stderr); }
+		pp.sort_stride = next_pow2(capc);
+		pp.srow_stride = 2 * ((u64)LYmax + 1);
+		const bool need_sort_scr = next_pow2(capc) > pp.sort_cap, need_srow_scr = LYmax + 1 > pp.srow_cap;
+		HIPCHK(c, c->d_sort_scratch.ensure(need_sort_scr ? (u64)pgrid * pp.sort_stride * 8 : 8));
+		HIPCHK(c, c->d_srow_scratch.ensure(need_srow_scr ? (u64)pgrid * pp.srow_stride * 4 : 8));
+		pp.sort_scratch = c->d_sort_scratch.as<u64>(); pp.srow_scratch = c->d_srow_scratch.as<float>();
+		pp.res = c->d_res.as<u32>(); pp.res_stride = res_stride;
+		pp.nnz = c->d_nnz.as<u32>(); pp.ea = c->d_ea.as<float>(); pp.flags = c->d_flags.as<u32>();
+		pp.count = (u32)B;
+		pp.long_min = long_min;
+		const size_t psmem = (size_t)pp.sort_cap * 8 + (size_t)pp.srow_cap * 2 * 4;
+		if (span_begin(c, 1, &sp)) return 1;
+		MPC_LAUNCH(post_kernel, pgrid, 64, psmem, c->stream, pp);
+		HIPCHK(c, hipGetLastError());
+		if (span_end(c, &sp)) return 1;
+		}
+		// ---- the next batch's host work, while the device runs this one (before the copies below: a copy into pageable host
+		// memory returns only when it is done)
 		lap(1);
-		// the next batch: host side now, and — two batches in flight — its sweeps queued before the wait for this batch's sizes
-		const u64 B = fl_cur.P.B;
-		fl_nxt.P.valid = false; fl_nxt.fb_launched = false;
-		if (done + B < np) {
-			if (prepare(done + B, fl_nxt.P)) return 1;
-			fl_nxt.set = pipeline ? (fl_cur.set ^ 1) : 0;
-			if (pipeline && launch_fb(fl_nxt)) return 1;
-		}
+		nxt.valid = false;
+		if (done + B < np && prepare(done + B, nxt)) return 1;
 		lap(2);
+		// ---- sizes back, overflow check, pack
+		std::vector<u32> flags(B);
+		HIPCHK(c, hipMemcpyAsync(&c->sh_nnz[done], c->d_nnz.p, B * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(&c->sh_ea[done], c->d_ea.p, B * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipMemcpyAsync(flags.data(), c->d_flags.p, B * 4, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		lap(3);
 		bool overflow = false;
-		if (finish(fl_cur, &overflow)) return 1;
+		for (u64 q = 0; q < B; ++q) overflow = overflow || (flags[q] & 1u);
 		if (overflow) {
-			// drain what is in flight (the next batch's sweeps included) and start over from this batch
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			HIPCHK(c, hipStreamSynchronize(stream_post));
-			post_pending[0] = post_pending[1] = false;
+			if (capc >= LXmax * (u64)LYmax)
+				return fail(c, "mpcgpu_calc_posteriors: candidate overflow at full capacity (internal error)");
 			capc = (u32)std::min<u64>((u64)capc * 2, (u64)LXmax * LYmax);
-			fl_cur.P.valid = false; fl_nxt.P.valid = false;
-			continue;
+			continue; // redo this batch with a larger candidate capacity
 		}
-		last_set = fl_cur.set;
+		std::vector<u64> dstbase(B), recw(B);
+		u64 w = words_done;
+		for (u64 q = 0; q < B; ++q) {
+			recw[q] = rec_words(c->len[bx[q]], c->len[by[q]], c->sh_nnz[done + q]);
+			dstbase[q] = hdr / 4 + w;
+			w += recw[q];
+		}
+		// capacity estimate for the whole shard from the words seen so far
+		const double per = double(w) / double(done + B);
+		const u64 est = hdr + (u64)(per * 1.05 * double(np) + 1024) * 4;
+		HIPCHK(c, c->d_shard.ensure(std::max<u64>(est, hdr + w * 4), true, c->stream));
+		if (upload(c, c->d_dstbase, dstbase) || upload(c, c->d_recwords, recw)) return 1;
+		if (span_begin(c, 1, &sp)) return 1;
+		MPC_LAUNCH(pack_kernel, (u32)std::min<u64>(B, (u64)cus * 8), 256, 0, c->stream, c->d_res.as<u32>(), res_stride,
+			c->d_dstbase.as<u64>(), c->d_recwords.as<u64>(), c->d_shard.as<u32>(), (u32)B);
+		HIPCHK(c, hipGetLastError());
+		if (span_end(c, &sp)) return 1;
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		words_done = w;
+		// what the LAST batch left in the scratch buffers (mpcgpu_align_pairs reads the candidate lists of a one-batch stage)
+		c->sa_b0 = done; c->sa_B = B; c->sa_capc = capc; c->sa_post_rows = post_rows; c->sa_long_min = long_min;
 		done += B;
-		std::swap(fl_cur, fl_nxt);
+		c->sa_chains += batch_chains; c->sa_chained += batch_chained;
+		std::swap(cur, nxt);
 		lap(4);
 	}
-	HIPCHK(c, hipStreamSynchronize(c->stream));
-	HIPCHK(c, hipStreamSynchronize(stream_post));
-	if (last_set) { SetSwap tmp(c, 1); tmp.on = false; } // what the last batch left behind (mpcgpu_align_pairs reads it) goes under the usual names
 	if (host_trace)
 		fprintf(stderr, "[mpcgpu] stage A host seconds: prepare (first batch / retries) %.4f, uploads + launches %.4f, next batch prepared %.4f, "
 			"waiting for the device %.4f, sizes -> pack -> wait %.4f\n", lap_t[0], lap_t[1], lap_t[2], lap_t[3], lap_t[4]);

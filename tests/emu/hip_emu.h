@@ -211,9 +211,6 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emuEvent; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-#define hipEventDisableTiming 0x2
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emuEvent; return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; } // launches run to completion: nothing to wait for
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
