@@ -421,11 +421,12 @@ void var_lds_geometry(u32 geo, u32 nbuf, u32 *buf_bytes, size_t *smem)
 u32 var_max_slots(u32 geo) { return geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : 26u; }
 u32 var_geo_from_env()
 {
-	// default: two 768-thread workgroups per CU (6 waves per SIMD): measured 1748 ms per two iterations at 1000 x L~400 against
-	// 1984 (512 x 2), 2017 (1024 x 2: spills in the walk), 2060 (1024 x 1, two staging buffers), 2759 (640 x 2) and 2932 (896 x 2:
-	// both spill inside the walk; not kept) — profiles/r02e, r02h
-	const int t = env_int("MPCGPU_RELAX_WG", 768);
-	return t == 512 ? 512u : t == 1024 ? 1024u : t == 2048 ? 2048u : 768u;
+	// default: two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs, 14 cells per lane). Round 2 (profiles/r02e, r02h):
+	// 768 x 2 1748 ms per two iterations at 1000 x L~400 against 1984 (512 x 2), 2017 (1024 x 2: spills in the walk), 2060 (1024 x 1,
+	// two staging buffers). With round 3's walk (no spills at 64 VGPRs) 1024 x 2 is level or ahead: 1192 against 1203 ms (768 x 2)
+	// on the synthetic family, 12.45 against 12.94 s on real data (profiles/r04a, r04e)
+	const int t = env_int("MPCGPU_RELAX_WG", 2048);
+	return t == 512 ? 512u : t == 1024 ? 1024u : t == 768 ? 768u : 2048u;
 }
 
 template <int TH, int SL, int WGS, int DG = 0, class BL = MpcRvBlocksAsm> void launch_relax_var(const RelaxVarParams &rp, u32 grid, size_t smem, hipStream_t st)
@@ -640,12 +641,7 @@ int build_var_store(mpcgpu_ctx *c)
 		// staging overlaps the other's merges) and give the rest to a second launch of the one-workgroup geometry; 0: everything
 		// to the one-workgroup geometry
 		if (!(threads == 1024 && nbuf == 1) && env_int("MPCGPU_RELAX_MIXED", 1)) {
-			c->var_mixed = true;
-			// such runs end up with tiles of one pair (two records of 20..40 KB per step for ~3 slots of cells): two 1024-thread
-			// workgroups per CU (8 waves per SIMD) measured 4 % faster than two of 768 on the first 1000 rdrp records
-			// (profiles/r04a), unless the geometry was asked for
-			const char *wg_env = getenv("MPCGPU_RELAX_WG");
-			if (!(wg_env && *wg_env) && slots_ok(2048)) { threads = 2048; nbuf = 1; var_lds_geometry(threads, nbuf, &buf_bytes, &smem); }
+			c->var_mixed = true; // (such runs end up with tiles of one pair: two records of 20..40 KB per step for ~3 slots of cells)
 		}
 		else { threads = 1024; nbuf = 1; buf_bytes = bb1; smem = sm1; }
 	}
