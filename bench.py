@@ -155,7 +155,7 @@ def main():
     import torch
     import torch.distributed as dist
     from muscle_amd._lib import MpcGpu
-    from muscle_amd.mpcflat import TorchExchange, run_stage
+    from muscle_amd.mpcflat import CONSISTENCY_ITERS, TorchExchange, run_stage
     from muscle_amd.synth import make_family
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,8 +272,14 @@ def main():
                 r["bound"], r["frac"], r["achieved"], r["peak"], r["unit"] = None, None, None, None, None
             return r
 
+        n_seqs_ge3 = a.n >= 3
+
         def relax_roof():
             ms, launches = timers["relax"]
+            # per relax ITERATION: real data runs two launches per iteration (the pairs whose records only fit the 160 KB geometry
+            # get a second, tiny one — relax_geometry says so); the counters in pmc_traffic.json are those of the dominant launch
+            iters = max(a.steps * CONSISTENCY_ITERS, 1) if n_seqs_ge3 else max(launches, 1)
+            launches = iters
             avg_s = ms * 1e-3 / max(launches, 1)
             per_launch = stage_b_bytes(lens, nnz) * my_frac  # one launch = one relax iteration over this rank's pairs
             launched = geo.split("kernel=")[1].split(";")[0].strip() if "kernel=" in geo else None
