@@ -124,13 +124,14 @@ def cpu_baseline(seqs, n_full, budget_s=20.0):
     # the same reference TIMED (nothing extrapolated) on a GPU box's host cores, and what this formula predicted for that size
     # from a 128-sequence sample in the same run: committed by diag/ref_time.py (scripts/gpu.sh ... sh:python diag/ref_time.py)
     try:
-        with open(os.path.join(ROOT, "profiles", "r03i_ref_time_512.json")) as f:
+        src = "r04g_ref_time_1000.json" if os.path.exists(os.path.join(ROOT, "profiles", "r04g_ref_time_1000.json")) else "r03i_ref_time_512.json"
+        with open(os.path.join(ROOT, "profiles", src)) as f:
             m = json.load(f)
         out["measured_reference_run"] = {
             "n": m["timed"]["n"], "pairs": m["timed"]["pairs"], "pairs_per_s": m["timed"]["pairs_per_s"], "cores": m["cores"], "cpu": m.get("cpu"),
             "stage_a_s": m["timed"]["stage_a_s"], "relax_2it_s": m["timed"]["relax_2it_s"], "extrapolated": False,
             "extrapolation_formula_error_at_this_size": m["extrapolation_error"],
-            "source": "profiles/r03i_ref_time_512.json (diag/ref_time.py on an MI355X box: EPYC 9575F, 16-core quota)"}
+            "source": "profiles/%s (diag/ref_time.py on an MI355X box: EPYC 9575F, 16-core quota)" % src}
     except (OSError, ValueError, KeyError):
         pass
     return out

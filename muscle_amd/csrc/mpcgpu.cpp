@@ -1097,10 +1097,11 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 				while (hi < chains.size() && chains[hi].H == chains[lo].H) ++hi;
 				const u32 H = chains[lo].H;
 				const u64 waves = (u64)cus * (u32)occ_fbc_h((int)H, block, fbc_smem) * waves_per_block;
+				const u64 gw = std::max<u64>(waves * (u64)std::max(env_int("MPCGPU_FB_CHAIN_GRADE_Q", 4), 1) / 4, 1); // pairs per grade, in quarters of a round of resident waves
 				u64 seen = 0; // pairs, counted from the end of the bin
 				for (size_t k = hi; k-- > lo;) {
 					const Chain &ch = chains[k];
-					const u32 piece = !chain_grade ? ch.cnt : seen < waves ? 1u : seen < 3 * waves ? 2u : seen < 7 * waves ? 4u : ch.cnt;
+					const u32 piece = !chain_grade ? ch.cnt : seen < gw ? 1u : seen < 3 * gw ? 2u : seen < 7 * gw ? 4u : ch.cnt;
 					seen += ch.cnt;
 					const u32 LX = c->len[P.bx[ch.q0]];
 					for (u32 o = 0; o < ch.cnt; o += piece) {
