@@ -1042,6 +1042,11 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		HIPCHK(c, hipMemGetInfo(&freeb, &totb));
 		// the scratch of the previous batch (or of an overflow retry) is already owned and gets reused: count it as available
 		const u64 owned = (u64)c->d_cand.cap + c->d_res.cap + c->d_fm.cap;
+		// 16 GB: four batches at 1000 x L~400. Fewer, larger batches save the tails of waves that finish alone (24 GB / 3 batches: fb
+		// 551 -> 545 ms, step 1832 -> 1822; 32 / 2: 541, 1840: the first batch's host preparation is not covered by device work) —
+		// but the scratch is allocated inside the first call, and with 24 GB that call's allocations took 1.2 s longer (some hipMalloc
+		// crosses a slow path): `muscle_gpu -align` of the same 1000 sequences 5.07 -> 6.42 s; 8 GB: 4.97 s, 4 GB: 5.22 s
+		// (profiles/r05a, r05c, r05d)
 		u64 budget = std::min<u64>((u64)env_int("MPCGPU_SCRATCH_GB", 16) << 30, (u64)((freeb + owned) * 0.4));
 		u64 B = std::max<u64>(1, std::min<u64>(np - b0, budget / per_pair));
 		B = std::min<u64>(B, 1u << 22);
