@@ -104,54 +104,6 @@ __device__ __forceinline__ void mpc_dma16(const void *gsrc, void *lds_wave_base)
 		(__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ void mpc_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// waits until at most k of this wave's vector-memory operations are outstanding (k is rounded DOWN to a value the code
-// below knows: a longer wait, never a shorter one); LDS-DMA transfers complete in issue order, so "at most k outstanding"
-// = everything but the youngest k has landed
-__device__ __forceinline__ void mpc_wait_vmcnt(unsigned k)
-{
-#define MPC_VMCNT_CASE(v) if (k >= v) { asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); return; }
-	MPC_VMCNT_CASE(63) MPC_VMCNT_CASE(48) MPC_VMCNT_CASE(40) MPC_VMCNT_CASE(32) MPC_VMCNT_CASE(28) MPC_VMCNT_CASE(24) MPC_VMCNT_CASE(20)
-	MPC_VMCNT_CASE(18) MPC_VMCNT_CASE(16) MPC_VMCNT_CASE(14) MPC_VMCNT_CASE(12) MPC_VMCNT_CASE(11) MPC_VMCNT_CASE(10) MPC_VMCNT_CASE(9)
-	MPC_VMCNT_CASE(8) MPC_VMCNT_CASE(7) MPC_VMCNT_CASE(6) MPC_VMCNT_CASE(5) MPC_VMCNT_CASE(4) MPC_VMCNT_CASE(3) MPC_VMCNT_CASE(2) MPC_VMCNT_CASE(1)
-#undef MPC_VMCNT_CASE
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-// LDS by 32-bit address (see mpc_lds_addr), for code that has no address-space-3 pointer at hand — a function that receives the
-// dynamic LDS as a generic pointer would read it with flat instructions, whose results are waited for with vmcnt. Volatile: the
-// words relax_stream_kernel's waves signal each other through.
-__device__ __forceinline__ unsigned mpc_lds_vread(unsigned addr) { return *(volatile __attribute__((address_space(3))) unsigned *)(unsigned long long)addr; }
-__device__ __forceinline__ void mpc_lds_vwrite(unsigned addr, unsigned v) { *(volatile __attribute__((address_space(3))) unsigned *)(unsigned long long)addr = v; }
-__device__ __forceinline__ void mpc_dma16_at(const void *gsrc, unsigned lds_wave_addr)
-{
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-		(__attribute__((address_space(3))) void *)(unsigned long long)lds_wave_addr, 16, 0, 0);
-}
-// the same with the instruction's immediate offset (bytes, added to BOTH addresses): chunk k of a run goes out as offset 1024 * k
-// on one M0, instead of a new M0 per chunk
-template <int OFF> __device__ __forceinline__ void mpc_dma16_at_off(const void *gsrc, unsigned lds_wave_addr)
-{
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-		(__attribute__((address_space(3))) void *)(unsigned long long)lds_wave_addr, 16, OFF, 0);
-}
-// minimum of v over lanes 0..15 of the wave, as a wave-uniform scalar (DPP row shifts inside the first row of 16 lanes, lanes
-// without a source keep their own value; the result is lane 15's)
-__device__ __forceinline__ unsigned mpc_row16_min_u32(unsigned v)
-{
-#define MPC_DPP_MINU(ctrl_) { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl_, 0xf, 0xf, false); v = o_ < v ? o_ : v; }
-	MPC_DPP_MINU(0x111) MPC_DPP_MINU(0x112) MPC_DPP_MINU(0x114) MPC_DPP_MINU(0x118) // row_shr:1, 2, 4, 8
-#undef MPC_DPP_MINU
-	return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
-}
-// this lane's number within its wave, computed on the spot (v_mbcnt: two VALU instructions, nothing to keep in a register or to
-// reload from a spill slot — relax_stream_kernel's producer must not touch memory through the vector path between transfers)
-__device__ __forceinline__ unsigned mpc_lane_fresh()
-{
-	unsigned l;
-	asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-	return l;
-}
-// inside a wait loop on an LDS word another wave will change
-#define MPC_SPIN_PAUSE() __builtin_amdgcn_s_sleep(2)
 // issue priority of this wave among the waves of its SIMD (0..3)
 #define MPC_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 // Measurement knob of relax_var_kernel (MPCGPU_RELAX_STAGGER): the workgroup in an odd threadgroup slot of its CU (HW_ID.TG_ID,

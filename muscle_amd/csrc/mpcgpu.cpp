@@ -12,13 +12,6 @@
 #include "kernels_post.h"
 #include "kernels_store.h"
 #include "kernels_relaxv.h"
-#include "kernels_relaxs.h"
-#define MPC_STR2(x) #x
-#define MPC_STR(x) MPC_STR2(x)
-#define MPC_RS_HOST_THREADS 768 // relax_stream_kernel as launched: 9 consumer waves + 3 producer waves, two workgroups per CU (80 VGPRs)
-#define MPC_RS_HOST_NPROD 3
-#define MPC_RS_HOST_SLOTS 17
-#define MPC_RS_HOST_NY 6 // Y records per tile (<= MPC_RS_NY): 12 pairs of ~790 wave-aligned cells fill 17 slots of 9 waves at L~400
 #include "kernels_aln.h"
 #include "kernels_prog.h"
 
@@ -162,11 +155,6 @@ struct mpcgpu_ctx {
 	bool var_mixed = false;    // two launches per relax: the configured geometry + 1 x 1024 threads / 160 KB for what does not fit it
 	u64 tiles_k0 = ~0ull, tiles_k1 = ~0ull;
 	u32 tiles_bx = 0, tiles_by = 0;
-	// relax_stream_kernel (kernels_relaxs.h): its tiles (6 u32 each); what does not fit them goes through h_tiles / h_tiles2
-	std::vector<u32> h_tiles_s;
-	DevBuf d_tiles_s, d_rs_err;
-	u32 stream_ring4 = 0;     // tiles whose worst step leaves room for 4 ring slots (else 3)
-	bool stream_used = false; // the last relax launched relax_stream_kernel (its error word is checked at the commit)
 
 	// scratch
 	DevBuf d_bnd;
@@ -430,10 +418,14 @@ void var_lds_geometry(u32 geo, u32 nbuf, u32 *buf_bytes, size_t *smem)
 // workgroup sizes of relax_var_kernel: 1024 (one per CU), or two per CU of 512 / 640 / 768 threads (4 / 5 / 6 waves per SIMD:
 // 128 / 96 / 80 VGPRs); slots = cells per lane a tile may need (about 12.7 k wave-aligned cells per 4x4 tile at L~400)
 // geometry id = threads per workgroup, except 2048 = two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs)
-u32 var_max_slots(u32 geo) { return geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : 26u; }
+// cells per lane of the default geometry (two 1024-thread workgroups per CU, 64 VGPRs): 13. With 14 the compiler keeps five row-offset
+// registers in spill slots and reloads them inside the walk (each reload waits for vmcnt(0)); 13 has none, and although 2 600 more
+// 4x4 tiles then split into 4x2 the two iterations at 1000 x L~400 take 1171 ms against 1195 (12: 1282, most tiles split) — profiles/r05g
+u32 var_slots_2048() { const int v = env_int("MPCGPU_RELAX_DIAG", 0) ? 13 : env_int("MPCGPU_RELAX_SLOTS_2048", 13); return v == 12 ? 12u : v == 14 ? 14u : 13u; } // (the measurement-only DIAG kernels exist with 13)
+u32 var_max_slots(u32 geo) { return geo == 1024 ? 16u : geo == 2048 ? var_slots_2048() : geo == 768 ? 18u : 26u; }
 u32 var_geo_from_env()
 {
-	// default: two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs, 14 cells per lane). Round 2 (profiles/r02e, r02h):
+	// default: two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs, 13 cells per lane: var_slots_2048). Round 2 (profiles/r02e, r02h):
 	// 768 x 2 1748 ms per two iterations at 1000 x L~400 against 1984 (512 x 2), 2017 (1024 x 2: spills in the walk), 2060 (1024 x 1,
 	// two staging buffers). With round 3's walk (no spills at 64 VGPRs) 1024 x 2 is level or ahead: 1192 against 1203 ms (768 x 2)
 	// on the synthetic family, 12.45 against 12.94 s on real data (profiles/r04a, r04e)
@@ -465,15 +457,15 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 	const char *merge_env = getenv("MPCGPU_RELAX_MERGE"); // "cxx": the compiler's code for the merge instead of the hand-scheduled one (A/B, 768 geometry)
 	const bool merge_cxx = merge_env && !strcmp(merge_env, "cxx");
 	const void *fn = geo == 1024 ? (const void *)relax_var_kernel<1024, 16, 1>
-	               : geo == 2048 ? (diag == 1 ? (const void *)relax_var_kernel<1024, 14, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<1024, 14, 2, 2> : diag == 3 ? (const void *)relax_var_kernel<1024, 14, 2, 3>
-	                                : (const void *)relax_var_kernel<1024, 14, 2>)
+	               : geo == 2048 ? (diag == 1 ? (const void *)relax_var_kernel<1024, 13, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<1024, 13, 2, 2> : diag == 3 ? (const void *)relax_var_kernel<1024, 13, 2, 3>
+	                                : var_slots_2048() == 14 ? (const void *)relax_var_kernel<1024, 14, 2> : var_slots_2048() == 12 ? (const void *)relax_var_kernel<1024, 12, 2> : (const void *)relax_var_kernel<1024, 13, 2>)
 	               : geo == 768 ? (diag == 1 ? (const void *)relax_var_kernel<768, 18, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<768, 18, 2, 2> : diag == 3 ? (const void *)relax_var_kernel<768, 18, 2, 3>
 	                               : merge_cxx ? (const void *)relax_var_kernel<768, 18, 2, 0, MpcRvBlocksCxx> : (const void *)relax_var_kernel<768, 18, 2>)
 	               : (const void *)relax_var_kernel<512, 26, 2>;
 	HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 	if (primary) {
 		char kn[128];
-		snprintf(kn, sizeof(kn), "relax_var_kernel<%u, %u, %d, %d, %s>", threads, geo == 1024 ? 16u : geo == 2048 ? 14u : geo == 768 ? 18u : 26u,
+		snprintf(kn, sizeof(kn), "relax_var_kernel<%u, %u, %d, %d, %s>", threads, geo == 1024 ? 16u : geo == 2048 ? var_slots_2048() : geo == 768 ? 18u : 26u,
 			geo == 1024 ? 1 : 2, (geo == 768 || geo == 2048) ? diag : 0, (geo == 768 && merge_cxx && !diag) ? "MpcRvBlocksCxx" : "MpcRvBlocksAsm");
 		c->relax_kernel_name = kn;
 	}
@@ -488,10 +480,12 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 	if (span_begin(c, 3, &ts)) return 1;
 	if (geo == 1024) launch_relax_var<1024, 16, 1>(rp, grid, smem, c->stream);
 	else if (geo == 2048) {
-		if (diag == 1) launch_relax_var<1024, 14, 2, 1>(rp, grid, smem, c->stream);
-		else if (diag == 2) launch_relax_var<1024, 14, 2, 2>(rp, grid, smem, c->stream);
-		else if (diag == 3) launch_relax_var<1024, 14, 2, 3>(rp, grid, smem, c->stream);
-		else launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
+		if (diag == 1) launch_relax_var<1024, 13, 2, 1>(rp, grid, smem, c->stream);
+		else if (diag == 2) launch_relax_var<1024, 13, 2, 2>(rp, grid, smem, c->stream);
+		else if (diag == 3) launch_relax_var<1024, 13, 2, 3>(rp, grid, smem, c->stream);
+		else if (var_slots_2048() == 14) launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
+		else if (var_slots_2048() == 12) launch_relax_var<1024, 12, 2>(rp, grid, smem, c->stream);
+		else launch_relax_var<1024, 13, 2>(rp, grid, smem, c->stream);
 	}
 	else if (geo == 768) {
 		if (diag == 1) launch_relax_var<768, 18, 2, 1>(rp, grid, smem, c->stream);
@@ -583,80 +577,10 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 				if (hist[a][bb] && o < (int)sizeof(b) - 24) o += snprintf(b + o, sizeof(b) - o, " %ux%u x %u", a, bb, hist[a][bb]);
 		return std::string(b);
 	};
-	// MPCGPU_RELAX_STREAM=1: relax_stream_kernel (kernels_relaxs.h: 2 x 8 tiles, a producer wave, no barriers in the walk) for the
-	// default two-workgroup geometry when every record fits it; tiles it cannot take go to relax_var_kernel below
-	const bool stream_on = c->var_threads == 2048 && !c->var_mixed && env_int("MPCGPU_RELAX_STREAM", 0) != 0;
-	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != (stream_on ? 2u : 4u) || c->tiles_by != (stream_on ? 8u : 4u)) {
+	if (c->tiles_k0 != k0 || c->tiles_k1 != k1 || c->tiles_bx != 4 || c->tiles_by != 4) {
 		c->tiles_k0 = c->tiles_k1 = ~0ull;
-		std::vector<u32> cand;
-		c->h_tiles_s.clear();
-		if (stream_on) {
-			// X blocks of 2, Y blocks of 8 (aligned), the workgroups of an XCD on the same Y block; a tile's cells must fit the 14 slots
-			// of 15 consumer waves, its worst step 2 X buffers + 3 ring slots of LDS (measured on the device); else: split over Y, and
-			// what still does not fit becomes candidates of the barrier kernel (Y blocks of 4)
-			auto tile_cells = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
-				u64 cells = 0;
-				for (u32 X = x0; X < x0 + nx; ++X)
-					for (u32 Y = std::max(y0, X + 1); Y < y0 + ny; ++Y) {
-						const u64 k = pidx(X, Y);
-						if (k >= k0 && k < k1) cells += ((u64)c->all_nnz[k] + 63) & ~63ull;
-					}
-				return cells;
-			};
-			const u64 cap_cells = (u64)MPC_RS_HOST_SLOTS * (MPC_RS_HOST_THREADS / 64 - MPC_RS_HOST_NPROD) * 64;
-			std::vector<u32> st; // 4 u32 per candidate stream tile
-			u32 nring4 = 0;
-			std::function<void(u32, u32, u32, u32)> emit_s = [&](u32 x0, u32 nx, u32 y0, u32 ny) {
-				const u64 cells = tile_cells(x0, nx, y0, ny);
-				if (cells == 0) return;
-				if (cells <= cap_cells) { st.insert(st.end(), {x0, nx, y0, ny}); return; }
-				if (ny > 1) { emit_s(x0, nx, y0, ny / 2); emit_s(x0, nx, y0 + ny / 2, ny - ny / 2); }
-				else if (nx > 1) { emit_s(x0, 1, y0, ny); emit_s(x0 + 1, nx - 1, y0, ny); }
-				else cand.insert(cand.end(), {x0, nx, y0, ny});
-			};
-			const u32 NY = MPC_RS_HOST_NY;
-			const u32 nbx = (n + 1) / 2, nby = (n + NY - 1) / NY;
-			for (u32 sx = 0; sx < nbx; sx += 8)
-				for (u32 yb = 0; yb < nby; ++yb)
-					for (u32 xb = sx; xb < std::min(sx + 8, nbx); ++xb) {
-						const u32 x0 = xb * 2, nx = std::min(2u, n - x0), y0 = yb * NY, ny = std::min(NY, n - y0);
-						if (y0 + ny <= x0 + 1) continue; // no pair X < Y in this block
-						emit_s(x0, nx, y0, ny);
-					}
-			const u32 lds_budget_blocks = (80u * 1024u - MPC_RS_TAB_BYTES) / 16u;
-			const u32 ring_max = (u32)std::min(std::max(env_int("MPCGPU_RELAX_STREAM_RING", 4), 3), 4);
-			if (!st.empty()) {
-				const u32 nt = (u32)(st.size() / 4);
-				std::vector<u32> t6((size_t)nt * 6, 0);
-				for (u32 t = 0; t < nt; ++t) for (u32 w = 0; w < 4; ++w) t6[6 * t + w] = st[4 * t + w];
-				if (upload(c, c->d_tiles_s, t6)) return 1;
-				HIPCHK(c, c->d_tilefit.ensure((size_t)nt * 8));
-				MPC_LAUNCH(stream_tile_fit_kernel, std::min<u32>(nt, (u32)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_tiles_s.as<u32>(), nt,
-					c->d_tilefit.as<u32>());
-				HIPCHK(c, hipGetLastError());
-				std::vector<u32> fit((size_t)nt * 2);
-				HIPCHK(c, hipMemcpyAsync(fit.data(), c->d_tilefit.p, (size_t)nt * 8, hipMemcpyDeviceToHost, c->stream));
-				HIPCHK(c, hipStreamSynchronize(c->stream));
-				u32 nleft = 0;
-				for (u32 t = 0; t < nt; ++t) {
-					const u32 xcap = fit[2 * t], ycap = fit[2 * t + 1];
-					const u32 ring = (ring_max == 4 && 2ull * xcap + 4ull * ycap <= lds_budget_blocks) ? 4u : 3u;
-					if (ring == 4) ++nring4;
-					if (2ull * xcap + (u64)ring * ycap <= lds_budget_blocks)
-						c->h_tiles_s.insert(c->h_tiles_s.end(), {st[4 * t], st[4 * t + 1], st[4 * t + 2], st[4 * t + 3] | (ring << 8), xcap, ycap});
-					else { // to the barrier kernel, in Y blocks of at most 4
-						const u32 x0 = st[4 * t], nx = st[4 * t + 1], y0 = st[4 * t + 2], ny = st[4 * t + 3];
-						for (u32 o = 0; o < ny; o += 4) cand.insert(cand.end(), {x0, nx, y0 + o, std::min(4u, ny - o)});
-						++nleft;
-					}
-				}
-				if (trace_on()) { fprintf(stderr, "[mpcgpu] relax stream: %u tiles, %u with 4 ring slots, %u over the LDS budget (to relax_var_kernel)\n", nt, nring4, nleft); fflush(stderr); }
-				c->stream_ring4 = nring4;
-				if (!c->h_tiles_s.empty() && upload(c, c->d_tiles_s, c->h_tiles_s)) return 1;
-				HIPCHK(c, hipStreamSynchronize(c->stream));
-			}
-		} else {
 		// X blocks of 4, Y blocks of 4, walked in 8x8 super-tiles (the workgroups of an XCD read the same sequences' records)
+		std::vector<u32> cand;
 		const u32 nbx = (n + 3) / 4, nby = (n + 3) / 4;
 		for (u32 sx = 0; sx < nbx; sx += 8)
 			for (u32 sy = 0; sy < nby; sy += 8)
@@ -666,58 +590,23 @@ int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 						if (y0 + ny <= x0 + 1) continue; // no pair X < Y in this block
 						cand.insert(cand.end(), {x0, nx, y0, ny});
 					}
-		}
 		std::vector<u32> ok, ok2, left;
 		if (build_tiles(c->var_threads, c->var_nbuf, cand, ok, c->var_mixed ? &left : nullptr)) return 1;
 		if (!left.empty() && build_tiles(1024, 1, left, ok2, nullptr)) return 1;
 		c->tiles_desc = describe(ok);
-		if (!c->h_tiles_s.empty()) {
-			char b[256];
-			snprintf(b, sizeof(b), "relax_stream_kernel: %zu tiles of 2 x " MPC_STR(MPC_RS_HOST_NY) " (%d consumer waves + " MPC_STR(MPC_RS_HOST_NPROD) " producer waves, 2 X buffers + a ring of Y records: 4 slots in %u tiles, else 3)",
-				c->h_tiles_s.size() / 6, MPC_RS_HOST_THREADS / 64 - MPC_RS_HOST_NPROD, c->stream_ring4);
-			c->tiles_desc = ok.empty() ? std::string(b) : std::string(b) + "; relax_var_kernel for " + c->tiles_desc;
-		}
 		if (!ok2.empty()) c->tiles_desc += "; + 1 x 1024-thread workgroup per CU, 1 staging buffer of 160 KB for " + describe(ok2);
 		c->h_tiles.swap(ok);
 		c->h_tiles2.swap(ok2);
 		if (upload(c, c->d_tiles, c->h_tiles)) return 1;
 		if (!c->h_tiles2.empty() && upload(c, c->d_tiles2, c->h_tiles2)) return 1;
 		HIPCHK(c, hipStreamSynchronize(c->stream)); // the source of the async copy lives in the context; drained before any rebuild
-		c->tiles_k0 = k0; c->tiles_k1 = k1; c->tiles_bx = stream_on ? 2 : 4; c->tiles_by = stream_on ? 8 : 4;
+		c->tiles_k0 = k0; c->tiles_k1 = k1; c->tiles_bx = 4; c->tiles_by = 4;
 	}
-	if (c->h_tiles.empty() && c->h_tiles2.empty() && c->h_tiles_s.empty()) return 0;
-	HIPCHK(c, c->d_tile_next.ensure(24 * 4));
-	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 24 * 4, c->stream));
-	c->stream_used = false;
-	if (!c->h_tiles_s.empty()) {
-		RelaxStreamParams rp;
-		rp.s = sp; rp.tiles = c->d_tiles_s.as<u32>(); rp.ntiles = (u32)(c->h_tiles_s.size() / 6);
-		rp.k0 = k0; rp.k1 = k1; rp.tile_next = c->d_tile_next.as<u32>() + 16;
-		HIPCHK(c, c->d_rs_err.ensure(4));
-		HIPCHK(c, hipMemsetAsync(c->d_rs_err.p, 0, 4, c->stream));
-		rp.err = c->d_rs_err.as<u32>();
-		rp.diag = (u32)std::max(env_int("MPCGPU_RELAX_DIAG", 0), 0);
-		auto kern = relax_stream_kernel<MPC_RS_HOST_THREADS, MPC_RS_HOST_NPROD, MPC_RS_HOST_SLOTS, MpcRvBlocksAsm>;
-		const size_t smem = 80 * 1024;
-		HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-		int occ = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, MPC_RS_HOST_THREADS, smem) != hipSuccess || occ < 1) occ = 1;
-		const u32 grid = std::max(std::min<u32>(rp.ntiles, (u32)c->prop.multiProcessorCount * (u32)occ), 1u);
-		{
-			char kn[96];
-			snprintf(kn, sizeof(kn), "relax_stream_kernel<%d, %d, %d, MpcRvBlocksAsm>", MPC_RS_HOST_THREADS, MPC_RS_HOST_NPROD, MPC_RS_HOST_SLOTS);
-			c->relax_kernel_name = kn;
-		}
-		if (trace_on()) { fprintf(stderr, "[mpcgpu] relax stream: tiles=%u occ=%d grid=%u\n", rp.ntiles, occ, grid); fflush(stderr); }
-		TimedSpan ts;
-		if (span_begin(c, 3, &ts)) return 1;
-		MPC_LAUNCH(kern, grid, MPC_RS_HOST_THREADS, smem, c->stream, rp);
-		HIPCHK(c, hipGetLastError());
-		if (span_end(c, &ts)) return 1;
-		c->stream_used = true;
-	}
-	if (!c->h_tiles.empty() && relax_var_launch(c, sp, k0, k1, c->var_threads, c->var_nbuf, c->d_tiles, (u32)(c->h_tiles.size() / 4), 0, c->h_tiles_s.empty())) return 1;
-	if (!c->h_tiles2.empty() && relax_var_launch(c, sp, k0, k1, 1024, 1, c->d_tiles2, (u32)(c->h_tiles2.size() / 4), 1, c->h_tiles.empty() && c->h_tiles_s.empty())) return 1;
+	if (c->h_tiles.empty() && c->h_tiles2.empty()) return 0;
+	HIPCHK(c, c->d_tile_next.ensure(16 * 4));
+	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 16 * 4, c->stream));
+	if (!c->h_tiles.empty() && relax_var_launch(c, sp, k0, k1, c->var_threads, c->var_nbuf, c->d_tiles, (u32)(c->h_tiles.size() / 4), 0, true)) return 1;
+	if (!c->h_tiles2.empty() && relax_var_launch(c, sp, k0, k1, 1024, 1, c->d_tiles2, (u32)(c->h_tiles2.size() / 4), 1, c->h_tiles.empty())) return 1;
 	return 0;
 }
 
@@ -863,7 +752,6 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 	c->d_ap_off.release();
 	c->d_chain_first.release(); c->d_chain_cnt.release();
 	c->d_tiles2.release();
-	c->d_tiles_s.release(); c->d_rs_err.release();
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -1794,13 +1682,6 @@ int mpcgpu_cons_commit(mpcgpu_ctx *c)
 	if (!c->have_store) return fail(c, "mpcgpu_cons_commit: no store");
 	HIPCHK(c, hipSetDevice(c->device));
 	if (c->total_entries == 0) return 0;
-	if (c->stream_used) { // relax_stream_kernel's waits give up instead of hanging: a set word means its results are not to be used
-		u32 e = 0;
-		HIPCHK(c, hipMemcpyAsync(&e, c->d_rs_err.p, 4, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipStreamSynchronize(c->stream));
-		c->stream_used = false;
-		if (e) return fail(c, "mpcgpu_cons_commit: relax_stream_kernel gave up waiting (producer / consumer protocol error)");
-	}
 	StoreParams sp;
 	fill_store_params(c, sp);
 	TimedSpan ts;

@@ -134,18 +134,6 @@ static inline unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { ret
 static inline void mpc_dma16(const void *gsrc, void *lds_wave_base) { memcpy((unsigned char *)lds_wave_base + 16 * emu::t_lane, gsrc, 16); }
 static inline void mpc_dma_wait() {}
 #define MPC_SETPRIO(n) ((void)0)
-static inline void mpc_wait_vmcnt(unsigned) {}
-template <int OFF> static inline void mpc_dma16_at_off(const void *gsrc, unsigned lds_wave_addr) { memcpy(emu::g_block->dyn_smem + lds_wave_addr + OFF + 16 * emu::t_lane, (const unsigned char *)gsrc + OFF, 16); }
-static inline unsigned mpc_lds_vread(unsigned addr) { return *(volatile unsigned *)(emu::g_block->dyn_smem + addr); }
-static inline void mpc_lds_vwrite(unsigned addr, unsigned v) { *(volatile unsigned *)(emu::g_block->dyn_smem + addr) = v; }
-static inline void mpc_dma16_at(const void *gsrc, unsigned lds_wave_addr) { memcpy(emu::g_block->dyn_smem + lds_wave_addr + 16 * emu::t_lane, gsrc, 16); }
-static inline unsigned mpc_lane_fresh() { return emu::t_lane; }
-static inline unsigned mpc_row16_min_u32(unsigned v)
-{
-	for (int d = 1; d < 16; d <<= 1) { const unsigned o = __shfl_up(v, d); if ((int)emu::t_lane >= d && o < v) v = o; }
-	return __shfl(v, 15);
-}
-#define MPC_SPIN_PAUSE() emu::yield() // the waited-for fiber gets the OS thread
 static inline void mpc_stagger_second_workgroup(unsigned) {}
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
 static inline unsigned long long mpc_clock() { return 0ull; }

@@ -368,36 +368,6 @@ def test_emu_relax_var_geometries(emu, env):
     P.assert_same(got, P.run_oracle(seqs), "relax_var_kernel %s" % env)
 
 
-@pytest.mark.parametrize("fam", ["ragged", "eleven", "wide"])
-def test_emu_relax_stream_kernel(emu, fam):
-    """relax_stream_kernel (MPCGPU_RELAX_STREAM=1): 2 x 8 tiles, wave 15 moves the records (X runs double-buffered, Y records through a
-    ring of 3), the 15 consumer waves merge with counters instead of barriers — the arithmetic and its order are relax_var_kernel's,
-    so every bit equals the oracle's. Families: ragged edge tiles (n not a multiple of 2 or 8, a 3-residue sequence), one full and
-    one partial Y block, wide rows (several blocks per row)."""
-    if fam == "ragged":
-        seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0], "MKV"]
-    elif fam == "eleven":
-        seqs = make_family(19, 22, seed=12)
-    else:
-        seqs = make_family(6, 60, seed=8, p_sub=0.7) + make_family(3, 50, seed=9, p_sub=0.6)
-    info = {}
-
-    def run():
-        s, t, m, i, thr = G.hmm_tables()
-        g = MpcGpu(0, emu)
-        g.set_hmm(s, t, m, i, thr)
-        g.set_seqs(seqs)
-        g.calc_posteriors()
-        g.build_store()
-        g.cons_iter()
-        info["geo"] = g.relax_info()[0]
-        g.close()
-        return P.run_lib(seqs, lib_path=emu)
-    got = _with_env({"MPCGPU_RELAX_STREAM": "1"}, run)
-    assert "relax_stream_kernel" in info["geo"], info["geo"]
-    P.assert_same(got, P.run_oracle(seqs), "relax_stream_kernel %s" % fam)
-
-
 def test_emu_dense_records_long_rows(emu):
     """rows with many entries (weakly related sequences: several blocks per row chained through the overflow region)"""
     seqs = make_family(6, 60, seed=8, p_sub=0.7) + make_family(2, 50, seed=9, p_sub=0.6)
