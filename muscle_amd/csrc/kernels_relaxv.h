@@ -39,8 +39,6 @@ struct RelaxVarParams {
 	u32 nbuf;      // LDS staging buffers: 2 = DMA of step Z+1 under the merges of step Z, 1 = DMA, wait, merge
 	u32 buf_bytes; // capacity of one staging buffer (the second starts buf_bytes after the first)
 	u32 *tile_next; // 8 counters, zeroed before the launch: next tile of each XCD's range
-	u32 stage_prio; // measurement knob (MPCGPU_RELAX_PRIO): issue priority of a wave while it stages a step's records (0 = as the merges)
-	u32 stagger;    // measurement knob (MPCGPU_RELAX_STAGGER): late start of the CU's second workgroup, in units of 1024 clocks
 };
 
 // One merge step on the blocks va (row x of M(X,Z)) and vb (row y of M(Y,Z)), block = {p0, p1, c0 | dist << 16, c1}:
@@ -120,7 +118,6 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 	const u32 G = gridDim.x < 8u ? gridDim.x : 8u;
 	const u32 xcd = blockIdx.x % G;
 	const u32 chunk = (p.ntiles + G - 1u) / G;
-	if (p.stagger) mpc_stagger_second_workgroup(p.stagger);
 
 	for (;;) {
 		__syncthreads(); // the previous tile is done with the pair table and the staging buffers
@@ -255,11 +252,9 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 				}
 			} else {
 				__syncthreads(); // step Z-1's readers are done
-				if (p.stage_prio) MPC_SETPRIO(3);
 				vbase_cur = issue_dma(tab_nxt, 0);
 				if (Z + 1 < n) tab_nxt = load_table(Z + 1);
 				mpc_dma_wait();
-				if (p.stage_prio) MPC_SETPRIO(0);
 				__syncthreads();
 			}
 			if (DIAG != 1 && nact != 0u) {

@@ -104,15 +104,6 @@ __device__ __forceinline__ void mpc_dma16(const void *gsrc, void *lds_wave_base)
 		(__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ void mpc_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// issue priority of this wave among the waves of its SIMD (0..3)
-#define MPC_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-// Measurement knob of relax_var_kernel (MPCGPU_RELAX_STAGGER): the workgroup in an odd threadgroup slot of its CU (HW_ID.TG_ID,
-// bits 19:16) starts `units` x 1024 clocks late, so that two resident workgroups of a CU do not stage and merge in phase.
-__device__ __forceinline__ void mpc_stagger_second_workgroup(unsigned units)
-{
-	const unsigned tg = (unsigned)__builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));
-	if (tg & 1u) for (unsigned i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
-}
 // LDS by 32-bit address: the address of a dynamic-LDS location as an integer, and an aligned 16-byte read through such an
 // address (ds_read_b128 on the register as it is: no per-access add of the dynamic-LDS base).
 struct __attribute__((aligned(16))) MpcQuad { unsigned x, y, z, w; };

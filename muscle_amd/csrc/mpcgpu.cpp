@@ -451,8 +451,6 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 	rp.s = sp; rp.tiles = d_tiles.as<u32>(); rp.ntiles = ntiles;
 	rp.k0 = k0; rp.k1 = k1; rp.nbuf = nbuf; rp.buf_bytes = buf_bytes;
 	rp.tile_next = c->d_tile_next.as<u32>() + 8 * counter_slot;
-	rp.stage_prio = (u32)std::max(env_int("MPCGPU_RELAX_PRIO", 0), 0);
-	rp.stagger = (u32)std::min(std::max(env_int("MPCGPU_RELAX_STAGGER", 0), 0), 64);
 	const int diag = primary ? env_int("MPCGPU_RELAX_DIAG", 0) : 0; // measurement only (results wrong): 1 = staging only, 2 = merges only
 	const char *merge_env = getenv("MPCGPU_RELAX_MERGE"); // "cxx": the compiler's code for the merge instead of the hand-scheduled one (A/B, 768 geometry)
 	const bool merge_cxx = merge_env && !strcmp(merge_env, "cxx");

@@ -133,8 +133,6 @@ static inline unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { ret
 // LDS-DMA stand-in: synchronous copy (the emulator has no asynchronous memory pipeline; what it checks is addressing)
 static inline void mpc_dma16(const void *gsrc, void *lds_wave_base) { memcpy((unsigned char *)lds_wave_base + 16 * emu::t_lane, gsrc, 16); }
 static inline void mpc_dma_wait() {}
-#define MPC_SETPRIO(n) ((void)0)
-static inline void mpc_stagger_second_workgroup(unsigned) {}
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
 static inline unsigned long long mpc_clock() { return 0ull; }
 static inline unsigned long long __ballot(int pred)
