@@ -122,6 +122,10 @@ int mpcgpu_values_import(mpcgpu_ctx *ctx, uint64_t first, uint64_t count, const 
  * swap of consflat.cpp:22). */
 int mpcgpu_cons_iter(mpcgpu_ctx *ctx, uint64_t k0, uint64_t k1);
 int mpcgpu_cons_commit(mpcgpu_ctx *ctx);
+/* The same swap for the canonical entries [first, first+count) only (see mpcgpu_values_slice): a rank of a pair-sharded run
+ * commits the slice it relaxed itself while the other ranks' values are still arriving, and the rest after them. Committing
+ * every entry exactly once, in any split, equals mpcgpu_cons_commit (consflat.cpp:22). */
+int mpcgpu_cons_commit_range(mpcgpu_ctx *ctx, uint64_t first, uint64_t count);
 
 /* ---- results back to the host (the reference's in-memory formats) ------------------------- */
 /* EA per pair: what calcposteriorflat.cpp:89-91 stores in m_DistMx[i][j]. Valid for own shard

@@ -18,7 +18,7 @@ SYMBOLS = [
     "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_version", "mpcgpu_set_hmm",
     "mpcgpu_set_seqs", "mpcgpu_set_mega", "mpcgpu_pair_count", "mpcgpu_calc_posteriors", "mpcgpu_build_store",
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
-    "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
+    "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_cons_commit_range", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
     "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_align_pairs", "mpcgpu_get_list_sparse", "mpcgpu_stage_a_info", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
@@ -65,6 +65,7 @@ def load(lib_path=None):
     L.mpcgpu_values_slice.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(u64)]
     L.mpcgpu_cons_iter.argtypes = [vp, u64, u64]
     L.mpcgpu_cons_commit.argtypes = [vp]
+    L.mpcgpu_cons_commit_range.argtypes = [vp, u64, u64]
     L.mpcgpu_get_ea.argtypes = [vp, u64, u64, vp]
     L.mpcgpu_get_nnz.argtypes = [vp, u64, u64, vp]
     L.mpcgpu_get_sparse.argtypes = [vp, u64, vp, vp]
@@ -303,6 +304,9 @@ class MpcGpu:
 
     def cons_commit(self):
         self._ck(self.L.mpcgpu_cons_commit(self.h))
+
+    def cons_commit_range(self, first, count):
+        self._ck(self.L.mpcgpu_cons_commit_range(self.h, first, count))
 
     def synchronize(self):
         self._ck(self.L.mpcgpu_synchronize(self.h))

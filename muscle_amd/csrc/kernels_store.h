@@ -297,11 +297,11 @@ __global__ void __launch_bounds__(256) relax_kernel(StoreParams s, u64 k0, u64 k
 }
 
 // Make vnext current everywhere it is stored: both slab orientations and the packed record
-// (the swap of consflat.cpp:22). One thread per stored cell of ALL pairs.
-__global__ void __launch_bounds__(256) commit_kernel(StoreParams s)
+// (the swap of consflat.cpp:22). One thread per stored cell in the canonical entry range [e0, e1) (everything: [0, vbase[npairs])).
+__global__ void __launch_bounds__(256) commit_kernel(StoreParams s, u64 e0, u64 e1)
 {
-	const u64 last = s.vbase[s.npairs];
-	for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < last; e += (u64)gridDim.x * blockDim.x) {
+	const u64 last = e1;
+	for (u64 e = e0 + (u64)blockIdx.x * blockDim.x + threadIdx.x; e < last; e += (u64)gridDim.x * blockDim.x) {
 		const u64 k = mpc_find_pair(s.vbase, 0, s.npairs, e);
 		const u32 X = s.pair_x[k], Y = s.pair_y[k];
 		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];
@@ -318,10 +318,10 @@ __global__ void __launch_bounds__(256) commit_kernel(StoreParams s)
 }
 
 // commit for the record layout: the packed record of the pair and both orientations' records
-__global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s)
+__global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s, u64 e0, u64 e1)
 {
-	const u64 last = s.vbase[s.npairs];
-	for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < last; e += (u64)gridDim.x * blockDim.x) {
+	const u64 last = e1;
+	for (u64 e = e0 + (u64)blockIdx.x * blockDim.x + threadIdx.x; e < last; e += (u64)gridDim.x * blockDim.x) {
 		const u64 k = mpc_find_pair(s.vbase, 0, s.npairs, e);
 		const u32 X = s.pair_x[k], Y = s.pair_y[k];
 		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];

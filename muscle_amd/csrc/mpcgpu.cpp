@@ -1674,23 +1674,32 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	return 0;
 }
 
-int mpcgpu_cons_commit(mpcgpu_ctx *c)
+int mpcgpu_cons_commit_range(mpcgpu_ctx *c, uint64_t first, uint64_t count)
 {
 	if (!c) return 1;
 	if (!c->have_store) return fail(c, "mpcgpu_cons_commit: no store");
+	if (first + count > c->total_entries) return fail(c, "mpcgpu_cons_commit_range: range out of bounds");
 	HIPCHK(c, hipSetDevice(c->device));
-	if (c->total_entries == 0) return 0;
+	if (count == 0) return 0;
 	StoreParams sp;
 	fill_store_params(c, sp);
 	TimedSpan ts;
 	if (span_begin(c, 4, &ts)) return 1;
 	const u32 block = 256;
-	const u64 blocks = (c->total_entries + block - 1) / block;
-	if (c->have_pad) MPC_LAUNCH(commit_pad_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64), block, 0, c->stream, sp);
-	else MPC_LAUNCH(commit_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64), block, 0, c->stream, sp);
+	const u64 blocks = (count + block - 1) / block;
+	const u32 grid = (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64);
+	if (c->have_pad) MPC_LAUNCH(commit_pad_kernel, grid, block, 0, c->stream, sp, (u64)first, (u64)(first + count));
+	else MPC_LAUNCH(commit_kernel, grid, block, 0, c->stream, sp, (u64)first, (u64)(first + count));
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
 	return 0;
+}
+
+int mpcgpu_cons_commit(mpcgpu_ctx *c)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_cons_commit: no store");
+	return mpcgpu_cons_commit_range(c, 0, c->total_entries);
 }
 
 int mpcgpu_get_ea(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, float *ea)

@@ -71,11 +71,22 @@ class TorchExchange:
         offs = [0]
         for sz in sizes:
             offs.append(offs[-1] + int(sz))
-        works = [self.dist.broadcast(full[offs[r]:offs[r + 1]], src=r, async_op=True) for r in range(self.world) if sizes[r]]
+        works = self.start_gather_segments(full, sizes)
+        return self.finish_gather_segments(full, sizes, works)
+
+    def start_gather_segments(self, full, sizes):
+        """queues the `world` broadcasts of all_gather_segments and returns their handles: the caller has its own device work
+        (the commit of its own slice) run under the transfers before it waits for them"""
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + int(sz))
+        return [self.dist.broadcast(full[offs[r]:offs[r + 1]], src=r, async_op=True) for r in range(self.world) if sizes[r]]
+
+    def finish_gather_segments(self, full, sizes, works):
         for w in works:
             if w is not None:
                 w.wait()
-        return full[:offs[-1]]
+        return full[:int(sum(int(sz) for sz in sizes))]
 
     def all_gather_var(self, mine, sizes, dtype):
         """mine: 1-D tensor of sizes[rank] elements. Returns a 1-D tensor = concatenation over ranks."""
@@ -132,11 +143,20 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
             engine.cons_iter(k0, k1)
             t0 = time.perf_counter()
             engine.values_export(first, count, allv.data_ptr() + 4 * int(voffs[exchange.rank]))
-            got = exchange.all_gather_segments(allv, counts)
+            works = exchange.start_gather_segments(allv, counts)
+            # my own slice is already in the store's values array: it is committed (library stream) while the peers' slices
+            # arrive (collective stream); theirs follow — every entry once, which equals one commit of everything
+            engine.cons_commit_range(first, count)
+            got = exchange.finish_gather_segments(allv, counts, works)
             _sync(torch, exchange.device)
             t_x += time.perf_counter() - t0
-            engine.values_import(0, int(got.numel()), got.data_ptr())
-            engine.cons_commit()
+            total = int(got.numel())
+            if first:
+                engine.values_import(0, first, got.data_ptr())
+                engine.cons_commit_range(0, first)
+            if first + count < total:
+                engine.values_import(first + count, total - first - count, got.data_ptr() + 4 * (first + count))
+                engine.cons_commit_range(first + count, total - first - count)
     engine.synchronize()
     engine._exchange_seconds = getattr(engine, "_exchange_seconds", 0.0) + t_x
     return k0, k1

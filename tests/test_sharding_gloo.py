@@ -79,6 +79,18 @@ class FakeEngine:
     def cons_commit(self):
         self.log.append(self.values.copy())
 
+    def cons_commit_range(self, first, count):
+        # every entry must be committed exactly once per iteration; the log gets the store once all of them are
+        if not hasattr(self, "committed") or self.committed is None:
+            self.committed = np.zeros(len(self.values), np.int32)
+            self.store = np.zeros(len(self.values), np.float32)
+        self.committed[first:first + count] += 1
+        self.store[first:first + count] = self.values[first:first + count]
+        if self.committed.min() >= 1:
+            assert self.committed.max() == 1, "an entry committed twice"
+            self.log.append(self.store.copy())
+            self.committed = None
+
     def build_store(self):
         pass
 
