@@ -341,27 +341,35 @@ int mpcgpu_group_cons_iter(mpcgpu_group *g)
 		return 0;
 	});
 	if (rc) return rc;
-	if (R > 1) {
-		// ---- all-gather of the new probabilities, in place in every device's values array (canonical entry order)
-		std::vector<const void *> src(R, nullptr);
-		std::vector<void *> dst(R, nullptr);
-		std::vector<uint64_t> off(R, 0), bytes(R, 0);
-		for (uint32_t r = 0; r < R; ++r) {
-			void *vp = nullptr;
-			uint64_t total = 0, first = 0, count = 0;
-			if (mpcgpu_values_info(g->ctx[r], &vp, &total) || mpcgpu_values_slice(g->ctx[r], g->k0[r], g->k1[r], &first, &count))
-				return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
-			dst[r] = vp;
-			off[r] = first * 4;
-			bytes[r] = count * 4;
-			src[r] = (const char *)vp + first * 4;
-		}
-		rc = all_gather_segments(g, src, dst, off, bytes, true);
-		if (rc) return rc;
+	if (R == 1) { // ---- the swap of consflat.cpp:22
+		if (mpcgpu_cons_commit(g->ctx[0]) || mpcgpu_synchronize(g->ctx[0])) return gfail(g, "rank 0: %s", mpcgpu_last_error(g->ctx[0]));
+		return 0;
 	}
-	// ---- the swap of consflat.cpp:22 on every device
+	// ---- all-gather of the new probabilities, in place in every device's values array (canonical entry order). Every device
+	// first queues the swap of consflat.cpp:22 for the slice it relaxed itself — it runs under the exchange — and commits the
+	// other devices' slices once they are in: every entry exactly once.
+	std::vector<const void *> src(R, nullptr);
+	std::vector<void *> dst(R, nullptr);
+	std::vector<uint64_t> off(R, 0), bytes(R, 0), first(R, 0), count(R, 0), total(R, 0);
+	for (uint32_t r = 0; r < R; ++r) {
+		void *vp = nullptr;
+		if (mpcgpu_values_info(g->ctx[r], &vp, &total[r]) || mpcgpu_values_slice(g->ctx[r], g->k0[r], g->k1[r], &first[r], &count[r]))
+			return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
+		dst[r] = vp;
+		off[r] = first[r] * 4;
+		bytes[r] = count[r] * 4;
+		src[r] = (const char *)vp + first[r] * 4;
+	}
+	rc = per_rank(g, [&](uint32_t r) -> int {
+		if (mpcgpu_cons_commit_range(g->ctx[r], first[r], count[r])) return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
+		return 0;
+	});
+	if (rc) return rc;
+	rc = all_gather_segments(g, src, dst, off, bytes, true);
+	if (rc) return rc;
 	return per_rank(g, [&](uint32_t r) -> int {
-		if (mpcgpu_cons_commit(g->ctx[r]) || mpcgpu_synchronize(g->ctx[r]))
+		if (mpcgpu_cons_commit_range(g->ctx[r], 0, first[r]) ||
+		    mpcgpu_cons_commit_range(g->ctx[r], first[r] + count[r], total[r] - first[r] - count[r]) || mpcgpu_synchronize(g->ctx[r]))
 			return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
 		return 0;
 	});
