@@ -48,6 +48,7 @@ struct Fiber {
 	char *stack = nullptr;
 	unsigned tid = 0;
 	bool done = false;
+	std::vector<std::pair<void *, const void *>> dma; // EMU_DMA=late: 16-byte copies issued and not yet waited for
 };
 
 struct Worker {
@@ -67,6 +68,7 @@ void fiber_entry()
 {
 	Worker *w = t_worker;
 	(*w->body)();
+	dma_complete(); // a thread that ends with transfers in flight: they land
 	w->cur->done = true;
 	emu_switch(&w->cur->sp, w->sched_sp); // never resumed
 	abort();
@@ -139,6 +141,16 @@ void run_block(Worker &w, unsigned bid, dim3 block, size_t smem)
 }
 } // namespace
 
+bool g_dma_late = false, g_dma_never = false; // never: the waits deliver nothing (only the thread's end does) — the negative control of the late mode
+void dma_enqueue(void *dst, const void *src) { t_worker->cur->dma.emplace_back(dst, src); }
+void dma_complete()
+{
+	Fiber *f = t_worker ? t_worker->cur : nullptr;
+	if (!f) return;
+	for (auto &c : f->dma) memcpy(c.first, c.second, 16);
+	f->dma.clear();
+}
+
 void yield()
 {
 	Worker *w = t_worker;
@@ -153,6 +165,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()> &bod
 	std::lock_guard<std::mutex> guard(one_launch);
 	blockDim = block;
 	gridDim = grid;
+	{ const char *m = getenv("EMU_DMA"); g_dma_late = m && (!strcmp(m, "late") || !strcmp(m, "never")); g_dma_never = m && !strcmp(m, "never"); }
 	static const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
 	const unsigned nworkers = std::min(hw, grid.x);
 	auto work = [&](unsigned wi) {

@@ -53,6 +53,12 @@ extern thread_local BlockState *g_block; // the block this OS thread is running
 extern thread_local WaveState *t_wave;   // of the running fiber
 extern thread_local unsigned t_lane;
 void yield(); // give the OS thread to the next fiber of the block
+// LDS-DMA stand-in. Default: the copy happens at issue. EMU_DMA=late (read at every launch): the 16 destination bytes are
+// poisoned at issue and the copy happens when the ISSUING thread waits (mpc_dma_wait), i.e. as late as the hardware may deliver —
+// a kernel that reads staged data before its wait + barrier then computes with garbage and fails its parity test.
+extern bool g_dma_late, g_dma_never;
+void dma_enqueue(void *dst, const void *src);
+void dma_complete();
 // all fibers of a barrier live on one OS thread: plain counters
 static inline void barrier_wait(Barrier &b)
 {
@@ -131,8 +137,13 @@ typedef const unsigned *mpc_const_u32p;
 #define MPC_CONST_U32(p) ((mpc_const_u32p)(p))
 static inline unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { return emu::t_lane == l ? sv : v; }
 // LDS-DMA stand-in: synchronous copy (the emulator has no asynchronous memory pipeline; what it checks is addressing)
-static inline void mpc_dma16(const void *gsrc, void *lds_wave_base) { memcpy((unsigned char *)lds_wave_base + 16 * emu::t_lane, gsrc, 16); }
-static inline void mpc_dma_wait() {}
+static inline void mpc_dma16(const void *gsrc, void *lds_wave_base)
+{
+	unsigned char *dst = (unsigned char *)lds_wave_base + 16 * emu::t_lane;
+	if (emu::g_dma_late) { memset(dst, 0xee, 16); emu::dma_enqueue(dst, gsrc); }
+	else memcpy(dst, gsrc, 16);
+}
+static inline void mpc_dma_wait() { if (emu::g_dma_late && !emu::g_dma_never) emu::dma_complete(); }
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
 static inline unsigned long long mpc_clock() { return 0ull; }
 static inline unsigned long long __ballot(int pred)

@@ -368,6 +368,22 @@ def test_emu_relax_var_geometries(emu, env):
     P.assert_same(got, P.run_oracle(seqs), "relax_var_kernel %s" % env)
 
 
+@pytest.mark.parametrize("env", [{}, {"MPCGPU_RELAX_WG": "1024"}, {"MPCGPU_RELAX_WG": "1024", "MPCGPU_RELAX_NBUF": "1"}, {"MPCGPU_RELAX_WG": "768"}])
+def test_emu_relax_staging_with_late_dma(emu, env):
+    """EMU_DMA=late: an LDS-DMA transfer poisons its 16 destination bytes when it is issued and delivers them only when the issuing
+    thread waits for it (mpc_dma_wait) — as late as the hardware may. A walk that merged a record before the wait + barrier that
+    follows its staging (one staging buffer), or that let step Z+1's transfers into a buffer step Z still reads (two buffers),
+    computes with garbage: the results must still be the oracle's."""
+    seqs = make_family(9, 18, seed=5) + [make_family(1, 70, seed=9)[0], "MKV"]
+    got = _with_env(dict(env, EMU_DMA="late"), lambda: P.run_lib(seqs, lib_path=emu))
+    want = P.run_oracle(seqs)
+    P.assert_same(got, want, "late DMA %s" % env)
+    if not env:  # the checker checks: when the waits deliver nothing the same run must NOT reproduce the oracle
+        bad = _with_env({"EMU_DMA": "never"}, lambda: P.run_lib(seqs, lib_path=emu))
+        with pytest.raises(AssertionError):
+            P.assert_same(bad, want, "transfers never delivered")
+
+
 def test_emu_dense_records_long_rows(emu):
     """rows with many entries (weakly related sequences: several blocks per row chained through the overflow region)"""
     seqs = make_family(6, 60, seed=8, p_sub=0.7) + make_family(2, 50, seed=9, p_sub=0.6)
