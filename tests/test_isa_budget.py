@@ -4,8 +4,7 @@ allocator did is a performance property that parity tests cannot see.
 relax_var_kernel walks Z with every accumulator and row offset in VGPRs; a value the compiler keeps in a spill slot instead is
 reloaded between the merges of a step, and each reload waits for vmcnt(0). The 14-cells-per-lane instantiation of the default
 geometry had five such reloads (1195 ms per two iterations at 1000 x L~400 against 1171 with 13 cells per lane and none:
-profiles/r05g); the barrier-free relax experiment of round 3 died of 16..78 of them (profiles/r05f). The forward/backward
-kernels must not spill at all."""
+profiles/r05g). The forward/backward kernels must not spill at all."""
 import os
 import re
 import shutil
