@@ -1,0 +1,594 @@
+// kernels_relaxb.h — consistency relax over BAND tiles of the variable-size records: relax_band_kernel (the default since round 4).
+//
+// Same arithmetic, same order of additions and the same merge step as relax_var_kernel (kernels_relaxv.h; reference:
+// conspairflat.cpp:10-110 -> relaxflat.cpp:4-94 -> mysparsemx.cpp:87-113): per stored cell (x,y) of (X,Y)
+//     acc = 2*P_XY(x,y);  for Z = 0..N-1: acc += sum_z M(X,Z)(x,z) * M(Y,Z)(y,z)  (z ascending);  P' = acc / N
+// What changed is WHICH cells a workgroup owns and WHAT it stages per step. relax_var_kernel owned all cells of <= 4x4 pairs and
+// staged their <= 8 whole records per step (65 KB of the 80 KB a workgroup has: no room for step Z+1, a quarter of the kernel an
+// exposed DMA wait; on wide-row data two 24 KB records per pair-step and no reuse at all). Stored cells hug the alignment
+// diagonal, so the cells of the ROW BAND [r0,r1) of a pair need only rows [r0,r1) of M(X,Z) and a contiguous row range
+// [ylo,yhi) of M(Y,Z). A band tile is
+//     {X in [x0,x0+nx)} x {Y in [y0,y0+ny)} x rows [r0,r1) of the X sequences,   nx, ny <= 8:
+// up to 64 pairs share 16 PARTIAL records per step — at 1000 x L~400: 8x8 pairs x ~100 rows, 33 KB per step for 15 pair-
+// equivalents (whole records: 65 KB for 16), and two steps fit the LDS: the DMA of step Z+1 runs under the merges of step Z.
+//
+// A partial record is two pieces, because a record is [first block of every row][overflow blocks in row order]
+// (kernels_store.h): rows [a0,a1) of the first-block region (row a at block a: no table needed) and the overflow blocks of the
+// index bands (MPC_RB_HB = 16 rows) those rows lie in (ovf_off: where the overflow of band b of record (A,Z) starts, written by
+// var_build_kernel). In LDS the first pieces of all records come first, at offsets that do NOT depend on Z — a cell's two row
+// addresses inside a step's buffer are constants of the walk, no per-step base — and the overflow pieces follow back to back,
+// at offsets that do. The only thing the merge needs per step and record is the HOP BIAS: a first block's distance field is
+// relative to the record as it lies in HBM; (address of the first block in LDS) + bias + distance is its overflow block in
+// LDS. The bias of a slot's X record is a scalar (cells are laid out X-major and every X group is rounded up to whole waves,
+// so the 64 cells of a (wave, slot) share their X record); the Y record differs per lane: one cross-lane gather per slot.
+//
+// Buffers: a step's pieces are placed at the bottom or at the top of the staging area, alternating; the next step is
+// prefetched when both fit (the host cuts the bands so that they do on average), otherwise — wide-row data: one step fills most
+// of the area — it is staged after the merges, as relax_var_kernel did, and the CU's second workgroup fills the wait.
+#pragma once
+#include "kernels_relaxv.h"
+
+#define MPC_RB_HB 16u           // rows per index band (overflow offsets, cell offsets, y ranges are kept per band)
+#define MPC_RB_MAXN 8u          // sequences per side of a tile
+#define MPC_RB_TILE_WORDS 16u   // x0, nx, y0, ny, r0, r1, first-piece blocks, slots, then ylo | yhi << 16 per Y (yhi exclusive)
+#define MPC_RB_TAB_BYTES 2560u  // tables at the head of the dynamic LDS: pairs 64 x 16 B, records 16 x 32 B, groups, misc, step tables, biases
+#define MPC_RB_PTAB 0u
+#define MPC_RB_RTAB 1024u
+#define MPC_RB_GTAB 1536u       // 8 x {group base, group end}
+#define MPC_RB_MISC 1600u       // tile number, total cells, first-piece blocks
+#define MPC_RB_TTAB 1664u       // step tables of two steps: 2 x 64 words
+#define MPC_RB_BTAB 2176u       // hop biases of two steps: 2 x 16 words (.. 2304; the rest is spare)
+#define MPC_RB_MAXFIRST 4095u   // blocks of first pieces per step: a cell keeps its two byte offsets in 16 bits each
+
+struct RelaxBandParams {
+	StoreParams s;
+	const u32 *ovf_off;  // [(Z*n + A) * nb1 + b]: block index (in `pad`) where the overflow blocks of rows >= b*HB of record (A,Z) start; the record's end for b*HB >= len(A)
+	u32 nb1;             // entries per record / per pair in the band tables: ceil(max_len / HB) + 1
+	const u32 *cell_off; // [k * nb1 + b]: stored cells of pair k in rows < b*HB (canonical entry order is row-major)
+	const u32 *tiles;    // MPC_RB_TILE_WORDS per tile
+	u32 ntiles;
+	u64 k0, k1;          // only pairs in [k0,k1) are relaxed (multi-GPU shard)
+	u32 cap_bytes;       // staging area (after the tables)
+	u32 *tile_next;      // 8 counters, zeroed before the launch: next tile of each XCD's range
+};
+
+// ---- band tables -------------------------------------------------------------------------------------------------------------
+// cell_off (see RelaxBandParams) and yr[k * nb1 + b] = ymin | ymax << 16 over the stored cells of pair k in rows [b*HB, (b+1)*HB)
+// (0xffff | 0 when there are none). One wave per pair; the columns of a row ascend (MySparseMx order).
+__global__ void __launch_bounds__(64) band_index_kernel(StoreParams s, u32 nb1, u32 *cell_off, u32 *yr)
+{
+	const u32 t = threadIdx.x;
+	for (u64 k = blockIdx.x; k < s.npairs; k += gridDim.x) {
+		const u32 LX = s.seq_len[s.pair_x[k]], LY = s.seq_len[s.pair_y[k]];
+		const u32 *rec = s.packed + s.pbase[k];
+		const u32 *ent = rec + LX + LY;
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		u32 carry = 0;
+		for (u32 a0 = 0; a0 < LX; a0 += 64) {
+			const u32 a = a0 + t;
+			const u32 v = a < LX ? rec[a] : 0u;
+			u32 incl = v;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d);
+				if (t >= (u32)d) incl += o;
+			}
+			const u32 start = carry + incl - v;
+			u32 lo = v ? ent[2 * (u64)start + 1] : 0xffffu;
+			u32 hi = v ? ent[2 * (u64)(start + v - 1) + 1] : 0u;
+			for (int d = 8; d >= 1; d >>= 1) { // the 16 rows of a band are 16 consecutive lanes
+				const u32 ol = __shfl_down(lo, d), oh = __shfl_down(hi, d);
+				lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+			}
+			if ((t & (MPC_RB_HB - 1u)) == 0u && a < LX) {
+				cell_off[k * nb1 + a / MPC_RB_HB] = start;
+				yr[k * nb1 + a / MPC_RB_HB] = lo | (hi << 16);
+			}
+			carry += __shfl(incl, 63);
+		}
+		for (u32 b = (LX + MPC_RB_HB - 1u) / MPC_RB_HB + t; b < nb1; b += 64) { cell_off[k * nb1 + b] = nnz; yr[k * nb1 + b] = 0xffffu; }
+	}
+}
+
+// Per (sequence A, band b), over all Z: ovf_sum[A*nb1+b] = sum_Z (overflow blocks of record (A,Z) in rows < b*HB) — the mean the
+// tile cutter estimates a step's LDS need with — and ovf_maxc[A*nb1+b] = sum_{b' < b} max_Z (overflow blocks of band b') — an upper
+// bound of any step's need. One wave per sequence.
+__global__ void __launch_bounds__(64) ovf_stats_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, u32 *ovf_sum, u32 *ovf_maxc)
+{
+	const u32 t = threadIdx.x, n = s.n;
+	for (u32 A = blockIdx.x; A < n; A += gridDim.x) {
+		const u32 LA = s.seq_len[A];
+		u32 carry = 0;
+		for (u32 b0 = 0; b0 < nb1; b0 += 64) {
+			const u32 b = b0 + t;
+			u32 sum = 0, mx = 0;
+			if (b < nb1)
+				for (u32 Z = 0; Z < n; ++Z) {
+					const u64 r = mpc_rec_index(n, A, Z);
+					const u32 here = ovf_off[r * nb1 + b];
+					sum += here - (s.rec_off[r] + LA);
+					if (b + 1 < nb1) { const u32 d = ovf_off[r * nb1 + b + 1] - here; mx = d > mx ? d : mx; }
+				}
+			u32 incl = mx;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d);
+				if (t >= (u32)d) incl += o;
+			}
+			if (b < nb1) { ovf_sum[(u64)A * nb1 + b] = sum; ovf_maxc[(u64)A * nb1 + b] = carry + incl - mx; }
+			carry += __shfl(incl, 63);
+		}
+	}
+}
+
+// ---- tiles: statistics of one band tile, by one wave (lane = pair ix*8+iy) --------------------------------------------------------
+struct RbTileTabs {
+	const u32 *cell_off, *yr, *ovf_sum, *ovf_maxc;
+	u32 nb1, threads;
+	u64 k0, k1;
+};
+struct RbTileStats {
+	u32 cells;       // stored cells of the tile's pairs in the band
+	u32 slots;       // cells per lane the tile needs (X groups rounded up to whole waves)
+	u32 first;       // blocks of the first pieces
+	u32 est, bound;  // blocks per step: mean over Z (rounded up) / upper bound
+	u32 yr;          // lane iy (< 8): ylo | yhi << 16 of Y record iy (yhi exclusive; 0 when it has no cell)
+};
+__device__ __forceinline__ u32 rb_wave_sum(u32 v) { for (int d = 1; d < 64; d <<= 1) v += __shfl(v, (int)((threadIdx.x & 63u) ^ (u32)d)); return v; }
+
+// c, lo, hi: per lane, the cells of the lane's pair in the band and their column range (lo > hi: none); b0, b1: the band range.
+__device__ __forceinline__ RbTileStats rb_tile_stats(const StoreParams &s, const RbTileTabs &tb, u32 x0, u32 nx, u32 y0, u32 ny, u32 b0, u32 b1,
+	u32 c, u32 lo, u32 hi)
+{
+	const u32 lane = threadIdx.x & 63u, ix = lane >> 3, iy = lane & 7u, n = s.n;
+	RbTileStats r;
+	// Y ranges: over the X of the tile (lanes with the same iy: xor 8, 16, 32)
+	for (int d = 8; d < 64; d <<= 1) {
+		const u32 ol = __shfl(lo, (int)(lane ^ (u32)d)), oh = __shfl(hi, (int)(lane ^ (u32)d));
+		lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+	}
+	const bool yany = lo <= hi;
+	const u32 ylo = yany ? lo : 0u, yhi = yany ? hi + 1u : 0u;
+	r.yr = ylo | (yhi << 16);
+	// cells per X group (lanes with the same ix: xor 1, 2, 4), each rounded up to whole waves
+	u32 g = c;
+	for (int d = 1; d < 8; d <<= 1) g += __shfl(g, (int)(lane ^ (u32)d));
+	const u32 grnd = (g + 63u) & ~63u;
+	r.cells = rb_wave_sum(iy == 0u ? g : 0u);
+	const u32 rounded = rb_wave_sum(iy == 0u ? grnd : 0u);
+	r.slots = (rounded + tb.threads - 1u) / tb.threads;
+	// pieces: lane ix*8 speaks for X record ix, lane iy (ix == 0) for Y record iy
+	u32 first = 0, sum = 0, mxc = 0;
+	if (iy == 0u && ix < nx) {
+		const u32 A = x0 + ix, LA = s.seq_len[A];
+		const u32 a0 = b0 * MPC_RB_HB, a1 = (b1 * MPC_RB_HB < LA) ? b1 * MPC_RB_HB : LA;
+		if (a1 > a0) {
+			const u32 e1 = (a1 + MPC_RB_HB - 1u) / MPC_RB_HB;
+			first = a1 - a0;
+			sum = tb.ovf_sum[(u64)A * tb.nb1 + e1] - tb.ovf_sum[(u64)A * tb.nb1 + b0];
+			mxc = tb.ovf_maxc[(u64)A * tb.nb1 + e1] - tb.ovf_maxc[(u64)A * tb.nb1 + b0];
+		}
+	}
+	u32 fy = 0, sy = 0, my = 0;
+	if (ix == 0u && iy < ny && yany) {
+		const u32 A = y0 + iy;
+		const u32 e0 = ylo / MPC_RB_HB, e1 = (yhi + MPC_RB_HB - 1u) / MPC_RB_HB;
+		fy = yhi - ylo;
+		sy = tb.ovf_sum[(u64)A * tb.nb1 + e1] - tb.ovf_sum[(u64)A * tb.nb1 + e0];
+		my = tb.ovf_maxc[(u64)A * tb.nb1 + e1] - tb.ovf_maxc[(u64)A * tb.nb1 + e0];
+	}
+	r.first = rb_wave_sum(first + fy);
+	const u32 tot = rb_wave_sum(sum + sy);
+	r.est = r.first + (tot + n - 1u) / n;
+	r.bound = r.first + rb_wave_sum(mxc + my);
+	return r;
+}
+
+// the lane's pair of tile (x0, nx, y0, ny): its index, or ~0 when the lane has none inside [k0,k1)
+__device__ __forceinline__ u64 rb_lane_pair(const StoreParams &s, const RbTileTabs &tb, u32 x0, u32 nx, u32 y0, u32 ny)
+{
+	const u32 lane = threadIdx.x & 63u, ix = lane >> 3, iy = lane & 7u;
+	const u32 X = x0 + ix, Y = y0 + iy;
+	if (ix >= nx || iy >= ny || X >= Y) return ~0ull;
+	const u64 k = mpc_pair_index(s.n, X, Y);
+	return (k >= tb.k0 && k < tb.k1) ? k : ~0ull;
+}
+
+// Cuts the super-tiles (x0, nx, y0, ny) of `cand` (4 words each) into row bands: a band is closed when the next index band
+// would take the tile over `max_slots` cells per lane or over `target` blocks per step (mean), or when it has reached the
+// super-tile's even share of cells. write == 0: count[c] = bands of candidate c; write == 1: the bands' tile words 0..5 go to
+// tiles + MPC_RB_TILE_WORDS * base[c]. One wave per candidate.
+__global__ void __launch_bounds__(64) band_cut_kernel(StoreParams s, RbTileTabs tb, const u32 *cand, u32 ncand, u32 max_slots, u32 target,
+	int write, u32 *count, const u32 *base, u32 *tiles)
+{
+	const u32 lane = threadIdx.x & 63u;
+	for (u32 ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
+		const u32 x0 = cand[4 * ci], nx = cand[4 * ci + 1], y0 = cand[4 * ci + 2], ny = cand[4 * ci + 3];
+		const u64 k = rb_lane_pair(s, tb, x0, nx, y0, ny);
+		const u32 *co = tb.cell_off + (k == ~0ull ? 0ull : k) * tb.nb1, *yrp = tb.yr + (k == ~0ull ? 0ull : k) * tb.nb1;
+		u32 maxlen = 0;
+		for (u32 q = 0; q < nx; ++q) { const u32 l = s.seq_len[x0 + q]; maxlen = l > maxlen ? l : maxlen; }
+		const u32 nb = (maxlen + MPC_RB_HB - 1u) / MPC_RB_HB;
+		const u32 mine = k == ~0ull ? 0u : co[nb] - co[0];
+		const u32 T = rb_wave_sum(mine);
+		u32 emitted = 0;
+		if (T != 0u) {
+			const u32 budget = max_slots * tb.threads;
+			const u32 parts = (T + budget - 1u) / budget;
+			const u32 goal = (T + parts - 1u) / parts;
+			u32 bstart = 0, c = 0, lo = 0xffffu, hi = 0u;
+			auto emit = [&](u32 b0, u32 b1) {
+				if (write && lane == 0u) {
+					u32 *t = tiles + (u64)MPC_RB_TILE_WORDS * (base[ci] + emitted);
+					t[0] = x0; t[1] = nx; t[2] = y0; t[3] = ny; t[4] = b0 * MPC_RB_HB; t[5] = b1 * MPC_RB_HB;
+				}
+				++emitted;
+			};
+			for (u32 b = 0; b < nb; ++b) {
+				const u32 cb = k == ~0ull ? 0u : co[b + 1] - co[b];
+				const u32 w = k == ~0ull ? 0xffffu : yrp[b];
+				const u32 blo = cb ? (w & 0xffffu) : 0xffffu, bhi = cb ? (w >> 16) : 0u;
+				const u32 nc = c + cb, nlo = blo < lo ? blo : lo, nhi = bhi > hi ? bhi : hi;
+				if (b > bstart) {
+					const RbTileStats st = rb_tile_stats(s, tb, x0, nx, y0, ny, bstart, b + 1u, nc, nlo, nhi);
+					if (st.slots > max_slots || st.est > target) { // band b does not go in: close [bstart, b)
+						if (rb_wave_sum(c) != 0u) emit(bstart, b);
+						bstart = b; c = cb; lo = blo; hi = bhi;
+						continue;
+					}
+				}
+				c = nc; lo = nlo; hi = nhi;
+				if (rb_wave_sum(c) >= goal) { emit(bstart, b + 1u); bstart = b + 1u; c = 0; lo = 0xffffu; hi = 0u; }
+			}
+			if (bstart < nb && rb_wave_sum(c) != 0u) emit(bstart, nb);
+		}
+		if (!write && lane == 0u) count[ci] = emitted;
+	}
+}
+
+// Fills tile words 6..15 (first-piece blocks, slots, Y ranges) of tiles whose words 0..5 are set, and out[4t..] = slots, mean
+// blocks per step, upper bound of the blocks of any step, cells. One wave per tile.
+__global__ void __launch_bounds__(64) band_eval_kernel(StoreParams s, RbTileTabs tb, u32 *tiles, u32 ntiles, u32 *out)
+{
+	const u32 lane = threadIdx.x & 63u;
+	for (u32 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+		u32 *tw = tiles + (u64)MPC_RB_TILE_WORDS * t;
+		const u32 x0 = tw[0], nx = tw[1], y0 = tw[2], ny = tw[3], r0 = tw[4], r1 = tw[5];
+		const u32 b0 = r0 / MPC_RB_HB, b1 = (r1 + MPC_RB_HB - 1u) / MPC_RB_HB < tb.nb1 - 1u ? (r1 + MPC_RB_HB - 1u) / MPC_RB_HB : tb.nb1 - 1u;
+		const u64 k = rb_lane_pair(s, tb, x0, nx, y0, ny);
+		u32 c = 0, lo = 0xffffu, hi = 0u;
+		if (k != ~0ull) {
+			const u32 *co = tb.cell_off + k * tb.nb1, *yrp = tb.yr + k * tb.nb1;
+			c = co[b1] - co[b0];
+			for (u32 b = b0; b < b1; ++b) {
+				if (co[b + 1] == co[b]) continue;
+				const u32 w = yrp[b];
+				lo = (w & 0xffffu) < lo ? (w & 0xffffu) : lo; hi = (w >> 16) > hi ? (w >> 16) : hi;
+			}
+		}
+		const RbTileStats st = rb_tile_stats(s, tb, x0, nx, y0, ny, b0, b1, c, lo, hi);
+		if (lane < 8u) tw[8 + lane] = st.yr;
+		if (lane == 0u) {
+			tw[6] = st.first; tw[7] = st.slots;
+			out[4 * t] = st.slots; out[4 * t + 1] = st.est; out[4 * t + 2] = st.bound; out[4 * t + 3] = st.cells;
+		}
+	}
+}
+
+// The 16 records of a tile as relax_band_kernel stages them: record i < 8 is X sequence x0+i with rows [r0, min(r1, len)),
+// record 8+j is Y sequence y0+j with rows [ylo_j, yhi_j). Returns sequence, first row, rows, and the index bands [e0, e1) whose
+// overflow blocks belong to the piece (rows == 0: nothing is staged).
+__device__ __forceinline__ void rb_record(const StoreParams &s, const u32 *tw, u32 i, u32 *S, u32 *row0, u32 *rows, u32 *e0, u32 *e1)
+{
+	const u32 x0 = tw[0], nx = tw[1], y0 = tw[2], ny = tw[3], r0 = tw[4], r1 = tw[5];
+	u32 a0 = 0, a1 = 0, A = x0;
+	if (i < MPC_RB_MAXN) {
+		if (i < nx) { A = x0 + i; const u32 LA = s.seq_len[A]; a0 = r0; a1 = r1 < LA ? r1 : LA; }
+	} else if (i - MPC_RB_MAXN < ny) {
+		A = y0 + (i - MPC_RB_MAXN);
+		const u32 w = tw[8 + (i - MPC_RB_MAXN)];
+		a0 = w & 0xffffu; a1 = w >> 16;
+	}
+	if (a1 <= a0) { a0 = 0; a1 = 0; }
+	*S = A; *row0 = a0; *rows = a1 - a0;
+	*e0 = a0 / MPC_RB_HB; *e1 = a1 > a0 ? (a1 + MPC_RB_HB - 1u) / MPC_RB_HB : a0 / MPC_RB_HB;
+}
+
+// out[t] = max over Z of the blocks tile list[t] stages at step Z (first pieces + overflow pieces): the exact LDS need of its
+// worst step. One wave per tile, lanes stride over Z.
+__global__ void __launch_bounds__(64) band_fit_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, const u32 *tiles, const u32 *list, u32 nlist, u32 *out)
+{
+	const u32 lane = threadIdx.x & 63u, n = s.n;
+	for (u32 q = blockIdx.x; q < nlist; q += gridDim.x) {
+		const u32 *tw = tiles + (u64)MPC_RB_TILE_WORDS * list[q];
+		u32 S[16], e0[16], e1[16], first = 0;
+		for (u32 i = 0; i < 16u; ++i) { u32 row0, rows; rb_record(s, tw, i, &S[i], &row0, &rows, &e0[i], &e1[i]); first += rows; }
+		u32 best = 0;
+		for (u32 Z = lane; Z < n; Z += 64) {
+			u32 sum = first;
+			for (u32 i = 0; i < 16u; ++i) {
+				if (e1[i] == e0[i]) continue;
+				const u64 r = mpc_rec_index(n, S[i], Z) * nb1;
+				sum += ovf_off[r + e1[i]] - ovf_off[r + e0[i]];
+			}
+			best = sum > best ? sum : best;
+		}
+		for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_down(best, d); best = o > best ? o : best; }
+		if (lane == 0u) out[q] = best;
+	}
+}
+
+// ---- the relax --------------------------------------------------------------------------------------------------------------------
+// THREADS: workgroup size; MAXSLOTS: cells per lane; WGS: workgroups per CU the register allocation has to allow;
+// DIAG (measurement only, results wrong; compiled only with MPC_RELAX_DIAG_BUILD): 1 = staging and barriers only, 2 = merges only
+// (step 0's records for every step), 3 = as 2 with the barriers; BLOCKS: MpcRvBlocksAsm (hand-scheduled merge) or MpcRvBlocksCxx.
+template <int THREADS, int MAXSLOTS, int WGS, int DIAG = 0, class BLOCKS = MpcRvBlocksAsm>
+__global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kernel(RelaxBandParams p)
+{
+	MPC_DYN_SMEM(smem_raw);
+	const StoreParams &s = p.s;
+	const u32 tid = threadIdx.x;
+	const u32 lane = tid & 63u;
+	const u32 n = s.n;
+	constexpr u32 NWAVES = THREADS / 64;
+	constexpr u32 YREGS = (MAXSLOTS + 5) / 6; // 4 * iy of a slot's cell: 5 bits, 6 slots per register
+	const u32 wave = mpc_wave_first(tid >> 6); // scalar
+	u32 *ptab = (u32 *)(smem_raw + MPC_RB_PTAB); // [64][4]: first cell, cells, pair, first entry
+	u32 *rtab = (u32 *)(smem_raw + MPC_RB_RTAB); // [16][8]: first-piece block offset, rows, row0 - offset, sequence, e0, e1
+	u32 *gtab = (u32 *)(smem_raw + MPC_RB_GTAB); // [8][2]: first cell of X group, end of its cells
+	u32 *misc = (u32 *)(smem_raw + MPC_RB_MISC);
+	u32 *ttab = (u32 *)(smem_raw + MPC_RB_TTAB);
+	u32 *btab = (u32 *)(smem_raw + MPC_RB_BTAB);
+	const unsigned char *padb = (const unsigned char *)s.pad;
+	unsigned char *stage = smem_raw + MPC_RB_TAB_BYTES;
+	const u32 lds_stage = mpc_lds_addr(stage);
+
+	// XCD-aware schedule, as relax_var_kernel: 8 contiguous ranges of the tile list, a counter each, stealing at the end
+	const u32 G = gridDim.x < 8u ? gridDim.x : 8u;
+	const u32 xcd = blockIdx.x % G;
+	const u32 chunk = (p.ntiles + G - 1u) / G;
+
+	for (;;) {
+		__syncthreads(); // the previous tile is done with the tables and the staging area
+		if (tid == 0) {
+			u32 got = 0xffffffffu;
+			for (u32 k = 0; k < G && got == 0xffffffffu; ++k) {
+				const u32 r = (xcd + k) % G;
+				const u32 t_begin = r * chunk, t_end = (t_begin + chunk < p.ntiles) ? t_begin + chunk : p.ntiles;
+				if (t_begin >= t_end) continue;
+				const u32 t = atomicAdd(&p.tile_next[r], 1u);
+				if (t < t_end - t_begin) got = t_begin + t;
+			}
+			misc[0] = got;
+		}
+		__syncthreads();
+		const u32 tl = mpc_wave_first(misc[0]);
+		if (tl == 0xffffffffu) break;
+		const u32 *tw = p.tiles + (u64)MPC_RB_TILE_WORDS * tl;
+		const u32 x0 = mpc_wave_first(tw[0]), nx = mpc_wave_first(tw[1]), y0 = mpc_wave_first(tw[2]), ny = mpc_wave_first(tw[3]);
+		const u32 r0 = mpc_wave_first(tw[4]), r1 = mpc_wave_first(tw[5]);
+
+		// ---- tables, by wave 0: lane = pair ix*8+iy for the cells, lane = record for the pieces
+		if (tid < 64u) {
+			const u32 ix = lane >> 3, iy = lane & 7u;
+			const u32 X = x0 + ix, Y = y0 + iy;
+			u32 cnt = 0, e0 = 0, kk = 0;
+			if (ix < nx && iy < ny && X < Y) {
+				const u64 k = mpc_pair_index(n, X, Y);
+				if (k >= p.k0 && k < p.k1) {
+					const u32 b0 = r0 / MPC_RB_HB, b1r = (r1 + MPC_RB_HB - 1u) / MPC_RB_HB, b1 = b1r < p.nb1 - 1u ? b1r : p.nb1 - 1u;
+					e0 = p.cell_off[k * p.nb1 + b0];
+					cnt = p.cell_off[k * p.nb1 + b1] - e0;
+					kk = (u32)k;
+				}
+			}
+			// cells laid end to end pair after pair inside an X group; every group rounded up to whole waves
+			u32 w = cnt;
+			for (int d = 1; d < 8; d <<= 1) { const u32 o = __shfl_up(w, d); if (iy >= (u32)d) w += o; }
+			const u32 gtot = __shfl(w, (int)(lane | 7u));
+			const u32 grnd = (gtot + MPC_RV_WAVE - 1u) & ~(MPC_RV_WAVE - 1u);
+			u32 gi = iy == 0u ? grnd : 0u;
+			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(gi, d); if (lane >= (u32)d) gi += o; }
+			const u32 gbase = __shfl(gi, (int)(lane & ~7u)) - grnd;
+			const u32 total = __shfl(gi, 63);
+			u32 *e = ptab + 4 * lane;
+			e[0] = gbase + w - cnt; e[1] = cnt; e[2] = kk; e[3] = e0;
+			if (iy == 0u) { gtab[2 * ix] = gbase; gtab[2 * ix + 1] = gbase + gtot; }
+			// pieces
+			u32 S, row0, rows, b0, b1;
+			rb_record(s, tw, lane & 15u, &S, &row0, &rows, &b0, &b1);
+			u32 fi = lane < 16u ? rows : 0u;
+			for (int d = 1; d < 16; d <<= 1) { const u32 o = __shfl_up(fi, d); if (lane >= (u32)d) fi += o; }
+			const u32 ftot = __shfl(fi, 15);
+			if (lane < 16u) {
+				u32 *r = rtab + 8 * lane;
+				const u32 fst = fi - rows;
+				r[0] = fst; r[1] = rows; r[2] = row0 - fst; r[3] = S; r[4] = b0; r[5] = b1;
+			}
+			if (lane == 0u) { misc[1] = total; misc[2] = ftot; }
+		}
+		__syncthreads();
+		const u32 total = mpc_wave_first(misc[1]);
+		const u32 ftot = mpc_wave_first(misc[2]); // blocks of the first pieces: where the overflow pieces start
+		const u32 wave_first = wave * 64u;
+		u32 nact = total > wave_first ? (total - wave_first + THREADS - 1u) / THREADS : 0u;
+
+		// ---- my cells. Slot q of this wave covers cells [q*THREADS + wave*64, +64): all of ONE X group. Lanes past the group's
+		// last cell repeat it (their sums are dropped): every lane merges real rows.
+		float acc[MAXSLOTS];
+		u32 xy[MAXSLOTS];       // byte offsets of the cell's two first blocks inside a step's buffer: X row | Y row << 16
+		u32 yreg[YREGS];        // 4 * iy of every slot's cell, 5 bits each: the lane of its Y record in the bias gather
+		u32 sel_a[(MAXSLOTS + 9) / 10]; // ix of every slot of this wave, 3 bits each (wave-uniform: scalar registers)
+#pragma unroll
+		for (int j = 0; j < (MAXSLOTS + 9) / 10; ++j) sel_a[j] = 0u;
+#pragma unroll
+		for (int j = 0; j < (int)YREGS; ++j) yreg[j] = 0u;
+		auto find_cell = [&](u32 q, u32 *kout, u32 *eout, u32 *ixo, u32 *iyo) -> bool { // the cell of (slot q, this lane); false: a repeat
+			const u32 g0 = q * THREADS + wave_first;
+			u32 ix = 0;
+			for (u32 j = 1; j < MPC_RB_MAXN; ++j) if (mpc_wave_first(gtab[2 * j]) <= g0 && mpc_wave_first(gtab[2 * j + 1]) > mpc_wave_first(gtab[2 * j])) ix = j;
+			const u32 gend = mpc_wave_first(gtab[2 * ix + 1]);
+			u32 ln = lane;
+			MPC_OPAQUE(ln); // (the epilogue's searches must not be the prologue's, kept in 12 registers across the walk)
+			const u32 g = g0 + ln;
+			const u32 ge = g < gend ? g : gend - 1u;
+			u32 iy = 0;
+			for (u32 j = 0; j < MPC_RB_MAXN; ++j) {
+				const u32 b = ptab[4 * (8 * ix + j)], c = ptab[4 * (8 * ix + j) + 1];
+				if (c != 0u && b <= ge && ge - b < c) iy = j;
+			}
+			const u32 *e = ptab + 4 * (8 * ix + iy);
+			*kout = e[2]; *eout = e[3] + (ge - e[0]); *ixo = ix; *iyo = iy;
+			return g < gend;
+		};
+#pragma unroll
+		for (int q = 0; q < MAXSLOTS; ++q) {
+			MPC_SCHED_BARRIER();
+			acc[q] = 1.0f; xy[q] = 0u;
+			if ((u32)q < nact) {
+				u32 k, e, ix, iy;
+				find_cell((u32)q, &k, &e, &ix, &iy);
+				const u32 nnz = (u32)(s.vbase[(u64)k + 1] - s.vbase[k]);
+				const u32 *ent = s.packed + s.pbase[k] + s.seq_len[s.pair_x[k]] + s.seq_len[s.pair_y[k]];
+				acc[q] = __uint_as_float(ent[2 * (u64)e]) * 2.0f; // conspairflat.cpp:29-30
+				const u32 col = ent[2 * (u64)e + 1], row = ent[2 * (u64)nnz + e];
+				// row - row0 + first-piece offset, in bytes (rtab[..][2] = row0 - offset)
+				const u32 xo = (row - rtab[8 * ix + 2]) << 4, yo = (col - rtab[8 * (MPC_RB_MAXN + iy) + 2]) << 4;
+				xy[q] = xo | (yo << 16);
+				yreg[q / 6] |= (4u * iy) << (5 * (q % 6));
+				sel_a[q / 10] |= mpc_wave_first(ix) << (3 * (q % 10));
+			}
+		}
+
+		// ---- walk Z. The step table of step Z, one word per lane: lane i (< 16) = rec_off of record i, lane 16+i / 32+i = ovf_off at
+		// the first / past the last index band of its piece. Wave 0 fetches it two steps ahead by LDS-DMA (4 bytes per lane) into
+		// one of two slots; every wave reads it from there: neither a pointer nor a loaded table lives in registers across the merges.
+		// (`ln`: the lane number through an optimisation barrier — what is derived from it is recomputed per step; hoisted out of the
+		// walk, those per-lane constants were 15 registers that lived across the merges without being used there)
+		auto issue_table = [&](u32 Zt) { // wave 0 only
+			u32 ln = lane;
+			MPC_OPAQUE(ln);
+			const u32 li = ln & 15u, role = ln >> 4;
+			const u32 S = rtab[8 * li + 3], b0 = rtab[8 * li + 4], b1 = rtab[8 * li + 5];
+			const u64 rec = (u64)Zt * n + S;
+			const u32 *src = (role == 1u || role == 2u) ? p.ovf_off + rec * p.nb1 + (role == 1u ? b0 : b1) : s.rec_off + rec;
+			if (ln < 48u) mpc_dma4(src, ttab + 64u * (Zt & 1u));
+		};
+		// From a step's table: bias (lane i: hop bias of record i, bytes), and what the DMA needs (lane i: source / length / place of
+		// record i's two pieces, in blocks); returns the step's length in blocks. The records' constants (first-piece offset, rows,
+		// row0 - offset) are re-read from the LDS table: nothing of this lives in registers across the merges.
+		u32 d_src0, d_len0, d_dst0, d_src1, d_len1, d_dst1;
+		auto step_vectors = [&](u32 Zs, u32 *bias) -> u32 {
+			u32 ln = lane;
+			MPC_OPAQUE(ln);
+			const u32 li = ln & 15u;
+			const u32 tab = ttab[64u * (Zs & 1u) + (ln < 48u ? ln : li)];
+			const u32 rt_first = rtab[8 * li], rt_rows = rtab[8 * li + 1], rt_c = rtab[8 * li + 2];
+			const u32 R = mpc_lane_gather(tab, 4u * li), Oa = mpc_lane_gather(tab, 4u * (16u + li)), Ob = mpc_lane_gather(tab, 4u * (32u + li));
+			const u32 ovl = Ob - Oa;
+			u32 incl = ovl;
+			for (u32 d = 1; d < 16u; d <<= 1) { const u32 o = mpc_lane_gather(incl, 4u * ((ln - d) & 63u)); if (li >= d) incl += o; }
+			const u32 O = ftot + incl - ovl;
+			d_src0 = R + rt_c + rt_first; d_len0 = rt_rows; d_dst0 = rt_first; d_src1 = Oa; d_len1 = ovl; d_dst1 = O;
+			*bias = (O + R - Oa + rt_c) << 4;
+			return ftot + mpc_lane_gather(incl, 4u * 15u);
+		};
+		auto issue_dma = [&](u32 at) { // at: byte offset of the step's buffer in the staging area
+			u32 ln = lane;
+			MPC_OPAQUE(ln);
+			for (u32 pc = wave; pc < 32u; pc += NWAVES) {
+				const u32 rec = pc & 15u;
+				u32 src, len, dst;
+				if (pc < 16u) { src = mpc_read_lane(d_src0, rec); len = mpc_read_lane(d_len0, rec); dst = mpc_read_lane(d_dst0, rec); }
+				else { src = mpc_read_lane(d_src1, rec); len = mpc_read_lane(d_len1, rec); dst = mpc_read_lane(d_dst1, rec); }
+				for (u32 c0 = 0; c0 < len; c0 += 64u)
+					if (c0 + ln < len) mpc_dma16(padb + 16 * ((u64)src + c0 + ln), stage + at + 16 * (dst + c0));
+			}
+		};
+		// the biases of a step go through LDS as well (every wave computes the same 16 words and writes them to the same place)
+		auto put_bias = [&](u32 Zs, u32 bias) { u32 ln = lane; MPC_OPAQUE(ln); if (ln < 16u) btab[16u * (Zs & 1u) + ln] = bias; };
+
+		u32 cur_at = 0, cur_len, nxt_at = 0, nxt_len = 0;
+		if (wave == 0u) {
+			issue_table(0);
+			if (n > 1) issue_table(1);
+			mpc_dma_wait();
+		}
+		__syncthreads();
+		{
+			u32 b;
+			cur_len = 16u * step_vectors(0, &b);
+			put_bias(0, b);
+			issue_dma(0);
+			mpc_dma_wait();
+		}
+		constexpr bool STAGING = DIAG < 2; // DIAG 2, 3: step 0's records for every step
+		for (u32 Z = 0; Z < n; ++Z) {
+			bool pre = false;
+			if (STAGING) {
+				__syncthreads(); // step Z's pieces and step Z+1's table have landed (every wave waited for its own DMA); step Z-1's readers are done
+				if (Z + 1 < n) {
+					u32 b;
+					nxt_len = 16u * step_vectors(Z + 1, &b);
+					put_bias(Z + 1, b);
+					// bottom and top of the staging area alternate; the next step is prefetched when it fits beside this one
+					if (cur_at == 0u) { nxt_at = p.cap_bytes - nxt_len; pre = nxt_len <= p.cap_bytes && nxt_at >= cur_len; }
+					else { nxt_at = 0u; pre = nxt_len <= cur_at; }
+					if (pre) issue_dma(nxt_at);
+					if (wave == 0u && Z + 2 < n) issue_table(Z + 2);
+				}
+			} else if (DIAG == 3 || Z == 0) __syncthreads();
+			if (DIAG != 1 && nact != 0u) {
+				const u32 sb = lds_stage + cur_at;
+				u32 ln = lane;
+				MPC_OPAQUE(ln);
+				const u32 bias_cur = btab[16u * ((STAGING ? Z : 0u) & 1u) + (ln & 15u)]; // lane i: hop bias of record i at this step
+#pragma unroll
+				for (int j = 0; j < (int)YREGS; ++j) MPC_OPAQUE(yreg[j]); // the 5-bit fields are unpacked per step (hoisted, they would be 12 more live registers)
+#pragma unroll
+				for (int j = 0; j < (MAXSLOTS + 9) / 10; ++j) MPC_OPAQUE_S(sel_a[j]); // likewise the scalar selectors
+				MPC_OPAQUE_S(nact);
+				const u32 bias_y = mpc_lane_gather(bias_cur, 4u * (MPC_RB_MAXN + (ln & 7u)));   // lane j < 8: hop bias of Y record j
+				BLOCKS blk;
+				auto addr_a = [&](int q) -> u32 { return sb + (xy[q] & 0xffffu); };
+				auto addr_b = [&](int q) -> u32 { return sb + (xy[q] >> 16); };
+				auto hop_b = [&](int q) -> u32 { return mpc_lane_gather(bias_y, (yreg[q / 6] >> (5 * (q % 6))) & 31u); };
+				u32 nia = addr_a(0), nib = addr_b(0), nhb = hop_b(0);
+				blk.load(0, nia, nib);
+				auto slot = [&](auto &&self, auto qc) __attribute__((always_inline)) {
+					constexpr int q = decltype(qc)::value;
+					if constexpr (q < MAXSLOTS) {
+						if ((u32)q >= nact) return; // wave-uniform
+						const u32 ia = nia + mpc_read_lane(bias_cur, (sel_a[q / 10] >> (3 * (q % 10))) & 7u), ib = nib + nhb; // X record: scalar
+						constexpr int qn = q + 1 < MAXSLOTS ? q + 1 : q;
+						nia = addr_a(qn); nib = addr_b(qn); nhb = hop_b(qn);
+						float sum = acc[q];
+						blk.template merge<q & 1>(sum, ia, ib, nia, nib);
+						acc[q] = sum;
+						self(self, std::integral_constant<int, q + 1>{});
+					}
+				};
+				slot(slot, std::integral_constant<int, 0>{});
+			}
+			if (STAGING && Z + 1 < n) {
+				if (!pre) { // the next step did not fit beside this one: stage it now that this one's readers are done
+					__syncthreads();
+					u32 b;
+					nxt_len = 16u * step_vectors(Z + 1, &b);
+					nxt_at = 0u;
+					issue_dma(0u);
+				}
+				mpc_dma_wait();
+				cur_at = nxt_at; cur_len = nxt_len;
+			}
+		}
+		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern
+#pragma unroll
+		for (int q = 0; q < MAXSLOTS; ++q) {
+			MPC_SCHED_BARRIER();
+			if ((u32)q < nact) {
+				u32 k, e, ix, iy;
+				if (find_cell((u32)q, &k, &e, &ix, &iy))
+					s.vnext[s.vbase[k] + e] = acc[q] / (float)n; // uint -> float, IEEE divide (mysparsemx.cpp:108)
+			}
+		}
+	}
+}

@@ -68,9 +68,10 @@ __device__ __forceinline__ void mpc_rv_merge_cxx(float &sum, MpcQuad va, MpcQuad
 	u32 da = va.z >> 16, db = vb.z >> 16;
 	bool more = !((adv_a && da == 0u) || (adv_b && db == 0u));
 	while (more) {
-		ia += adv_a ? da : 0u;
-		ib += adv_b ? db : 0u;
-		va = mpc_lds_load16(ia); vb = mpc_lds_load16(ib);
+		// only the row that advanced is read again (as the hand-scheduled merge does under its advance masks): relax_band_kernel
+		// passes first-block addresses that are already biased for the hop — valid addresses only after a distance has been added
+		if (adv_a) { ia += da; va = mpc_lds_load16(ia); }
+		if (adv_b) { ib += db; vb = mpc_lds_load16(ib); }
 		MPC_RV_TERMS(sum, va, vb);
 		adv_a = va.w <= vb.w; adv_b = vb.w <= va.w;
 		da = va.z >> 16; db = vb.z >> 16;

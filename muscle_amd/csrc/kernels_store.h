@@ -58,6 +58,11 @@ struct StoreParams {
 	u32 lcap1; // >= the longest sequence: LDS scratch of var_build_kernel
 	unsigned short *pos_f, *pos_t;
 	const u32 *rec_off;
+	// band index of the records' overflow regions (relax_band_kernel, kernels_relaxb.h): ovf_off[(Z*n + A) * nb1 + b] = block index
+	// in `pad` where the overflow blocks of rows >= 16*b of record (A,Z) start (overflow blocks are stored in row order); the
+	// record's end when 16*b >= len(A). nb1 = ceil(longest sequence / 16) + 1. Written by var_build_kernel; null: not wanted.
+	u32 *ovf_off;
+	u32 nb1;
 };
 
 #define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128)
@@ -159,7 +164,10 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 		for (u32 q = t; q < units; q += 64) { // every block starts as an empty one
 			rec_out[4 * q] = 0u; rec_out[4 * q + 1] = 0u; rec_out[4 * q + 2] = MPC_PAD_SENTINEL; rec_out[4 * q + 3] = MPC_PAD_SENTINEL;
 		}
-		if (A == Z) continue; // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
+		if (A == Z) { // empty matrix: conspairflat.cpp:39-40 skips Z == X and Z == Y
+			if (s.ovf_off) for (u32 q = t; q < s.nb1; q += 64) s.ovf_off[b * s.nb1 + q] = s.rec_off[b + 1];
+			continue;
+		}
 		const bool fwd = A < Z;
 		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
 		const u32 *rec = s.packed + s.pbase[k];
@@ -186,6 +194,9 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 			carry_o += __shfl(incl_o, 63);
 		}
 		__syncthreads(); // empty blocks and scans are in place before the entries go in
+		if (s.ovf_off)
+			for (u32 q = t; q < s.nb1; q += 64)
+				s.ovf_off[b * s.nb1 + q] = 16u * q < LA ? s.rec_off[b] + LA + s_ovf[16u * q] : s.rec_off[b + 1];
 		const u32 *e = rec + LX + LY;
 		const u32 *rowv = e + 2 * (u64)nnz;
 		const u32 *tperm = rowv + nnz;

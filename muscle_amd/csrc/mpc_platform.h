@@ -86,6 +86,7 @@ __device__ __forceinline__ float mpc_read_lane(float v, unsigned l) { return __b
 __device__ __forceinline__ unsigned mpc_lane_gather(unsigned v, unsigned byte_index) { return (unsigned)__builtin_amdgcn_ds_bpermute((int)byte_index, (int)v); }
 // optimisation barrier on one VGPR value (no code): stops hoisting of what is derived from it
 #define MPC_OPAQUE(v) asm volatile("" : "+v"(v))
+#define MPC_OPAQUE_S(v) asm volatile("" : "+s"(v)) // the same for a wave-uniform value in a scalar register
 // orders this wave's earlier global stores before its later global loads (other lanes' data): s_waitcnt only,
 // the waves of a workgroup share the CU's L1
 #define MPC_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
@@ -102,6 +103,12 @@ __device__ __forceinline__ void mpc_dma16(const void *gsrc, void *lds_wave_base)
 {
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
 		(__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+// the same with 4 bytes per lane: lane L's dword goes to `lds_wave_base + 4 * L` (global_load_lds_dword)
+__device__ __forceinline__ void mpc_dma4(const void *gsrc, void *lds_wave_base)
+{
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+		(__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
 }
 __device__ __forceinline__ void mpc_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // LDS by 32-bit address: the address of a dynamic-LDS location as an integer, and an aligned 16-byte read through such an

@@ -12,6 +12,7 @@
 #include "kernels_post.h"
 #include "kernels_store.h"
 #include "kernels_relaxv.h"
+#include "kernels_relaxb.h"
 #include "kernels_aln.h"
 #include "kernels_prog.h"
 
@@ -155,6 +156,13 @@ struct mpcgpu_ctx {
 	bool var_mixed = false;    // two launches per relax: the configured geometry + 1 x 1024 threads / 160 KB for what does not fit it
 	u64 tiles_k0 = ~0ull, tiles_k1 = ~0ull;
 	u32 tiles_bx = 0, tiles_by = 0;
+	// band tiles (relax_band_kernel, kernels_relaxb.h): band tables of the store, the tile list of the cached pair range
+	bool band_ok = false;      // the band tables exist for this store
+	bool var_pairs_ok = true;  // every pair's two whole records fit a tile of relax_var_kernel (else: band tiles or nothing)
+	u32 band_nb1 = 0;
+	DevBuf d_ovf_off, d_cell_off, d_yr, d_ovf_sum, d_ovf_maxc, d_btiles, d_bt_out, d_bt_cand, d_bt_count, d_bt_list;
+	std::vector<u32> h_btiles;
+	u64 btiles_k0 = ~0ull, btiles_k1 = ~0ull;
 
 	// scratch
 	DevBuf d_bnd;
@@ -402,6 +410,8 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.pos_f = c->d_pos.as<unsigned short>();
 	s.pos_t = c->d_pos.as<unsigned short>() + c->total_entries;
 	s.rec_off = c->d_rec_off.as<u32>();
+	s.ovf_off = c->band_ok ? c->d_ovf_off.as<u32>() : nullptr;
+	s.nb1 = c->band_nb1;
 }
 
 // ---- variable-size records + relax_var_kernel (kernels_relaxv.h) -------------------------------------------------------
@@ -495,6 +505,252 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 	else launch_relax_var<512, 26, 2>(rp, grid, smem, c->stream);
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
+	return 0;
+}
+
+// ---- band tiles + relax_band_kernel (kernels_relaxb.h) ---------------------------------------------------------------------
+#ifdef MPC_RELAX_DIAG_BUILD
+#define MPC_RB_DIAG_CASES(TH, SL) \
+	if (diag == 1) { fn = (const void *)relax_band_kernel<TH, SL, 2, 1>; if (go) MPC_LAUNCH((relax_band_kernel<TH, SL, 2, 1>), grid, TH, smem, c->stream, rp); } \
+	else if (diag == 2) { fn = (const void *)relax_band_kernel<TH, SL, 2, 2>; if (go) MPC_LAUNCH((relax_band_kernel<TH, SL, 2, 2>), grid, TH, smem, c->stream, rp); } \
+	else if (diag == 3) { fn = (const void *)relax_band_kernel<TH, SL, 2, 3>; if (go) MPC_LAUNCH((relax_band_kernel<TH, SL, 2, 3>), grid, TH, smem, c->stream, rp); } \
+	else
+#else
+#define MPC_RB_DIAG_CASES(TH, SL)
+#endif
+constexpr u32 kBandThreads = 1024, kBandSlots = 12; // two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs), 12 cells per lane
+
+// 0 = launched (or nothing to do), 1 = error, 2 = not for band tiles (the caller runs relax_var)
+int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
+{
+	const u32 n = c->n, nb1 = c->band_nb1;
+	const u32 lds_bytes = (u32)std::max(env_int("MPCGPU_RELAX_LDS_KB", 80), 3) * 1024u;
+	const u32 cap = (lds_bytes - MPC_RB_TAB_BYTES) & ~15u, cap_blocks = cap / 16;
+	const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)kBandSlots), 1), (int)kBandSlots);
+	const u32 cus = (u32)c->prop.multiProcessorCount;
+	if (c->btiles_k0 != k0 || c->btiles_k1 != k1) {
+		c->btiles_k0 = c->btiles_k1 = ~0ull;
+		RbTileTabs tb;
+		tb.cell_off = c->d_cell_off.as<u32>(); tb.yr = c->d_yr.as<u32>(); tb.ovf_sum = c->d_ovf_sum.as<u32>(); tb.ovf_maxc = c->d_ovf_maxc.as<u32>();
+		tb.nb1 = nb1; tb.threads = kBandThreads; tb.k0 = k0; tb.k1 = k1;
+		// tile words of a list of tiles whose words 0..5 are set: Y ranges, first-piece blocks, slots; out: slots, mean blocks, bound, cells
+		auto eval_tiles = [&](std::vector<u32> &words, std::vector<u32> &out) -> int {
+			const u32 nt = (u32)(words.size() / MPC_RB_TILE_WORDS);
+			out.assign((size_t)nt * 4, 0u);
+			if (!nt) return 0;
+			if (upload(c, c->d_btiles, words)) return 1;
+			HIPCHK(c, c->d_bt_out.ensure((size_t)nt * 16));
+			MPC_LAUNCH(band_eval_kernel, std::min<u32>(nt, cus * 32), 64, 0, c->stream, sp, tb, c->d_btiles.as<u32>(), nt, c->d_bt_out.as<u32>());
+			HIPCHK(c, hipGetLastError());
+			HIPCHK(c, hipMemcpyAsync(words.data(), c->d_btiles.p, words.size() * 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipMemcpyAsync(out.data(), c->d_bt_out.p, out.size() * 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			return 0;
+		};
+		// super-tiles of nx x ny sequences cut into row bands of <= max_slots cells per lane and <= target blocks per step (mean)
+		auto cut = [&](u32 nx, u32 ny, u32 target, std::vector<u32> &words, std::vector<u32> &out) -> int {
+			std::vector<u32> cand;
+			const u32 nbx = (n + nx - 1) / nx, nby = (n + ny - 1) / ny;
+			for (u32 xb = 0; xb < nbx; ++xb)
+				for (u32 yb = 0; yb < nby; ++yb) {
+					const u32 x0 = xb * nx, cx = std::min(nx, n - x0), y0 = yb * ny, cy = std::min(ny, n - y0);
+					if (y0 + cy <= x0 + 1) continue; // no pair X < Y in this block
+					cand.insert(cand.end(), {x0, cx, y0, cy});
+				}
+			const u32 nc = (u32)(cand.size() / 4);
+			words.clear();
+			if (!nc) { out.clear(); return 0; }
+			if (upload(c, c->d_bt_cand, cand)) return 1;
+			HIPCHK(c, c->d_bt_count.ensure((size_t)nc * 4));
+			HIPCHK(c, c->d_bt_list.ensure((size_t)nc * 4));
+			const u32 grid = std::min<u32>(nc, cus * 32);
+			MPC_LAUNCH(band_cut_kernel, grid, 64, 0, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 0, c->d_bt_count.as<u32>(),
+				(const u32 *)nullptr, (u32 *)nullptr);
+			HIPCHK(c, hipGetLastError());
+			std::vector<u32> cnt(nc), base(nc);
+			HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_bt_count.p, (size_t)nc * 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			u64 tot = 0;
+			for (u32 q = 0; q < nc; ++q) { base[q] = (u32)tot; tot += cnt[q]; }
+			if (tot > 0x7fffffffull / MPC_RB_TILE_WORDS) return fail(c, "mpcgpu_cons_iter: too many band tiles");
+			words.assign((size_t)tot * MPC_RB_TILE_WORDS, 0u);
+			if (!tot) { out.clear(); return 0; }
+			HIPCHK(c, hipMemcpyAsync(c->d_bt_list.p, base.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(c, c->d_btiles.ensure(words.size() * 4));
+			MPC_LAUNCH(band_cut_kernel, grid, 64, 0, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 1, (u32 *)nullptr,
+				c->d_bt_list.as<u32>(), c->d_btiles.as<u32>());
+			HIPCHK(c, hipGetLastError());
+			HIPCHK(c, hipMemcpyAsync(words.data(), c->d_btiles.p, words.size() * 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream)); // `base` dies with this frame
+			return eval_tiles(words, out);
+		};
+		struct Score { double fill, bytes_per_cell, in_target; u64 tiles; };
+		auto score = [&](const std::vector<u32> &out, u32 target) {
+			Score sc = {0, 0, 0, out.size() / 4};
+			u64 cells = 0, est = 0, ok = 0;
+			for (size_t t = 0; t + 3 < out.size(); t += 4) { cells += out[t + 3]; est += out[t + 1]; ok += out[t + 1] <= target ? 1 : 0; }
+			if (sc.tiles) { sc.fill = (double)cells / ((double)sc.tiles * max_slots * kBandThreads); sc.in_target = (double)ok / (double)sc.tiles; }
+			sc.bytes_per_cell = cells ? 16.0 * (double)est / (double)cells : 0.0;
+			return sc;
+		};
+		// Shape of the super-tiles. First choice: the largest shape whose bands leave room for the next step beside the current one
+		// (mean step <= half of the staging area) and still fill the register slots; else the shape with the least traffic per
+		// cell among those whose steps fill the area alone. MPCGPU_RELAX_SHAPE=nx,ny[,kb]: forced shape (and target per step).
+		static const u32 menu[7][2] = {{8, 8}, {8, 4}, {4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+		std::vector<u32> words, out;
+		u32 use_nx = 0, use_ny = 0, use_target = 0;
+		const u32 margin = std::min<u32>(cap_blocks / 16, 64); // blocks: steps vary around the mean
+		const u32 half = cap_blocks / 2 > margin ? cap_blocks / 2 - margin : cap_blocks / 2, full = cap_blocks > 2 * margin ? cap_blocks - 2 * margin : cap_blocks;
+		if (const char *sh = getenv("MPCGPU_RELAX_SHAPE")) {
+			unsigned a = 0, b = 0, kb = 0;
+			const int got = sscanf(sh, "%u,%u,%u", &a, &b, &kb);
+			if (got >= 2 && a >= 1 && a <= MPC_RB_MAXN && b >= 1 && b <= MPC_RB_MAXN) {
+				use_nx = a; use_ny = b; use_target = got == 3 && kb ? std::min<u32>(kb * 64, cap_blocks) : half;
+				if (cut(use_nx, use_ny, use_target, words, out)) return 1;
+			}
+		}
+		if (!use_nx) {
+			for (u32 m = 0; m < 3 && !use_nx; ++m) {
+				if (cut(menu[m][0], menu[m][1], half, words, out)) return 1;
+				const Score sc = score(out, half);
+				if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles %ux%u, two steps resident: %llu tiles, fill %.2f, %.2f B/cell-step, %.0f %% within target\n",
+					menu[m][0], menu[m][1], (unsigned long long)sc.tiles, sc.fill, sc.bytes_per_cell, 100 * sc.in_target);
+				if (sc.tiles && sc.fill >= 0.70 && sc.in_target >= 0.90) { use_nx = menu[m][0]; use_ny = menu[m][1]; use_target = half; }
+				else if (m == 0 && sc.tiles && sc.in_target >= 1.0) {
+					// few cells: when the target did not cut anything (a whole staging area gives the same bands), these are the tiles
+					std::vector<u32> w2, o2;
+					if (cut(menu[0][0], menu[0][1], full, w2, o2)) return 1;
+					if (o2.size() == out.size()) { use_nx = menu[0][0]; use_ny = menu[0][1]; use_target = half; }
+				}
+			}
+		}
+		if (!use_nx) {
+			double best = 0;
+			u32 bm = 7;
+			std::vector<u32> w2, o2;
+			for (u32 m = 0; m < 7; ++m) {
+				if (cut(menu[m][0], menu[m][1], full, w2, o2)) return 1;
+				const Score sc = score(o2, full);
+				if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles %ux%u, one step resident: %llu tiles, fill %.2f, %.2f B/cell-step, %.0f %% within target\n",
+					menu[m][0], menu[m][1], (unsigned long long)sc.tiles, sc.fill, sc.bytes_per_cell, 100 * sc.in_target);
+				if (!sc.tiles) continue;
+				// traffic per cell, charged for idle register slots and for steps over the target (those tiles will be split)
+				const double cost = sc.bytes_per_cell / std::max(std::min(sc.fill / 0.70, 1.0), 0.05) / std::max(sc.in_target, 0.05);
+				if (bm == 7 || cost < best) { best = cost; bm = m; words.swap(w2); out.swap(o2); }
+			}
+			if (bm == 7) { c->h_btiles.clear(); c->btiles_k0 = k0; c->btiles_k1 = k1; return 0; } // no cell in [k0,k1)
+			use_nx = menu[bm][0]; use_ny = menu[bm][1]; use_target = full;
+		}
+		// every tile must fit: cells per lane, 16-bit first-piece offsets, and its WORST step in the staging area (upper bound
+		// first; the exact maximum over Z only where the bound does not settle it). What does not fit is halved: band, then Y, then X.
+		std::vector<u32> okw;
+		u64 nsplit = 0;
+		if (!words.empty() && upload(c, c->d_btiles, words)) return 1; // (the device copy is that of the last shape tried)
+		for (int round = 0; round < 24 && !words.empty(); ++round) {
+			const u32 nt = (u32)(words.size() / MPC_RB_TILE_WORDS);
+			std::vector<u32> need, exact;
+			for (u32 t = 0; t < nt; ++t)
+				if (out[4 * t] <= max_slots && words[(size_t)t * MPC_RB_TILE_WORDS + 6] <= MPC_RB_MAXFIRST && out[4 * t + 2] > cap_blocks) need.push_back(t);
+			if (!need.empty()) {
+				if (upload(c, c->d_bt_list, need)) return 1;
+				HIPCHK(c, c->d_bt_count.ensure(need.size() * 4));
+				MPC_LAUNCH(band_fit_kernel, std::min<u32>((u32)need.size(), cus * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), nb1,
+					c->d_btiles.as<u32>(), c->d_bt_list.as<u32>(), (u32)need.size(), c->d_bt_count.as<u32>());
+				HIPCHK(c, hipGetLastError());
+				exact.resize(need.size());
+				HIPCHK(c, hipMemcpyAsync(exact.data(), c->d_bt_count.p, need.size() * 4, hipMemcpyDeviceToHost, c->stream));
+				HIPCHK(c, hipStreamSynchronize(c->stream));
+				for (size_t q = 0; q < need.size(); ++q) out[4 * need[q] + 2] = exact[q]; // the bound becomes the exact worst step
+			}
+			std::vector<u32> next;
+			for (u32 t = 0; t < nt; ++t) {
+				const u32 *w = &words[(size_t)t * MPC_RB_TILE_WORDS];
+				if (out[4 * t + 3] == 0) continue; // no cell
+				if (out[4 * t] <= max_slots && w[6] <= MPC_RB_MAXFIRST && out[4 * t + 2] <= cap_blocks) { okw.insert(okw.end(), w, w + MPC_RB_TILE_WORDS); continue; }
+				++nsplit;
+				auto push = [&](u32 x0, u32 nx, u32 y0, u32 ny, u32 r0, u32 r1) {
+					u32 nw[MPC_RB_TILE_WORDS] = {x0, nx, y0, ny, r0, r1};
+					next.insert(next.end(), nw, nw + MPC_RB_TILE_WORDS);
+				};
+				const u32 x0 = w[0], nx = w[1], y0 = w[2], ny = w[3], r0 = w[4], r1 = w[5];
+				const u32 hb = (r1 - r0) / MPC_RB_HB;
+				if (hb > 1) { const u32 mid = r0 + (hb / 2) * MPC_RB_HB; push(x0, nx, y0, ny, r0, mid); push(x0, nx, y0, ny, mid, r1); }
+				else if (ny > 1) { push(x0, nx, y0, ny / 2, r0, r1); push(x0, nx, y0 + ny / 2, ny - ny / 2, r0, r1); }
+				else if (nx > 1) { push(x0, nx / 2, y0, ny, r0, r1); push(x0 + nx / 2, nx - nx / 2, y0, ny, r0, r1); }
+				else {
+					if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles: rows [%u,%u) of pair (%u,%u) do not fit (slots %u, first %u, worst step %u blocks of %u)\n",
+						r0, r1, x0, y0, out[4 * t], w[6], out[4 * t + 2], cap_blocks);
+					return 2;
+				}
+			}
+			words.swap(next);
+			if (eval_tiles(words, out)) return 1;
+		}
+		if (!words.empty()) return 2;
+		{
+			u64 cells = 0, est = 0;
+			std::vector<u32> o2;
+			std::vector<u32> w2 = okw;
+			if (eval_tiles(w2, o2)) return 1; // (also leaves the final list's statistics for the description)
+			for (size_t t = 0; t + 3 < o2.size(); t += 4) { cells += o2[t + 3]; est += o2[t + 1]; }
+			const size_t nt = okw.size() / MPC_RB_TILE_WORDS;
+			char b[320];
+			snprintf(b, sizeof(b), "%zu band tiles of <= %ux%u pairs (%llu split), target %u B per step of %u B staging (%s), mean step %.0f B, %.1f of %u cells per lane, %.2f B per cell-step",
+				nt, use_nx, use_ny, (unsigned long long)nsplit, use_target * 16, cap, use_target <= cap_blocks / 2 ? "two steps resident" : "one step resident",
+				nt ? 16.0 * (double)est / (double)nt : 0.0, nt ? (double)cells / ((double)nt * kBandThreads) : 0.0, max_slots, cells ? 16.0 * (double)est / (double)cells : 0.0);
+			c->tiles_desc = b;
+		}
+		c->h_btiles.swap(okw);
+		if (trace_on() && env_int("MPCGPU_TRACE_TILES", 0))
+			for (size_t t = 0; t < c->h_btiles.size() / MPC_RB_TILE_WORDS && t < (size_t)env_int("MPCGPU_TRACE_TILES", 0); ++t) {
+				const u32 *w = &c->h_btiles[t * MPC_RB_TILE_WORDS];
+				fprintf(stderr, "[mpcgpu] tile %zu: X %u+%u Y %u+%u rows [%u,%u) first %u slots %u; Y rows", t, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+				for (u32 j = 0; j < w[3]; ++j) fprintf(stderr, " [%u,%u)", w[8 + j] & 0xffffu, w[8 + j] >> 16);
+				fprintf(stderr, "\n");
+			}
+		if (upload(c, c->d_btiles, c->h_btiles)) return 1;
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		c->btiles_k0 = k0; c->btiles_k1 = k1;
+	}
+	const u32 ntiles = (u32)(c->h_btiles.size() / MPC_RB_TILE_WORDS);
+	if (!ntiles) return 0;
+	HIPCHK(c, c->d_tile_next.ensure(16 * 4));
+	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 16 * 4, c->stream));
+	RelaxBandParams rp;
+	rp.s = sp; rp.ovf_off = c->d_ovf_off.as<u32>(); rp.nb1 = nb1; rp.cell_off = c->d_cell_off.as<u32>();
+	rp.tiles = c->d_btiles.as<u32>(); rp.ntiles = ntiles; rp.k0 = k0; rp.k1 = k1; rp.cap_bytes = cap;
+	rp.tile_next = c->d_tile_next.as<u32>();
+	const size_t smem = MPC_RB_TAB_BYTES + (size_t)cap;
+	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only (results wrong): needs a library built with -DMPC_RELAX_DIAG_BUILD
+#ifndef MPC_RELAX_DIAG_BUILD
+	if (diag) return fail(c, "MPCGPU_RELAX_DIAG needs a library built with -DMPC_RELAX_DIAG_BUILD (measurement kernels: wrong results by design)");
+#else
+	if (diag) { fprintf(stderr, "[mpcgpu] WARNING: MPCGPU_RELAX_DIAG=%d: measurement kernel, the relax results are WRONG by design\n", diag); c->relax_fallback = true; }
+#endif
+	const char *merge_env = getenv("MPCGPU_RELAX_MERGE"); // "cxx": the compiler's code for the merge instead of the hand-scheduled one (A/B)
+	const bool merge_cxx = merge_env && !strcmp(merge_env, "cxx");
+	u32 grid = 1;
+	const void *fn = nullptr;
+	for (int go = 0; go < 2; ++go) { // pass 0: which instantiation (attributes, occupancy); pass 1: launch
+		TimedSpan ts;
+		if (go && span_begin(c, 3, &ts)) return 1;
+		MPC_RB_DIAG_CASES(kBandThreads, kBandSlots)
+		if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRvBlocksCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRvBlocksCxx>), grid, kBandThreads, smem, c->stream, rp); }
+		else { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2>), grid, kBandThreads, smem, c->stream, rp); }
+		if (!go) {
+			HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+			int occ = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)kBandThreads, smem) != hipSuccess || occ < 1) occ = 1;
+			grid = std::max(std::min<u32>(ntiles, cus * (u32)occ), 1u);
+			char kn[128];
+			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, 2, %d, %s>", kBandThreads, kBandSlots, diag, merge_cxx && !diag ? "MpcRvBlocksCxx" : "MpcRvBlocksAsm");
+			c->relax_kernel_name = kn;
+			if (trace_on()) { fprintf(stderr, "[mpcgpu] relax band: %s; lds=%zu B occ=%d grid=%u\n", c->tiles_desc.c_str(), smem, occ, grid); fflush(stderr); }
+		} else {
+			HIPCHK(c, hipGetLastError());
+			if (span_end(c, &ts)) return 1;
+		}
+	}
 	return 0;
 }
 
@@ -644,15 +900,22 @@ int build_var_store(mpcgpu_ctx *c)
 	size_t smem = 0;
 	var_lds_geometry(threads, nbuf, &buf_bytes, &smem);
 	c->var_mixed = false;
+	const char *tiles_mode = getenv("MPCGPU_RELAX_TILES"); // "pairs": whole-record tiles of relax_var_kernel only
+	const bool want_band = !(tiles_mode && !strcmp(tiles_mode, "pairs")) && c->npairs < 0xffffffffull;
+	bool pairs_ok = true;
 	if (2ull * max_rec * 16 > buf_bytes || !slots_ok(threads)) { // not every single pair (two records, its cells) fits a tile of this geometry
 		u32 bb1 = 0;
 		size_t sm1 = 0;
 		var_lds_geometry(1024, 1, &bb1, &sm1);
-		if (2ull * max_rec * 16 > bb1 || !slots_ok(1024)) return 2;
+		if (2ull * max_rec * 16 > bb1 || !slots_ok(1024)) {
+			if (!want_band) return 2;
+			pairs_ok = false; // whole-record tiles are not an option for this run; band tiles may still be (relax_band)
+		}
 		// MPCGPU_RELAX_MIXED (default 1): keep the configured geometry for the pairs that fit it (two workgroups per CU: one's
 		// staging overlaps the other's merges) and give the rest to a second launch of the one-workgroup geometry; 0: everything
 		// to the one-workgroup geometry
-		if (!(threads == 1024 && nbuf == 1) && env_int("MPCGPU_RELAX_MIXED", 1)) {
+		if (!pairs_ok) {}
+		else if (!(threads == 1024 && nbuf == 1) && env_int("MPCGPU_RELAX_MIXED", 1)) {
 			c->var_mixed = true; // (such runs end up with tiles of one pair: two records of 20..40 KB per step for ~3 slots of cells)
 		}
 		else { threads = 1024; nbuf = 1; buf_bytes = bb1; smem = sm1; }
@@ -682,6 +945,30 @@ int build_var_store(mpcgpu_ctx *c)
 		if (c->var_mixed) c->store_desc += " (pairs whose records do not fit it: 1 x 1024-thread workgroup per CU with 160 KB, second launch)";
 		c->tiles_desc.clear(); c->relax_kernel_name.clear(); c->relax_fallback = false;
 	}
+	// band tables for relax_band_kernel (kernels_relaxb.h; MPCGPU_RELAX_TILES=pairs: whole-record tiles of relax_var_kernel only)
+	c->band_ok = false;
+	c->btiles_k0 = c->btiles_k1 = ~0ull;
+	{
+		const u32 nb1 = (c->max_len + MPC_RB_HB - 1) / MPC_RB_HB + 1;
+		const u64 tab_bytes = (nn + 2 * c->npairs + 2ull * n) * nb1 * 4;
+		size_t free2 = 0, tot2 = 0;
+		HIPCHK(c, hipMemGetInfo(&free2, &tot2));
+		if (want_band && (c->d_ovf_off.cap >= nn * nb1 * 4 || tab_bytes + ((u64)1 << 30) <= (u64)free2)) {
+			HIPCHK(c, c->d_ovf_off.ensure(nn * nb1 * 4));
+			HIPCHK(c, c->d_cell_off.ensure(std::max<u64>(c->npairs, 1) * nb1 * 4));
+			HIPCHK(c, c->d_yr.ensure(std::max<u64>(c->npairs, 1) * nb1 * 4));
+			HIPCHK(c, c->d_ovf_sum.ensure((u64)n * nb1 * 4));
+			HIPCHK(c, c->d_ovf_maxc.ensure((u64)n * nb1 * 4));
+			c->band_ok = true;
+			c->band_nb1 = nb1;
+			char b[256];
+			snprintf(b, sizeof(b), "variable-size dense records: %u x %u records, %.2f GB, mean %.0f B, largest %u B, band index of %u rows",
+				n, n, (double)run * 16 / 1e9, (double)run * 16 / (double)nn, max_rec * 16, (unsigned)MPC_RB_HB);
+			c->store_desc = b; // (the tiles and the kernel are described when the first relax has cut them: relax_band)
+		}
+		if (!c->band_ok && !pairs_ok) { c->have_pad = false; return 2; }
+		c->var_pairs_ok = pairs_ok;
+	}
 	StoreParams sp;
 	fill_store_params(c, sp);
 	if (trace_on()) {
@@ -693,12 +980,78 @@ int build_var_store(mpcgpu_ctx *c)
 	if (span_begin(c, 2, &ts)) return 1;
 	MPC_LAUNCH(var_build_kernel, (u32)std::min<u64>(nn, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)std::max(sp.lcap1, 1u) * 8, c->stream, sp);
 	HIPCHK(c, hipGetLastError());
+	if (c->band_ok) {
+		MPC_LAUNCH(band_index_kernel, (u32)std::min<u64>(std::max<u64>(c->npairs, 1), (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->band_nb1,
+			c->d_cell_off.as<u32>(), c->d_yr.as<u32>());
+		HIPCHK(c, hipGetLastError());
+		MPC_LAUNCH(ovf_stats_kernel, std::min<u32>(n, (u32)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), c->band_nb1,
+			c->d_ovf_sum.as<u32>(), c->d_ovf_maxc.as<u32>());
+		HIPCHK(c, hipGetLastError());
+	}
 	if (span_end(c, &ts)) return 1;
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	return 0;
 }
 
 } // namespace
+
+// The fallback layout: compact CSR slabs per sequence + the gather kernel (relax_kernel). Built from the packed records, which
+// always hold the current values: also the way out when a store of dense records turns out not to tile (mpcgpu_cons_iter).
+static int build_slab_store(mpcgpu_ctx *c)
+{
+	const u32 n = c->n;
+	c->have_pad = false;
+	c->band_ok = false;
+	TimedSpan ts;
+	c->d_pad.release();
+	c->d_pos.release();
+	{
+		const char *rm = getenv("MPCGPU_RELAX");
+		c->store_desc = "CSR slabs per sequence; relax_kernel (one thread per stored cell gathers its rows from HBM: the slow path, ~5x the LDS-tiled kernels)";
+		c->tiles_desc.clear();
+		c->relax_kernel_name = "relax_kernel";
+		c->relax_fallback = !(rm && !strcmp(rm, "gather"));
+	}
+	// ---- slab geometry: per ordered pair entry counts -> mbase (within slab), slab bases
+	std::vector<u32> mbase((size_t)n * (n + 1), 0);
+	std::vector<u64> ent_base(n + 1, 0), rp_base(n + 1, 0);
+	{
+		std::vector<u64> slab(n, 0);
+		// nnz(A,Z) = nnz of the unordered pair
+		for (u32 A = 0; A < n; ++A) {
+			u64 run = 0;
+			for (u32 Z = 0; Z < n; ++Z) {
+				if (run > 0xffffffffull) return fail(c, "mpcgpu_store_import: slab of sequence %u exceeds 2^32 entries", A);
+				mbase[(size_t)A * (n + 1) + Z] = (u32)run;
+				if (Z != A) {
+					const u64 k = A < Z ? (u64)A * n - ((u64)A * (A + 1)) / 2 + (Z - A - 1)
+					                    : (u64)Z * n - ((u64)Z * (Z + 1)) / 2 + (A - Z - 1);
+					run += c->all_nnz[k];
+				}
+			}
+			if (run > 0xffffffffull) return fail(c, "mpcgpu_store_import: slab of sequence %u exceeds 2^32 entries", A);
+			mbase[(size_t)A * (n + 1) + n] = (u32)run;
+			slab[A] = run;
+		}
+		for (u32 A = 0; A < n; ++A) {
+			ent_base[A + 1] = ent_base[A] + slab[A];
+			rp_base[A + 1] = rp_base[A] + (u64)n * (c->len[A] + 1);
+		}
+	}
+	HIPCHK(c, c->d_rp.ensure(rp_base[n] * 4));
+	HIPCHK(c, c->d_ent.ensure(std::max<u64>(ent_base[n], 1) * 8));
+	if (upload(c, c->d_mbase, mbase) || upload(c, c->d_ent_base, ent_base) || upload(c, c->d_rp_base, rp_base)) return 1;
+	StoreParams sp;
+	fill_store_params(c, sp);
+	if (span_begin(c, 2, &ts)) return 1;
+	const u64 blocks = (u64)n * n;
+	MPC_LAUNCH(slab_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp);
+	HIPCHK(c, hipGetLastError());
+	if (span_end(c, &ts)) return 1;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->have_store = true;
+	return 0;
+}
 
 extern "C" {
 
@@ -1547,55 +1900,7 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 			if (rc == 0) { c->have_store = true; return 0; }
 		}
 	}
-	TimedSpan ts;
-	c->d_pad.release();
-	c->d_pos.release();
-	{
-		const char *rm = getenv("MPCGPU_RELAX");
-		c->store_desc = "CSR slabs per sequence; relax_kernel (one thread per stored cell gathers its rows from HBM: the slow path, ~5x the LDS-tiled kernels)";
-		c->tiles_desc.clear();
-		c->relax_kernel_name = "relax_kernel";
-		c->relax_fallback = !(rm && !strcmp(rm, "gather"));
-	}
-	// ---- slab geometry: per ordered pair entry counts -> mbase (within slab), slab bases
-	std::vector<u32> mbase((size_t)n * (n + 1), 0);
-	std::vector<u64> ent_base(n + 1, 0), rp_base(n + 1, 0);
-	{
-		std::vector<u64> slab(n, 0);
-		// nnz(A,Z) = nnz of the unordered pair
-		for (u32 A = 0; A < n; ++A) {
-			u64 run = 0;
-			for (u32 Z = 0; Z < n; ++Z) {
-				if (run > 0xffffffffull) return fail(c, "mpcgpu_store_import: slab of sequence %u exceeds 2^32 entries", A);
-				mbase[(size_t)A * (n + 1) + Z] = (u32)run;
-				if (Z != A) {
-					const u64 k = A < Z ? (u64)A * n - ((u64)A * (A + 1)) / 2 + (Z - A - 1)
-					                    : (u64)Z * n - ((u64)Z * (Z + 1)) / 2 + (A - Z - 1);
-					run += c->all_nnz[k];
-				}
-			}
-			if (run > 0xffffffffull) return fail(c, "mpcgpu_store_import: slab of sequence %u exceeds 2^32 entries", A);
-			mbase[(size_t)A * (n + 1) + n] = (u32)run;
-			slab[A] = run;
-		}
-		for (u32 A = 0; A < n; ++A) {
-			ent_base[A + 1] = ent_base[A] + slab[A];
-			rp_base[A + 1] = rp_base[A] + (u64)n * (c->len[A] + 1);
-		}
-	}
-	HIPCHK(c, c->d_rp.ensure(rp_base[n] * 4));
-	HIPCHK(c, c->d_ent.ensure(std::max<u64>(ent_base[n], 1) * 8));
-	if (upload(c, c->d_mbase, mbase) || upload(c, c->d_ent_base, ent_base) || upload(c, c->d_rp_base, rp_base)) return 1;
-	StoreParams sp;
-	fill_store_params(c, sp);
-	if (span_begin(c, 2, &ts)) return 1;
-	const u64 blocks = (u64)n * n;
-	MPC_LAUNCH(slab_build_kernel, (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp);
-	HIPCHK(c, hipGetLastError());
-	if (span_end(c, &ts)) return 1;
-	HIPCHK(c, hipStreamSynchronize(c->stream));
-	c->have_store = true;
-	return 0;
+	return build_slab_store(c);
 }
 
 int mpcgpu_build_store(mpcgpu_ctx *c)
@@ -1662,7 +1967,16 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	if (cnt == 0) return 0;
 	StoreParams sp;
 	fill_store_params(c, sp);
-	if (c->have_pad) return relax_var(c, sp, k0, k1);
+	if (c->have_pad) {
+		if (c->band_ok) {
+			const int r = relax_band(c, sp, k0, k1);
+			if (r != 2) return r;
+			c->band_ok = false; // this store's rows do not cut into band tiles that fit: whole-record tiles from here on
+		}
+		if (c->var_pairs_ok) return relax_var(c, sp, k0, k1);
+		if (build_slab_store(c)) return 1; // neither: CSR slabs + the gather kernel (same results)
+		fill_store_params(c, sp);
+	}
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
 	const u32 block = 256;

@@ -31,6 +31,8 @@ def run_lib(seqs, iters=2, lib_path=None, hmm_name="hmm_amino", expf_variant=-1,
             g.cons_iter()
             g.cons_commit()
             stages.append(g.get_sparse_range())
+        if info is not None:
+            info["relax_info"], info["relax_fallback"] = g.relax_info()
     g.close()
     return stages, ea
 

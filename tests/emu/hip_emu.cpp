@@ -48,7 +48,8 @@ struct Fiber {
 	char *stack = nullptr;
 	unsigned tid = 0;
 	bool done = false;
-	std::vector<std::pair<void *, const void *>> dma; // EMU_DMA=late: 16-byte copies issued and not yet waited for
+	struct Dma { void *dst; const void *src; unsigned bytes; };
+	std::vector<Dma> dma; // EMU_DMA=late: copies issued and not yet waited for
 };
 
 struct Worker {
@@ -68,7 +69,7 @@ void fiber_entry()
 {
 	Worker *w = t_worker;
 	(*w->body)();
-	dma_complete(); // a thread that ends with transfers in flight: they land
+	dma_complete(true); // a thread that ends with transfers in flight: they land
 	w->cur->done = true;
 	emu_switch(&w->cur->sp, w->sched_sp); // never resumed
 	abort();
@@ -87,6 +88,7 @@ void run_block(Worker &w, unsigned bid, dim3 block, size_t smem)
 	}
 	std::vector<unsigned char> dyn(smem + 64);
 	bs.dyn_smem = (unsigned char *)(((uintptr_t)dyn.data() + 15) & ~(uintptr_t)15);
+	bs.dyn_size = smem;
 	g_block = &bs;
 	if (w.fibers.size() < nthreads) w.fibers.resize(nthreads);
 	for (unsigned t = 0; t < nthreads; ++t) {
@@ -142,13 +144,17 @@ void run_block(Worker &w, unsigned bid, dim3 block, size_t smem)
 } // namespace
 
 bool g_dma_late = false, g_dma_never = false; // never: the waits deliver nothing (only the thread's end does) — the negative control of the late mode
-void dma_enqueue(void *dst, const void *src) { t_worker->cur->dma.emplace_back(dst, src); }
-void dma_complete()
+void dma_enqueue(void *dst, const void *src, unsigned bytes) { t_worker->cur->dma.push_back({dst, src, bytes}); }
+void dma_complete(bool data_too)
 {
 	Fiber *f = t_worker ? t_worker->cur : nullptr;
 	if (!f) return;
-	for (auto &c : f->dma) memcpy(c.first, c.second, 16);
-	f->dma.clear();
+	size_t keep = 0;
+	for (auto &c : f->dma) {
+		if (data_too || c.bytes < 16) memcpy(c.dst, c.src, c.bytes);
+		else f->dma[keep++] = c;
+	}
+	f->dma.resize(keep);
 }
 
 void yield()

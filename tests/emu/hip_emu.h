@@ -48,6 +48,7 @@ struct BlockState {
 	Barrier bar;
 	std::vector<WaveState> waves;
 	unsigned char *dyn_smem;
+	size_t dyn_size;
 };
 extern thread_local BlockState *g_block; // the block this OS thread is running
 extern thread_local WaveState *t_wave;   // of the running fiber
@@ -57,8 +58,8 @@ void yield(); // give the OS thread to the next fiber of the block
 // poisoned at issue and the copy happens when the ISSUING thread waits (mpc_dma_wait), i.e. as late as the hardware may deliver —
 // a kernel that reads staged data before its wait + barrier then computes with garbage and fails its parity test.
 extern bool g_dma_late, g_dma_never;
-void dma_enqueue(void *dst, const void *src);
-void dma_complete();
+void dma_enqueue(void *dst, const void *src, unsigned bytes);
+void dma_complete(bool data_too);
 // all fibers of a barrier live on one OS thread: plain counters
 static inline void barrier_wait(Barrier &b)
 {
@@ -100,6 +101,7 @@ template <class T> static inline T __shfl_up(T v, unsigned d) { return emu_xchg(
 template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xchg(v, (int)d, false); }
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
 #define MPC_OPAQUE(v) ((void)0)
+#define MPC_OPAQUE_S(v) ((void)0)
 #define MPC_SCHED_BARRIER() ((void)0)
 #define MPC_WAVE_LDS_ORDER() ((void)__shfl(0, 0)) // a rendezvous of the WAVE (any collective is one): the emulator runs lanes one after the other between synchronisation points
 #define MPC_WAVE_FENCE() ((void)0) // emulated lanes meet at every shuffle
@@ -132,7 +134,12 @@ static inline float mpc_wave_scan_max_nonneg(float v)
 static inline unsigned mpc_cvt_u32_sat(float f) { return !(f > 0.0f) ? 0u : (f >= 4294967296.0f ? 0xffffffffu : (unsigned)f); }
 struct __attribute__((aligned(16))) MpcQuad { unsigned x, y, z, w; };
 static inline unsigned mpc_lds_addr(const void *p) { return (unsigned)((const unsigned char *)p - emu::g_block->dyn_smem); }
-static inline MpcQuad mpc_lds_load16(unsigned addr) { return *(const MpcQuad *)(emu::g_block->dyn_smem + addr); }
+// (an LDS read beyond the allocation returns zeros on the hardware: a merge fed with poison may hop anywhere)
+static inline MpcQuad mpc_lds_load16(unsigned addr)
+{
+	if ((size_t)addr + 16 > emu::g_block->dyn_size) return MpcQuad{0, 0, 0, 0};
+	return *(const MpcQuad *)(emu::g_block->dyn_smem + addr);
+}
 typedef const unsigned *mpc_const_u32p;
 #define MPC_CONST_U32(p) ((mpc_const_u32p)(p))
 static inline unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { return emu::t_lane == l ? sv : v; }
@@ -140,10 +147,18 @@ static inline unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { ret
 static inline void mpc_dma16(const void *gsrc, void *lds_wave_base)
 {
 	unsigned char *dst = (unsigned char *)lds_wave_base + 16 * emu::t_lane;
-	if (emu::g_dma_late) { memset(dst, 0xee, 16); emu::dma_enqueue(dst, gsrc); }
+	if (emu::g_dma_late) { memset(dst, 0xee, 16); emu::dma_enqueue(dst, gsrc, 16); }
 	else memcpy(dst, gsrc, 16);
 }
-static inline void mpc_dma_wait() { if (emu::g_dma_late && !emu::g_dma_never) emu::dma_complete(); }
+static inline void mpc_dma4(const void *gsrc, void *lds_wave_base)
+{
+	unsigned char *dst = (unsigned char *)lds_wave_base + 4 * emu::t_lane;
+	if (emu::g_dma_late) { memset(dst, 0xee, 4); emu::dma_enqueue(dst, gsrc, 4); }
+	else memcpy(dst, gsrc, 4);
+}
+// EMU_DMA=never (the negative control): a wait delivers only the 4-byte transfers (tables of block numbers: withheld, the
+// poison would be used as addresses), never the 16-byte data transfers
+static inline void mpc_dma_wait() { if (emu::g_dma_late) emu::dma_complete(!emu::g_dma_never); }
 static inline unsigned mpc_wave_first(unsigned v) { return __shfl(v, 0); }
 static inline unsigned long long mpc_clock() { return 0ull; }
 static inline unsigned long long __ballot(int pred)

@@ -516,3 +516,42 @@ def test_emu_relax_two_geometries(emu):
     P.assert_same(got, want, "two geometries")
     got0 = _with_env({"MPCGPU_RELAX_LDS_KB": "1", "MPCGPU_RELAX_LDS_KB_1024": "8", "MPCGPU_RELAX_MIXED": "0"}, lambda: P.run_lib(seqs, lib_path=emu))
     P.assert_same(got0, want, "one-workgroup geometry alone")
+
+
+# ---- band tiles (relax_band_kernel, kernels_relaxb.h) ----------------------------------------------------------------------
+@pytest.mark.parametrize("env", [
+    {"MPCGPU_RELAX_SHAPE": "8,8"},                                   # several row bands per super-tile come from the slot budget
+    {"MPCGPU_RELAX_SHAPE": "8,8", "MPCGPU_RELAX_SLOTS": "1"},        # many bands, tiles split further (band, Y, X)
+    {"MPCGPU_RELAX_SHAPE": "4,2", "MPCGPU_RELAX_SLOTS": "2"},
+    {"MPCGPU_RELAX_SHAPE": "1,1"},
+    {"MPCGPU_RELAX_LDS_KB": "10"},                                   # the shape search ends in "one step resident": every step staged after the merges
+    {"MPCGPU_RELAX_LDS_KB": "8"},                                    # one 16-row band of the (18, 70)-residue pair needs 7.2 KB: no tiling -> CSR slabs + gather kernel
+    {"MPCGPU_RELAX_LDS_KB": "12", "MPCGPU_RELAX_SHAPE": "2,2,5"},   # target 5 KB of 9.5: most steps prefetched, the large ones late
+    {"MPCGPU_RELAX_TILES": "pairs"},                                 # the whole-record tiles of relax_var_kernel (A/B)
+])
+def test_emu_relax_band_tiles(emu, env):
+    """relax_band_kernel over forced tile shapes, slot budgets and staging areas: row bands of 16..80 rows, Y ranges that start
+    inside a record, ragged lengths (a 3-residue and a 70-residue sequence among 18-residue ones), both staging modes (next
+    step prefetched beside the current one / staged after the merges), tiles split by the host — bit-identical to the oracle."""
+    seqs = make_family(7, 75, seed=11) + make_family(3, 18, seed=5) + [make_family(1, 70, seed=9)[0], "MKV"]
+    info = {}
+    got = _with_env(env, lambda: P.run_lib(seqs, lib_path=emu, info=info))
+    P.assert_same(got, P.run_oracle(seqs), "band tiles %s" % env)
+    if env.get("MPCGPU_RELAX_TILES") == "pairs":
+        assert "relax_var_kernel" in info["relax_info"], info["relax_info"]
+    elif env.get("MPCGPU_RELAX_LDS_KB") == "8":
+        assert "relax_kernel" in info["relax_info"] and info["relax_fallback"], info["relax_info"]
+    else:
+        assert "relax_band_kernel" in info["relax_info"] and "band tiles" in info["relax_info"], info["relax_info"]
+
+
+@pytest.mark.parametrize("mode", ["late", "reverse", "random"])
+def test_emu_relax_band_tiles_races(emu, mode):
+    """the band kernel's staging under the emulator's race finders: EMU_DMA=late (transfers land at the issuing thread's wait, the
+    destination poisoned meanwhile) with step Z+1 prefetched beside step Z, and threads run in reverse / random order between
+    synchronisation points"""
+    seqs = make_family(6, 40, seed=3) + make_family(3, 18, seed=5)
+    env = {"MPCGPU_RELAX_SHAPE": "4,4,3", "MPCGPU_RELAX_LDS_KB": "10"}
+    env.update({"EMU_DMA": "late"} if mode == "late" else {"EMU_SCHED": mode})
+    got = _with_env(env, lambda: P.run_lib(seqs, lib_path=emu))
+    P.assert_same(got, P.run_oracle(seqs), "band tiles, %s" % mode)
