@@ -14,7 +14,7 @@
 //
 // A partial record is two pieces, because a record is [first block of every row][overflow blocks in row order]
 // (kernels_store.h): rows [a0,a1) of the first-block region (row a at block a: no table needed) and the overflow blocks of the
-// index bands (MPC_RB_HB = 16 rows) those rows lie in (ovf_off: where the overflow of band b of record (A,Z) starts, written by
+// index bands (MPC_RB_HB = 8 rows) those rows lie in (ovf_off: where the overflow of band b of record (A,Z) starts, written by
 // var_build_kernel). In LDS the first pieces of all records come first, at offsets that do NOT depend on Z — a cell's two row
 // addresses inside a step's buffer are constants of the walk, no per-step base — and the overflow pieces follow back to back,
 // at offsets that do. The only thing the merge needs per step and record is the HOP BIAS: a first block's distance field is
@@ -28,7 +28,7 @@
 #pragma once
 #include "kernels_relaxv.h"
 
-#define MPC_RB_HB 16u           // rows per index band (overflow offsets, cell offsets, y ranges are kept per band)
+// MPC_RB_HB (kernels_store.h): rows per index band — overflow offsets, cell offsets and y ranges are kept per band
 #define MPC_RB_MAXN 8u          // sequences per side of a tile
 #define MPC_RB_TILE_WORDS 16u   // x0, nx, y0, ny, r0, r1, first-piece blocks, slots, then ylo | yhi << 16 per Y (yhi exclusive)
 #define MPC_RB_TAB_BYTES 2560u  // tables at the head of the dynamic LDS: pairs 64 x 16 B, records 16 x 32 B, groups, misc, step tables, biases
@@ -39,6 +39,27 @@
 #define MPC_RB_TTAB 1664u       // step tables of two steps: 2 x 64 words
 #define MPC_RB_BTAB 2176u       // hop biases of two steps: 2 x 16 words (.. 2304; the rest is spare)
 #define MPC_RB_MAXFIRST 4095u   // blocks of first pieces per step: a cell keeps its two byte offsets in 16 bits each
+
+// relax_band_kernel's merge of one (cell, Z) in C++ (what MpcRbBlocksAsm, mpc_platform.h, does with hand-scheduled instructions;
+// the emulator runs this one, the device can: MPCGPU_RELAX_MERGE=cxx). ia: address of the X row's first block + the X record's hop
+// bias; ib: address of the Y row's first block — its record's bias, gathered one slot ahead, is added here.
+struct MpcRbBlocksCxx {
+	MpcQuad a[2], b[2];
+	u32 hb;
+	__device__ __forceinline__ void load(u32 ia, u32 ib, u32 idx, u32 bias_y) { a[0] = mpc_lds_load16(ia); b[0] = mpc_lds_load16(ib); hb = mpc_lane_gather(bias_y, idx); }
+	__device__ __forceinline__ void drain() {}
+	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32 ib, u32 nia, u32 nib, u32 nidx, u32 bias_y)
+	{
+		const MpcQuad va = a[SET], vb = b[SET];
+		ib += hb;
+		a[SET ^ 1] = mpc_lds_load16(nia); b[SET ^ 1] = mpc_lds_load16(nib); // the next slot's first blocks and Y bias: in flight during this slot's arithmetic
+		hb = mpc_lane_gather(bias_y, nidx);
+		mpc_rv_merge_cxx(sum, va, vb, ia, ib);
+	}
+};
+#ifndef MPC_RB_HAVE_ASM
+typedef MpcRbBlocksCxx MpcRbBlocksAsm; // the emulator has the C++ statement only
+#endif
 
 struct RelaxBandParams {
 	StoreParams s;
@@ -75,7 +96,7 @@ __global__ void __launch_bounds__(64) band_index_kernel(StoreParams s, u32 nb1, 
 			const u32 start = carry + incl - v;
 			u32 lo = v ? ent[2 * (u64)start + 1] : 0xffffu;
 			u32 hi = v ? ent[2 * (u64)(start + v - 1) + 1] : 0u;
-			for (int d = 8; d >= 1; d >>= 1) { // the 16 rows of a band are 16 consecutive lanes
+			for (int d = (int)MPC_RB_HB / 2; d >= 1; d >>= 1) { // the rows of a band are consecutive lanes
 				const u32 ol = __shfl_down(lo, d), oh = __shfl_down(hi, d);
 				lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
 			}
@@ -192,13 +213,15 @@ __device__ __forceinline__ u64 rb_lane_pair(const StoreParams &s, const RbTileTa
 	return (k >= tb.k0 && k < tb.k1) ? k : ~0ull;
 }
 
-// Cuts the super-tiles (x0, nx, y0, ny) of `cand` (4 words each) into row bands: a band is closed when the next index band
-// would take the tile over `max_slots` cells per lane or over `target` blocks per step (mean), or when it has reached the
-// super-tile's even share of cells. write == 0: count[c] = bands of candidate c; write == 1: the bands' tile words 0..5 go to
-// tiles + MPC_RB_TILE_WORDS * base[c]. One wave per candidate.
+// Cuts the super-tiles (x0, nx, y0, ny) of `cand` (4 words each) into row bands of about equal numbers of cells: the fewest bands
+// such that none needs more than `max_slots` cells per lane or more than `target` blocks per step (mean over Z) — a band of one
+// index band that does is emitted as it is (the host splits it by sequences). write == 0: count[c] = bands of candidate c;
+// write == 1: the bands' tile words 0..5 go to tiles + MPC_RB_TILE_WORDS * base[c]. One wave per candidate; dynamic LDS: nb1 words.
 __global__ void __launch_bounds__(64) band_cut_kernel(StoreParams s, RbTileTabs tb, const u32 *cand, u32 ncand, u32 max_slots, u32 target,
 	int write, u32 *count, const u32 *base, u32 *tiles)
 {
+	MPC_DYN_SMEM(smem_raw);
+	u32 *cum = (u32 *)smem_raw; // cum[b]: cells of the super-tile's pairs in rows < b*HB
 	const u32 lane = threadIdx.x & 63u;
 	for (u32 ci = blockIdx.x; ci < ncand; ci += gridDim.x) {
 		const u32 x0 = cand[4 * ci], nx = cand[4 * ci + 1], y0 = cand[4 * ci + 2], ny = cand[4 * ci + 3];
@@ -207,38 +230,60 @@ __global__ void __launch_bounds__(64) band_cut_kernel(StoreParams s, RbTileTabs 
 		u32 maxlen = 0;
 		for (u32 q = 0; q < nx; ++q) { const u32 l = s.seq_len[x0 + q]; maxlen = l > maxlen ? l : maxlen; }
 		const u32 nb = (maxlen + MPC_RB_HB - 1u) / MPC_RB_HB;
-		const u32 mine = k == ~0ull ? 0u : co[nb] - co[0];
-		const u32 T = rb_wave_sum(mine);
+		MPC_WAVE_LDS_ORDER(); // the previous candidate's readers are done with cum
+		for (u32 b = 0; b <= nb; ++b) {
+			const u32 v = rb_wave_sum(k == ~0ull ? 0u : co[b]);
+			if (lane == 0u) cum[b] = v;
+		}
+		MPC_WAVE_LDS_ORDER();
+		const u32 T = cum[nb];
 		u32 emitted = 0;
 		if (T != 0u) {
-			const u32 budget = max_slots * tb.threads;
-			const u32 parts = (T + budget - 1u) / budget;
-			const u32 goal = (T + parts - 1u) / parts;
-			u32 bstart = 0, c = 0, lo = 0xffffu, hi = 0u;
-			auto emit = [&](u32 b0, u32 b1) {
-				if (write && lane == 0u) {
-					u32 *t = tiles + (u64)MPC_RB_TILE_WORDS * (base[ci] + emitted);
-					t[0] = x0; t[1] = nx; t[2] = y0; t[3] = ny; t[4] = b0 * MPC_RB_HB; t[5] = b1 * MPC_RB_HB;
-				}
-				++emitted;
+			// band [b0, b1) of the cut into `parts`: the index band boundary nearest to the even share
+			auto boundary = [&](u32 i, u32 parts, u32 b0) -> u32 {
+				if (i == parts) return nb;
+				const u32 goal = (u32)(((u64)T * i) / parts);
+				u32 b1 = b0 + 1u;
+				while (b1 < nb && cum[b1] < goal) ++b1;
+				if (b1 > b0 + 1u && cum[b1] - goal > goal - cum[b1 - 1u]) --b1;
+				return b1;
 			};
-			for (u32 b = 0; b < nb; ++b) {
-				const u32 cb = k == ~0ull ? 0u : co[b + 1] - co[b];
-				const u32 w = k == ~0ull ? 0xffffu : yrp[b];
-				const u32 blo = cb ? (w & 0xffffu) : 0xffffu, bhi = cb ? (w >> 16) : 0u;
-				const u32 nc = c + cb, nlo = blo < lo ? blo : lo, nhi = bhi > hi ? bhi : hi;
-				if (b > bstart) {
-					const RbTileStats st = rb_tile_stats(s, tb, x0, nx, y0, ny, bstart, b + 1u, nc, nlo, nhi);
-					if (st.slots > max_slots || st.est > target) { // band b does not go in: close [bstart, b)
-						if (rb_wave_sum(c) != 0u) emit(bstart, b);
-						bstart = b; c = cb; lo = blo; hi = bhi;
-						continue;
+			auto fits = [&](u32 b0, u32 b1) -> bool {
+				u32 c = 0, lo = 0xffffu, hi = 0u;
+				if (k != ~0ull) {
+					c = co[b1] - co[b0];
+					for (u32 b = b0; b < b1; ++b) {
+						if (co[b + 1] == co[b]) continue;
+						const u32 w = yrp[b];
+						lo = (w & 0xffffu) < lo ? (w & 0xffffu) : lo; hi = (w >> 16) > hi ? (w >> 16) : hi;
 					}
 				}
-				c = nc; lo = nlo; hi = nhi;
-				if (rb_wave_sum(c) >= goal) { emit(bstart, b + 1u); bstart = b + 1u; c = 0; lo = 0xffffu; hi = 0u; }
+				const RbTileStats st = rb_tile_stats(s, tb, x0, nx, y0, ny, b0, b1, c, lo, hi);
+				return st.slots <= max_slots && st.est <= target;
+			};
+			const u32 budget = max_slots * tb.threads;
+			u32 parts = (T + budget - 1u) / budget;
+			for (; parts < nb; ++parts) {
+				bool ok = true;
+				for (u32 i = 1, b0 = 0; i <= parts && ok; ++i) {
+					const u32 b1 = boundary(i, parts, b0);
+					if (cum[b1] != cum[b0] && b1 - b0 > 1u && !fits(b0, b1)) ok = false;
+					b0 = b1;
+				}
+				if (ok) break;
 			}
-			if (bstart < nb && rb_wave_sum(c) != 0u) emit(bstart, nb);
+			if (parts > nb) parts = nb;
+			for (u32 i = 1, b0 = 0; i <= parts; ++i) {
+				const u32 b1 = boundary(i, parts, b0);
+				if (cum[b1] != cum[b0]) {
+					if (write && lane == 0u) {
+						u32 *t = tiles + (u64)MPC_RB_TILE_WORDS * (base[ci] + emitted);
+						t[0] = x0; t[1] = nx; t[2] = y0; t[3] = ny; t[4] = b0 * MPC_RB_HB; t[5] = b1 * MPC_RB_HB;
+					}
+					++emitted;
+				}
+				b0 = b1;
+			}
 		}
 		if (!write && lane == 0u) count[ci] = emitted;
 	}
@@ -319,8 +364,8 @@ __global__ void __launch_bounds__(64) band_fit_kernel(StoreParams s, const u32 *
 // ---- the relax --------------------------------------------------------------------------------------------------------------------
 // THREADS: workgroup size; MAXSLOTS: cells per lane; WGS: workgroups per CU the register allocation has to allow;
 // DIAG (measurement only, results wrong; compiled only with MPC_RELAX_DIAG_BUILD): 1 = staging and barriers only, 2 = merges only
-// (step 0's records for every step), 3 = as 2 with the barriers; BLOCKS: MpcRvBlocksAsm (hand-scheduled merge) or MpcRvBlocksCxx.
-template <int THREADS, int MAXSLOTS, int WGS, int DIAG = 0, class BLOCKS = MpcRvBlocksAsm>
+// (step 0's records for every step), 3 = as 2 with the barriers; BLOCKS: MpcRbBlocksAsm (hand-scheduled merge) or MpcRbBlocksCxx.
+template <int THREADS, int MAXSLOTS, int WGS, int DIAG = 0, class BLOCKS = MpcRbBlocksAsm>
 __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kernel(RelaxBandParams p)
 {
 	MPC_DYN_SMEM(smem_raw);
@@ -533,6 +578,9 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 					if (cur_at == 0u) { nxt_at = p.cap_bytes - nxt_len; pre = nxt_len <= p.cap_bytes && nxt_at >= cur_len; }
 					else { nxt_at = 0u; pre = nxt_len <= cur_at; }
 					if (pre) issue_dma(nxt_at);
+#ifdef MPC_RELAX_DIAG_BUILD
+					if (tid == 0) atomicAdd(&p.tile_next[pre ? 9 : 8], 1u); // measurement build: steps prefetched / staged late
+#endif
 					if (wave == 0u && Z + 2 < n) issue_table(Z + 2);
 				}
 			} else if (DIAG == 3 || Z == 0) __syncthreads();
@@ -550,23 +598,24 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 				BLOCKS blk;
 				auto addr_a = [&](int q) -> u32 { return sb + (xy[q] & 0xffffu); };
 				auto addr_b = [&](int q) -> u32 { return sb + (xy[q] >> 16); };
-				auto hop_b = [&](int q) -> u32 { return mpc_lane_gather(bias_y, (yreg[q / 6] >> (5 * (q % 6))) & 31u); };
-				u32 nia = addr_a(0), nib = addr_b(0), nhb = hop_b(0);
-				blk.load(0, nia, nib);
+				auto idx_b = [&](int q) -> u32 { return (yreg[q / 6] >> (5 * (q % 6))) & 31u; }; // 4 * (lane of bias_y that holds the cell's Y record)
+				u32 nia = addr_a(0), nib = addr_b(0);
+				blk.load(nia, nib, idx_b(0), bias_y);
 				auto slot = [&](auto &&self, auto qc) __attribute__((always_inline)) {
 					constexpr int q = decltype(qc)::value;
 					if constexpr (q < MAXSLOTS) {
 						if ((u32)q >= nact) return; // wave-uniform
-						const u32 ia = nia + mpc_read_lane(bias_cur, (sel_a[q / 10] >> (3 * (q % 10))) & 7u), ib = nib + nhb; // X record: scalar
+						const u32 ia = nia + mpc_read_lane(bias_cur, (sel_a[q / 10] >> (3 * (q % 10))) & 7u), ib = nib; // X record: scalar bias
 						constexpr int qn = q + 1 < MAXSLOTS ? q + 1 : q;
-						nia = addr_a(qn); nib = addr_b(qn); nhb = hop_b(qn);
+						nia = addr_a(qn); nib = addr_b(qn);
 						float sum = acc[q];
-						blk.template merge<q & 1>(sum, ia, ib, nia, nib);
+						blk.template merge<q & 1>(sum, ia, ib, nia, nib, idx_b(qn), bias_y);
 						acc[q] = sum;
 						self(self, std::integral_constant<int, q + 1>{});
 					}
 				};
 				slot(slot, std::integral_constant<int, 0>{});
+				blk.drain(); // the last slot's look-ahead reads have landed before their registers mean anything else
 			}
 			if (STAGING && Z + 1 < n) {
 				if (!pre) { // the next step did not fit beside this one: stage it now that this one's readers are done

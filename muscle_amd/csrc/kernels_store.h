@@ -59,13 +59,15 @@ struct StoreParams {
 	unsigned short *pos_f, *pos_t;
 	const u32 *rec_off;
 	// band index of the records' overflow regions (relax_band_kernel, kernels_relaxb.h): ovf_off[(Z*n + A) * nb1 + b] = block index
-	// in `pad` where the overflow blocks of rows >= 16*b of record (A,Z) start (overflow blocks are stored in row order); the
-	// record's end when 16*b >= len(A). nb1 = ceil(longest sequence / 16) + 1. Written by var_build_kernel; null: not wanted.
+	// in `pad` where the overflow blocks of rows >= HB*b of record (A,Z) start (overflow blocks are stored in row order); the
+	// record's end when HB*b >= len(A). HB = MPC_RB_HB rows, nb1 = ceil(longest sequence / HB) + 1. Written by var_build_kernel;
+	// null: not wanted.
 	u32 *ovf_off;
 	u32 nb1;
 };
 
 #define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128)
+#define MPC_RB_HB 8u  // rows per index band of the band tables (overflow offsets here; cell offsets, y ranges: kernels_relaxb.h)
 #define MPC_PAD_SENTINEL 0x1fffu // larger than any column: sequences in the padded layout are <= 8191 long
 
 __device__ __forceinline__ u64 mpc_pair_index(u32 n, u32 i, u32 j) // i<j, mpcflat.cpp:145-155 order
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 		__syncthreads(); // empty blocks and scans are in place before the entries go in
 		if (s.ovf_off)
 			for (u32 q = t; q < s.nb1; q += 64)
-				s.ovf_off[b * s.nb1 + q] = 16u * q < LA ? s.rec_off[b] + LA + s_ovf[16u * q] : s.rec_off[b + 1];
+				s.ovf_off[b * s.nb1 + q] = MPC_RB_HB * q < LA ? s.rec_off[b] + LA + s_ovf[MPC_RB_HB * q] : s.rec_off[b + 1];
 		const u32 *e = rec + LX + LY;
 		const u32 *rowv = e + 2 * (u64)nnz;
 		const u32 *tperm = rowv + nnz;

@@ -201,6 +201,88 @@ struct MpcRvBlocksAsm {
 #undef MPC_RV_MERGE_ASM
 };
 #define MPC_RV_HAVE_ASM 1
+// ---- the same merge for relax_band_kernel (kernels_relaxb.h: MpcRbBlocksCxx is its C++ statement). Differences: the addresses
+// ia, ib are those of the rows' FIRST blocks plus the records' hop biases — valid block addresses only once a block's distance has
+// been added — and the bias of the Y record differs per lane: it is gathered across lanes (ds_bpermute_b32 on the register that
+// holds the Y records' biases in lanes 0..7) one slot ahead, inside the statement, so that its latency hides behind the merge like
+// that of the next slot's first blocks; the gathered value lives in v40 from statement to statement (`hb`). Every LDS operation
+// issued here is covered by the NEXT statement's opening wait or by drain() after the last slot.
+struct MpcRbBlocksAsm {
+	mpc_uint4v a0, b0, a1, b1; // set 0: v[24:27], v[28:31]; set 1: v[32:35], v[36:39]
+	unsigned hb;               // v40: hop bias of the next slot's Y record (in flight until the next opening wait)
+	// first blocks of the first slot into set 0, and its Y bias
+	__device__ __forceinline__ void load(unsigned ia, unsigned ib, unsigned idx, unsigned bias_y)
+	{
+		asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_bpermute_b32 %2, %5, %6"
+			: "={v[24:27]}"(a0), "={v[28:31]}"(b0), "={v40}"(hb) : "v"(ia), "v"(ib), "v"(idx), "v"(bias_y) : "memory");
+	}
+	__device__ __forceinline__ void drain() { asm volatile("s_waitcnt lgkmcnt(0)" : "+{v[24:27]}"(a0), "+{v[28:31]}"(b0), "+{v[32:35]}"(a1), "+{v[36:39]}"(b1), "+{v40}"(hb) : : "memory"); }
+#define MPC_RB_MERGE_ASM(A0_, A1_, A2_, A3_, B0_, B1_, B2_, B3_, CURA_, CURB_, NXTA_, NXTB_)                           \
+	"s_waitcnt lgkmcnt(0)\n\t" /* this slot's first blocks and its Y bias (issued during the previous slot) have landed */ \
+	"v_add_u32_e32 %[ib], %[ib], %[hb]\n\t"                                                                              \
+	"ds_read_b128 " NXTA_ ", %[nia]\n\t"                                                                                 \
+	"ds_read_b128 " NXTB_ ", %[nib]\n\t"                                                                                 \
+	"ds_bpermute_b32 %[hb], %[nidx], %[by]\n\t"                                                                          \
+	"s_mov_b64 %[sv], exec\n"                                                                                            \
+	".Lrv_step_%=:\n\t"                                                                                                  \
+	"v_cmp_eq_u32_sdwa %[e01], " A2_ ", " B3_ " src0_sel:WORD_0 src1_sel:DWORD\n\t"                                      \
+	"v_cmp_eq_u32_sdwa %[e00], " A2_ ", " B2_ " src0_sel:WORD_0 src1_sel:WORD_0\n\t"                                     \
+	"v_cmp_eq_u32_e64 %[e11], " A3_ ", " B3_ "\n\t"                                                                      \
+	"v_cmp_eq_u32_sdwa %[e10], " A3_ ", " B2_ " src0_sel:DWORD src1_sel:WORD_0\n\t"                                      \
+	"v_cmp_le_u32_e64 %[ada], " A3_ ", " B3_ "\n\t"                                                                      \
+	"v_cmp_le_u32_e64 %[adb], " B3_ ", " A3_ "\n\t"                                                                      \
+	"v_cmp_lt_u32_e64 %[nla], %[kf], " A2_ "\n\t"                                                                        \
+	"v_cmp_lt_u32_e64 %[nlb], %[kf], " B2_ "\n\t"                                                                        \
+	"v_cndmask_b32_e64 %[t0], 0, " B1_ ", %[e01]\n\t"                                                                    \
+	"v_cndmask_b32_e64 %[t1], 0, " B1_ ", %[e11]\n\t"                                                                    \
+	"v_cndmask_b32_e64 %[t0], %[t0], " B0_ ", %[e00]\n\t" /* of two equal columns in B the first wins */                 \
+	"v_cndmask_b32_e64 %[t1], %[t1], " B0_ ", %[e10]\n\t"                                                                \
+	"v_mul_f32_e32 %[t0], " A0_ ", %[t0]\n\t"                                                                            \
+	"v_mul_f32_e32 %[t1], " A1_ ", %[t1]\n\t"                                                                            \
+	"v_add_f32_e32 %[sum], %[sum], %[t0]\n\t" /* z ascending: relaxflat.cpp:27, product rounded, then added */           \
+	"v_add_f32_e32 %[sum], %[sum], %[t1]\n\t"                                                                            \
+	"s_orn2_b64 %[nla], %[nla], %[ada]\n\t"                                                                              \
+	"s_orn2_b64 %[nlb], %[nlb], %[adb]\n\t"                                                                              \
+	"s_and_b64 %[nla], %[nla], %[nlb]\n\t"                                                                               \
+	"s_and_b64 exec, exec, %[nla]\n\t" /* the lanes that go on; scc = any */                                             \
+	"s_cbranch_scc0 .Lrv_done_%=\n\t"                                                                                    \
+	"s_mov_b64 %[nlb], exec\n\t"                                                                                         \
+	"s_and_b64 exec, %[nlb], %[ada]\n\t"                                                                                 \
+	"v_add_u32_sdwa %[ia], %[ia], " A2_ " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"        \
+	"ds_read_b128 " CURA_ ", %[ia]\n\t" /* only the lanes whose row advanced read its next block: the others keep theirs */ \
+	"s_and_b64 exec, %[nlb], %[adb]\n\t"                                                                                 \
+	"v_add_u32_sdwa %[ib], %[ib], " B2_ " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"        \
+	"ds_read_b128 " CURB_ ", %[ib]\n\t"                                                                                  \
+	"s_mov_b64 exec, %[nlb]\n\t"                                                                                         \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
+	"s_branch .Lrv_step_%=\n"                                                                                            \
+	".Lrv_done_%=:\n\t"                                                                                                  \
+	"s_mov_b64 exec, %[sv]"
+	// merges the slot whose first blocks are in set SET (first-block addresses + X bias in ia, Y first-block address in ib) onto
+	// sum; reads the blocks at nia, nib into the other set and gathers lane nidx/4 of bias_y for the next slot
+	template <int SET> __device__ __forceinline__ void merge(float &sum, unsigned ia, unsigned ib, unsigned nia, unsigned nib, unsigned nidx, unsigned bias_y)
+	{
+		mpc_u64s sv, e00, e01, e10, e11, ada, adb, nla, nlb;
+		float t0, t1;
+		const unsigned kf = 0xffffu;
+		if (SET == 0)
+			asm volatile(MPC_RB_MERGE_ASM("v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v[24:27]", "v[28:31]", "v[32:35]", "v[36:39]")
+				: [sum] "+v"(sum), [ia] "+v"(ia), [ib] "+v"(ib), [hb] "+{v40}"(hb), "+{v[24:27]}"(a0), "+{v[28:31]}"(b0), "=&{v[32:35]}"(a1), "=&{v[36:39]}"(b1),
+				  [t0] "=&v"(t0), [t1] "=&v"(t1), [sv] "=&s"(sv), [e00] "=&s"(e00), [e01] "=&s"(e01), [e10] "=&s"(e10), [e11] "=&s"(e11),
+				  [ada] "=&s"(ada), [adb] "=&s"(adb), [nla] "=&s"(nla), [nlb] "=&s"(nlb)
+				: [nia] "v"(nia), [nib] "v"(nib), [nidx] "v"(nidx), [by] "v"(bias_y), [kf] "s"(kf)
+				: "vcc", "scc", "memory");
+		else
+			asm volatile(MPC_RB_MERGE_ASM("v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v[32:35]", "v[36:39]", "v[24:27]", "v[28:31]")
+				: [sum] "+v"(sum), [ia] "+v"(ia), [ib] "+v"(ib), [hb] "+{v40}"(hb), "+{v[32:35]}"(a1), "+{v[36:39]}"(b1), "=&{v[24:27]}"(a0), "=&{v[28:31]}"(b0),
+				  [t0] "=&v"(t0), [t1] "=&v"(t1), [sv] "=&s"(sv), [e00] "=&s"(e00), [e01] "=&s"(e01), [e10] "=&s"(e10), [e11] "=&s"(e11),
+				  [ada] "=&s"(ada), [adb] "=&s"(adb), [nla] "=&s"(nla), [nlb] "=&s"(nlb)
+				: [nia] "v"(nia), [nib] "v"(nib), [nidx] "v"(nidx), [by] "v"(bias_y), [kf] "s"(kf)
+				: "vcc", "scc", "memory");
+	}
+#undef MPC_RB_MERGE_ASM
+};
+#define MPC_RB_HAVE_ASM 1
 // A pointer through which wave-uniform reads of memory that this kernel never writes become scalar loads (s_load_dword*:
 // SGPR results, no VGPRs, no vmcnt): the constant address space. (Through a plain global pointer the compiler has to assume
 // the kernel's own stores may alias and issues vector loads.)

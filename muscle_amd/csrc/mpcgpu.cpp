@@ -461,14 +461,23 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 	rp.s = sp; rp.tiles = d_tiles.as<u32>(); rp.ntiles = ntiles;
 	rp.k0 = k0; rp.k1 = k1; rp.nbuf = nbuf; rp.buf_bytes = buf_bytes;
 	rp.tile_next = c->d_tile_next.as<u32>() + 8 * counter_slot;
-	const int diag = primary ? env_int("MPCGPU_RELAX_DIAG", 0) : 0; // measurement only (results wrong): 1 = staging only, 2 = merges only
+	// MPCGPU_RELAX_DIAG=1|2|3 (staging only / merges only / merges + barriers): measurement kernels whose results are WRONG by design;
+	// they exist only in a library built with -DMPC_RELAX_DIAG_BUILD (make diag), which also says so on stderr at every launch
+	int diag = primary ? env_int("MPCGPU_RELAX_DIAG", 0) : 0;
+#ifndef MPC_RELAX_DIAG_BUILD
+	if (diag) return fail(c, "MPCGPU_RELAX_DIAG needs a library built with -DMPC_RELAX_DIAG_BUILD (measurement kernels: wrong results by design)");
+#else
+	if (diag) { fprintf(stderr, "[mpcgpu] WARNING: MPCGPU_RELAX_DIAG=%d: measurement kernel, the relax results are WRONG by design\n", diag); c->relax_fallback = true; }
+#endif
 	const char *merge_env = getenv("MPCGPU_RELAX_MERGE"); // "cxx": the compiler's code for the merge instead of the hand-scheduled one (A/B, 768 geometry)
 	const bool merge_cxx = merge_env && !strcmp(merge_env, "cxx");
 	const void *fn = geo == 1024 ? (const void *)relax_var_kernel<1024, 16, 1>
-	               : geo == 2048 ? (diag == 1 ? (const void *)relax_var_kernel<1024, 13, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<1024, 13, 2, 2> : diag == 3 ? (const void *)relax_var_kernel<1024, 13, 2, 3>
-	                                : var_slots_2048() == 14 ? (const void *)relax_var_kernel<1024, 14, 2> : var_slots_2048() == 12 ? (const void *)relax_var_kernel<1024, 12, 2> : (const void *)relax_var_kernel<1024, 13, 2>)
-	               : geo == 768 ? (diag == 1 ? (const void *)relax_var_kernel<768, 18, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<768, 18, 2, 2> : diag == 3 ? (const void *)relax_var_kernel<768, 18, 2, 3>
-	                               : merge_cxx ? (const void *)relax_var_kernel<768, 18, 2, 0, MpcRvBlocksCxx> : (const void *)relax_var_kernel<768, 18, 2>)
+#ifdef MPC_RELAX_DIAG_BUILD
+	               : geo == 2048 && diag ? (diag == 1 ? (const void *)relax_var_kernel<1024, 13, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<1024, 13, 2, 2> : (const void *)relax_var_kernel<1024, 13, 2, 3>)
+	               : geo == 768 && diag ? (diag == 1 ? (const void *)relax_var_kernel<768, 18, 2, 1> : diag == 2 ? (const void *)relax_var_kernel<768, 18, 2, 2> : (const void *)relax_var_kernel<768, 18, 2, 3>)
+#endif
+	               : geo == 2048 ? (var_slots_2048() == 14 ? (const void *)relax_var_kernel<1024, 14, 2> : var_slots_2048() == 12 ? (const void *)relax_var_kernel<1024, 12, 2> : (const void *)relax_var_kernel<1024, 13, 2>)
+	               : geo == 768 ? (merge_cxx ? (const void *)relax_var_kernel<768, 18, 2, 0, MpcRvBlocksCxx> : (const void *)relax_var_kernel<768, 18, 2>)
 	               : (const void *)relax_var_kernel<512, 26, 2>;
 	HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 	if (primary) {
@@ -487,19 +496,21 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 	TimedSpan ts;
 	if (span_begin(c, 3, &ts)) return 1;
 	if (geo == 1024) launch_relax_var<1024, 16, 1>(rp, grid, smem, c->stream);
+#ifdef MPC_RELAX_DIAG_BUILD
+	else if (geo == 2048 && diag == 1) launch_relax_var<1024, 13, 2, 1>(rp, grid, smem, c->stream);
+	else if (geo == 2048 && diag == 2) launch_relax_var<1024, 13, 2, 2>(rp, grid, smem, c->stream);
+	else if (geo == 2048 && diag == 3) launch_relax_var<1024, 13, 2, 3>(rp, grid, smem, c->stream);
+	else if (geo == 768 && diag == 1) launch_relax_var<768, 18, 2, 1>(rp, grid, smem, c->stream);
+	else if (geo == 768 && diag == 2) launch_relax_var<768, 18, 2, 2>(rp, grid, smem, c->stream);
+	else if (geo == 768 && diag == 3) launch_relax_var<768, 18, 2, 3>(rp, grid, smem, c->stream);
+#endif
 	else if (geo == 2048) {
-		if (diag == 1) launch_relax_var<1024, 13, 2, 1>(rp, grid, smem, c->stream);
-		else if (diag == 2) launch_relax_var<1024, 13, 2, 2>(rp, grid, smem, c->stream);
-		else if (diag == 3) launch_relax_var<1024, 13, 2, 3>(rp, grid, smem, c->stream);
-		else if (var_slots_2048() == 14) launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
+		if (var_slots_2048() == 14) launch_relax_var<1024, 14, 2>(rp, grid, smem, c->stream);
 		else if (var_slots_2048() == 12) launch_relax_var<1024, 12, 2>(rp, grid, smem, c->stream);
 		else launch_relax_var<1024, 13, 2>(rp, grid, smem, c->stream);
 	}
 	else if (geo == 768) {
-		if (diag == 1) launch_relax_var<768, 18, 2, 1>(rp, grid, smem, c->stream);
-		else if (diag == 2) launch_relax_var<768, 18, 2, 2>(rp, grid, smem, c->stream);
-		else if (diag == 3) launch_relax_var<768, 18, 2, 3>(rp, grid, smem, c->stream);
-		else if (merge_cxx) launch_relax_var<768, 18, 2, 0, MpcRvBlocksCxx>(rp, grid, smem, c->stream);
+		if (merge_cxx) launch_relax_var<768, 18, 2, 0, MpcRvBlocksCxx>(rp, grid, smem, c->stream);
 		else launch_relax_var<768, 18, 2>(rp, grid, smem, c->stream);
 	}
 	else launch_relax_var<512, 26, 2>(rp, grid, smem, c->stream);
@@ -518,7 +529,7 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 #else
 #define MPC_RB_DIAG_CASES(TH, SL)
 #endif
-constexpr u32 kBandThreads = 1024, kBandSlots = 12; // two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs), 12 cells per lane
+constexpr u32 kBandThreads = 1024, kBandSlots = 14; // two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs), 14 cells per lane (16: spill reloads inside the walk)
 
 // 0 = launched (or nothing to do), 1 = error, 2 = not for band tiles (the caller runs relax_var)
 int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
@@ -564,7 +575,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			HIPCHK(c, c->d_bt_count.ensure((size_t)nc * 4));
 			HIPCHK(c, c->d_bt_list.ensure((size_t)nc * 4));
 			const u32 grid = std::min<u32>(nc, cus * 32);
-			MPC_LAUNCH(band_cut_kernel, grid, 64, 0, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 0, c->d_bt_count.as<u32>(),
+			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 4, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 0, c->d_bt_count.as<u32>(),
 				(const u32 *)nullptr, (u32 *)nullptr);
 			HIPCHK(c, hipGetLastError());
 			std::vector<u32> cnt(nc), base(nc);
@@ -577,7 +588,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			if (!tot) { out.clear(); return 0; }
 			HIPCHK(c, hipMemcpyAsync(c->d_bt_list.p, base.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
 			HIPCHK(c, c->d_btiles.ensure(words.size() * 4));
-			MPC_LAUNCH(band_cut_kernel, grid, 64, 0, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 1, (u32 *)nullptr,
+			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 4, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 1, (u32 *)nullptr,
 				c->d_bt_list.as<u32>(), c->d_btiles.as<u32>());
 			HIPCHK(c, hipGetLastError());
 			HIPCHK(c, hipMemcpyAsync(words.data(), c->d_btiles.p, words.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -640,6 +651,37 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			}
 			if (bm == 7) { c->h_btiles.clear(); c->btiles_k0 = k0; c->btiles_k1 = k1; return 0; } // no cell in [k0,k1)
 			use_nx = menu[bm][0]; use_ny = menu[bm][1]; use_target = full;
+		}
+		// One step resident: the cut was made on MEAN steps, but the worst step of every tile has to fit the area. The exact worst
+		// steps of a sample of tiles give the ratio worst / mean of this data set (95th percentile); the bands are cut again with the
+		// target lowered by it, so that only stragglers are left to the halving below.
+		if (use_target > half && !words.empty()) {
+			const u32 nt = (u32)(words.size() / MPC_RB_TILE_WORDS);
+			std::vector<u32> sample;
+			const u32 stride = std::max(nt / 4096u, 1u);
+			for (u32 t = 0; t < nt; t += stride) if (out[4 * t + 3]) sample.push_back(t);
+			if (!sample.empty()) {
+				if (upload(c, c->d_btiles, words) || upload(c, c->d_bt_list, sample)) return 1;
+				HIPCHK(c, c->d_bt_count.ensure(sample.size() * 4));
+				MPC_LAUNCH(band_fit_kernel, std::min<u32>((u32)sample.size(), cus * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), nb1,
+					c->d_btiles.as<u32>(), c->d_bt_list.as<u32>(), (u32)sample.size(), c->d_bt_count.as<u32>());
+				HIPCHK(c, hipGetLastError());
+				std::vector<u32> worst(sample.size());
+				HIPCHK(c, hipMemcpyAsync(worst.data(), c->d_bt_count.p, sample.size() * 4, hipMemcpyDeviceToHost, c->stream));
+				HIPCHK(c, hipStreamSynchronize(c->stream));
+				std::vector<double> ratio;
+				for (size_t q = 0; q < sample.size(); ++q) if (out[4 * sample[q] + 1]) ratio.push_back((double)worst[q] / (double)out[4 * sample[q] + 1]);
+				if (!ratio.empty()) {
+					std::sort(ratio.begin(), ratio.end());
+					const double r95 = ratio[std::min(ratio.size() - 1, (size_t)(0.95 * (double)ratio.size()))];
+					const u32 lowered = (u32)((double)cap_blocks / std::max(r95, 1.0) * 0.98);
+					if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles: worst step / mean step = %.3f (95th percentile of %zu tiles): target %u -> %u blocks\n", r95, ratio.size(), use_target, std::min(lowered, use_target));
+					if (lowered < use_target) {
+						use_target = std::max(lowered, 1u);
+						if (cut(use_nx, use_ny, use_target, words, out)) return 1;
+					}
+				}
+			}
 		}
 		// every tile must fit: cells per lane, 16-bit first-piece offsets, and its WORST step in the staging area (upper bound
 		// first; the exact maximum over Z only where the bound does not settle it). What does not fit is halved: band, then Y, then X.
@@ -735,7 +777,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		TimedSpan ts;
 		if (go && span_begin(c, 3, &ts)) return 1;
 		MPC_RB_DIAG_CASES(kBandThreads, kBandSlots)
-		if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRvBlocksCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRvBlocksCxx>), grid, kBandThreads, smem, c->stream, rp); }
+		if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbBlocksCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbBlocksCxx>), grid, kBandThreads, smem, c->stream, rp); }
 		else { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2>), grid, kBandThreads, smem, c->stream, rp); }
 		if (!go) {
 			HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -743,7 +785,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)kBandThreads, smem) != hipSuccess || occ < 1) occ = 1;
 			grid = std::max(std::min<u32>(ntiles, cus * (u32)occ), 1u);
 			char kn[128];
-			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, 2, %d, %s>", kBandThreads, kBandSlots, diag, merge_cxx && !diag ? "MpcRvBlocksCxx" : "MpcRvBlocksAsm");
+			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, 2, %d, %s>", kBandThreads, kBandSlots, diag, merge_cxx && !diag ? "MpcRbBlocksCxx" : "MpcRbBlocksAsm");
 			c->relax_kernel_name = kn;
 			if (trace_on()) { fprintf(stderr, "[mpcgpu] relax band: %s; lds=%zu B occ=%d grid=%u\n", c->tiles_desc.c_str(), smem, occ, grid); fflush(stderr); }
 		} else {
@@ -751,6 +793,14 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			if (span_end(c, &ts)) return 1;
 		}
 	}
+#ifdef MPC_RELAX_DIAG_BUILD
+	if (trace_on()) {
+		u32 cnt[16];
+		HIPCHK(c, hipMemcpyAsync(cnt, c->d_tile_next.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		fprintf(stderr, "[mpcgpu] relax band (measurement build): %u steps prefetched beside the current one, %u staged after the merges\n", cnt[9], cnt[8]);
+	}
+#endif
 	return 0;
 }
 

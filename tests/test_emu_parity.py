@@ -511,10 +511,10 @@ def test_emu_relax_two_geometries(emu):
         info["geo"] = g.relax_info()[0]
         g.close()
         return P.run_lib(seqs, lib_path=emu)
-    got = _with_env({"MPCGPU_RELAX_LDS_KB": "1", "MPCGPU_RELAX_LDS_KB_1024": "8"}, run)
+    got = _with_env({"MPCGPU_RELAX_TILES": "pairs", "MPCGPU_RELAX_LDS_KB": "1", "MPCGPU_RELAX_LDS_KB_1024": "8"}, run)
     assert "second launch" in info["geo"] and "+ 1 x 1024" in info["geo"], info["geo"]
     P.assert_same(got, want, "two geometries")
-    got0 = _with_env({"MPCGPU_RELAX_LDS_KB": "1", "MPCGPU_RELAX_LDS_KB_1024": "8", "MPCGPU_RELAX_MIXED": "0"}, lambda: P.run_lib(seqs, lib_path=emu))
+    got0 = _with_env({"MPCGPU_RELAX_TILES": "pairs", "MPCGPU_RELAX_LDS_KB": "1", "MPCGPU_RELAX_LDS_KB_1024": "8", "MPCGPU_RELAX_MIXED": "0"}, lambda: P.run_lib(seqs, lib_path=emu))
     P.assert_same(got0, want, "one-workgroup geometry alone")
 
 
