@@ -513,39 +513,47 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			MPC_OPAQUE(ln);
 			const u32 li = ln & 15u, role = ln >> 4;
 			const u32 S = rtab[8 * li + 3], b0 = rtab[8 * li + 4], b1 = rtab[8 * li + 5];
-			const u64 rec = (u64)Zt * n + S;
-			const u32 *src = (role == 1u || role == 2u) ? p.ovf_off + rec * p.nb1 + (role == 1u ? b0 : b1) : s.rec_off + rec;
-			if (ln < 48u) mpc_dma4(src, ttab + 64u * (Zt & 1u));
+			const u32 rec = Zt * n + S; // (32-bit: the store has fewer than 2^32 blocks, and more blocks than table entries)
+			// one base pointer and an element offset (a select between two POINTERS became a two-entry table in scratch memory, read
+			// back with a load whose wait — vmcnt(0) — also waited for the prefetch the wave had just issued)
+			const bool wide = role == 1u || role == 2u;
+			const long long off = wide ? (long long)(p.ovf_off - s.rec_off) + (long long)(rec * p.nb1 + (role == 1u ? b0 : b1)) : (long long)rec;
+			if (ln < 48u) mpc_dma4(s.rec_off + off, ttab + 64u * (Zt & 1u));
 		};
-		// From a step's table: bias (lane i: hop bias of record i, bytes), and what the DMA needs (lane i: source / length / place of
-		// record i's two pieces, in blocks); returns the step's length in blocks. The records' constants (first-piece offset, rows,
-		// row0 - offset) are re-read from the LDS table: nothing of this lives in registers across the merges.
-		u32 d_src0, d_len0, d_dst0, d_src1, d_len1, d_dst1;
-		auto step_vectors = [&](u32 Zs, u32 *bias) -> u32 {
+		// From a step's table (lane i = record i, in every row of 16 lanes): the hop bias (bytes) and the block offset of the record's
+		// overflow piece inside the step's buffer; returns the step's length in blocks. The records' constants are re-read from the
+		// LDS table: nothing of this lives in registers across the merges.
+		auto step_vectors = [&](u32 Zs, u32 *bias, u32 *ovf_at) -> u32 {
 			u32 ln = lane;
 			MPC_OPAQUE(ln);
 			const u32 li = ln & 15u;
-			const u32 tab = ttab[64u * (Zs & 1u) + (ln < 48u ? ln : li)];
-			const u32 rt_first = rtab[8 * li], rt_rows = rtab[8 * li + 1], rt_c = rtab[8 * li + 2];
-			const u32 R = mpc_lane_gather(tab, 4u * li), Oa = mpc_lane_gather(tab, 4u * (16u + li)), Ob = mpc_lane_gather(tab, 4u * (32u + li));
+			const u32 *tt = ttab + 64u * (Zs & 1u);
+			const u32 R = tt[li], Oa = tt[16u + li], Ob = tt[32u + li]; // (three reads side by side: no cross-lane round trips)
+			const u32 rt_c = rtab[8 * li + 2];
 			const u32 ovl = Ob - Oa;
-			u32 incl = ovl;
-			for (u32 d = 1; d < 16u; d <<= 1) { const u32 o = mpc_lane_gather(incl, 4u * ((ln - d) & 63u)); if (li >= d) incl += o; }
+			const u32 incl = mpc_row16_scan_add(ovl); // the 16 records are the 16 lanes of a DPP row
 			const u32 O = ftot + incl - ovl;
-			d_src0 = R + rt_c + rt_first; d_len0 = rt_rows; d_dst0 = rt_first; d_src1 = Oa; d_len1 = ovl; d_dst1 = O;
+			*ovf_at = O;
 			*bias = (O + R - Oa + rt_c) << 4;
-			return ftot + mpc_lane_gather(incl, 4u * 15u);
+			return ftot + mpc_read_lane(incl, 15u);
 		};
-		auto issue_dma = [&](u32 at) { // at: byte offset of the step's buffer in the staging area
+		// Piece pc of step Zs: pc < 16 the first piece of record pc (rows of its first-block region), else the overflow piece of
+		// record pc - 16. What it needs comes out of the LDS tables as scalars (uniform reads); ovf_at: step_vectors' offsets.
+		auto issue_dma = [&](u32 at, u32 Zs, u32 ovf_at) { // at: byte offset of the step's buffer in the staging area
 			u32 ln = lane;
 			MPC_OPAQUE(ln);
+			const u32 *tt = ttab + 64u * (Zs & 1u);
 			for (u32 pc = wave; pc < 32u; pc += NWAVES) {
 				const u32 rec = pc & 15u;
 				u32 src, len, dst;
-				if (pc < 16u) { src = mpc_read_lane(d_src0, rec); len = mpc_read_lane(d_len0, rec); dst = mpc_read_lane(d_dst0, rec); }
-				else { src = mpc_read_lane(d_src1, rec); len = mpc_read_lane(d_len1, rec); dst = mpc_read_lane(d_dst1, rec); }
+				if (pc < 16u) {
+					const u32 first = mpc_wave_first(rtab[8 * rec]);
+					src = mpc_wave_first(tt[rec]) + mpc_wave_first(rtab[8 * rec + 2]) + first; len = mpc_wave_first(rtab[8 * rec + 1]); dst = first;
+				} else {
+					src = mpc_wave_first(tt[16u + rec]); len = mpc_wave_first(tt[32u + rec]) - src; dst = mpc_read_lane(ovf_at, rec);
+				}
 				for (u32 c0 = 0; c0 < len; c0 += 64u)
-					if (c0 + ln < len) mpc_dma16(padb + 16 * ((u64)src + c0 + ln), stage + at + 16 * (dst + c0));
+					if (c0 + ln < len) mpc_dma16(padb + 16 * (u64)(src + c0 + ln), stage + at + 16 * (dst + c0));
 			}
 		};
 		// the biases of a step go through LDS as well (every wave computes the same 16 words and writes them to the same place)
@@ -559,42 +567,51 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 		}
 		__syncthreads();
 		{
-			u32 b;
-			cur_len = 16u * step_vectors(0, &b);
+			u32 b, oa;
+			cur_len = 16u * step_vectors(0, &b, &oa);
 			put_bias(0, b);
-			issue_dma(0);
+			issue_dma(0, 0, oa);
 			mpc_dma_wait();
 		}
-		constexpr bool STAGING = DIAG < 2; // DIAG 2, 3: step 0's records for every step
-		for (u32 Z = 0; Z < n; ++Z) {
-			bool pre = false;
-			if (STAGING) {
-				__syncthreads(); // step Z's pieces and step Z+1's table have landed (every wave waited for its own DMA); step Z-1's readers are done
-				if (Z + 1 < n) {
-					u32 b;
-					nxt_len = 16u * step_vectors(Z + 1, &b);
-					put_bias(Z + 1, b);
-					// bottom and top of the staging area alternate; the next step is prefetched when it fits beside this one
-					if (cur_at == 0u) { nxt_at = p.cap_bytes - nxt_len; pre = nxt_len <= p.cap_bytes && nxt_at >= cur_len; }
-					else { nxt_at = 0u; pre = nxt_len <= cur_at; }
-					if (pre) issue_dma(nxt_at);
+		constexpr bool STAGING = DIAG < 2 || DIAG == 4; // DIAG 2, 3: step 0's records for every step
+		bool pre = false;
+		// vectors of step Z+1, its place (bottom and top of the staging area alternate), the prefetch when it fits beside step Z,
+		// and — wave 0 — the table of step Z+2
+		auto stage_next = [&](u32 Z) {
+			pre = false;
+			if (Z + 1 >= n) return;
+			u32 b, oa;
+			nxt_len = 16u * step_vectors(Z + 1, &b, &oa);
+			put_bias(Z + 1, b);
+			if (cur_at == 0u) { nxt_at = p.cap_bytes - nxt_len; pre = nxt_len <= p.cap_bytes && nxt_at >= cur_len; }
+			else { nxt_at = 0u; pre = nxt_len <= cur_at; }
+			if (pre) issue_dma(nxt_at, Z + 1, oa);
 #ifdef MPC_RELAX_DIAG_BUILD
-					if (tid == 0) atomicAdd(&p.tile_next[pre ? 9 : 8], 1u); // measurement build: steps prefetched / staged late
+			if (tid == 0) atomicAdd(&p.tile_next[pre ? 9 : 8], 1u); // measurement build: steps prefetched / staged late
 #endif
-					if (wave == 0u && Z + 2 < n) issue_table(Z + 2);
-				}
-			} else if (DIAG == 3 || Z == 0) __syncthreads();
+			if (wave == 0u && Z + 2 < n) issue_table(Z + 2);
+		};
+		unsigned long long tm_bar = 0, tm_wait = 0, tm_stage = 0, tm_all = 0, tm0 = 0; // DIAG 4: where a wave's time goes (100 MHz ticks)
+		if (DIAG == 4) tm0 = mpc_clock();
+		for (u32 Z = 0; Z < n; ++Z) {
+			unsigned long long tq = 0;
+			if (DIAG == 4) tq = mpc_clock();
+			if (STAGING) __syncthreads(); // step Z's pieces and step Z+1's table have landed (every wave waited for its own DMA); step Z-1's readers are done
+			else if (DIAG == 3 || Z == 0) __syncthreads();
+			if (DIAG == 4) tm_bar += mpc_clock() - tq;
+			bool staged = false;
 			if (DIAG != 1 && nact != 0u) {
 				const u32 sb = lds_stage + cur_at;
 				u32 ln = lane;
 				MPC_OPAQUE(ln);
-				const u32 bias_cur = btab[16u * ((STAGING ? Z : 0u) & 1u) + (ln & 15u)]; // lane i: hop bias of record i at this step
+				const u32 *bt = btab + 16u * ((STAGING ? Z : 0u) & 1u);
+				const u32 bias_cur = bt[ln & 15u];                  // lane i: hop bias of record i at this step
+				const u32 bias_y = bt[MPC_RB_MAXN + (ln & 7u)];     // lane j < 8: hop bias of Y record j
 #pragma unroll
 				for (int j = 0; j < (int)YREGS; ++j) MPC_OPAQUE(yreg[j]); // the 5-bit fields are unpacked per step (hoisted, they would be 12 more live registers)
 #pragma unroll
 				for (int j = 0; j < (MAXSLOTS + 9) / 10; ++j) MPC_OPAQUE_S(sel_a[j]); // likewise the scalar selectors
 				MPC_OPAQUE_S(nact);
-				const u32 bias_y = mpc_lane_gather(bias_cur, 4u * (MPC_RB_MAXN + (ln & 7u)));   // lane j < 8: hop bias of Y record j
 				BLOCKS blk;
 				auto addr_a = [&](int q) -> u32 { return sb + (xy[q] & 0xffffu); };
 				auto addr_b = [&](int q) -> u32 { return sb + (xy[q] >> 16); };
@@ -611,23 +628,40 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 						float sum = acc[q];
 						blk.template merge<q & 1>(sum, ia, ib, nia, nib, idx_b(qn), bias_y);
 						acc[q] = sum;
+						// the next step's staging goes out after the first slot: its chain of table reads and scalar work then runs beside the
+						// other waves' merges instead of holding every wave of the workgroup at the top of the step
+						if (STAGING && q == 0) {
+							unsigned long long ts = 0;
+							if (DIAG == 4) ts = mpc_clock();
+							stage_next(Z); staged = true;
+							if (DIAG == 4) tm_stage += mpc_clock() - ts;
+						}
 						self(self, std::integral_constant<int, q + 1>{});
 					}
 				};
 				slot(slot, std::integral_constant<int, 0>{});
 				blk.drain(); // the last slot's look-ahead reads have landed before their registers mean anything else
 			}
+			if (STAGING && !staged) stage_next(Z);
 			if (STAGING && Z + 1 < n) {
 				if (!pre) { // the next step did not fit beside this one: stage it now that this one's readers are done
 					__syncthreads();
-					u32 b;
-					nxt_len = 16u * step_vectors(Z + 1, &b);
+					u32 b, oa;
+					nxt_len = 16u * step_vectors(Z + 1, &b, &oa);
 					nxt_at = 0u;
-					issue_dma(0u);
+					issue_dma(0u, Z + 1, oa);
 				}
+				unsigned long long tw = 0;
+				if (DIAG == 4) tw = mpc_clock();
 				mpc_dma_wait();
+				if (DIAG == 4) tm_wait += mpc_clock() - tw;
 				cur_at = nxt_at; cur_len = nxt_len;
 			}
+		}
+		if (DIAG == 4 && lane == 0u && (wave == 0u || wave == 7u)) {
+			tm_all = mpc_clock() - tm0;
+			unsigned long long *tt = (unsigned long long *)(p.tile_next + 16) + (wave == 0u ? 0 : 4);
+			atomicAdd(tt + 0, tm_all); atomicAdd(tt + 1, tm_bar); atomicAdd(tt + 2, tm_stage); atomicAdd(tt + 3, tm_wait);
 		}
 		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern
 #pragma unroll

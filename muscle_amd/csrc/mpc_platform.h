@@ -79,6 +79,15 @@ __device__ __forceinline__ float mpc_wave_scan_max_nonneg(float v)
 #undef MPC_DPP_MAX
 	return v;
 }
+// inclusive prefix sum inside every DPP row of 16 lanes (v_add_u32 with row_shr:1,2,4,8 sources; a lane without a source adds 0)
+__device__ __forceinline__ unsigned mpc_row16_scan_add(unsigned v)
+{
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+	return v;
+}
 // value of lane `l` (wave-uniform index) as a scalar: v_readlane_b32, no LDS
 __device__ __forceinline__ unsigned mpc_read_lane(unsigned v, unsigned l) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ float mpc_read_lane(float v, unsigned l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l)); }

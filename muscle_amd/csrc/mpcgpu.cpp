@@ -525,17 +525,21 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 	if (diag == 1) { fn = (const void *)relax_band_kernel<TH, SL, 2, 1>; if (go) MPC_LAUNCH((relax_band_kernel<TH, SL, 2, 1>), grid, TH, smem, c->stream, rp); } \
 	else if (diag == 2) { fn = (const void *)relax_band_kernel<TH, SL, 2, 2>; if (go) MPC_LAUNCH((relax_band_kernel<TH, SL, 2, 2>), grid, TH, smem, c->stream, rp); } \
 	else if (diag == 3) { fn = (const void *)relax_band_kernel<TH, SL, 2, 3>; if (go) MPC_LAUNCH((relax_band_kernel<TH, SL, 2, 3>), grid, TH, smem, c->stream, rp); } \
+	else if (diag == 4) { fn = (const void *)relax_band_kernel<TH, SL, 2, 4>; if (go) MPC_LAUNCH((relax_band_kernel<TH, SL, 2, 4>), grid, TH, smem, c->stream, rp); } \
 	else
 #else
 #define MPC_RB_DIAG_CASES(TH, SL)
 #endif
-constexpr u32 kBandThreads = 1024, kBandSlots = 14; // two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs), 14 cells per lane (16: spill reloads inside the walk)
+constexpr u32 kBandThreads = 1024, kBandSlots = 13; // two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs), 13 cells per lane (14: spill reloads inside the walk, and every reload waits for vmcnt(0) - the prefetch)
 
 // 0 = launched (or nothing to do), 1 = error, 2 = not for band tiles (the caller runs relax_var)
 int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 {
 	const u32 n = c->n, nb1 = c->band_nb1;
-	const u32 lds_bytes = (u32)std::max(env_int("MPCGPU_RELAX_LDS_KB", 80), 3) * 1024u;
+	// geometry: 2 x 1024 threads per CU (default) or 4 x 512 (MPCGPU_RELAX_WG=512): 8 waves per SIMD either way; a barrier of the
+	// walk then holds 8 waves instead of 16, and three other workgroups fill a waiting one's issue slots
+	const u32 bthreads = env_int("MPCGPU_RELAX_WG", 1024) == 512 ? 512u : 1024u;
+	const u32 lds_bytes = (u32)std::max(env_int("MPCGPU_RELAX_LDS_KB", bthreads == 512 ? 40 : 80), 3) * 1024u;
 	const u32 cap = (lds_bytes - MPC_RB_TAB_BYTES) & ~15u, cap_blocks = cap / 16;
 	const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)kBandSlots), 1), (int)kBandSlots);
 	const u32 cus = (u32)c->prop.multiProcessorCount;
@@ -543,7 +547,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		c->btiles_k0 = c->btiles_k1 = ~0ull;
 		RbTileTabs tb;
 		tb.cell_off = c->d_cell_off.as<u32>(); tb.yr = c->d_yr.as<u32>(); tb.ovf_sum = c->d_ovf_sum.as<u32>(); tb.ovf_maxc = c->d_ovf_maxc.as<u32>();
-		tb.nb1 = nb1; tb.threads = kBandThreads; tb.k0 = k0; tb.k1 = k1;
+		tb.nb1 = nb1; tb.threads = bthreads; tb.k0 = k0; tb.k1 = k1;
 		// tile words of a list of tiles whose words 0..5 are set: Y ranges, first-piece blocks, slots; out: slots, mean blocks, bound, cells
 		auto eval_tiles = [&](std::vector<u32> &words, std::vector<u32> &out) -> int {
 			const u32 nt = (u32)(words.size() / MPC_RB_TILE_WORDS);
@@ -600,7 +604,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			Score sc = {0, 0, 0, out.size() / 4};
 			u64 cells = 0, est = 0, ok = 0;
 			for (size_t t = 0; t + 3 < out.size(); t += 4) { cells += out[t + 3]; est += out[t + 1]; ok += out[t + 1] <= target ? 1 : 0; }
-			if (sc.tiles) { sc.fill = (double)cells / ((double)sc.tiles * max_slots * kBandThreads); sc.in_target = (double)ok / (double)sc.tiles; }
+			if (sc.tiles) { sc.fill = (double)cells / ((double)sc.tiles * max_slots * bthreads); sc.in_target = (double)ok / (double)sc.tiles; }
 			sc.bytes_per_cell = cells ? 16.0 * (double)est / (double)cells : 0.0;
 			return sc;
 		};
@@ -739,7 +743,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			char b[320];
 			snprintf(b, sizeof(b), "%zu band tiles of <= %ux%u pairs (%llu split), target %u B per step of %u B staging (%s), mean step %.0f B, %.1f of %u cells per lane, %.2f B per cell-step",
 				nt, use_nx, use_ny, (unsigned long long)nsplit, use_target * 16, cap, use_target <= cap_blocks / 2 ? "two steps resident" : "one step resident",
-				nt ? 16.0 * (double)est / (double)nt : 0.0, nt ? (double)cells / ((double)nt * kBandThreads) : 0.0, max_slots, cells ? 16.0 * (double)est / (double)cells : 0.0);
+				nt ? 16.0 * (double)est / (double)nt : 0.0, nt ? (double)cells / ((double)nt * bthreads) : 0.0, max_slots, cells ? 16.0 * (double)est / (double)cells : 0.0);
 			c->tiles_desc = b;
 		}
 		c->h_btiles.swap(okw);
@@ -756,8 +760,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 	const u32 ntiles = (u32)(c->h_btiles.size() / MPC_RB_TILE_WORDS);
 	if (!ntiles) return 0;
-	HIPCHK(c, c->d_tile_next.ensure(16 * 4));
-	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 16 * 4, c->stream));
+	HIPCHK(c, c->d_tile_next.ensure(32 * 4));
+	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 32 * 4, c->stream));
 	RelaxBandParams rp;
 	rp.s = sp; rp.ovf_off = c->d_ovf_off.as<u32>(); rp.nb1 = nb1; rp.cell_off = c->d_cell_off.as<u32>();
 	rp.tiles = c->d_btiles.as<u32>(); rp.ntiles = ntiles; rp.k0 = k0; rp.k1 = k1; rp.cap_bytes = cap;
@@ -776,16 +780,18 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	for (int go = 0; go < 2; ++go) { // pass 0: which instantiation (attributes, occupancy); pass 1: launch
 		TimedSpan ts;
 		if (go && span_begin(c, 3, &ts)) return 1;
+		if (bthreads == 512) { fn = (const void *)relax_band_kernel<512, kBandSlots, 4>; if (go) MPC_LAUNCH((relax_band_kernel<512, kBandSlots, 4>), grid, 512, smem, c->stream, rp); }
+		else
 		MPC_RB_DIAG_CASES(kBandThreads, kBandSlots)
 		if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbBlocksCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbBlocksCxx>), grid, kBandThreads, smem, c->stream, rp); }
 		else { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2>), grid, kBandThreads, smem, c->stream, rp); }
 		if (!go) {
 			HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
 			int occ = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)kBandThreads, smem) != hipSuccess || occ < 1) occ = 1;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)bthreads, smem) != hipSuccess || occ < 1) occ = 1;
 			grid = std::max(std::min<u32>(ntiles, cus * (u32)occ), 1u);
 			char kn[128];
-			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, 2, %d, %s>", kBandThreads, kBandSlots, diag, merge_cxx && !diag ? "MpcRbBlocksCxx" : "MpcRbBlocksAsm");
+			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, %u, %d, %s>", bthreads, kBandSlots, bthreads == 512 ? 4u : 2u, bthreads == 512 ? 0 : diag, merge_cxx && !diag ? "MpcRbBlocksCxx" : "MpcRbBlocksAsm");
 			c->relax_kernel_name = kn;
 			if (trace_on()) { fprintf(stderr, "[mpcgpu] relax band: %s; lds=%zu B occ=%d grid=%u\n", c->tiles_desc.c_str(), smem, occ, grid); fflush(stderr); }
 		} else {
@@ -795,10 +801,17 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 #ifdef MPC_RELAX_DIAG_BUILD
 	if (trace_on()) {
-		u32 cnt[16];
+		u32 cnt[32];
 		HIPCHK(c, hipMemcpyAsync(cnt, c->d_tile_next.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		fprintf(stderr, "[mpcgpu] relax band (measurement build): %u steps prefetched beside the current one, %u staged after the merges\n", cnt[9], cnt[8]);
+		if (diag == 4) {
+			const unsigned long long *t = (const unsigned long long *)(cnt + 16);
+			for (int w = 0; w < 2; ++w)
+				fprintf(stderr, "[mpcgpu] relax band timers, wave %d of every workgroup, summed over tiles (100 MHz ticks): walk %llu, top barrier %llu (%.1f %%), staging block %llu (%.1f %%), DMA wait %llu (%.1f %%)\n",
+					w ? 7 : 0, t[4 * w], t[4 * w + 1], 100.0 * t[4 * w + 1] / std::max<double>(t[4 * w], 1), t[4 * w + 2], 100.0 * t[4 * w + 2] / std::max<double>(t[4 * w], 1), t[4 * w + 3],
+					100.0 * t[4 * w + 3] / std::max<double>(t[4 * w], 1));
+		}
 	}
 #endif
 	return 0;

@@ -106,6 +106,14 @@ template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src
 #define MPC_WAVE_LDS_ORDER() ((void)__shfl(0, 0)) // a rendezvous of the WAVE (any collective is one): the emulator runs lanes one after the other between synchronisation points
 #define MPC_WAVE_FENCE() ((void)0) // emulated lanes meet at every shuffle
 template <class T> static inline T mpc_read_lane(T v, unsigned l) { return __shfl(v, (int)l); }
+static inline unsigned mpc_row16_scan_add(unsigned v)
+{
+	for (int d = 1; d < 16; d <<= 1) {
+		const unsigned o = __shfl_up(v, d);
+		if ((int)(emu::t_lane & 15u) >= d) v += o;
+	}
+	return v;
+}
 static inline unsigned mpc_lane_gather(unsigned v, unsigned byte_index) { return __shfl(v, (int)(byte_index / 4u)); }
 template <class T> static inline T mpc_lane_up1(T v) { return __shfl_up(v, 1); }
 template <class T> static inline T mpc_lane_down1(T v) { return __shfl_down(v, 1); }
