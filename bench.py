@@ -227,11 +227,28 @@ def main():
         # dominant kernel family of THIS rank over the timed steps (hipEvents on the library's stream)
         my_frac = 1.0 / world  # this rank's share of the pair-sharded work
         geo, _fallback = g.relax_info()
-        kname = ("relax_var_kernel" if "relax_var_kernel" in geo else "relax_dense_kernel" if "relax_dense_kernel" in geo
-                 else "relax_tile_kernel" if "relax_tile_kernel" in geo else "relax_kernel")
+        kname = ("relax_band_kernel" if "relax_band_kernel" in geo else "relax_var_kernel" if "relax_var_kernel" in geo
+                 else "relax_kernel")
         fixture_shape = (a.n, a.len) if not a.fasta else (a.n, 0)
 
-        CHIP_SIMDS, CHIP_CUS, CLOCK_HZ = 1024, 256, 2.1e9  # MI355X: 256 CUs x 4 SIMDs; the clock the chip sustains under these kernels
+        CHIP_SIMDS, CHIP_CUS, CLOCK_ASSUMED_HZ = 1024, 256, 2.1e9  # MI355X: 256 CUs x 4 SIMDs; clock only when no counter pass gives one
+
+        def clock_of(pmc):
+            """(Hz, where it comes from): the clock the chip sustained under this kernel, from the committed counter pass
+            (scripts/pmc_summary.py: SQ_BUSY_CYCLES / 32 shader engines / launch duration of the --kernel-trace --stats pass)."""
+            if pmc and pmc.get("clock_hz"):
+                return float(pmc["clock_hz"]), pmc.get("clock_method", "counter pass")
+            return CLOCK_ASSUMED_HZ, "ASSUMED 2.1 GHz (no counter pass with launch durations for this kernel)"
+
+        def issue_cost_of(kernel, fallback):
+            """(mean issue cost of the kernel's VALU mix in full-rate ops, source): muscle_amd/csrc/isa_cost.json, written at build time
+            by scripts/isa_cost.py --json from the gfx950 listing of the shipped instantiations (make asm)."""
+            try:
+                with open(os.path.join(ROOT, "muscle_amd", "csrc", "isa_cost.json")) as f:
+                    e = json.load(f)[kernel]
+                return float(e["mean_issue_cost"]), "scripts/isa_cost.py over %s of %s (%d VALU instructions)" % (e["region"], e["mangled"], e["valu_instructions"])
+            except (OSError, ValueError, KeyError):
+                return fallback, "literal %.2f (muscle_amd/csrc/isa_cost.json missing: run __graft_entry__.build())" % fallback
 
         def issue_fraction(pmc, avg_s, units_per_inst):
             """VALU issue time / launch time from the committed SQ pass: wave-instructions x issue cost (diag/pkbench: a full-rate
@@ -239,15 +256,15 @@ def main():
             over 1024 SIMDs at the 2.1 GHz the chip sustains under this load."""
             if not pmc or "sq_per_launch" not in pmc or "SQ_INSTS_VALU" not in pmc["sq_per_launch"]:
                 return None
-            return pmc["sq_per_launch"]["SQ_INSTS_VALU"] * units_per_inst * 2.0 / (CHIP_SIMDS * CLOCK_HZ) / avg_s
+            return pmc["sq_per_launch"]["SQ_INSTS_VALU"] * units_per_inst * 2.0 / (CHIP_SIMDS * clock_of(pmc)[0]) / avg_s
 
         def lds_fraction(pmc, avg_s):
             """LDS-array cycles (SQ_LDS_IDX_ACTIVE, conflicts included) / cycles of the launch, per CU."""
             if not pmc or "SQ_LDS_IDX_ACTIVE" not in pmc.get("sq_per_launch", {}):
                 return None
-            return pmc["sq_per_launch"]["SQ_LDS_IDX_ACTIVE"] / (CHIP_CUS * CLOCK_HZ) / avg_s
+            return pmc["sq_per_launch"]["SQ_LDS_IDX_ACTIVE"] / (CHIP_CUS * clock_of(pmc)[0]) / avg_s
 
-        def measured_roof(r, pmc, avg_s, units_per_inst, launched_kernel):
+        def measured_roof(r, pmc, avg_s, kernel_for_cost, cost_fallback, launched_kernel):
             """roofline.bound / frac from MEASURED counters: the binding resource is the one with the largest measured fraction of
             its own roof (HBM bytes per launch / 8 TB/s, VALU issue time / launch time, LDS-array cycles / launch cycles); frac is
             that fraction, always <= 1. Counters are taken only from a committed PMC pass of the SAME kernel instantiation that just
@@ -255,6 +272,9 @@ def main():
             if pmc is not None and launched_kernel is not None and launched_kernel not in pmc.get("kernel", ""):
                 r["pmc_rejected"] = "committed PMC pass is of %r, this run launched %r" % (pmc.get("kernel"), launched_kernel)
                 pmc = None
+            units_per_inst, cost_src = issue_cost_of(kernel_for_cost, cost_fallback)
+            r["issue_cost"] = {"mean_valu_issue_cost": units_per_inst, "source": cost_src}
+            r["clock"] = dict(zip(("hz", "source"), clock_of(pmc)))
             traffic = None if pmc is None else float(pmc["hbm_bytes_per_launch"])
             fr = {"hbm": None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS,
                   "valu_issue": issue_fraction(pmc, avg_s, units_per_inst), "lds": lds_fraction(pmc, avg_s)}
@@ -280,22 +300,24 @@ def main():
             # per relax ITERATION: real data runs two launches per iteration (the pairs whose records only fit the 160 KB geometry
             # get a second, tiny one — relax_geometry says so); the counters in pmc_traffic.json are those of the dominant launch
             iters = max(a.steps * CONSISTENCY_ITERS, 1) if n_seqs_ge3 else max(launches, 1)
-            launches = iters
+            measured_launches = launches
+            launches = iters  # the figures below are per relax ITERATION (relax_band_kernel: one launch each; `launches_measured` says)
             avg_s = ms * 1e-3 / max(launches, 1)
             per_launch = stage_b_bytes(lens, nnz) * my_frac  # one launch = one relax iteration over this rank's pairs
             launched = geo.split("kernel=")[1].split(";")[0].strip() if "kernel=" in geo else None
             r = {"kernel": (launched or kname) + " (consistency relax: sampled sparse product over the all-pairs store, LDS-tiled)",
-                 "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+                 "launches": launches, "iterations": iters, "launches_measured": measured_launches, "avg_launch_ms": ms / max(launches, 1),
+                 "avg_iteration_ms": ms / max(iters, 1),
                  "algorithmic_bytes_per_launch": per_launch, "algorithmic_rate_GBs": per_launch / avg_s / 1e9,
                  "note": "bound / frac: the resource with the largest MEASURED fraction of its roof (see measured_fractions): HBM = "
                          "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch from separate rocprofv3 --pmc passes / launch time / 8 TB/s "
-                         "(MI355X_MICROARCH.md HBM section); valu_issue = SQ_INSTS_VALU x mean issue cost x 2 cycles / (1024 SIMDs x 2.1 GHz) "
-                         "/ launch time; lds = SQ_LDS_IDX_ACTIVE / (256 CUs x 2.1 GHz) / launch time. Launch time: hipEvents on the "
+                         "(MI355X_MICROARCH.md HBM section); valu_issue = SQ_INSTS_VALU x mean issue cost (issue_cost) x 2 cycles / (1024 SIMDs x clock) "
+                         "/ launch time; lds = SQ_LDS_IDX_ACTIVE / (256 CUs x clock) / launch time; clock: see `clock` (derived from counters). Launch time: hipEvents on the "
                          "library's stream (profiles/*kernel_stats*.csv agrees). algorithmic_rate_GBs = SURVEY.md 8d stage-B bytes "
                          "(every (pair,Z) reads both operand matrices once: sum of 8*(nnz_XZ+nnz_YZ)+4*(LX+LY+2), + 4*nnz written) / "
-                         "launch time: a progress figure, NOT a fraction of a roof (the LDS tiling serves 16 pairs from 8 records, so "
+                         "launch time: a progress figure, NOT a fraction of a roof (the LDS tiling serves up to 64 pairs' row bands from 16 partial records, so "
                          "far fewer bytes cross the fabric). null = no committed PMC pass for this workload and this kernel."}
-            return measured_roof(r, pmc_entry(kname, *fixture_shape), avg_s, 1.20, launched)
+            return measured_roof(r, pmc_entry(kname, *fixture_shape), avg_s, kname, 1.20, launched)
 
         def fb_roof():
             ms, launches = timers["fb"]
@@ -315,7 +337,7 @@ def main():
                          "the launch's pairs of 164(LX+1)(LY+1)+5LXLY flop (SURVEY.md 8d) / launch time; frac_of_fp32_vector_peak is against "
                          "157.3 TFLOP/s, which counts v_pk_fma_f32 — measured on this chip (diag/pkbench, profiles/r02b_pkbench.log) plain "
                          "add/mul issue at 63 Tlane-op/s and min/max/cvt/select at 0.6 of that, so 63 TFLOP/s is the ceiling of an FMA-free stream."}
-            return measured_roof(r, pmc_entry(fb_name, *fixture_shape), avg_s, 1.27, fb_name)
+            return measured_roof(r, pmc_entry(fb_name, *fixture_shape), avg_s, fb_name, 1.18, fb_name)
 
         roof = relax_roof() if timers["relax"][0] >= timers["fb"][0] else fb_roof()
         roof_other = fb_roof() if timers["relax"][0] >= timers["fb"][0] else relax_roof()

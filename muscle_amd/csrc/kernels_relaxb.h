@@ -46,7 +46,7 @@
 struct MpcRbBlocksCxx {
 	MpcQuad a[2], b[2];
 	u32 hb;
-	__device__ __forceinline__ void load(u32 ia, u32 ib, u32 idx, u32 bias_y) { a[0] = mpc_lds_load16(ia); b[0] = mpc_lds_load16(ib); hb = mpc_lane_gather(bias_y, idx); }
+	__device__ __forceinline__ void load(u32 ia, u32 ib, u32 hb_addr) { a[0] = mpc_lds_load16(ia); b[0] = mpc_lds_load16(ib); hb = mpc_lds_load4(hb_addr); } // hb_addr: LDS address of the first slot's Y bias
 	__device__ __forceinline__ void drain() {}
 	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32 ib, u32 nia, u32 nib, u32 nidx, u32 bias_y)
 	{
@@ -261,28 +261,44 @@ __global__ void __launch_bounds__(64) band_cut_kernel(StoreParams s, RbTileTabs 
 				const RbTileStats st = rb_tile_stats(s, tb, x0, nx, y0, ny, b0, b1, c, lo, hi);
 				return st.slots <= max_slots && st.est <= target;
 			};
-			const u32 budget = max_slots * tb.threads;
-			u32 parts = (T + budget - 1u) / budget;
-			for (; parts < nb; ++parts) {
-				bool ok = true;
-				for (u32 i = 1, b0 = 0; i <= parts && ok; ++i) {
-					const u32 b1 = boundary(i, parts, b0);
+			auto emit = [&](u32 b0, u32 b1) {
+				if (cum[b1] == cum[b0]) return;
+				if (write && lane == 0u) {
+					u32 *t = tiles + (u64)MPC_RB_TILE_WORDS * (base[ci] + emitted);
+					t[0] = x0; t[1] = nx; t[2] = y0; t[3] = ny; t[4] = b0 * MPC_RB_HB; t[5] = b1 * MPC_RB_HB;
+				}
+				++emitted;
+			};
+			// greedy first: a band takes index bands while it fits. That cut is always valid, but its last band is whatever was left
+			// over (25 index bands as 6+6+6+6+1); when an even cut into the same number of bands — or one more — fits everywhere, that
+			// one is taken. (Raising the number of bands until an even cut fits is not an option: one dense region would shred the
+			// whole super-tile into single index bands.)
+			u32 greedy = 0;
+			for (u32 b0 = 0; b0 < nb;) {
+				u32 b1 = b0 + 1u;
+				while (b1 < nb && fits(b0, b1 + 1u)) ++b1;
+				if (cum[b1] != cum[b0]) ++greedy;
+				b0 = b1;
+			}
+			u32 parts = 0;
+			for (u32 cand_parts = greedy; cand_parts <= greedy + 1u && cand_parts <= nb && !parts; ++cand_parts) {
+				bool ok = cand_parts != 0u;
+				for (u32 i = 1, b0 = 0; i <= cand_parts && ok; ++i) {
+					const u32 b1 = boundary(i, cand_parts, b0);
 					if (cum[b1] != cum[b0] && b1 - b0 > 1u && !fits(b0, b1)) ok = false;
 					b0 = b1;
 				}
-				if (ok) break;
+				if (ok) parts = cand_parts;
 			}
-			if (parts > nb) parts = nb;
-			for (u32 i = 1, b0 = 0; i <= parts; ++i) {
-				const u32 b1 = boundary(i, parts, b0);
-				if (cum[b1] != cum[b0]) {
-					if (write && lane == 0u) {
-						u32 *t = tiles + (u64)MPC_RB_TILE_WORDS * (base[ci] + emitted);
-						t[0] = x0; t[1] = nx; t[2] = y0; t[3] = ny; t[4] = b0 * MPC_RB_HB; t[5] = b1 * MPC_RB_HB;
-					}
-					++emitted;
+			if (parts) {
+				for (u32 i = 1, b0 = 0; i <= parts; ++i) { const u32 b1 = boundary(i, parts, b0); emit(b0, b1); b0 = b1; }
+			} else {
+				for (u32 b0 = 0; b0 < nb;) {
+					u32 b1 = b0 + 1u;
+					while (b1 < nb && fits(b0, b1 + 1u)) ++b1;
+					emit(b0, b1);
+					b0 = b1;
 				}
-				b0 = b1;
 			}
 		}
 		if (!write && lane == 0u) count[ci] = emitted;
@@ -520,41 +536,43 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			const long long off = wide ? (long long)(p.ovf_off - s.rec_off) + (long long)(rec * p.nb1 + (role == 1u ? b0 : b1)) : (long long)rec;
 			if (ln < 48u) mpc_dma4(s.rec_off + off, ttab + 64u * (Zt & 1u));
 		};
-		// From a step's table (lane i = record i, in every row of 16 lanes): the hop bias (bytes) and the block offset of the record's
-		// overflow piece inside the step's buffer; returns the step's length in blocks. The records' constants are re-read from the
-		// LDS table: nothing of this lives in registers across the merges.
-		auto step_vectors = [&](u32 Zs, u32 *bias, u32 *ovf_at) -> u32 {
+		// Everything the staging of a step needs comes out of ONE round of LDS reads — the step's table (lane i = record i, in every
+		// row of 16 lanes) and the records' constants — followed by register work only (a DPP row scan, v_readlane): the chain of
+		// dependent LDS round trips this block used to be (uniform reads per piece, a cross-lane scan through the LDS crossbar) was
+		// a microsecond per step on every wave's critical path. Returns the step's length in blocks; *bias: lane i = hop bias of
+		// record i (bytes); pieces of this wave (s_src, s_len, s_dst: blocks): piece pc < 16 is the first piece of record pc, else
+		// the overflow piece of record pc - 16; a wave stages pieces wave, wave + NWAVES, ...
+		constexpr u32 PIECES = 32u / NWAVES;
+		u32 s_src[PIECES], s_len[PIECES], s_dst[PIECES];
+		auto step_vectors = [&](u32 Zs, u32 *bias) -> u32 {
 			u32 ln = lane;
 			MPC_OPAQUE(ln);
 			const u32 li = ln & 15u;
 			const u32 *tt = ttab + 64u * (Zs & 1u);
-			const u32 R = tt[li], Oa = tt[16u + li], Ob = tt[32u + li]; // (three reads side by side: no cross-lane round trips)
-			const u32 rt_c = rtab[8 * li + 2];
+			const u32 R = tt[li], Oa = tt[16u + li], Ob = tt[32u + li];
+			const u32 rt_first = rtab[8 * li], rt_rows = rtab[8 * li + 1], rt_c = rtab[8 * li + 2];
 			const u32 ovl = Ob - Oa;
 			const u32 incl = mpc_row16_scan_add(ovl); // the 16 records are the 16 lanes of a DPP row
 			const u32 O = ftot + incl - ovl;
-			*ovf_at = O;
+			const u32 src0 = R + rt_c + rt_first;
+#pragma unroll
+			for (u32 j = 0; j < PIECES; ++j) {
+				const u32 pc = wave + j * NWAVES, rec = pc & 15u;
+				const bool fp = pc < 16u; // wave-uniform
+				s_src[j] = fp ? mpc_read_lane(src0, rec) : mpc_read_lane(Oa, rec);
+				s_len[j] = fp ? mpc_read_lane(rt_rows, rec) : mpc_read_lane(ovl, rec);
+				s_dst[j] = fp ? mpc_read_lane(rt_first, rec) : mpc_read_lane(O, rec);
+			}
 			*bias = (O + R - Oa + rt_c) << 4;
 			return ftot + mpc_read_lane(incl, 15u);
 		};
-		// Piece pc of step Zs: pc < 16 the first piece of record pc (rows of its first-block region), else the overflow piece of
-		// record pc - 16. What it needs comes out of the LDS tables as scalars (uniform reads); ovf_at: step_vectors' offsets.
-		auto issue_dma = [&](u32 at, u32 Zs, u32 ovf_at) { // at: byte offset of the step's buffer in the staging area
+		auto issue_dma = [&](u32 at) { // at: byte offset of the step's buffer in the staging area
 			u32 ln = lane;
 			MPC_OPAQUE(ln);
-			const u32 *tt = ttab + 64u * (Zs & 1u);
-			for (u32 pc = wave; pc < 32u; pc += NWAVES) {
-				const u32 rec = pc & 15u;
-				u32 src, len, dst;
-				if (pc < 16u) {
-					const u32 first = mpc_wave_first(rtab[8 * rec]);
-					src = mpc_wave_first(tt[rec]) + mpc_wave_first(rtab[8 * rec + 2]) + first; len = mpc_wave_first(rtab[8 * rec + 1]); dst = first;
-				} else {
-					src = mpc_wave_first(tt[16u + rec]); len = mpc_wave_first(tt[32u + rec]) - src; dst = mpc_read_lane(ovf_at, rec);
-				}
-				for (u32 c0 = 0; c0 < len; c0 += 64u)
-					if (c0 + ln < len) mpc_dma16(padb + 16 * (u64)(src + c0 + ln), stage + at + 16 * (dst + c0));
-			}
+#pragma unroll
+			for (u32 j = 0; j < PIECES; ++j)
+				for (u32 c0 = 0; c0 < s_len[j]; c0 += 64u)
+					if (c0 + ln < s_len[j]) mpc_dma16(padb + 16 * (u64)(s_src[j] + c0 + ln), stage + at + 16 * (s_dst[j] + c0));
 		};
 		// the biases of a step go through LDS as well (every wave computes the same 16 words and writes them to the same place)
 		auto put_bias = [&](u32 Zs, u32 bias) { u32 ln = lane; MPC_OPAQUE(ln); if (ln < 16u) btab[16u * (Zs & 1u) + ln] = bias; };
@@ -567,10 +585,10 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 		}
 		__syncthreads();
 		{
-			u32 b, oa;
-			cur_len = 16u * step_vectors(0, &b, &oa);
+			u32 b;
+			cur_len = 16u * step_vectors(0, &b);
 			put_bias(0, b);
-			issue_dma(0, 0, oa);
+			issue_dma(0);
 			mpc_dma_wait();
 		}
 		constexpr bool STAGING = DIAG < 2 || DIAG == 4; // DIAG 2, 3: step 0's records for every step
@@ -580,12 +598,12 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 		auto stage_next = [&](u32 Z) {
 			pre = false;
 			if (Z + 1 >= n) return;
-			u32 b, oa;
-			nxt_len = 16u * step_vectors(Z + 1, &b, &oa);
+			u32 b;
+			nxt_len = 16u * step_vectors(Z + 1, &b);
 			put_bias(Z + 1, b);
 			if (cur_at == 0u) { nxt_at = p.cap_bytes - nxt_len; pre = nxt_len <= p.cap_bytes && nxt_at >= cur_len; }
 			else { nxt_at = 0u; pre = nxt_len <= cur_at; }
-			if (pre) issue_dma(nxt_at, Z + 1, oa);
+			if (pre) issue_dma(nxt_at);
 #ifdef MPC_RELAX_DIAG_BUILD
 			if (tid == 0) atomicAdd(&p.tile_next[pre ? 9 : 8], 1u); // measurement build: steps prefetched / staged late
 #endif
@@ -606,7 +624,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 				MPC_OPAQUE(ln);
 				const u32 *bt = btab + 16u * ((STAGING ? Z : 0u) & 1u);
 				const u32 bias_cur = bt[ln & 15u];                  // lane i: hop bias of record i at this step
-				const u32 bias_y = bt[MPC_RB_MAXN + (ln & 7u)];     // lane j < 8: hop bias of Y record j
+				const u32 bias_y = mpc_row16_ror8(bias_cur);        // lane j < 8: hop bias of Y record j (record 8 + j: the row rotated by 8 lanes)
 #pragma unroll
 				for (int j = 0; j < (int)YREGS; ++j) MPC_OPAQUE(yreg[j]); // the 5-bit fields are unpacked per step (hoisted, they would be 12 more live registers)
 #pragma unroll
@@ -617,7 +635,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 				auto addr_b = [&](int q) -> u32 { return sb + (xy[q] >> 16); };
 				auto idx_b = [&](int q) -> u32 { return (yreg[q / 6] >> (5 * (q % 6))) & 31u; }; // 4 * (lane of bias_y that holds the cell's Y record)
 				u32 nia = addr_a(0), nib = addr_b(0);
-				blk.load(nia, nib, idx_b(0), bias_y);
+				blk.load(nia, nib, mpc_lds_addr(bt + MPC_RB_MAXN) + idx_b(0)); // (the first slot's Y bias straight from the table: one round of LDS reads opens the step)
 				auto slot = [&](auto &&self, auto qc) __attribute__((always_inline)) {
 					constexpr int q = decltype(qc)::value;
 					if constexpr (q < MAXSLOTS) {
@@ -646,10 +664,10 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			if (STAGING && Z + 1 < n) {
 				if (!pre) { // the next step did not fit beside this one: stage it now that this one's readers are done
 					__syncthreads();
-					u32 b, oa;
-					nxt_len = 16u * step_vectors(Z + 1, &b, &oa);
+					u32 b;
+					nxt_len = 16u * step_vectors(Z + 1, &b);
 					nxt_at = 0u;
-					issue_dma(0u, Z + 1, oa);
+					issue_dma(0u);
 				}
 				unsigned long long tw = 0;
 				if (DIAG == 4) tw = mpc_clock();
@@ -658,9 +676,9 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 				cur_at = nxt_at; cur_len = nxt_len;
 			}
 		}
-		if (DIAG == 4 && lane == 0u && (wave == 0u || wave == 7u)) {
+		if (DIAG == 4 && lane == 0u) { // per wave number, summed over workgroups and tiles: walk, barrier, staging block, DMA wait
 			tm_all = mpc_clock() - tm0;
-			unsigned long long *tt = (unsigned long long *)(p.tile_next + 16) + (wave == 0u ? 0 : 4);
+			unsigned long long *tt = (unsigned long long *)(p.tile_next + 16) + 4 * wave;
 			atomicAdd(tt + 0, tm_all); atomicAdd(tt + 1, tm_bar); atomicAdd(tt + 2, tm_stage); atomicAdd(tt + 3, tm_wait);
 		}
 		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern

@@ -88,6 +88,9 @@ __device__ __forceinline__ unsigned mpc_row16_scan_add(unsigned v)
 	v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
 	return v;
 }
+// lane l receives the value of lane (l + 8) mod 16 of its DPP row (row_ror:8)
+__device__ __forceinline__ unsigned mpc_row16_ror8(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned mpc_lds_load4(unsigned addr) { return *(const __attribute__((address_space(3))) unsigned *)(unsigned long long)addr; }
 // value of lane `l` (wave-uniform index) as a scalar: v_readlane_b32, no LDS
 __device__ __forceinline__ unsigned mpc_read_lane(unsigned v, unsigned l) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ float mpc_read_lane(float v, unsigned l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l)); }
@@ -219,11 +222,11 @@ struct MpcRvBlocksAsm {
 struct MpcRbBlocksAsm {
 	mpc_uint4v a0, b0, a1, b1; // set 0: v[24:27], v[28:31]; set 1: v[32:35], v[36:39]
 	unsigned hb;               // v40: hop bias of the next slot's Y record (in flight until the next opening wait)
-	// first blocks of the first slot into set 0, and its Y bias
-	__device__ __forceinline__ void load(unsigned ia, unsigned ib, unsigned idx, unsigned bias_y)
+	// first blocks of the first slot into set 0, and its Y bias (read from the bias table in LDS at hb_addr)
+	__device__ __forceinline__ void load(unsigned ia, unsigned ib, unsigned hb_addr)
 	{
-		asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_bpermute_b32 %2, %5, %6"
-			: "={v[24:27]}"(a0), "={v[28:31]}"(b0), "={v40}"(hb) : "v"(ia), "v"(ib), "v"(idx), "v"(bias_y) : "memory");
+		asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b32 %2, %5"
+			: "={v[24:27]}"(a0), "={v[28:31]}"(b0), "={v40}"(hb) : "v"(ia), "v"(ib), "v"(hb_addr) : "memory");
 	}
 	__device__ __forceinline__ void drain() { asm volatile("s_waitcnt lgkmcnt(0)" : "+{v[24:27]}"(a0), "+{v[28:31]}"(b0), "+{v[32:35]}"(a1), "+{v[36:39]}"(b1), "+{v40}"(hb) : : "memory"); }
 #define MPC_RB_MERGE_ASM(A0_, A1_, A2_, A3_, B0_, B1_, B2_, B3_, CURA_, CURB_, NXTA_, NXTB_)                           \

@@ -608,10 +608,14 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			sc.bytes_per_cell = cells ? 16.0 * (double)est / (double)cells : 0.0;
 			return sc;
 		};
-		// Shape of the super-tiles. First choice: the largest shape whose bands leave room for the next step beside the current one
-		// (mean step <= half of the staging area) and still fill the register slots; else the shape with the least traffic per
-		// cell among those whose steps fill the area alone. MPCGPU_RELAX_SHAPE=nx,ny[,kb]: forced shape (and target per step).
-		static const u32 menu[7][2] = {{8, 8}, {8, 4}, {4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+		// Shape of the super-tiles and the target the bands are cut to. MPCGPU_RELAX_SHAPE=nx,ny[,kb]: forced.
+		// Narrow rows (1000 x L~400: 2 cells per row, y ranges that follow the diagonal): 8x8 super-tiles whose steps leave room for
+		// the next step beside the current one fill the register slots — taken at once. Otherwise (real data: 7 cells per row, the
+		// cells of 50 rows spread over 200 rows of the partner, and steps that vary by a factor of 1.6 around their mean) every
+		// shape of the menu is cut in both modes and priced: a tile-step costs a fixed part (staging block, barrier; plus the exposed
+		// transfer when the next step cannot be prefetched) and a part per cell slot. Shapes with more X than Y sequences are on the
+		// menu because the X pieces are the band's rows only, the Y pieces the whole range those rows' cells reach.
+		static const u32 menu[10][2] = {{8, 8}, {8, 4}, {8, 2}, {8, 1}, {4, 4}, {4, 2}, {4, 1}, {2, 2}, {2, 1}, {1, 1}};
 		std::vector<u32> words, out;
 		u32 use_nx = 0, use_ny = 0, use_target = 0;
 		const u32 margin = std::min<u32>(cap_blocks / 16, 64); // blocks: steps vary around the mean
@@ -625,67 +629,68 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			}
 		}
 		if (!use_nx) {
-			for (u32 m = 0; m < 3 && !use_nx; ++m) {
-				if (cut(menu[m][0], menu[m][1], half, words, out)) return 1;
-				const Score sc = score(out, half);
-				if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles %ux%u, two steps resident: %llu tiles, fill %.2f, %.2f B/cell-step, %.0f %% within target\n",
-					menu[m][0], menu[m][1], (unsigned long long)sc.tiles, sc.fill, sc.bytes_per_cell, 100 * sc.in_target);
-				if (sc.tiles && sc.fill >= 0.70 && sc.in_target >= 0.90) { use_nx = menu[m][0]; use_ny = menu[m][1]; use_target = half; }
-				else if (m == 0 && sc.tiles && sc.in_target >= 1.0) {
-					// few cells: when the target did not cut anything (a whole staging area gives the same bands), these are the tiles
-					std::vector<u32> w2, o2;
-					if (cut(menu[0][0], menu[0][1], full, w2, o2)) return 1;
-					if (o2.size() == out.size()) { use_nx = menu[0][0]; use_ny = menu[0][1]; use_target = half; }
-				}
+			if (cut(8, 8, half, words, out)) return 1;
+			const Score sc = score(out, half);
+			if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles 8x8, two steps resident: %llu tiles, fill %.2f, %.2f B/cell-step, %.0f %% within target\n",
+				(unsigned long long)sc.tiles, sc.fill, sc.bytes_per_cell, 100 * sc.in_target);
+			if (!sc.tiles) { c->h_btiles.clear(); c->btiles_k0 = k0; c->btiles_k1 = k1; return 0; } // no cell in [k0,k1)
+			if (sc.fill >= 0.70 && sc.in_target >= 0.90) { use_nx = 8; use_ny = 8; use_target = half; }
+			else if (sc.in_target >= 1.0) {
+				// few cells: when the target did not cut anything (a whole staging area gives the same bands), these are the tiles
+				std::vector<u32> w2, o2;
+				if (cut(8, 8, full, w2, o2)) return 1;
+				if (o2.size() == out.size()) { use_nx = 8; use_ny = 8; use_target = half; }
 			}
 		}
 		if (!use_nx) {
-			double best = 0;
-			u32 bm = 7;
-			std::vector<u32> w2, o2;
-			for (u32 m = 0; m < 7; ++m) {
-				if (cut(menu[m][0], menu[m][1], full, w2, o2)) return 1;
-				const Score sc = score(o2, full);
-				if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles %ux%u, one step resident: %llu tiles, fill %.2f, %.2f B/cell-step, %.0f %% within target\n",
-					menu[m][0], menu[m][1], (unsigned long long)sc.tiles, sc.fill, sc.bytes_per_cell, 100 * sc.in_target);
-				if (!sc.tiles) continue;
-				// traffic per cell, charged for idle register slots and for steps over the target (those tiles will be split)
-				const double cost = sc.bytes_per_cell / std::max(std::min(sc.fill / 0.70, 1.0), 0.05) / std::max(sc.in_target, 0.05);
-				if (bm == 7 || cost < best) { best = cost; bm = m; words.swap(w2); out.swap(o2); }
-			}
-			if (bm == 7) { c->h_btiles.clear(); c->btiles_k0 = k0; c->btiles_k1 = k1; return 0; } // no cell in [k0,k1)
-			use_nx = menu[bm][0]; use_ny = menu[bm][1]; use_target = full;
-		}
-		// One step resident: the cut was made on MEAN steps, but the worst step of every tile has to fit the area. The exact worst
-		// steps of a sample of tiles give the ratio worst / mean of this data set (95th percentile); the bands are cut again with the
-		// target lowered by it, so that only stragglers are left to the halving below.
-		if (use_target > half && !words.empty()) {
-			const u32 nt = (u32)(words.size() / MPC_RB_TILE_WORDS);
-			std::vector<u32> sample;
-			const u32 stride = std::max(nt / 4096u, 1u);
-			for (u32 t = 0; t < nt; t += stride) if (out[4 * t + 3]) sample.push_back(t);
-			if (!sample.empty()) {
-				if (upload(c, c->d_btiles, words) || upload(c, c->d_bt_list, sample)) return 1;
-				HIPCHK(c, c->d_bt_count.ensure(sample.size() * 4));
-				MPC_LAUNCH(band_fit_kernel, std::min<u32>((u32)sample.size(), cus * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), nb1,
-					c->d_btiles.as<u32>(), c->d_bt_list.as<u32>(), (u32)sample.size(), c->d_bt_count.as<u32>());
-				HIPCHK(c, hipGetLastError());
-				std::vector<u32> worst(sample.size());
-				HIPCHK(c, hipMemcpyAsync(worst.data(), c->d_bt_count.p, sample.size() * 4, hipMemcpyDeviceToHost, c->stream));
-				HIPCHK(c, hipStreamSynchronize(c->stream));
-				std::vector<double> ratio;
-				for (size_t q = 0; q < sample.size(); ++q) if (out[4 * sample[q] + 1]) ratio.push_back((double)worst[q] / (double)out[4 * sample[q] + 1]);
-				if (!ratio.empty()) {
-					std::sort(ratio.begin(), ratio.end());
-					const double r95 = ratio[std::min(ratio.size() - 1, (size_t)(0.95 * (double)ratio.size()))];
-					const u32 lowered = (u32)((double)cap_blocks / std::max(r95, 1.0) * 0.98);
-					if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles: worst step / mean step = %.3f (95th percentile of %zu tiles): target %u -> %u blocks\n", r95, ratio.size(), use_target, std::min(lowered, use_target));
-					if (lowered < use_target) {
-						use_target = std::max(lowered, 1u);
-						if (cut(use_nx, use_ny, use_target, words, out)) return 1;
-					}
+			// worst step / mean step of this data set: the exact worst steps of a sample of 4x2 tiles cut to the whole area (95th percentile)
+			double r95 = 1.0;
+			{
+				if (cut(4, 2, full, words, out)) return 1;
+				const u32 nt = (u32)(words.size() / MPC_RB_TILE_WORDS);
+				std::vector<u32> sample;
+				const u32 stride = std::max(nt / 4096u, 1u);
+				for (u32 t = 0; t < nt; t += stride) if (out[4 * t + 3]) sample.push_back(t);
+				if (!sample.empty()) {
+					if (upload(c, c->d_btiles, words) || upload(c, c->d_bt_list, sample)) return 1;
+					HIPCHK(c, c->d_bt_count.ensure(sample.size() * 4));
+					MPC_LAUNCH(band_fit_kernel, std::min<u32>((u32)sample.size(), cus * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), nb1,
+						c->d_btiles.as<u32>(), c->d_bt_list.as<u32>(), (u32)sample.size(), c->d_bt_count.as<u32>());
+					HIPCHK(c, hipGetLastError());
+					std::vector<u32> worst(sample.size());
+					HIPCHK(c, hipMemcpyAsync(worst.data(), c->d_bt_count.p, sample.size() * 4, hipMemcpyDeviceToHost, c->stream));
+					HIPCHK(c, hipStreamSynchronize(c->stream));
+					std::vector<double> ratio;
+					for (size_t q = 0; q < sample.size(); ++q) if (out[4 * sample[q] + 1]) ratio.push_back((double)worst[q] / (double)out[4 * sample[q] + 1]);
+					if (!ratio.empty()) { std::sort(ratio.begin(), ratio.end()); r95 = std::max(ratio[std::min(ratio.size() - 1, (size_t)(0.95 * (double)ratio.size()))], 1.0); }
 				}
 			}
+			const u32 single = std::max(std::min((u32)((double)cap_blocks / r95 * 0.98), full), 1u); // mean step such that the worst one still fits
+			// cost of a tile-step in units of one cell slot of this data (a slot's merges grow with the rows' entries)
+			u64 rows = 0;
+			for (u32 i = 0; i + 1 < n; ++i) rows += (u64)c->len[i] * (n - 1 - i);
+			const double per_row = rows ? (double)c->total_entries / (double)rows : 2.0;
+			const double slot_us = 0.3 + 0.2 * per_row, fixed = 1.0 / slot_us, exposed = 1.5 / slot_us;
+			if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles: %.1f cells per row; worst step / mean step = %.3f (95th percentile): one step resident = %u blocks mean\n", per_row, r95, single);
+			double best = 0;
+			bool have = false;
+			std::vector<u32> w2, o2;
+			for (u32 mode = 0; mode < 2; ++mode)
+				for (u32 m = 0; m < 10; ++m) {
+					const u32 target = mode == 0 ? half : single;
+					if (cut(menu[m][0], menu[m][1], target, w2, o2)) return 1;
+					u64 slots = 0, over = 0;
+					const u64 nt = o2.size() / 4;
+					for (size_t t = 0; t + 3 < o2.size(); t += 4) { slots += std::min(o2[t], max_slots); over += o2[t + 1] > target ? 1 : 0; }
+					if (!nt) continue;
+					// tiles over the target (single index bands that do not fit) will be split by sequences: charged double
+					const double cost = ((double)nt + (double)over) * (fixed + (mode ? exposed : 0.0)) + (double)slots;
+					if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles %ux%u, %s: %llu tiles (%llu over the target), %.1f cells per lane, cost %.3g\n",
+						menu[m][0], menu[m][1], mode ? "one step resident" : "two steps resident", (unsigned long long)nt, (unsigned long long)over,
+						(double)slots / (double)nt, cost);
+					if (!have || cost < best) { have = true; best = cost; words.swap(w2); out.swap(o2); use_nx = menu[m][0]; use_ny = menu[m][1]; use_target = target; }
+				}
+			if (!have) { c->h_btiles.clear(); c->btiles_k0 = k0; c->btiles_k1 = k1; return 0; }
 		}
 		// every tile must fit: cells per lane, 16-bit first-piece offsets, and its WORST step in the staging area (upper bound
 		// first; the exact maximum over Z only where the bound does not settle it). What does not fit is halved: band, then Y, then X.
@@ -760,8 +765,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 	const u32 ntiles = (u32)(c->h_btiles.size() / MPC_RB_TILE_WORDS);
 	if (!ntiles) return 0;
-	HIPCHK(c, c->d_tile_next.ensure(32 * 4));
-	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 32 * 4, c->stream));
+	HIPCHK(c, c->d_tile_next.ensure(160 * 4));
+	HIPCHK(c, hipMemsetAsync(c->d_tile_next.p, 0, 160 * 4, c->stream));
 	RelaxBandParams rp;
 	rp.s = sp; rp.ovf_off = c->d_ovf_off.as<u32>(); rp.nb1 = nb1; rp.cell_off = c->d_cell_off.as<u32>();
 	rp.tiles = c->d_btiles.as<u32>(); rp.ntiles = ntiles; rp.k0 = k0; rp.k1 = k1; rp.cap_bytes = cap;
@@ -801,16 +806,16 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	}
 #ifdef MPC_RELAX_DIAG_BUILD
 	if (trace_on()) {
-		u32 cnt[32];
+		u32 cnt[160];
 		HIPCHK(c, hipMemcpyAsync(cnt, c->d_tile_next.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		fprintf(stderr, "[mpcgpu] relax band (measurement build): %u steps prefetched beside the current one, %u staged after the merges\n", cnt[9], cnt[8]);
 		if (diag == 4) {
 			const unsigned long long *t = (const unsigned long long *)(cnt + 16);
-			for (int w = 0; w < 2; ++w)
-				fprintf(stderr, "[mpcgpu] relax band timers, wave %d of every workgroup, summed over tiles (100 MHz ticks): walk %llu, top barrier %llu (%.1f %%), staging block %llu (%.1f %%), DMA wait %llu (%.1f %%)\n",
-					w ? 7 : 0, t[4 * w], t[4 * w + 1], 100.0 * t[4 * w + 1] / std::max<double>(t[4 * w], 1), t[4 * w + 2], 100.0 * t[4 * w + 2] / std::max<double>(t[4 * w], 1), t[4 * w + 3],
-					100.0 * t[4 * w + 3] / std::max<double>(t[4 * w], 1));
+			fprintf(stderr, "[mpcgpu] relax band timers per wave number (share of the walk: barrier / staging block / DMA wait):");
+			for (int w = 0; w < 16; ++w)
+				fprintf(stderr, " %d: %.1f/%.1f/%.1f", w, 100.0 * t[4 * w + 1] / std::max<double>(t[4 * w], 1), 100.0 * t[4 * w + 2] / std::max<double>(t[4 * w], 1), 100.0 * t[4 * w + 3] / std::max<double>(t[4 * w], 1));
+			fprintf(stderr, "\n");
 		}
 	}
 #endif

@@ -57,7 +57,10 @@ for s in "$@"; do
 		prof ${TAG}_pmc_sq_$SUF --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -- "${BA[@]}"
 		prof ${TAG}_pmc_sq2_$SUF --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM -- "${BA[@]}"
 		for k in fetch write sq sq2; do for f in $(find $OUT/${TAG}_pmc_${k}_$SUF -name "*counter_collection.csv" | head -1); do cp $f $OUT/${TAG}_pmc_${k}_${SUF}_counter_collection.csv; done; done
-		step python scripts/pmc_summary.py $N $L $OUT/${TAG}_pmc_fetch_$SUF $OUT/${TAG}_pmc_write_$SUF $OUT/${TAG}_pmc_traffic_$SUF.json $OUT/${TAG}_pmc_sq_$SUF $OUT/${TAG}_pmc_sq2_$SUF;;
+		prof ${TAG}_pmc_grbm_$SUF --pmc GRBM_GUI_ACTIVE -- "${BA[@]}"
+		for f in $(find $OUT/${TAG}_pmc_grbm_$SUF -name "*counter_collection.csv" | head -1); do cp $f $OUT/${TAG}_pmc_grbm_${SUF}_counter_collection.csv; done
+		# (run `stats` / `rdrpstats` BEFORE this step: its kernel_stats csv gives the launch durations the clock is derived with)
+		step env PMC_STATS=$OUT/${TAG}_kernel_stats_$SUF.csv PMC_GRBM=$OUT/${TAG}_pmc_grbm_$SUF PMC_SOURCE="profiles/${TAG}_pmc_*_${SUF}_counter_collection.csv, profiles/${TAG}_kernel_stats_$SUF.csv" python scripts/pmc_summary.py $N $L $OUT/${TAG}_pmc_fetch_$SUF $OUT/${TAG}_pmc_write_$SUF $OUT/${TAG}_pmc_traffic_$SUF.json $OUT/${TAG}_pmc_sq_$SUF $OUT/${TAG}_pmc_sq2_$SUF;;
 	sh) step timeout 1500 bash -c "${s#sh:}";;
 	*) echo "gpu.sh: unknown step $s" | tee -a $LOG;;
 	esac

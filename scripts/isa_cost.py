@@ -31,7 +31,56 @@ def cost(op, line):
     return 1.67
 
 
+def mean_cost(path, key, walk=False):
+    """Mean issue cost (units of one full-rate VALU op) of the VALU instructions of kernel `key` in listing `path`: the whole
+    kernel, or — walk=True — what lies between the first and the last hand-scheduled merge loop (.Lrv_step_*), i.e. one step of
+    the relax walk. A static mean: every instruction of the region counts once."""
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l.split(":")[0] and ":" in l and "@" in l)
+    body = []
+    for l in lines[start + 1:]:
+        s = l.strip()
+        if s.startswith(".Lfunc_end"):
+            break
+        body.append(s)
+    if walk:
+        marks = [i for i, s in enumerate(body) if re.match(r"\.Lrv_step_\d+:", s)]
+        if marks:
+            body = body[marks[0]:marks[-1] + 60]
+    units = n = 0
+    in_loop = walk  # whole kernel: only the basic blocks the compiler marks as part of a loop count (prologue and epilogue run once)
+    for s in body:
+        if s.startswith(".LBB") or s.startswith("; %bb."):
+            in_loop = walk or "in Loop:" in s or "Loop Header" in s
+            continue
+        if s.startswith(";") and ("Parent Loop" in s or "Inner Loop Header" in s or "Loop Header" in s):
+            in_loop = True
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            continue
+        op = s.split()[0]
+        if in_loop and op.startswith("v_"):
+            units += cost(op, s)
+            n += 1
+    return units / max(n, 1), n
+
+
 def main():
+    if sys.argv[1] == "--json":  # --json <listing.s> <out.json>: the mean issue costs bench.py's roofline uses, for the default kernels
+        import json
+        path, out = sys.argv[2], sys.argv[3]
+        res = {}
+        for name, key, walk in (("relax_band_kernel", "relax_band_kernelILi1024ELi13ELi2ELi0E14MpcRbBlocksAsm", True),
+                                ("relax_var_kernel", "relax_var_kernelILi1024ELi13ELi2ELi0E14MpcRvBlocksAsm", True),
+                                ("fb_chain_kernel", "fb_chain_kernelILi7E", False), ("fb_kernel", "fb_kernelILi7ELb0ELb0E", False)):
+            try:
+                c, n = mean_cost(path, key, walk)
+                res[name] = {"mean_issue_cost": round(c, 4), "valu_instructions": n, "region": "one step of the walk" if walk else "the kernel's loops", "mangled": key}
+            except StopIteration:
+                pass
+        json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+        print(json.dumps(res))
+        return
     path, key = sys.argv[1], sys.argv[2]
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().split(":")[0].endswith(l.split(":")[0]))

@@ -70,6 +70,31 @@ def main():
         key = "%s@%dx%d" % (short, n, length)
         if key in d and d[key]["kernel"] == kname:
             d[key]["sq_per_launch"] = {c: sum(v) / len(v) for c, v in sorted(counters.items())}
+    # PMC_STATS=<kernel_stats.csv of `rocprofv3 --kernel-trace --stats` of the same command>: the launch duration under the profiler,
+    # and with it the clock the chip sustained under THIS kernel: SQ_BUSY_CYCLES is counted once per shader engine (MI355X: 8 XCDs
+    # x 4 = 32), each busy for the whole launch of a grid that fills the chip, so clock = SQ_BUSY_CYCLES / 32 / duration.
+    # PMC_GRBM=<dir of a --pmc GRBM_GUI_ACTIVE pass>: the same from the graphics register bus manager's busy counter (one per XCD).
+    stats = os.environ.get("PMC_STATS")
+    if stats and os.path.exists(stats):
+        with open(stats) as f:
+            for row in csv.DictReader(f):
+                key = "%s@%dx%d" % (short_of(row["Name"]), n, length)
+                if key in d and d[key]["kernel"] == row["Name"]:
+                    dur = float(row["AverageNs"]) * 1e-9
+                    d[key]["avg_duration_s_profiled"] = dur
+                    busy = d[key].get("sq_per_launch", {}).get("SQ_BUSY_CYCLES")
+                    if busy and dur > 0:
+                        d[key]["clock_hz"] = busy / 32.0 / dur
+                        d[key]["clock_method"] = "SQ_BUSY_CYCLES (one count per shader engine, 32 on MI355X) / 32 / mean launch duration of the --kernel-trace --stats pass"
+    grbm = os.environ.get("PMC_GRBM")
+    if grbm:
+        for kname, vals in read(grbm, "GRBM_GUI_ACTIVE").items():
+            key = "%s@%dx%d" % (short_of(kname), n, length)
+            if key in d and d[key]["kernel"] == kname and vals:
+                d[key]["GRBM_GUI_ACTIVE_per_launch"] = sum(vals) / len(vals)
+                dur = d[key].get("avg_duration_s_profiled")
+                if dur:
+                    d[key]["clock_hz_grbm_if_one_counter_per_xcd"] = d[key]["GRBM_GUI_ACTIVE_per_launch"] / 8.0 / dur
     with open(out, "w") as f:
         json.dump(d, f, indent=1, sort_keys=True)
 

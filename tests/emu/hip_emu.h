@@ -106,6 +106,7 @@ template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src
 #define MPC_WAVE_LDS_ORDER() ((void)__shfl(0, 0)) // a rendezvous of the WAVE (any collective is one): the emulator runs lanes one after the other between synchronisation points
 #define MPC_WAVE_FENCE() ((void)0) // emulated lanes meet at every shuffle
 template <class T> static inline T mpc_read_lane(T v, unsigned l) { return __shfl(v, (int)l); }
+static inline unsigned mpc_row16_ror8(unsigned v) { return __shfl(v, (int)((emu::t_lane & ~15u) | ((emu::t_lane + 8u) & 15u))); }
 static inline unsigned mpc_row16_scan_add(unsigned v)
 {
 	for (int d = 1; d < 16; d <<= 1) {
@@ -148,6 +149,7 @@ static inline MpcQuad mpc_lds_load16(unsigned addr)
 	if ((size_t)addr + 16 > emu::g_block->dyn_size) return MpcQuad{0, 0, 0, 0};
 	return *(const MpcQuad *)(emu::g_block->dyn_smem + addr);
 }
+static inline unsigned mpc_lds_load4(unsigned addr) { return (size_t)addr + 4 > emu::g_block->dyn_size ? 0u : *(const unsigned *)(emu::g_block->dyn_smem + addr); }
 typedef const unsigned *mpc_const_u32p;
 #define MPC_CONST_U32(p) ((mpc_const_u32p)(p))
 static inline unsigned mpc_write_lane(unsigned v, unsigned sv, unsigned l) { return emu::t_lane == l ? sv : v; }

@@ -1,7 +1,7 @@
 """Build-time checks of the compiled gfx950 code of the hot kernels (hipcc cross-compiles without a GPU): what the register
 allocator did is a performance property that parity tests cannot see.
 
-relax_var_kernel walks Z with every accumulator and row offset in VGPRs; a value the compiler keeps in a spill slot instead is
+relax_band_kernel (and relax_var_kernel before it) walks Z with every accumulator and row offset in VGPRs; a value the compiler keeps in a spill slot instead is
 reloaded between the merges of a step, and each reload waits for vmcnt(0). The 14-cells-per-lane instantiation of the default
 geometry had five such reloads (1195 ms per two iterations at 1000 x L~400 against 1171 with 13 cells per lane and none:
 profiles/r05g). The forward/backward kernels must not spill at all."""
@@ -38,15 +38,59 @@ def _scratch(lines):
     return [k for k, l in enumerate(lines) if re.search(r"\bscratch_(load|store)|\bbuffer_(load|store)", l)]
 
 
-def test_default_relax_walk_has_no_spill_reloads(isa):
-    # the instantiation relax_var_launch picks by default: var_slots_2048() == 13
-    src = open(os.path.join(CSRC, "mpcgpu.cpp")).read()
-    assert re.search(r'env_int\("MPCGPU_RELAX_SLOTS_2048", 13\)', src), "default cells per lane of the default geometry changed: update this test"
-    body = _body(isa, "_Z16relax_var_kernelILi1024ELi13ELi2ELi0E14MpcRvBlocksAsmEv14RelaxVarParams")
+BAND = "_Z17relax_band_kernelILi1024ELi13ELi2ELi0E14MpcRbBlocksAsmEv15RelaxBandParams"
+
+
+def _walk(body):
     merges = [k for k, l in enumerate(body) if re.match(r"\.Lrv_step_\d+:", l.strip())]
+    return merges
+
+
+def test_default_relax_walk_has_no_spill_reloads(isa):
+    """relax_band_kernel, the instantiation relax_band launches by default (kBandSlots cells per lane). A reload inside the walk is
+    worse here than in relax_var_kernel: its wait is vmcnt(0), and the prefetch of the next step is in flight on the same counter."""
+    src = open(os.path.join(CSRC, "mpcgpu.cpp")).read()
+    assert re.search(r"kBandThreads = 1024, kBandSlots = 13;", src), "default geometry of relax_band changed: update this test"
+    body = _body(isa, BAND)
+    merges = _walk(body)
     assert len(merges) == 13, len(merges)  # one hand-scheduled merge loop per cell slot
     inside = [k for k in _scratch(body) if merges[0] <= k <= merges[-1]]
     assert not inside, "spill code between the merges of a step: " + "; ".join(body[k].strip() for k in inside[:5])
+    # no wait for the VMEM counter between the prefetch (the staging block sits between the first and the second merge) and the last
+    # merge: the transfers of the next step must stay in flight under the merges
+    dma = [k for k, l in enumerate(body) if "global_load_lds_dwordx4" in l and merges[0] <= k <= merges[-1]]
+    assert dma, "the prefetch is expected between the merges of a step"
+    waits = [k for k, l in enumerate(body) if "vmcnt" in l and dma[0] < k <= merges[-1]]
+    assert not waits, "; ".join(body[k].strip() for k in waits[:5])
+
+
+def test_band_merge_registers_are_not_touched_between_statements(isa):
+    """The hand-scheduled merge leaves LDS reads in flight into v24..v40 (the next slot's first blocks, its Y bias) when a
+    statement ends; the compiler does not know. Between the end of one merge statement and the opening wait of the next
+    (or the drain after the last slot) no compiler-generated instruction may read or write those registers."""
+    body = _body(isa, BAND)
+    pinned = set(range(24, 41))
+
+    def regs(line):
+        out = set()
+        for m in re.finditer(r"\bv(\d+)\b", line):
+            out.add(int(m.group(1)))
+        for m in re.finditer(r"v\[(\d+):(\d+)\]", line):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        return out
+
+    in_gap, bad = False, []
+    for k, l in enumerate(body):
+        t = l.strip()
+        if re.match(r"\.Lrv_done_\d+:", t):
+            in_gap = "armed"  # the statement's last instruction (restore exec) follows, then ;;#ASMEND
+        elif in_gap == "armed" and t.startswith(";;#ASMEND"):
+            in_gap = True
+        elif in_gap is True and t.startswith("s_waitcnt lgkmcnt(0)"):
+            in_gap = False
+        elif in_gap is True and t and not t.startswith((";", ".")) and regs(t) & pinned:
+            bad.append("%d: %s" % (k, t))
+    assert not bad, "\n".join(bad[:8])
 
 
 def test_forward_backward_kernels_do_not_spill(isa):
