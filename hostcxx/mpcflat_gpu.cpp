@@ -109,8 +109,19 @@ Slot g_Slots[MAX_SLOTS];
 std::mutex g_MapMu;	// guards the two maps (not the batches themselves: a batch is used under its slot's mutex)
 std::map<const MPCFlat *, Batch> g_Batches;
 std::map<const MPCFlat *, int> g_SlotOf;
-std::mutex g_JoinMu;
-mpcgpu_ctx *g_CtxJoin = 0; // PProg joins: their own context, so a join never disturbs the store of an MPCFlat run
+// PProg joins and pair lists (AlignMSAsFlat, AlignPairFlat, UClust::Search): contexts of their own, so that they never disturb the
+// store of an MPCFlat run — ONE PER LISTED DEVICE (MUSCLE_GPU_DEVICES), each under its own mutex. A calling thread keeps the join
+// context it was dealt: the worker threads of the parallel shrub loop that of their slot's device (so a shrub's joins run where
+// its stage ran), any other thread the next one in turn (the OpenMP loops around AlignPairFlat spread over the devices).
+struct JoinCtx
+	{
+	std::mutex m_Mu;
+	mpcgpu_ctx *m_Ctx = 0;
+	};
+enum { MAX_JOIN_CTX = 64 };
+JoinCtx g_Join[MAX_JOIN_CTX];
+std::atomic<unsigned> g_JoinNext(0);
+thread_local int t_JoinIndex = -1;
 
 int SlotIndexOf(const MPCFlat *M)
 	{
@@ -170,6 +181,23 @@ vector<int> DeviceList()
 	if (s != 0 && *s != 0)
 		Device = atoi(s);
 	return vector<int>(1, Device);
+	}
+
+// The join context of the calling thread (see JoinCtx), created on first use; lock its m_Mu around the library calls.
+JoinCtx &JoinOfThisThread()
+	{
+	const vector<int> Devs = DeviceList();
+	const unsigned N = (unsigned) std::min<size_t>(Devs.size(), MAX_JOIN_CTX);
+	if (t_JoinIndex < 0 || (unsigned) t_JoinIndex >= N)
+		t_JoinIndex = (int) (g_JoinNext.fetch_add(1) % N);
+	JoinCtx &J = g_Join[t_JoinIndex];
+	std::lock_guard<std::mutex> Guard(J.m_Mu);
+	if (J.m_Ctx == 0)
+		{
+		if (mpcgpu_create(&J.m_Ctx, Devs[t_JoinIndex]) != 0)
+			Die("GPU posterior stage: %s", mpcgpu_last_error(0));
+		}
+	return J;
 	}
 
 // Context of a slot, created on first use (call with the slot's mutex held). Slot 0: a group when MUSCLE_GPU_DEVICES lists
@@ -512,6 +540,10 @@ void MPCFlat::CalcPosterior(uint PairIndex)
 	const uint SeqIndexX = Pair.first;
 	const uint SeqIndexY = Pair.second;
 	float EA;
+// the content hashes of this pair's two sequences, computed BEFORE the slot's lock is taken (the reference calls CalcPosterior
+// from an OpenMP loop: N^2 hashes of L bytes under one mutex were seconds at 10 000 sequences)
+	const uint64_t HashX = SeqEnds(GetBytePtr(SeqIndexX), GetSeqLength(SeqIndexX));
+	const uint64_t HashY = SeqEnds(GetBytePtr(SeqIndexY), GetSeqLength(SeqIndexY));
 		{
 		const int SlotIndex = SlotIndexOf(this);
 		Slot &S = g_Slots[SlotIndex];
@@ -523,11 +555,11 @@ void MPCFlat::CalcPosterior(uint PairIndex)
 			{
 // the two sequences of this pair are still the ones the batch was computed from
 			const uint Idx[2] = { SeqIndexX, SeqIndexY };
+			const uint64_t Hash[2] = { HashX, HashY };
 			for (int q = 0; q < 2; ++q)
 				{
 				const uint i = Idx[q];
-				if (B.m_SeqPtrs[i] != GetBytePtr(i) || B.m_SeqLens[i] != GetSeqLength(i) ||
-				  B.m_SeqEnds[i] != SeqEnds(GetBytePtr(i), GetSeqLength(i)))
+				if (B.m_SeqPtrs[i] != GetBytePtr(i) || B.m_SeqLens[i] != GetSeqLength(i) || B.m_SeqEnds[i] != Hash[q])
 					Fresh = false;
 				}
 			}
@@ -616,8 +648,6 @@ void MPCFlat::BuildPost(const MultiSequence &MSA1, const MultiSequence &MSA2, fl
 	const uint ColCount2 = MSA2.GetColCount();
 	const int SlotIndex = SlotIndexOf(this);
 	Slot &S = g_Slots[SlotIndex];
-	if (S.m_StoreOwner != this)
-		Die("GPU posterior stage: BuildPost on an MPCFlat whose posteriors are not the ones on the device");
 // weights by the ROW index in MSA1 / MSA2 (buildpostflat.cpp:41,52,74); callers outside Run may never have sized m_Weights
 	vector<float> W1(SeqCount1, 1.0f), W2(SeqCount2, 1.0f);
 	for (uint i = 0; i < SeqCount1 && i < SIZE(m_Weights); ++i)
@@ -628,6 +658,8 @@ void MPCFlat::BuildPost(const MultiSequence &MSA1, const MultiSequence &MSA2, fl
 	RowsOf(*this, MSA1, Seqs1, Map1);
 	RowsOf(*this, MSA2, Seqs2, Map2);
 	std::lock_guard<std::mutex> Guard(S.m_Mu);
+	if (S.m_StoreOwner != this) // (checked under the slot's lock: another MPCFlat's batch may be taking the context over)
+		Die("GPU posterior stage: BuildPost on an MPCFlat whose posteriors are not the ones on the device");
 	mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
 	GPUCHK(mpcgpu_build_post(Ctx, SeqCount1, Seqs1.data(), SeqCount2, Seqs2.data(), ColCount1, ColCount2,
 	  Map1.data(), Map2.data(), W1.data(), W2.data(), Post));
@@ -795,14 +827,9 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 	vector<float> EA(PairCount);
 	SW.Next(T_JOIN_LIB);
 		{
-		std::lock_guard<std::mutex> Guard(g_JoinMu);
-		if (g_CtxJoin == 0)
-			{
-			const int Device = DeviceList()[0];
-			if (mpcgpu_create(&g_CtxJoin, Device) != 0)
-				Die("GPU posterior stage: %s", mpcgpu_last_error(0));
-			}
-		mpcgpu_ctx *Ctx = g_CtxJoin;
+		JoinCtx &J = JoinOfThisThread();
+		std::lock_guard<std::mutex> Guard(J.m_Mu);
+		mpcgpu_ctx *Ctx = J.m_Ctx;
 		GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
 		  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
 		GPUCHK(mpcgpu_set_seqs_registry(Ctx, (uint32_t) Ptrs.size(), Ptrs.data(), Lens.data()));
@@ -837,8 +864,8 @@ struct PairReq
 	bool m_Done = false;
 	};
 
-// Runs the requests of one batch as ONE library call (under g_JoinMu).
-void RunPairBatch(const vector<PairReq *> &Batch)
+// Runs the requests of one batch as ONE library call on the calling thread's join context (locked by the caller).
+void RunPairBatch(const vector<PairReq *> &Batch, mpcgpu_ctx *Ctx)
 	{
 	std::map<const Sequence *, uint32_t> SeqToIndex;
 	vector<const uint8_t *> Ptrs;
@@ -876,13 +903,6 @@ void RunPairBatch(const vector<PairReq *> &Batch)
 	vector<char> PathBuf(size_t(PairCount)*Stride);
 	vector<uint32_t> PathLens(PairCount);
 	vector<float> EAs(PairCount);
-	if (g_CtxJoin == 0)
-		{
-		const int Device = DeviceList()[0];
-		if (mpcgpu_create(&g_CtxJoin, Device) != 0)
-			Die("GPU posterior stage: %s", mpcgpu_last_error(0));
-		}
-	mpcgpu_ctx *Ctx = g_CtxJoin;
 	Stopwatch SW(T_PAIRS_PREP);
 	GPUCHK(mpcgpu_set_hmm(Ctx, PairHMM::m_StartScore, &PairHMM::m_TransScore[0][0],
 	  &PairHMM::m_MatchScore[0][0], PairHMM::m_InsScore, MIN_SPARSE_SCORE, -1));
@@ -967,8 +987,9 @@ void AlignPairsByLabel(const vector<string> &Labels1, const vector<string> &Labe
 				}
 			Lock.unlock();
 				{
-				std::lock_guard<std::mutex> Guard(g_JoinMu);
-				RunPairBatch(Batch);
+				JoinCtx &J = JoinOfThisThread();
+				std::lock_guard<std::mutex> Guard(J.m_Mu);
+				RunPairBatch(Batch, J.m_Ctx);
 				}
 			Lock.lock();
 			for (size_t r = 0; r < Batch.size(); ++r)
@@ -1096,6 +1117,7 @@ void Super7::IntraAlignShrubs()
 				std::lock_guard<std::mutex> Guard(g_MapMu);
 				g_SlotOf[&Local] = 1 + (int) w;
 				}
+			t_JoinIndex = (int) (w % (uint) std::min<size_t>(DeviceList().size(), MAX_JOIN_CTX)); // = the device this worker's slot is dealt (CtxOfSlot)
 			for (;;)
 				{
 				const uint ShrubIndex = Next.fetch_add(1);

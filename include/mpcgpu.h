@@ -96,6 +96,10 @@ int mpcgpu_build_store(mpcgpu_ctx *ctx);
  * all-gather over xGMI on these device pointers — SURVEY.md §8e) --------------------------- */
 /* Size in bytes and device address of this context's packed shard (valid after calc_posteriors). */
 int mpcgpu_shard_info(mpcgpu_ctx *ctx, uint64_t *bytes, void **dev_ptr);
+/* Stored cells (sparse posterior entries) of this context's shard: this rank's share of the values a relax iteration exchanges
+ * (mpcgpu_values_slice gives the same count once the store exists; this one is known right after stage A, so that a caller sizes
+ * both exchanges — the shards' bytes and the values' counts — with ONE size exchange). */
+int mpcgpu_shard_entries(mpcgpu_ctx *ctx, uint64_t *entries);
 /* Copy the packed shard (bytes from mpcgpu_shard_info) into caller-owned device memory. */
 int mpcgpu_shard_export(mpcgpu_ctx *ctx, void *dev_dst);
 /* Build the all-pairs store from nshards packed shards laid out back to back in device memory
@@ -204,7 +208,11 @@ int mpcgpu_align_msas(mpcgpu_ctx *ctx, uint32_t npairs, const uint32_t *seq1, co
  * LIST of pairs of registered sequences: CalcPost (calcpost.cpp:4-36: fwd + bwd + CalcPostFlat), CalcAlnFlat + TraceBackFlat on the
  * dense thresholded posterior. paths: npairs slots of path_stride bytes (>= LX+LY of every pair), B/X/Y strings of pathlens[q]
  * characters; scores[q] = CalcAlnFlat's score, ea[q] = score / min(LX, LY) — what AlignPairFlat returns (either may be NULL).
- * The sparse matrices of the same pairs (AlignPairFlat_SparsePost) are then available through mpcgpu_get_list_sparse. */
+ * The sparse matrices of the same pairs (AlignPairFlat_SparsePost) are then available through mpcgpu_get_list_sparse.
+ * Like every stage-A call on a context, this one takes the context's scratch and INVALIDATES the all-pairs store the context may
+ * hold (mpcgpu_build_store / mpcgpu_store_import): callers that interleave pair lists with a consistency run use a context of
+ * their own for the lists (the drop-in's join contexts). A list is cut into chunks that one stage-A batch serves (halved as
+ * often as needed); sequences beyond ~12 000 residues are refused (error, not a fallback). */
 int mpcgpu_align_pairs(mpcgpu_ctx *ctx, uint32_t npairs, const uint32_t *seq1, const uint32_t *seq2, uint32_t path_stride,
                        char *paths, uint32_t *pathlens, float *scores, float *ea);
 /* MySparseMx::FromPost (mysparsemx.cpp:115-152) of pair q of the LAST list stage on this context (mpcgpu_align_pairs of at most 256

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mpcgpu_shard_info", "mpcgpu_shard_export", "mpcgpu_store_import", "mpcgpu_values_info", "mpcgpu_values_slice", "mpcgpu_values_export", "mpcgpu_values_import",
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_cons_commit_range", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
     "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_align_pairs", "mpcgpu_get_list_sparse", "mpcgpu_stage_a_info", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
-    "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info",
+    "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info", "mpcgpu_shard_entries",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
     "mpcgpu_group_calc_posteriors", "mpcgpu_group_cons_iter",
@@ -57,6 +57,7 @@ def load(lib_path=None):
     L.mpcgpu_calc_posteriors.argtypes = [vp, u64, u64]
     L.mpcgpu_build_store.argtypes = [vp]
     L.mpcgpu_shard_info.argtypes = [vp, C.POINTER(u64), C.POINTER(vp)]
+    L.mpcgpu_shard_entries.argtypes = [vp, C.POINTER(u64)]
     L.mpcgpu_shard_export.argtypes = [vp, vp]
     L.mpcgpu_values_export.argtypes = [vp, u64, u64, vp]
     L.mpcgpu_values_import.argtypes = [vp, u64, u64, vp]
@@ -275,6 +276,12 @@ class MpcGpu:
         b, p = C.c_uint64(), C.c_void_p()
         self._ck(self.L.mpcgpu_shard_info(self.h, C.byref(b), C.byref(p)))
         return b.value, p.value
+
+    def shard_entries(self):
+        """stored cells of this context's shard (known right after stage A)"""
+        e = C.c_uint64()
+        self._ck(self.L.mpcgpu_shard_entries(self.h, C.byref(e)))
+        return e.value
 
     def shard_export(self, dev_ptr):
         self._ck(self.L.mpcgpu_shard_export(self.h, dev_ptr))

@@ -82,6 +82,7 @@ __device__ __forceinline__ void mpc_rv_merge_cxx(float &sum, MpcQuad va, MpcQuad
 struct MpcRvBlocksCxx {
 	MpcQuad a[2], b[2];
 	__device__ __forceinline__ void load(int set, u32 ia, u32 ib) { a[set] = mpc_lds_load16(ia); b[set] = mpc_lds_load16(ib); }
+	__device__ __forceinline__ void drain() {}
 	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32 ib, u32 nia, u32 nib)
 	{
 		const MpcQuad va = a[SET], vb = b[SET];
@@ -285,6 +286,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 					}
 				};
 				slot(slot, std::integral_constant<int, 0>{});
+				blk.drain(); // the last slot's look-ahead reads land before v24..v39 can mean anything else
 			}
 			if (p.nbuf == 2 && DIAG != 2) {
 				mpc_dma_wait(); // my part of step Z+1's records is in LDS

@@ -150,6 +150,8 @@ struct MpcRvBlocksAsm {
 		if (set == 0) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "={v[24:27]}"(a0), "={v[28:31]}"(b0) : "v"(ia), "v"(ib) : "memory");
 		else asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "={v[32:35]}"(a1), "={v[36:39]}"(b1) : "v"(ia), "v"(ib) : "memory");
 	}
+	// after the last slot of a step: the look-ahead reads the last merge issued are still in flight into one of the register sets
+	__device__ __forceinline__ void drain() { asm volatile("s_waitcnt lgkmcnt(0)" : "+{v[24:27]}"(a0), "+{v[28:31]}"(b0), "+{v[32:35]}"(a1), "+{v[36:39]}"(b1) : : "memory"); }
 #define MPC_RV_MERGE_ASM(A0_, A1_, A2_, A3_, B0_, B1_, B2_, B3_, CURA_, CURB_, NXTA_, NXTB_)                           \
 	"s_waitcnt lgkmcnt(0)\n\t" /* this slot's first blocks (read during the previous slot) have landed */               \
 	"ds_read_b128 " NXTA_ ", %[nia]\n\t"                                                                                 \

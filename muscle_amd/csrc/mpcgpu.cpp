@@ -1882,6 +1882,16 @@ int mpcgpu_shard_info(mpcgpu_ctx *c, uint64_t *bytes, void **dev_ptr)
 	return 0;
 }
 
+int mpcgpu_shard_entries(mpcgpu_ctx *c, uint64_t *entries)
+{
+	if (!c) return 1;
+	if (!c->have_shard) return fail(c, "mpcgpu_shard_entries: no shard (call mpcgpu_calc_posteriors)");
+	u64 sum = 0;
+	for (u32 v : c->sh_nnz) sum += v;
+	if (entries) *entries = sum;
+	return 0;
+}
+
 int mpcgpu_shard_export(mpcgpu_ctx *c, void *dev_dst)
 {
 	if (!c) return 1;
@@ -2759,12 +2769,21 @@ int mpcgpu_align_pairs(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, con
 		const int rc = align_pairs_small(c, npairs, seq1, seq2, path_stride, paths, pathlens, scores, ea);
 		if (rc != 2) return rc;
 	}
-	const u32 CHUNK = 256; // pairs per stage-A call: their dense matrices (LX*LY floats each) live together
-	for (u32 q0 = 0; q0 < npairs; q0 += CHUNK) {
-		const u32 nq = std::min<u32>(CHUNK, npairs - q0);
-		if (stage_a(c, nq, seq1 + q0, seq2 + q0)) return 1;
-		if (c->sa_b0 != 0 || c->sa_B != nq || !c->sa_post_rows)
-			return fail(c, "mpcgpu_align_pairs: the pairs did not fit one stage-A batch of the row-list finishing kernel (sequences too long for this entry point)");
+	u32 chunk = 256; // pairs per stage-A call: their dense matrices (LX*LY floats each) live together
+	for (u32 q0 = 0; q0 < npairs;) {
+		u32 nq = std::min<u32>(chunk, npairs - q0);
+		// the dense matrices below are rebuilt from the candidate lists ONE stage-A batch leaves behind: a chunk that stage A had to
+		// cut into several batches (long sequences, little free memory) is halved and run again, down to a single pair
+		for (;;) {
+			if (stage_a(c, nq, seq1 + q0, seq2 + q0)) return 1;
+			if (c->sa_b0 == 0 && c->sa_B == nq) break;
+			if (nq == 1) return fail(c, "mpcgpu_align_pairs: pair %u (%u x %u residues) does not fit one stage-A batch", q0, c->len[seq1[q0]], c->len[seq2[q0]]);
+			nq = (nq + 1) / 2;
+			chunk = nq;
+		}
+		if (!c->sa_post_rows)
+			return fail(c, "mpcgpu_align_pairs: pair list with a sequence of more than ~12 000 residues (or MPCGPU_POST=sort): the row-list finishing kernel "
+				"whose candidate lists this entry point rebuilds the dense posteriors from does not take them");
 		// dense matrices
 		std::vector<u64> off(nq + 1, 0);
 		u32 Lsum_max = 0, LXmax = 0;
@@ -2832,6 +2851,7 @@ int mpcgpu_align_pairs(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, con
 				if (ea) ea[q0 + q] = sc / (float)std::min(LX, LY);
 			}
 		}
+		q0 += nq;
 	}
 	return 0;
 }

@@ -20,6 +20,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -57,7 +59,60 @@ struct Rccl {
 
 } // namespace
 
+// One host thread per rank, started once per group and parked between the phases of a sharded step (stage A, the two exchanges,
+// store import, relax, commit: a step used to start and join a fresh set of threads for each of them).
+struct RankPool {
+	std::vector<std::thread> th;
+	std::mutex mu;
+	std::condition_variable wake, done;
+	std::function<int(uint32_t)> fn;
+	uint64_t gen = 0;
+	uint32_t pending = 0;
+	bool stop = false;
+	std::vector<int> rc;
+	explicit RankPool(uint32_t R) : rc(R, 0)
+	{
+		for (uint32_t r = 0; r < R; ++r)
+			th.emplace_back([this, r]() {
+				uint64_t seen = 0;
+				for (;;) {
+					std::function<int(uint32_t)> job;
+					{
+						std::unique_lock<std::mutex> lk(mu);
+						wake.wait(lk, [&]() { return stop || gen != seen; });
+						if (stop) return;
+						seen = gen;
+						job = fn;
+					}
+					const int v = job(r);
+					std::lock_guard<std::mutex> lk(mu);
+					rc[r] = v;
+					if (--pending == 0) done.notify_all();
+				}
+			});
+	}
+	int run(const std::function<int(uint32_t)> &f)
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		fn = f;
+		pending = (uint32_t)th.size();
+		std::fill(rc.begin(), rc.end(), 0);
+		++gen;
+		wake.notify_all();
+		done.wait(lk, [&]() { return pending == 0; });
+		for (int v : rc) if (v) return v;
+		return 0;
+	}
+	~RankPool()
+	{
+		{ std::lock_guard<std::mutex> lk(mu); stop = true; }
+		wake.notify_all();
+		for (auto &t : th) t.join();
+	}
+};
+
 struct mpcgpu_group {
+	RankPool *pool = nullptr;
 	std::vector<int> dev;
 	std::vector<mpcgpu_ctx *> ctx;
 	std::vector<hipStream_t> xs;   // exchange stream per rank
@@ -94,15 +149,9 @@ int gfail(mpcgpu_group *g, const char *fmt, ...)
 template <class F> int per_rank(mpcgpu_group *g, F fn)
 {
 	const size_t R = g->ctx.size();
-	std::vector<int> rc(R, 0);
-	if (R == 1) { rc[0] = fn(0u); }
-	else {
-		std::vector<std::thread> th;
-		for (size_t r = 0; r < R; ++r) th.emplace_back([&, r]() { rc[r] = fn((uint32_t)r); });
-		for (auto &t : th) t.join();
-	}
-	for (size_t r = 0; r < R; ++r) if (rc[r]) return rc[r];
-	return 0;
+	if (R == 1) return fn(0u);
+	if (!g->pool) g->pool = new RankPool((uint32_t)R);
+	return g->pool->run(std::function<int(uint32_t)>(fn));
 }
 
 // Contiguous pair ranges balanced by DP cells sum (LX+1)(LY+1), InitPairs order (mpcflat.cpp:139-159): the same cuts as
@@ -186,6 +235,8 @@ const char *mpcgpu_group_transport(const mpcgpu_group *g) { return !g ? "" : g->
 void mpcgpu_group_destroy(mpcgpu_group *g)
 {
 	if (!g) return;
+	delete g->pool; // parks no more: the rank threads end before their contexts do
+	g->pool = nullptr;
 	for (size_t r = 0; r < g->ctx.size(); ++r) {
 		(void)hipSetDevice(g->dev[r]);
 		if (r < g->comm.size() && g->comm[r]) (void)g->rccl.CommDestroy(g->comm[r]);

@@ -46,12 +46,17 @@ class TorchExchange:
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
 
-    def all_sizes(self, n):
+    def all_sizes(self, *mine):
+        """ONE all-gather of this rank's counts (e.g. shard bytes and value count) -> one list per count, indexed by rank. The
+        host needs the numbers to size the gather buffers, so this is the one place of a step where it waits for a collective."""
         import torch
-        t = torch.tensor([int(n)], dtype=torch.int64, device=self.device)
-        out = torch.empty(self.world, dtype=torch.int64, device=self.device)
+        k = len(mine)
+        t = torch.tensor([int(x) for x in mine], dtype=torch.int64, device=self.device)
+        out = torch.empty(self.world * k, dtype=torch.int64, device=self.device)
         self.dist.all_gather_into_tensor(out, t)
-        return [int(x) for x in out.cpu()]
+        host = out.cpu().reshape(self.world, k)
+        cols = [[int(host[r, j]) for r in range(self.world)] for j in range(k)]
+        return cols[0] if k == 1 else cols
 
     def buffer(self, key, count, dtype):
         """a persistent 1-D device buffer of at least `count` elements (grown geometrically, reused by every step: the gathered
@@ -68,9 +73,6 @@ class TorchExchange:
         """full: 1-D tensor that already holds THIS rank's segment at its final place (offset = sum of the sizes before it);
         every other rank's segment is received straight into its own place: `world` broadcasts of exact sizes, queued
         together and waited for once — no padding to the largest shard, no staging copy."""
-        offs = [0]
-        for sz in sizes:
-            offs.append(offs[-1] + int(sz))
         works = self.start_gather_segments(full, sizes)
         return self.finish_gather_segments(full, sizes, works)
 
@@ -124,9 +126,11 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
     engine.calc_posteriors(k0, k1)
     nbytes, _ = engine.shard_info()
     t0 = time.perf_counter()
-    sizes = exchange.all_sizes(nbytes)
+    # shard bytes and value counts of every rank in one exchange (the stored cells of a shard are known once its stage A is done)
+    sizes, counts = exchange.all_sizes(nbytes, engine.shard_entries())
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    full = exchange.buffer("shards", int(offs[-1]), torch.uint8)
+    # (the buffers belong to this engine's store: an exchange that serves several engines keeps one set per engine)
+    full = exchange.buffer(("shards", id(engine)), int(offs[-1]), torch.uint8)
     engine.shard_export(full.data_ptr() + int(offs[exchange.rank]))
     full = exchange.all_gather_segments(full, sizes)
     _sync(torch, exchange.device)
@@ -136,9 +140,9 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
     # ---- relax on my shard, all-gather the values (each rank's slice straight into its place), commit everywhere
     if n >= 3:
         first, count = engine.values_slice(k0, k1)
-        counts = exchange.all_sizes(count)
+        assert count == counts[exchange.rank], (count, counts)
         voffs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        allv = exchange.buffer("values", int(voffs[-1]), torch.float32)
+        allv = exchange.buffer(("values", id(engine)), int(voffs[-1]), torch.float32)
         for _ in range(iters):
             engine.cons_iter(k0, k1)
             t0 = time.perf_counter()

@@ -61,6 +61,13 @@ def test_super7_shrubs_over_worker_contexts(emu_muscle, name, workers):
     assert md5 == _msa.golden_md5()[name]
 
 
+def test_super7_shrub_workers_over_a_device_list(emu_muscle):
+    """shrub workers + MUSCLE_GPU_DEVICES: worker contexts dealt over the listed devices, one join context per listed device, a
+    worker's joins on the join context of its device (hostcxx/mpcflat_gpu.cpp: JoinCtx)"""
+    md5, _ = _msa.run_muscle(emu_muscle, "super7_8x18_b4", threads=2, env={"MUSCLE_GPU_DEVICES": "0,0,0", "MUSCLE_GPU_SHRUB_CONTEXTS": "4"})
+    assert md5 == _msa.golden_md5()["super7_8x18_b4"]
+
+
 def test_super7_parallel_shrubs_with_progress_output(emu_muscle):
     """Default verbosity (no -quiet): MPCFlat::Run's ProgressStep keeps unguarded process globals (myutils.cpp:1453-1870), so the
     worker threads of the parallel shrub loop must not call it concurrently (round-2 advisor finding); same MSA, no crash."""

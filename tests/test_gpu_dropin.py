@@ -66,6 +66,16 @@ def test_super7_with_distmx_and_parallel_shrubs(gpu_muscle, name, workers):
     assert md5 == _msa.golden_md5()[name]
 
 
+@pytest.mark.parametrize("name", ["super7dm_300x100_b16", "super7dm_2000x250_b32"])
+def test_super7_shrub_workers_over_a_device_list(gpu_muscle, name):
+    """BASELINE config 5's second split (shrubs over GPUs): MUSCLE_GPU_DEVICES lists the devices, the shrub workers' contexts
+    are dealt over them and every worker's joins run on the join context of ITS device (one join context per listed device,
+    hostcxx/mpcflat_gpu.cpp: JoinCtx). With "0,0" on this one-GPU box: two join contexts, four workers. Same MSA."""
+    from muscle_amd.hostinfo import usable_cores
+    md5, _ = _msa.run_muscle(gpu_muscle, name, threads=usable_cores(), env={"MUSCLE_GPU_DEVICES": "0,0", "MUSCLE_GPU_SHRUB_CONTEXTS": "4"})
+    assert md5 == _msa.golden_md5()[name]
+
+
 def test_super7_parallel_shrubs_with_progress_output(gpu_muscle):
     """The same without -quiet: the reference's progress reporting is not thread-safe (myutils.cpp:1453-1870), the parallel shrub
     loop keeps its workers quiet and reports from the main thread; 40 shrubs on 8 workers, 3 repetitions."""
@@ -92,3 +102,22 @@ def test_super5_uclust_on_the_device(gpu_muscle):
     reference, 12.5 CPU-minutes — not repeated here)."""
     md5, _ = _msa.run_muscle(gpu_muscle, "super5_600x150", threads=1)
     assert md5 == _msa.golden_md5()["super5_600x150"]
+
+
+@pytest.mark.parametrize("name,env,limit_s", [
+    ("synth_1000x400_s1", {}, 60.0),                                            # BASELINE config 3 end to end: muscle -align
+    ("super7dm_10000x250_b32", {"MUSCLE_GPU_SHRUB_CONTEXTS": "8"}, 90.0),       # BASELINE config 5 end to end: -super7 + distance matrix
+])
+def test_baseline_configs_end_to_end(gpu_muscle, name, env, limit_s):
+    """BASELINE configs 3 and 5 END TO END through the reference's own CLI with the device stage linked in: the final MSA's MD5
+    is the one the unmodified compiled reference wrote (1000 x L~400 `-align`: 81 minutes on 6 threads, profiles/r01i_ref1000.log;
+    10 000 x L~250 `-super7 -distmxin`: 19 minutes on 7 threads, profiles/r03i_joins_e2e_reftime.log) — the reference is not run
+    again here. The time limits are loose guards against a silent slow path, not measurements (those are in profiles/)."""
+    import time
+    from muscle_amd.hostinfo import usable_cores
+    t0 = time.time()
+    md5, _ = _msa.run_muscle(gpu_muscle, name, threads=usable_cores(), env=env, timeout=600)
+    el = time.time() - t0
+    print("%s: %.1f s end to end, md5 %s" % (name, el, md5))
+    assert md5 == _msa.golden_md5()[name]
+    assert el < limit_s, "%s took %.1f s" % (name, el)

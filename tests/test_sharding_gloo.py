@@ -47,6 +47,9 @@ class FakeEngine:
     def shard_info(self):
         return int(self.blob.numel()), self.blob.data_ptr()
 
+    def shard_entries(self):
+        return int(self.nnz[self.k0:self.k1].sum())
+
     def shard_export(self, ptr):
         import ctypes
         ctypes.memmove(ptr, self.blob.data_ptr(), self.blob.numel())
@@ -98,10 +101,10 @@ class FakeEngine:
         pass
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, lens=(30, 45, 60, 75, 90, 33, 48)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    lens = [30, 45, 60, 75, 90, 33, 48]
+    lens = list(lens)
     eng = FakeEngine(lens)
     k0, k1 = run_stage(eng, lens, TorchExchange(dist, "cpu"), torch_mod=torch)
     q.put((rank, k0, k1, eng.imported, eng.cuts, [v for v in eng.log]))
@@ -131,6 +134,39 @@ def test_run_stage_world2_gloo():
     for it in (1, 2):
         expect = np.arange(total, dtype=np.float32) + 1000 * it
         assert np.array_equal(log0[it - 1], expect) and np.array_equal(log1[it - 1], expect)
+
+
+@pytest.mark.parametrize("world,lens", [(4, (30, 45, 60, 75, 90, 33, 48)), (8, (30, 45, 60, 75, 90, 33, 48, 52, 41)),
+                                        (8, (20, 25, 30))])  # 3 pairs on 8 ranks: five EMPTY shards
+def test_run_stage_world4_and_8_gloo(world, lens):
+    """the same exchange at the world sizes of the scaling run (4, 8), including ranks whose pair range is empty: every rank ends
+    with every shard, in order, and with every value committed exactly once per iteration"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, lens)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in ps], key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    eng = FakeEngine(list(lens))
+    npairs = eng.npairs
+    want = np.repeat(np.arange(npairs) % 251, eng.nnz).astype(np.uint8)
+    total = int(eng.vbase[-1])
+    prev_end = 0
+    for rank, k0, k1, imp, cuts, log in res:
+        assert k0 == prev_end and k1 >= k0
+        prev_end = k1
+        assert np.array_equal(imp, want), rank
+        assert cuts == res[0][4]
+        assert len(log) == 2, (rank, len(log))
+        for it in (1, 2):
+            assert np.array_equal(log[it - 1], np.arange(total, dtype=np.float32) + 1000 * it), (rank, it)
+    assert prev_end == npairs
+    if len(lens) == 3:
+        assert sum(1 for r in res if r[1] == r[2]) >= 5  # empty shards took part
 
 
 # ---------------------------------------------------------------------------------------------
