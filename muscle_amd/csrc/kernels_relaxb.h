@@ -111,30 +111,45 @@ __global__ void __launch_bounds__(64) band_index_kernel(StoreParams s, u32 nb1, 
 }
 
 // Per (sequence A, band b), over all Z: ovf_sum[A*nb1+b] = sum_Z (overflow blocks of record (A,Z) in rows < b*HB) — the mean the
-// tile cutter estimates a step's LDS need with — and ovf_maxc[A*nb1+b] = sum_{b' < b} max_Z (overflow blocks of band b') — an upper
-// bound of any step's need. One wave per sequence.
+// tile cutter estimates a step's LDS need with — and ovf_maxc[A*nb1+b] = sum over the GROUPS of MPC_RB_BG index bands that start
+// before band b of max_Z (overflow blocks of the group): an upper bound of any step's need for a range of whole groups (a range
+// is rounded out to groups; per single index band the sum of maxima was too loose to ever settle the question). One wave per
+// sequence.
+#define MPC_RB_BG 4u
 __global__ void __launch_bounds__(64) ovf_stats_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, u32 *ovf_sum, u32 *ovf_maxc)
 {
 	const u32 t = threadIdx.x, n = s.n;
 	for (u32 A = blockIdx.x; A < n; A += gridDim.x) {
 		const u32 LA = s.seq_len[A];
+		for (u32 b = t; b < nb1; b += 64) {
+			u32 sum = 0;
+			for (u32 Z = 0; Z < n; ++Z) {
+				const u64 r = mpc_rec_index(n, A, Z);
+				sum += ovf_off[r * nb1 + b] - (s.rec_off[r] + LA);
+			}
+			ovf_sum[(u64)A * nb1 + b] = sum;
+		}
+		const u32 ng = (nb1 - 1u + MPC_RB_BG - 1u) / MPC_RB_BG; // groups of bands 0 .. nb1-2 (band nb1-1 is the end marker)
 		u32 carry = 0;
-		for (u32 b0 = 0; b0 < nb1; b0 += 64) {
-			const u32 b = b0 + t;
-			u32 sum = 0, mx = 0;
-			if (b < nb1)
+		if (t == 0u) ovf_maxc[(u64)A * nb1] = 0u;
+		for (u32 g0 = 0; g0 < ng; g0 += 64) {
+			const u32 g = g0 + t;
+			u32 mx = 0;
+			if (g < ng) {
+				const u32 lo = g * MPC_RB_BG, hi = lo + MPC_RB_BG < nb1 - 1u ? lo + MPC_RB_BG : nb1 - 1u;
 				for (u32 Z = 0; Z < n; ++Z) {
 					const u64 r = mpc_rec_index(n, A, Z);
-					const u32 here = ovf_off[r * nb1 + b];
-					sum += here - (s.rec_off[r] + LA);
-					if (b + 1 < nb1) { const u32 d = ovf_off[r * nb1 + b + 1] - here; mx = d > mx ? d : mx; }
+					const u32 d = ovf_off[r * nb1 + hi] - ovf_off[r * nb1 + lo];
+					mx = d > mx ? d : mx;
 				}
+			}
 			u32 incl = mx;
 			for (int d = 1; d < 64; d <<= 1) {
 				const u32 o = __shfl_up(incl, d);
 				if (t >= (u32)d) incl += o;
 			}
-			if (b < nb1) { ovf_sum[(u64)A * nb1 + b] = sum; ovf_maxc[(u64)A * nb1 + b] = carry + incl - mx; }
+			if (g < ng)
+				for (u32 b = g * MPC_RB_BG + 1u; b <= (g + 1u) * MPC_RB_BG && b < nb1; ++b) ovf_maxc[(u64)A * nb1 + b] = carry + incl;
 			carry += __shfl(incl, 63);
 		}
 	}
@@ -185,7 +200,7 @@ __device__ __forceinline__ RbTileStats rb_tile_stats(const StoreParams &s, const
 			const u32 e1 = (a1 + MPC_RB_HB - 1u) / MPC_RB_HB;
 			first = a1 - a0;
 			sum = tb.ovf_sum[(u64)A * tb.nb1 + e1] - tb.ovf_sum[(u64)A * tb.nb1 + b0];
-			mxc = tb.ovf_maxc[(u64)A * tb.nb1 + e1] - tb.ovf_maxc[(u64)A * tb.nb1 + b0];
+			mxc = tb.ovf_maxc[(u64)A * tb.nb1 + e1] - tb.ovf_maxc[(u64)A * tb.nb1 + b0 / MPC_RB_BG * MPC_RB_BG];
 		}
 	}
 	u32 fy = 0, sy = 0, my = 0;
@@ -194,7 +209,7 @@ __device__ __forceinline__ RbTileStats rb_tile_stats(const StoreParams &s, const
 		const u32 e0 = ylo / MPC_RB_HB, e1 = (yhi + MPC_RB_HB - 1u) / MPC_RB_HB;
 		fy = yhi - ylo;
 		sy = tb.ovf_sum[(u64)A * tb.nb1 + e1] - tb.ovf_sum[(u64)A * tb.nb1 + e0];
-		my = tb.ovf_maxc[(u64)A * tb.nb1 + e1] - tb.ovf_maxc[(u64)A * tb.nb1 + e0];
+		my = tb.ovf_maxc[(u64)A * tb.nb1 + e1] - tb.ovf_maxc[(u64)A * tb.nb1 + e0 / MPC_RB_BG * MPC_RB_BG];
 	}
 	r.first = rb_wave_sum(first + fy);
 	const u32 tot = rb_wave_sum(sum + sy);
@@ -269,17 +284,36 @@ __global__ void __launch_bounds__(64) band_cut_kernel(StoreParams s, RbTileTabs 
 				}
 				++emitted;
 			};
-			// greedy first: a band takes index bands while it fits. That cut is always valid, but its last band is whatever was left
-			// over (25 index bands as 6+6+6+6+1); when an even cut into the same number of bands — or one more — fits everywhere, that
-			// one is taken. (Raising the number of bands until an even cut fits is not an option: one dense region would shred the
-			// whole super-tile into single index bands.)
-			u32 greedy = 0;
-			for (u32 b0 = 0; b0 < nb;) {
-				u32 b1 = b0 + 1u;
-				while (b1 < nb && fits(b0, b1 + 1u)) ++b1;
-				if (cum[b1] != cum[b0]) ++greedy;
-				b0 = b1;
+			// greedy first: a band takes index bands while it fits (running cell counts and column ranges: one evaluation per index
+			// band). That cut is always valid, but its last band is whatever was left over (25 index bands as 6+6+6+6+1); when an even
+			// cut into the same number of bands — or one more — fits everywhere, that one is taken. (Raising the number of bands until
+			// an even cut fits is not an option: one dense region would shred the whole super-tile into single index bands.)
+			u32 *gcut = cum + (nb + 1u); // the greedy cut's boundaries (second half of the dynamic LDS)
+			u32 greedy = 0, nbnd = 0;    // bands with cells / boundaries stored
+			{
+				u32 b0 = 0, c = 0, lo = 0xffffu, hi = 0u;
+				for (u32 b = 0; b < nb; ++b) {
+					const u32 cb = k == ~0ull ? 0u : co[b + 1] - co[b];
+					const u32 w = (k == ~0ull || !cb) ? 0xffffu : yrp[b];
+					const u32 blo = cb ? (w & 0xffffu) : 0xffffu, bhi = cb ? (w >> 16) : 0u;
+					const u32 nc = c + cb, nlo = blo < lo ? blo : lo, nhi = bhi > hi ? bhi : hi;
+					if (b > b0) {
+						const RbTileStats st = rb_tile_stats(s, tb, x0, nx, y0, ny, b0, b + 1u, nc, nlo, nhi);
+						if (st.slots > max_slots || st.est > target) { // band b does not go in: [b0, b) is closed
+							if (lane == 0u) gcut[nbnd] = b;
+							++nbnd;
+							if (cum[b] != cum[b0]) ++greedy;
+							b0 = b; c = cb; lo = blo; hi = bhi;
+							continue;
+						}
+					}
+					c = nc; lo = nlo; hi = nhi;
+				}
+				if (lane == 0u) gcut[nbnd] = nb;
+				++nbnd;
+				if (cum[nb] != cum[b0]) ++greedy;
 			}
+			MPC_WAVE_LDS_ORDER();
 			u32 parts = 0;
 			for (u32 cand_parts = greedy; cand_parts <= greedy + 1u && cand_parts <= nb && !parts; ++cand_parts) {
 				bool ok = cand_parts != 0u;
@@ -293,12 +327,7 @@ __global__ void __launch_bounds__(64) band_cut_kernel(StoreParams s, RbTileTabs 
 			if (parts) {
 				for (u32 i = 1, b0 = 0; i <= parts; ++i) { const u32 b1 = boundary(i, parts, b0); emit(b0, b1); b0 = b1; }
 			} else {
-				for (u32 b0 = 0; b0 < nb;) {
-					u32 b1 = b0 + 1u;
-					while (b1 < nb && fits(b0, b1 + 1u)) ++b1;
-					emit(b0, b1);
-					b0 = b1;
-				}
+				for (u32 i = 0, b0 = 0; i < nbnd; ++i) { const u32 b1 = gcut[i]; emit(b0, b1); b0 = b1; } // the greedy cut itself
 			}
 		}
 		if (!write && lane == 0u) count[ci] = emitted;

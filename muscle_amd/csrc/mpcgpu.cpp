@@ -562,6 +562,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			return 0;
 		};
+		u64 last_cut_candidates = 0; // super-tiles with cells in the last cut
 		// super-tiles of nx x ny sequences cut into row bands of <= max_slots cells per lane and <= target blocks per step (mean)
 		auto cut = [&](u32 nx, u32 ny, u32 target, std::vector<u32> &words, std::vector<u32> &out) -> int {
 			std::vector<u32> cand;
@@ -579,20 +580,21 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			HIPCHK(c, c->d_bt_count.ensure((size_t)nc * 4));
 			HIPCHK(c, c->d_bt_list.ensure((size_t)nc * 4));
 			const u32 grid = std::min<u32>(nc, cus * 32);
-			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 4, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 0, c->d_bt_count.as<u32>(),
+			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 8, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 0, c->d_bt_count.as<u32>(),
 				(const u32 *)nullptr, (u32 *)nullptr);
 			HIPCHK(c, hipGetLastError());
 			std::vector<u32> cnt(nc), base(nc);
 			HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_bt_count.p, (size_t)nc * 4, hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			u64 tot = 0;
-			for (u32 q = 0; q < nc; ++q) { base[q] = (u32)tot; tot += cnt[q]; }
+			last_cut_candidates = 0;
+			for (u32 q = 0; q < nc; ++q) { base[q] = (u32)tot; tot += cnt[q]; last_cut_candidates += cnt[q] ? 1 : 0; }
 			if (tot > 0x7fffffffull / MPC_RB_TILE_WORDS) return fail(c, "mpcgpu_cons_iter: too many band tiles");
 			words.assign((size_t)tot * MPC_RB_TILE_WORDS, 0u);
 			if (!tot) { out.clear(); return 0; }
 			HIPCHK(c, hipMemcpyAsync(c->d_bt_list.p, base.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
 			HIPCHK(c, c->d_btiles.ensure(words.size() * 4));
-			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 4, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 1, (u32 *)nullptr,
+			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 8, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 1, (u32 *)nullptr,
 				c->d_bt_list.as<u32>(), c->d_btiles.as<u32>());
 			HIPCHK(c, hipGetLastError());
 			HIPCHK(c, hipMemcpyAsync(words.data(), c->d_btiles.p, words.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -635,12 +637,9 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 				(unsigned long long)sc.tiles, sc.fill, sc.bytes_per_cell, 100 * sc.in_target);
 			if (!sc.tiles) { c->h_btiles.clear(); c->btiles_k0 = k0; c->btiles_k1 = k1; return 0; } // no cell in [k0,k1)
 			if (sc.fill >= 0.70 && sc.in_target >= 0.90) { use_nx = 8; use_ny = 8; use_target = half; }
-			else if (sc.in_target >= 1.0) {
-				// few cells: when the target did not cut anything (a whole staging area gives the same bands), these are the tiles
-				std::vector<u32> w2, o2;
-				if (cut(8, 8, full, w2, o2)) return 1;
-				if (o2.size() == out.size()) { use_nx = 8; use_ny = 8; use_target = half; }
-			}
+			// few cells (the shrubs of -super7: 32 sequences): nothing was cut — one band per super-tile — so no other shape or target
+			// gives fewer tile-steps, and the search below (20 more cuts) is skipped
+			else if (sc.in_target >= 1.0 && sc.tiles == last_cut_candidates) { use_nx = 8; use_ny = 8; use_target = half; }
 		}
 		if (!use_nx) {
 			// worst step / mean step of this data set: the exact worst steps of a sample of 4x2 tiles cut to the whole area (95th percentile)
