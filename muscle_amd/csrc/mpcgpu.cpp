@@ -163,6 +163,9 @@ struct mpcgpu_ctx {
 	DevBuf d_ovf_off, d_cell_off, d_yr, d_ovf_sum, d_ovf_maxc, d_btiles, d_bt_out, d_bt_cand, d_bt_count, d_bt_list;
 	std::vector<u32> h_btiles;
 	u64 btiles_k0 = ~0ull, btiles_k1 = ~0ull;
+	const void *band_fn = nullptr; // relax_band: kernel, LDS size and occupancy of the last launch (runtime queries cached)
+	size_t band_smem = 0;
+	int band_occ = 0;
 
 	// scratch
 	DevBuf d_bnd;
@@ -630,6 +633,20 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 				if (cut(use_nx, use_ny, use_target, words, out)) return 1;
 			}
 		}
+		if (!use_nx && n <= 64) {
+			// few sequences (the shrubs of -super7, the clusters of -super5): the 8 x 8 super-tiles with ALL their rows as one band
+			// each, evaluated in one pass; taken when every one of them fits the cell slots and leaves room for the next step
+			std::vector<u32> w2, o2;
+			for (u32 x0 = 0; x0 < n; x0 += 8)
+				for (u32 y0 = x0; y0 < n; y0 += 8) {
+					u32 nw[MPC_RB_TILE_WORDS] = {x0, std::min(8u, n - x0), y0, std::min(8u, n - y0), 0u, (nb1 - 1) * (u32)MPC_RB_HB};
+					if (y0 + nw[3] > x0 + 1) w2.insert(w2.end(), nw, nw + MPC_RB_TILE_WORDS);
+				}
+			if (eval_tiles(w2, o2)) return 1;
+			bool ok = !w2.empty();
+			for (size_t t = 0; t + 3 < o2.size(); t += 4) ok = ok && o2[t] <= max_slots && o2[t + 1] <= half;
+			if (ok) { words.swap(w2); out.swap(o2); use_nx = 8; use_ny = 8; use_target = half; }
+		}
 		if (!use_nx) {
 			if (cut(8, 8, half, words, out)) return 1;
 			const Score sc = score(out, half);
@@ -790,9 +807,15 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbBlocksCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbBlocksCxx>), grid, kBandThreads, smem, c->stream, rp); }
 		else { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2>), grid, kBandThreads, smem, c->stream, rp); }
 		if (!go) {
-			HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+			// (the two runtime queries cost a good fraction of a millisecond: once per context, kernel and LDS size — a -super7 run
+			// relaxes 400 small stores on every worker context)
 			int occ = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)bthreads, smem) != hipSuccess || occ < 1) occ = 1;
+			if (c->band_fn == fn && c->band_smem == smem) occ = c->band_occ;
+			else {
+				HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+				if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, (int)bthreads, smem) != hipSuccess || occ < 1) occ = 1;
+				c->band_fn = fn; c->band_smem = smem; c->band_occ = occ;
+			}
 			grid = std::max(std::min<u32>(ntiles, cus * (u32)occ), 1u);
 			char kn[128];
 			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, %u, %d, %s>", bthreads, kBandSlots, bthreads == 512 ? 4u : 2u, bthreads == 512 ? 0 : diag, merge_cxx && !diag ? "MpcRbBlocksCxx" : "MpcRbBlocksAsm");

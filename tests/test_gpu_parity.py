@@ -283,14 +283,24 @@ def test_relax_gather_equals_tiled():
         del os.environ["MPCGPU_RELAX"]
     P.assert_same(a, b, "gather vs tiled")
     P.assert_same(a, P.run_oracle(seqs), "tiled vs oracle")
-    # the other workgroup geometries of relax_var_kernel (default: two 768-thread workgroups per CU)
-    for geo, nbuf in (("1024", "2"), ("1024", "1"), ("512", "1"), ("2048", "1")):
-        os.environ["MPCGPU_RELAX_WG"], os.environ["MPCGPU_RELAX_NBUF"] = geo, nbuf
+    # relax_band_kernel (the default above) in forced tile shapes and staging modes, with the compiler's merge instead of the
+    # hand-scheduled one (the shipped asm is pinned only here, on hardware: the emulator runs the C++ statement), and in its
+    # four-workgroups-per-CU geometry; relax_var_kernel (whole-record tiles) in its geometries
+    variants = [{"MPCGPU_RELAX_SHAPE": "8,8"}, {"MPCGPU_RELAX_SHAPE": "4,2,12"}, {"MPCGPU_RELAX_SHAPE": "1,1"},
+                {"MPCGPU_RELAX_SHAPE": "8,8", "MPCGPU_RELAX_SLOTS": "2"}, {"MPCGPU_RELAX_LDS_KB": "24"},
+                {"MPCGPU_RELAX_MERGE": "cxx"}, {"MPCGPU_RELAX_WG": "512"}]
+    variants += [{"MPCGPU_RELAX_TILES": "pairs", "MPCGPU_RELAX_WG": geo, "MPCGPU_RELAX_NBUF": nbuf}
+                 for geo, nbuf in (("2048", "1"), ("1024", "2"), ("1024", "1"), ("512", "1"), ("768", "1"))]
+    for env in variants:
+        os.environ.update(env)
         try:
-            r = P.run_lib(seqs)
+            info = {}
+            r = P.run_lib(seqs, info=info)
         finally:
-            del os.environ["MPCGPU_RELAX_WG"], os.environ["MPCGPU_RELAX_NBUF"]
-        P.assert_same(a, r, "relax geometry %s, %s staging buffers" % (geo, nbuf))
+            for k in env:
+                del os.environ[k]
+        P.assert_same(a, r, "relax variant %s" % env)
+        assert ("relax_var_kernel" if "MPCGPU_RELAX_TILES" in env else "relax_band_kernel") in info["relax_info"], (env, info["relax_info"])
 
 
 @pytest.mark.parametrize("kernel", ["by size", "one wave", "waves", "lds rows"])
