@@ -44,6 +44,7 @@
 // the emulator runs this one, the device can: MPCGPU_RELAX_MERGE=cxx). ia: address of the X row's first block + the X record's hop
 // bias; ib: address of the Y row's first block — its record's bias, gathered one slot ahead, is added here.
 struct MpcRbBlocksCxx {
+	static constexpr bool WINDOW = false;
 	MpcQuad a[2], b[2];
 	u32 hb;
 	__device__ __forceinline__ void load(u32 ia, u32 ib, u32 hb_addr) { a[0] = mpc_lds_load16(ia); b[0] = mpc_lds_load16(ib); hb = mpc_lds_load4(hb_addr); } // hb_addr: LDS address of the first slot's Y bias
@@ -59,6 +60,43 @@ struct MpcRbBlocksCxx {
 };
 #ifndef MPC_RB_HAVE_ASM
 typedef MpcRbBlocksCxx MpcRbBlocksAsm; // the emulator has the C++ statement only
+#endif
+
+// The DIRECT-INDEX merge in C++ (MpcRbWinAsm, mpc_platform.h, is the hand-scheduled form): the X row is walked block by block,
+// every X entry (z, P) looks its partner up in the Y row's WINDOW (StoreParams::win): value = val[off + min(z - c0, span)] — a
+// column the row does not store reads 0.0f (inside the window) or the 0.0f guard at off + span (outside, also below c0: the
+// unsigned difference wraps). P * 0.0f = +0.0f leaves the strictly positive sum unchanged, so the additions that count are those of
+// the reference, in z order. yd: LDS address of the Y row's descriptor (the next row's follows it); hb: LDS address of the value
+// area of the cell's Y record as it lies in this step's buffer (gathered one slot ahead).
+struct MpcRbWinCxx {
+	static constexpr bool WINDOW = true;
+	MpcQuad a[2];
+	u32 d0[2], d1[2];
+	u32 hb;
+	__device__ __forceinline__ void load(u32 ia, u32 yd, u32 hb_addr) { a[0] = mpc_lds_load16(ia); d0[0] = mpc_lds_load4(yd); d1[0] = mpc_lds_load4(yd + 4u); hb = mpc_lds_load4(hb_addr); }
+	__device__ __forceinline__ void drain() {}
+	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32, u32 nia, u32 nyd, u32 nidx, u32 bias_y)
+	{
+		MpcQuad va = a[SET];
+		const u32 D0 = d0[SET], D1 = d1[SET], base = hb;
+		a[SET ^ 1] = mpc_lds_load16(nia); d0[SET ^ 1] = mpc_lds_load4(nyd); d1[SET ^ 1] = mpc_lds_load4(nyd + 4u);
+		hb = mpc_lane_gather(bias_y, nidx);
+		const u32 c0 = D0 & 0xfffu, off = D0 >> 12, span = (D1 >> 12) - off - 1u, vb = base + 4u * off;
+		for (;;) {
+			u32 j0 = (va.z & 0xffffu) - c0, j1 = va.w - c0;
+			j0 = j0 < span ? j0 : span; j1 = j1 < span ? j1 : span;
+			const float v0 = __uint_as_float(mpc_lds_load4(vb + 4u * j0)), v1 = __uint_as_float(mpc_lds_load4(vb + 4u * j1));
+			sum += __uint_as_float(va.x) * v0; // relaxflat.cpp:27 (w == 1.0f): product rounded, then added
+			sum += __uint_as_float(va.y) * v1;
+			const u32 d = va.z >> 16;
+			if (d == 0u) break;
+			ia += d;
+			va = mpc_lds_load16(ia);
+		}
+	}
+};
+#ifndef MPC_RW_HAVE_ASM
+typedef MpcRbWinCxx MpcRbWinAsm;
 #endif
 
 struct RelaxBandParams {
@@ -116,16 +154,19 @@ __global__ void __launch_bounds__(64) band_index_kernel(StoreParams s, u32 nb1, 
 // is rounded out to groups; per single index band the sum of maxima was too loose to ever settle the question). One wave per
 // sequence.
 #define MPC_RB_BG 4u
-__global__ void __launch_bounds__(64) ovf_stats_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, u32 *ovf_sum, u32 *ovf_maxc)
+// (win != 0: the same over the VALUE areas of the window records: ovf_off = wv_off, a record's dynamic part starts after its
+// descriptor blocks)
+__global__ void __launch_bounds__(64) ovf_stats_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, u32 *ovf_sum, u32 *ovf_maxc, int win)
 {
 	const u32 t = threadIdx.x, n = s.n;
+	const u32 *rstart = win ? s.wrec_off : s.rec_off;
 	for (u32 A = blockIdx.x; A < n; A += gridDim.x) {
-		const u32 LA = s.seq_len[A];
+		const u32 LA = win ? (s.seq_len[A] + 1u + 3u) / 4u : s.seq_len[A]; // blocks of the static part of a record
 		for (u32 b = t; b < nb1; b += 64) {
 			u32 sum = 0;
 			for (u32 Z = 0; Z < n; ++Z) {
 				const u64 r = mpc_rec_index(n, A, Z);
-				sum += ovf_off[r * nb1 + b] - (s.rec_off[r] + LA);
+				sum += ovf_off[r * nb1 + b] - (rstart[r] + LA);
 			}
 			ovf_sum[(u64)A * nb1 + b] = sum;
 		}
@@ -158,6 +199,8 @@ __global__ void __launch_bounds__(64) ovf_stats_kernel(StoreParams s, const u32 
 // ---- tiles: statistics of one band tile, by one wave (lane = pair ix*8+iy) --------------------------------------------------------
 struct RbTileTabs {
 	const u32 *cell_off, *yr, *ovf_sum, *ovf_maxc;
+	const u32 *ysum, *ymaxc; // the same two tables for the Y records' dynamic pieces: the overflow blocks again, or (win) the value areas of the window records
+	u32 win;                 // the Y records are staged as window records: descriptor rows (4 per block) + values
 	u32 nb1, threads;
 	u64 k0, k1;
 };
@@ -207,9 +250,10 @@ __device__ __forceinline__ RbTileStats rb_tile_stats(const StoreParams &s, const
 	if (ix == 0u && iy < ny && yany) {
 		const u32 A = y0 + iy;
 		const u32 e0 = ylo / MPC_RB_HB, e1 = (yhi + MPC_RB_HB - 1u) / MPC_RB_HB;
-		fy = yhi - ylo;
-		sy = tb.ovf_sum[(u64)A * tb.nb1 + e1] - tb.ovf_sum[(u64)A * tb.nb1 + e0];
-		my = tb.ovf_maxc[(u64)A * tb.nb1 + e1] - tb.ovf_maxc[(u64)A * tb.nb1 + e0 / MPC_RB_BG * MPC_RB_BG];
+		// window records: descriptors of rows [ylo & ~3, yhi] (4 per block) and the value blocks of the bands, + the block the range ends in
+		fy = tb.win ? (yhi + 1u - (ylo & ~3u) + 3u) / 4u : yhi - ylo;
+		sy = tb.ysum[(u64)A * tb.nb1 + e1] - tb.ysum[(u64)A * tb.nb1 + e0] + (tb.win ? n : 0u);
+		my = tb.ymaxc[(u64)A * tb.nb1 + e1] - tb.ymaxc[(u64)A * tb.nb1 + e0 / MPC_RB_BG * MPC_RB_BG] + (tb.win ? 1u : 0u);
 	}
 	r.first = rb_wave_sum(first + fy);
 	const u32 tot = rb_wave_sum(sum + sy);
@@ -364,9 +408,11 @@ __global__ void __launch_bounds__(64) band_eval_kernel(StoreParams s, RbTileTabs
 }
 
 // The 16 records of a tile as relax_band_kernel stages them: record i < 8 is X sequence x0+i with rows [r0, min(r1, len)),
-// record 8+j is Y sequence y0+j with rows [ylo_j, yhi_j). Returns sequence, first row, rows, and the index bands [e0, e1) whose
-// overflow blocks belong to the piece (rows == 0: nothing is staged).
-__device__ __forceinline__ void rb_record(const StoreParams &s, const u32 *tw, u32 i, u32 *S, u32 *row0, u32 *rows, u32 *e0, u32 *e1)
+// record 8+j is Y sequence y0+j with rows [ylo_j, yhi_j). Returns the sequence, the first block of the static piece inside the
+// record (*blk0), its blocks (*blocks; 0: nothing is staged), the index bands [e0, e1) whose dynamic blocks belong to the piece,
+// and *arow: the row the piece's first block starts with. Block form: one block per row. Window form (win, Y records only): the
+// static piece is the descriptors of rows [ylo & ~3, yhi] — 4 per block, the pair a cell reads ends with row yhi's successor.
+__device__ __forceinline__ void rb_record(const StoreParams &s, const u32 *tw, u32 i, u32 win, u32 *S, u32 *blk0, u32 *blocks, u32 *e0, u32 *e1, u32 *arow)
 {
 	const u32 x0 = tw[0], nx = tw[1], y0 = tw[2], ny = tw[3], r0 = tw[4], r1 = tw[5];
 	u32 a0 = 0, a1 = 0, A = x0;
@@ -378,26 +424,31 @@ __device__ __forceinline__ void rb_record(const StoreParams &s, const u32 *tw, u
 		a0 = w & 0xffffu; a1 = w >> 16;
 	}
 	if (a1 <= a0) { a0 = 0; a1 = 0; }
-	*S = A; *row0 = a0; *rows = a1 - a0;
+	*S = A;
 	*e0 = a0 / MPC_RB_HB; *e1 = a1 > a0 ? (a1 + MPC_RB_HB - 1u) / MPC_RB_HB : a0 / MPC_RB_HB;
+	if (win && i >= MPC_RB_MAXN) {
+		*arow = a0 & ~3u; *blk0 = a0 / 4u;
+		*blocks = a1 > a0 ? (a1 + 1u - (a0 & ~3u) + 3u) / 4u : 0u;
+	} else { *arow = a0; *blk0 = a0; *blocks = a1 - a0; }
 }
 
 // out[t] = max over Z of the blocks tile list[t] stages at step Z (first pieces + overflow pieces): the exact LDS need of its
 // worst step. One wave per tile, lanes stride over Z.
-__global__ void __launch_bounds__(64) band_fit_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, const u32 *tiles, const u32 *list, u32 nlist, u32 *out)
+__global__ void __launch_bounds__(64) band_fit_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, const u32 *tiles, const u32 *list, u32 nlist, u32 *out, u32 win)
 {
 	const u32 lane = threadIdx.x & 63u, n = s.n;
 	for (u32 q = blockIdx.x; q < nlist; q += gridDim.x) {
 		const u32 *tw = tiles + (u64)MPC_RB_TILE_WORDS * list[q];
 		u32 S[16], e0[16], e1[16], first = 0;
-		for (u32 i = 0; i < 16u; ++i) { u32 row0, rows; rb_record(s, tw, i, &S[i], &row0, &rows, &e0[i], &e1[i]); first += rows; }
+		for (u32 i = 0; i < 16u; ++i) { u32 blk0, blocks, arow; rb_record(s, tw, i, win, &S[i], &blk0, &blocks, &e0[i], &e1[i], &arow); first += blocks; }
 		u32 best = 0;
 		for (u32 Z = lane; Z < n; Z += 64) {
 			u32 sum = first;
 			for (u32 i = 0; i < 16u; ++i) {
 				if (e1[i] == e0[i]) continue;
 				const u64 r = mpc_rec_index(n, S[i], Z) * nb1;
-				sum += ovf_off[r + e1[i]] - ovf_off[r + e0[i]];
+				if (win && i >= MPC_RB_MAXN) sum += s.wv_off[r + e1[i]] - s.wv_off[r + e0[i]] + 1u;
+				else sum += ovf_off[r + e1[i]] - ovf_off[r + e0[i]];
 			}
 			best = sum > best ? sum : best;
 		}
@@ -419,6 +470,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 	const u32 lane = tid & 63u;
 	const u32 n = s.n;
 	constexpr u32 NWAVES = THREADS / 64;
+	constexpr bool WIN = BLOCKS::WINDOW;      // the Y records are window records, looked up by column (MpcRbWinAsm / MpcRbWinCxx)
 	constexpr u32 YREGS = (MAXSLOTS + 5) / 6; // 4 * iy of a slot's cell: 5 bits, 6 slots per register
 	const u32 wave = mpc_wave_first(tid >> 6); // scalar
 	u32 *ptab = (u32 *)(smem_raw + MPC_RB_PTAB); // [64][4]: first cell, cells, pair, first entry
@@ -483,15 +535,19 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			e[0] = gbase + w - cnt; e[1] = cnt; e[2] = kk; e[3] = e0;
 			if (iy == 0u) { gtab[2 * ix] = gbase; gtab[2 * ix + 1] = gbase + gtot; }
 			// pieces
-			u32 S, row0, rows, b0, b1;
-			rb_record(s, tw, lane & 15u, &S, &row0, &rows, &b0, &b1);
+			u32 S, row0, rows, b0, b1, arow;
+			rb_record(s, tw, lane & 15u, WIN ? 1u : 0u, &S, &row0, &rows, &b0, &b1, &arow);
 			u32 fi = lane < 16u ? rows : 0u;
 			for (int d = 1; d < 16; d <<= 1) { const u32 o = __shfl_up(fi, d); if (lane >= (u32)d) fi += o; }
 			const u32 ftot = __shfl(fi, 15);
 			if (lane < 16u) {
 				u32 *r = rtab + 8 * lane;
 				const u32 fst = fi - rows;
-				r[0] = fst; r[1] = rows; r[2] = row0 - fst; r[3] = S; r[4] = b0; r[5] = b1;
+				// [0] place of the static piece in a step's buffer (blocks), [1] its blocks, [2] its first block in the record minus [0],
+				// [3] sequence, [4] / [5] index bands of the dynamic piece, [6] first row of the static piece, [7] the record's bias
+				// constant: [2] again for block records (hop bias), the descriptor blocks of a window record (its value area starts there)
+				r[0] = fst; r[1] = rows; r[2] = row0 - fst; r[3] = S; r[4] = b0; r[5] = b1; r[6] = arow;
+				r[7] = (WIN && lane >= MPC_RB_MAXN) ? (s.seq_len[S] + 1u + 3u) / 4u : row0 - fst;
 			}
 			if (lane == 0u) { misc[1] = total; misc[2] = ftot; }
 		}
@@ -541,7 +597,9 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 				acc[q] = __uint_as_float(ent[2 * (u64)e]) * 2.0f; // conspairflat.cpp:29-30
 				const u32 col = ent[2 * (u64)e + 1], row = ent[2 * (u64)nnz + e];
 				// row - row0 + first-piece offset, in bytes (rtab[..][2] = row0 - offset)
-				const u32 xo = (row - rtab[8 * ix + 2]) << 4, yo = (col - rtab[8 * (MPC_RB_MAXN + iy) + 2]) << 4;
+				const u32 xo = (row - rtab[8 * ix + 2]) << 4;
+				const u32 yo = WIN ? (rtab[8 * (MPC_RB_MAXN + iy)] << 4) + ((col - rtab[8 * (MPC_RB_MAXN + iy) + 6]) << 2) // the row's descriptor
+				                   : (col - rtab[8 * (MPC_RB_MAXN + iy) + 2]) << 4;                                        // the row's first block
 				xy[q] = xo | (yo << 16);
 				yreg[q / 6] |= (4u * iy) << (5 * (q % 6));
 				sel_a[q / 10] |= mpc_wave_first(ix) << (3 * (q % 10));
@@ -562,7 +620,9 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			// one base pointer and an element offset (a select between two POINTERS became a two-entry table in scratch memory, read
 			// back with a load whose wait — vmcnt(0) — also waited for the prefetch the wave had just issued)
 			const bool wide = role == 1u || role == 2u;
-			const long long off = wide ? (long long)(p.ovf_off - s.rec_off) + (long long)(rec * p.nb1 + (role == 1u ? b0 : b1)) : (long long)rec;
+			const bool wrec = WIN && li >= MPC_RB_MAXN; // a window record: its own record table and band table
+			const long long off = (wide ? (long long)((wrec ? s.wv_off : p.ovf_off) - s.rec_off) + (long long)(rec * p.nb1 + (role == 1u ? b0 : b1))
+			                            : (wrec ? (long long)(s.wrec_off - s.rec_off) : 0ll) + (long long)rec);
 			if (ln < 48u) mpc_dma4(s.rec_off + off, ttab + 64u * (Zt & 1u));
 		};
 		// Everything the staging of a step needs comes out of ONE round of LDS reads — the step's table (lane i = record i, in every
@@ -579,8 +639,8 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			const u32 li = ln & 15u;
 			const u32 *tt = ttab + 64u * (Zs & 1u);
 			const u32 R = tt[li], Oa = tt[16u + li], Ob = tt[32u + li];
-			const u32 rt_first = rtab[8 * li], rt_rows = rtab[8 * li + 1], rt_c = rtab[8 * li + 2];
-			const u32 ovl = Ob - Oa;
+			const u32 rt_first = rtab[8 * li], rt_rows = rtab[8 * li + 1], rt_c = rtab[8 * li + 2], rt_d = rtab[8 * li + 7];
+			const u32 ovl = Ob - Oa + ((WIN && li >= MPC_RB_MAXN && rt_rows != 0u) ? 1u : 0u); // (value blocks: + the block the range ends in)
 			const u32 incl = mpc_row16_scan_add(ovl); // the 16 records are the 16 lanes of a DPP row
 			const u32 O = ftot + incl - ovl;
 			const u32 src0 = R + rt_c + rt_first;
@@ -592,17 +652,23 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 				s_len[j] = fp ? mpc_read_lane(rt_rows, rec) : mpc_read_lane(ovl, rec);
 				s_dst[j] = fp ? mpc_read_lane(rt_first, rec) : mpc_read_lane(O, rec);
 			}
-			*bias = (O + R - Oa + rt_c) << 4;
+			// block record: hop bias (first-block address + bias + distance = the overflow block); window record: where its value area
+			// would start in the buffer (+ the buffer's LDS address: stage_next), so that value d of the area is at bias + 4 d
+			*bias = (O + R - Oa + rt_d) << 4;
 			return ftot + mpc_read_lane(incl, 15u);
 		};
 		auto issue_dma = [&](u32 at) { // at: byte offset of the step's buffer in the staging area
 			u32 ln = lane;
 			MPC_OPAQUE(ln);
 #pragma unroll
-			for (u32 j = 0; j < PIECES; ++j)
+			for (u32 j = 0; j < PIECES; ++j) {
+				const unsigned char *src = (WIN && ((wave + j * NWAVES) & 15u) >= MPC_RB_MAXN) ? (const unsigned char *)s.win : padb;
 				for (u32 c0 = 0; c0 < s_len[j]; c0 += 64u)
-					if (c0 + ln < s_len[j]) mpc_dma16(padb + 16 * (u64)(s_src[j] + c0 + ln), stage + at + 16 * (s_dst[j] + c0));
+					if (c0 + ln < s_len[j]) mpc_dma16(src + 16 * (u64)(s_src[j] + c0 + ln), stage + at + 16 * (s_dst[j] + c0));
+			}
 		};
+		// window records: the Y lanes' biases become LDS addresses (the merge adds 4 * offset to them, nothing else)
+		auto y_abs = [&](u32 bias, u32 at) -> u32 { u32 ln = lane; MPC_OPAQUE(ln); return (WIN && (ln & 15u) >= MPC_RB_MAXN) ? bias + lds_stage + at : bias; };
 		// the biases of a step go through LDS as well (every wave computes the same 16 words and writes them to the same place)
 		auto put_bias = [&](u32 Zs, u32 bias) { u32 ln = lane; MPC_OPAQUE(ln); if (ln < 16u) btab[16u * (Zs & 1u) + ln] = bias; };
 
@@ -616,7 +682,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 		{
 			u32 b;
 			cur_len = 16u * step_vectors(0, &b);
-			put_bias(0, b);
+			put_bias(0, y_abs(b, 0u));
 			issue_dma(0);
 			mpc_dma_wait();
 		}
@@ -629,9 +695,9 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			if (Z + 1 >= n) return;
 			u32 b;
 			nxt_len = 16u * step_vectors(Z + 1, &b);
-			put_bias(Z + 1, b);
 			if (cur_at == 0u) { nxt_at = p.cap_bytes - nxt_len; pre = nxt_len <= p.cap_bytes && nxt_at >= cur_len; }
 			else { nxt_at = 0u; pre = nxt_len <= cur_at; }
+			put_bias(Z + 1, y_abs(b, pre ? nxt_at : 0u)); // (a step that is not prefetched is staged at the bottom, below)
 			if (pre) issue_dma(nxt_at);
 #ifdef MPC_RELAX_DIAG_BUILD
 			if (tid == 0) atomicAdd(&p.tile_next[pre ? 9 : 8], 1u); // measurement build: steps prefetched / staged late

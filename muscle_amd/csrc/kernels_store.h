@@ -64,6 +64,19 @@ struct StoreParams {
 	// null: not wanted.
 	u32 *ovf_off;
 	u32 nb1;
+	// WINDOW records (kernels_relaxb.h, the direct-index merge; null: not built): a second copy of every ordered pair's matrix for
+	// the role of the Y operand, in which a row is looked up BY COLUMN instead of being walked:
+	//   record (A,Z) = [desc: len(A)+1 words, padded to 16 bytes][values, + one spare block], at block wrec_off[Z*n+A] of `win`
+	//   desc[a] = c0 | off << 12: first stored column of row a (0: none) and the dword offset of its values in the value area;
+	//   desc[len(A)] = total << 12. Row a owns dwords off .. off + span (span = last - first + 1 columns, 0 for an empty row):
+	//   the probability of column c0 + j at off + j (0.0f where that column is not stored), and 0.0f at off + span — the GUARD that
+	//   every column outside the window is clamped to: value(z) = val[off + min(z - c0 (unsigned), span)].
+	// wv_off[(Z*n+A)*nb1 + b] = block of `win` that holds the first value of row MPC_RB_HB*b (the record's end beyond the last row).
+	// pos_wf / pos_wt: per canonical entry, the dword of its probability inside the value area of the record of (X,Y) / (Y,X).
+	u32 *win;
+	const u32 *wrec_off;
+	u32 *wv_off;
+	unsigned short *pos_wf, *pos_wt;
 };
 
 #define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128)
@@ -224,6 +237,130 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 	}
 }
 
+// ---- window records (see StoreParams::win) -----------------------------------------------------------------------------------
+// value dwords of window record (A,Z): sum over rows of (span + 1); sizes[b] = blocks of the record = desc blocks + value blocks
+// + 1 spare; *too_wide is set when a record's value area does not fit the 16-bit positions. One wave per record.
+__global__ void __launch_bounds__(64) win_size_kernel(StoreParams s, u32 *sizes, u32 *vals_total, u32 *too_wide)
+{
+	const int t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n);
+		const u32 LA = s.seq_len[A];
+		u32 mine = 0;
+		if (A != Z) {
+			const bool fwd = A < Z;
+			const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+			// the span of row a of M(A,Z) = last - first + 1 of the stored columns: from the record of (A,Z) in block form (first block
+			// of the row: its first column; the row's last block: its last column) — already built
+			const u32 *rec = s.pad + 4 * (u64)s.rec_off[b];
+			for (u32 a = t; a < LA; a += 64) {
+				u32 blk = a;
+				const u32 c_first = rec[4 * blk + 2] & 0xffffu;
+				u32 span = 0;
+				if (c_first != MPC_PAD_SENTINEL) {
+					for (u32 d = rec[4 * blk + 2] >> 20; d != 0u; d = rec[4 * blk + 2] >> 20) blk += d; // distance in blocks (bytes / 16)
+					span = rec[4 * blk + 3] - c_first + 1u;
+				}
+				mine += span + 1u;
+			}
+			for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
+			(void)k;
+		} else mine = LA; // empty matrix: every row is its guard alone
+		if (t == 0) {
+			sizes[b] = (LA + 1u + 3u) / 4u + (mine + 3u) / 4u + 1u;
+			vals_total[b] = mine;
+			if (mine > 0xffffu) atomicOr(too_wide, 1u);
+		}
+	}
+}
+
+// Builds window record (A,Z) from the block-form record of the same ordered pair, and wv_off. One wave per record; dynamic LDS:
+// lcap1 + 1 words (the rows' value offsets).
+__global__ void __launch_bounds__(64) win_build_kernel(StoreParams s)
+{
+	MPC_DYN_SMEM(smem_raw);
+	u32 *s_off = (u32 *)smem_raw;
+	const u32 t = threadIdx.x;
+	const u64 total = (u64)s.n * s.n;
+	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
+		const u32 A = (u32)(b % s.n);
+		const u32 LA = s.seq_len[A];
+		const u32 *rec = s.pad + 4 * (u64)s.rec_off[b];
+		u32 *wrec = s.win + 4 * (u64)s.wrec_off[b];
+		const u32 dblocks = (LA + 1u + 3u) / 4u;
+		u32 *desc = wrec, *vals = wrec + 4 * (u64)dblocks;
+		// spans and first columns per row, exclusive scan of span + 1
+		u32 carry = 0;
+		for (u32 a0 = 0; a0 <= LA; a0 += 64) {
+			const u32 a = a0 + t;
+			u32 c_first = 0, span = 0;
+			if (a < LA) {
+				u32 blk = a;
+				const u32 cf = rec[4 * blk + 2] & 0xffffu;
+				if (cf != MPC_PAD_SENTINEL) {
+					for (u32 d = rec[4 * blk + 2] >> 20; d != 0u; d = rec[4 * blk + 2] >> 20) blk += d;
+					c_first = cf; span = rec[4 * blk + 3] - cf + 1u;
+				}
+			}
+			const u32 v = a < LA ? span + 1u : 0u;
+			u32 incl = v;
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = __shfl_up(incl, d);
+				if (t >= (u32)d) incl += o;
+			}
+			const u32 off = carry + incl - v;
+			if (a <= LA) { desc[a] = c_first | (off << 12); s_off[a] = off; }
+			carry += __shfl(incl, 63);
+		}
+		for (u32 q = LA + 1u + t; q < 4u * dblocks; q += 64) desc[q] = carry << 12; // padding words repeat the end marker
+		__syncthreads();
+		const u32 vtotal = carry, vblocks = (vtotal + 3u) / 4u + 1u;
+		for (u32 q = t; q < 4u * vblocks; q += 64) vals[q] = 0u; // 0.0f everywhere: guards and the gaps inside the windows
+		if (s.wv_off)
+			for (u32 q = t; q < s.nb1; q += 64)
+				s.wv_off[b * s.nb1 + q] = MPC_RB_HB * q < LA ? s.wrec_off[b] + dblocks + s_off[MPC_RB_HB * q] / 4u : s.wrec_off[b + 1] - 1u;
+		__syncthreads();
+		// the probabilities: every entry of the block-form record goes to off(row) + (col - first col of the row)
+		for (u32 a = t; a < LA; a += 64) {
+			u32 blk = a;
+			const u32 cf = rec[4 * blk + 2] & 0xffffu;
+			if (cf == MPC_PAD_SENTINEL) continue;
+			const u32 off = s_off[a];
+			for (;;) {
+				const u32 c0 = rec[4 * blk + 2] & 0xffffu, c1 = rec[4 * blk + 3];
+				vals[off + (c0 - cf)] = rec[4 * blk];
+				if (c1 != c0) vals[off + (c1 - cf)] = rec[4 * blk + 1]; // (a one-entry block repeats its column with 0.0f)
+				const u32 d = rec[4 * blk + 2] >> 20;
+				if (d == 0u) break;
+				blk += d;
+			}
+		}
+		__syncthreads(); // s_off is reused by the next record
+	}
+}
+
+// pos_wf / pos_wt: the dword (inside the value area of its window record) of every canonical entry. One wave per pair.
+__global__ void __launch_bounds__(64) win_pos_kernel(StoreParams s)
+{
+	const u32 t = threadIdx.x;
+	for (u64 k = blockIdx.x; k < s.npairs; k += gridDim.x) {
+		const u32 X = s.pair_x[k], Y = s.pair_y[k];
+		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];
+		const u32 *prec = s.packed + s.pbase[k];
+		const u32 *ent = prec + LX + LY;
+		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
+		const u32 *dxy = s.win + 4 * (u64)s.wrec_off[mpc_rec_index(s.n, X, Y)];
+		const u32 *dyx = s.win + 4 * (u64)s.wrec_off[mpc_rec_index(s.n, Y, X)];
+		for (u32 q = t; q < nnz; q += 64) {
+			const u32 col = ent[2 * (u64)q + 1], row = ent[2 * (u64)nnz + q];
+			const u32 wf = dxy[row], wt = dyx[col];
+			s.pos_wf[s.vbase[k] + q] = (unsigned short)((wf >> 12) + (col - (wf & 0xfffu)));
+			s.pos_wt[s.vbase[k] + q] = (unsigned short)((wt >> 12) + (row - (wt & 0xfffu)));
+		}
+	}
+}
+
 // Largest LDS footprint of a tile's records over one walk: out[t] = max over Z of the blocks of the two runs relax_var_kernel
 // stages per step — records (x0..x0+nx-1, Z) and, of the Y range, the records beyond the X range (y >= x0+nx; a Y inside the X
 // range is already resident, a Y below it has no pair X < Y in the tile). One wave per tile, lanes stride over Z.
@@ -347,6 +484,10 @@ __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s, u64 e0, 
 		const u32 pf = s.pos_f[e], pt = s.pos_t[e];
 		s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, X, Y)] + (pf >> 1) * 4u + (pf & 1u)] = pb;
 		s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, Y, X)] + (pt >> 1) * 4u + (pt & 1u)] = pb;
+		if (s.win) { // the window copies of both orientations
+			s.win[4 * ((u64)s.wrec_off[mpc_rec_index(s.n, X, Y)] + (LX + 1u + 3u) / 4u) + s.pos_wf[e]] = pb;
+			s.win[4 * ((u64)s.wrec_off[mpc_rec_index(s.n, Y, X)] + (LY + 1u + 3u) / 4u) + s.pos_wt[e]] = pb;
+		}
 	}
 }
 

@@ -163,6 +163,9 @@ struct mpcgpu_ctx {
 	DevBuf d_ovf_off, d_cell_off, d_yr, d_ovf_sum, d_ovf_maxc, d_btiles, d_bt_out, d_bt_cand, d_bt_count, d_bt_list;
 	std::vector<u32> h_btiles;
 	u64 btiles_k0 = ~0ull, btiles_k1 = ~0ull;
+	bool win_ok = false;       // window records exist for this store (the direct-index merge: kernels_relaxb.h)
+	DevBuf d_win, d_wrec_off, d_wv_off, d_pos_w, d_wsum, d_wmaxc, d_wflag;
+	u64 win_total_blocks = 0;
 	const void *band_fn = nullptr; // relax_band: kernel, LDS size and occupancy of the last launch (runtime queries cached)
 	size_t band_smem = 0;
 	int band_occ = 0;
@@ -415,6 +418,11 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.rec_off = c->d_rec_off.as<u32>();
 	s.ovf_off = c->band_ok ? c->d_ovf_off.as<u32>() : nullptr;
 	s.nb1 = c->band_nb1;
+	s.win = c->win_ok ? c->d_win.as<u32>() : nullptr;
+	s.wrec_off = c->d_wrec_off.as<u32>();
+	s.wv_off = c->win_ok ? c->d_wv_off.as<u32>() : nullptr;
+	s.pos_wf = c->d_pos_w.as<unsigned short>();
+	s.pos_wt = c->d_pos_w.as<unsigned short>() + c->total_entries;
 }
 
 // ---- variable-size records + relax_var_kernel (kernels_relaxv.h) -------------------------------------------------------
@@ -546,11 +554,16 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	const u32 cap = (lds_bytes - MPC_RB_TAB_BYTES) & ~15u, cap_blocks = cap / 16;
 	const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)kBandSlots), 1), (int)kBandSlots);
 	const u32 cus = (u32)c->prop.multiProcessorCount;
+	// the direct-index merge (window records for the Y operand) where the store has them; the 512-thread geometry and the
+	// measurement kernels exist for the block walk only
+	const bool use_win = c->win_ok && bthreads == 1024 && !env_int("MPCGPU_RELAX_DIAG", 0);
 	if (c->btiles_k0 != k0 || c->btiles_k1 != k1) {
 		c->btiles_k0 = c->btiles_k1 = ~0ull;
 		RbTileTabs tb;
 		tb.cell_off = c->d_cell_off.as<u32>(); tb.yr = c->d_yr.as<u32>(); tb.ovf_sum = c->d_ovf_sum.as<u32>(); tb.ovf_maxc = c->d_ovf_maxc.as<u32>();
 		tb.nb1 = nb1; tb.threads = bthreads; tb.k0 = k0; tb.k1 = k1;
+		tb.win = use_win ? 1u : 0u;
+		tb.ysum = use_win ? c->d_wsum.as<u32>() : tb.ovf_sum; tb.ymaxc = use_win ? c->d_wmaxc.as<u32>() : tb.ovf_maxc;
 		// tile words of a list of tiles whose words 0..5 are set: Y ranges, first-piece blocks, slots; out: slots, mean blocks, bound, cells
 		auto eval_tiles = [&](std::vector<u32> &words, std::vector<u32> &out) -> int {
 			const u32 nt = (u32)(words.size() / MPC_RB_TILE_WORDS);
@@ -671,7 +684,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 					if (upload(c, c->d_btiles, words) || upload(c, c->d_bt_list, sample)) return 1;
 					HIPCHK(c, c->d_bt_count.ensure(sample.size() * 4));
 					MPC_LAUNCH(band_fit_kernel, std::min<u32>((u32)sample.size(), cus * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), nb1,
-						c->d_btiles.as<u32>(), c->d_bt_list.as<u32>(), (u32)sample.size(), c->d_bt_count.as<u32>());
+						c->d_btiles.as<u32>(), c->d_bt_list.as<u32>(), (u32)sample.size(), c->d_bt_count.as<u32>(), tb.win);
 					HIPCHK(c, hipGetLastError());
 					std::vector<u32> worst(sample.size());
 					HIPCHK(c, hipMemcpyAsync(worst.data(), c->d_bt_count.p, sample.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -722,7 +735,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 				if (upload(c, c->d_bt_list, need)) return 1;
 				HIPCHK(c, c->d_bt_count.ensure(need.size() * 4));
 				MPC_LAUNCH(band_fit_kernel, std::min<u32>((u32)need.size(), cus * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), nb1,
-					c->d_btiles.as<u32>(), c->d_bt_list.as<u32>(), (u32)need.size(), c->d_bt_count.as<u32>());
+					c->d_btiles.as<u32>(), c->d_bt_list.as<u32>(), (u32)need.size(), c->d_bt_count.as<u32>(), tb.win);
 				HIPCHK(c, hipGetLastError());
 				exact.resize(need.size());
 				HIPCHK(c, hipMemcpyAsync(exact.data(), c->d_bt_count.p, need.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -801,7 +814,11 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	for (int go = 0; go < 2; ++go) { // pass 0: which instantiation (attributes, occupancy); pass 1: launch
 		TimedSpan ts;
 		if (go && span_begin(c, 3, &ts)) return 1;
-		if (bthreads == 512) { fn = (const void *)relax_band_kernel<512, kBandSlots, 4>; if (go) MPC_LAUNCH((relax_band_kernel<512, kBandSlots, 4>), grid, 512, smem, c->stream, rp); }
+		if (use_win) { // window records for the Y operand: the direct-index merge
+			if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbWinCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbWinCxx>), grid, kBandThreads, smem, c->stream, rp); }
+			else { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbWinAsm>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbWinAsm>), grid, kBandThreads, smem, c->stream, rp); }
+		}
+		else if (bthreads == 512) { fn = (const void *)relax_band_kernel<512, kBandSlots, 4>; if (go) MPC_LAUNCH((relax_band_kernel<512, kBandSlots, 4>), grid, 512, smem, c->stream, rp); }
 		else
 		MPC_RB_DIAG_CASES(kBandThreads, kBandSlots)
 		if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbBlocksCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbBlocksCxx>), grid, kBandThreads, smem, c->stream, rp); }
@@ -818,7 +835,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			}
 			grid = std::max(std::min<u32>(ntiles, cus * (u32)occ), 1u);
 			char kn[128];
-			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, %u, %d, %s>", bthreads, kBandSlots, bthreads == 512 ? 4u : 2u, bthreads == 512 ? 0 : diag, merge_cxx && !diag ? "MpcRbBlocksCxx" : "MpcRbBlocksAsm");
+			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, %u, %d, %s>", bthreads, kBandSlots, bthreads == 512 ? 4u : 2u, bthreads == 512 ? 0 : diag,
+				use_win ? (merge_cxx ? "MpcRbWinCxx" : "MpcRbWinAsm") : merge_cxx && !diag && bthreads == 1024 ? "MpcRbBlocksCxx" : "MpcRbBlocksAsm");
 			c->relax_kernel_name = kn;
 			if (trace_on()) { fprintf(stderr, "[mpcgpu] relax band: %s; lds=%zu B occ=%d grid=%u\n", c->tiles_desc.c_str(), smem, occ, grid); fflush(stderr); }
 		} else {
@@ -1070,12 +1088,65 @@ int build_var_store(mpcgpu_ctx *c)
 	if (span_begin(c, 2, &ts)) return 1;
 	MPC_LAUNCH(var_build_kernel, (u32)std::min<u64>(nn, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)std::max(sp.lcap1, 1u) * 8, c->stream, sp);
 	HIPCHK(c, hipGetLastError());
+	// ---- window records (the Y operand of the direct-index merge): a second copy of the store whose rows are looked up by column.
+	// Built when the rows are narrow — the windows then cost about what the blocks cost (1000 x L~400: 93 % of the rows span <= 4
+	// columns); wide-row data (rdrp: half of the rows span >= 40 columns) keeps the walk of two block lists. MPCGPU_RELAX_FORM=walk: never.
+	c->win_ok = false;
+	{
+		const char *form = getenv("MPCGPU_RELAX_FORM");
+		if (c->band_ok && !(form && !strcmp(form, "walk"))) {
+			HIPCHK(c, c->d_sizes.ensure(nn * 4));
+			HIPCHK(c, c->d_tilefit.ensure(nn * 4)); // (scratch: value dwords per record)
+			HIPCHK(c, c->d_wflag.ensure(4));
+			HIPCHK(c, hipMemsetAsync(c->d_wflag.p, 0, 4, c->stream));
+			MPC_LAUNCH(win_size_kernel, (u32)std::min<u64>(nn, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_sizes.as<u32>(),
+				c->d_tilefit.as<u32>(), c->d_wflag.as<u32>());
+			HIPCHK(c, hipGetLastError());
+			std::vector<u32> woff(nn + 1);
+			u32 wide = 0;
+			HIPCHK(c, hipMemcpyAsync(woff.data() + 1, c->d_sizes.p, nn * 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipMemcpyAsync(&wide, c->d_wflag.p, 4, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			woff[0] = 0;
+			u64 wrun = 0;
+			for (u64 b = 0; b < nn; ++b) { wrun += woff[b + 1]; woff[b + 1] = (u32)std::min<u64>(wrun, 0xffffffffull); }
+			const double ratio = (double)wrun / (double)std::max<u64>(run, 1);
+			const double max_ratio = (double)env_int("MPCGPU_RELAX_WIN_PCT", 125) / 100.0;
+			size_t free3 = 0, tot3 = 0;
+			HIPCHK(c, hipMemGetInfo(&free3, &tot3));
+			const u64 need = wrun * 16 + 4 * std::max<u64>(c->total_entries, 1) + nn * c->band_nb1 * 4;
+			if (!wide && wrun <= 0xffffffffull && ratio <= max_ratio && (c->d_win.cap >= wrun * 16 || need + ((u64)1 << 30) <= (u64)free3)) {
+				HIPCHK(c, c->d_win.ensure(std::max<u64>(wrun, 1) * 16));
+				HIPCHK(c, c->d_pos_w.ensure(4 * std::max<u64>(c->total_entries, 1)));
+				HIPCHK(c, c->d_wv_off.ensure(nn * c->band_nb1 * 4));
+				HIPCHK(c, c->d_wsum.ensure((u64)n * c->band_nb1 * 4));
+				HIPCHK(c, c->d_wmaxc.ensure((u64)n * c->band_nb1 * 4));
+				if (upload(c, c->d_wrec_off, woff)) return 1;
+				HIPCHK(c, hipStreamSynchronize(c->stream)); // `woff` dies with this block
+				c->win_ok = true;
+				c->win_total_blocks = wrun;
+				fill_store_params(c, sp);
+				MPC_LAUNCH(win_build_kernel, (u32)std::min<u64>(nn, (u64)c->prop.multiProcessorCount * 32), 64, (size_t)(std::max(sp.lcap1, 1u) + 1) * 4, c->stream, sp);
+				HIPCHK(c, hipGetLastError());
+				MPC_LAUNCH(win_pos_kernel, (u32)std::min<u64>(std::max<u64>(c->npairs, 1), (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp);
+				HIPCHK(c, hipGetLastError());
+				MPC_LAUNCH(ovf_stats_kernel, std::min<u32>(n, (u32)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_wv_off.as<u32>(), c->band_nb1,
+					c->d_wsum.as<u32>(), c->d_wmaxc.as<u32>(), 1);
+				HIPCHK(c, hipGetLastError());
+				char wb[160];
+				snprintf(wb, sizeof(wb), " + window records for the Y operand (%.2f GB, %.0f %% of the blocks)", (double)wrun * 16 / 1e9, 100.0 * ratio);
+				c->store_desc += wb;
+			} else if (trace_on())
+				fprintf(stderr, "[mpcgpu] store: no window records (%s; they would take %.0f %% of the block records' %.2f GB)\n",
+					wide ? "a record's windows exceed 65535 values" : "rows too wide", 100.0 * ratio, (double)run * 16 / 1e9);
+		}
+	}
 	if (c->band_ok) {
 		MPC_LAUNCH(band_index_kernel, (u32)std::min<u64>(std::max<u64>(c->npairs, 1), (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->band_nb1,
 			c->d_cell_off.as<u32>(), c->d_yr.as<u32>());
 		HIPCHK(c, hipGetLastError());
 		MPC_LAUNCH(ovf_stats_kernel, std::min<u32>(n, (u32)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), c->band_nb1,
-			c->d_ovf_sum.as<u32>(), c->d_ovf_maxc.as<u32>());
+			c->d_ovf_sum.as<u32>(), c->d_ovf_maxc.as<u32>(), 0);
 		HIPCHK(c, hipGetLastError());
 	}
 	if (span_end(c, &ts)) return 1;
