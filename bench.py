@@ -317,7 +317,8 @@ def main():
                          "(every (pair,Z) reads both operand matrices once: sum of 8*(nnz_XZ+nnz_YZ)+4*(LX+LY+2), + 4*nnz written) / "
                          "launch time: a progress figure, NOT a fraction of a roof (the LDS tiling serves up to 64 pairs' row bands from 16 partial records, so "
                          "far fewer bytes cross the fabric). null = no committed PMC pass for this workload and this kernel."}
-            return measured_roof(r, pmc_entry(kname, *fixture_shape), avg_s, kname, 1.20, launched)
+            cost_key = kname + "/MpcRbBlocksAsm" if kname == "relax_band_kernel" and launched and "MpcRbBlocks" in launched else kname
+            return measured_roof(r, pmc_entry(kname, *fixture_shape), avg_s, cost_key, 1.20, launched)
 
         def fb_roof():
             ms, launches = timers["fb"]

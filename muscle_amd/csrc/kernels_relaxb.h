@@ -436,24 +436,29 @@ __device__ __forceinline__ void rb_record(const StoreParams &s, const u32 *tw, u
 // worst step. One wave per tile, lanes stride over Z.
 __global__ void __launch_bounds__(64) band_fit_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, const u32 *tiles, const u32 *list, u32 nlist, u32 *out, u32 win)
 {
-	const u32 lane = threadIdx.x & 63u, n = s.n;
+	// lane = (Z parity, bound, record): the 16 records' band entries of one Z lie in two neighbourhoods of the tables (consecutive
+	// sequences), so a step of the loop touches a handful of cache lines — with lanes over Z every load was 64 lines
+	const u32 lane = threadIdx.x & 63u, n = s.n, li = lane & 15u, hi_bound = (lane >> 4) & 1u, par = lane >> 5;
 	for (u32 q = blockIdx.x; q < nlist; q += gridDim.x) {
 		const u32 *tw = tiles + (u64)MPC_RB_TILE_WORDS * list[q];
-		u32 S[16], e0[16], e1[16], first = 0;
-		for (u32 i = 0; i < 16u; ++i) { u32 blk0, blocks, arow; rb_record(s, tw, i, win, &S[i], &blk0, &blocks, &e0[i], &e1[i], &arow); first += blocks; }
+		u32 S, blk0, blocks, e0, e1, arow;
+		rb_record(s, tw, li, win, &S, &blk0, &blocks, &e0, &e1, &arow);
+		u32 first = (lane < 16u) ? blocks : 0u;
+		first = rb_wave_sum(first);
+		const bool wrec = win && li >= MPC_RB_MAXN;
+		const u32 *tab = wrec ? s.wv_off : ovf_off;
+		const u32 e = hi_bound ? e1 : e0;
 		u32 best = 0;
-		for (u32 Z = lane; Z < n; Z += 64) {
-			u32 sum = first;
-			for (u32 i = 0; i < 16u; ++i) {
-				if (e1[i] == e0[i]) continue;
-				const u64 r = mpc_rec_index(n, S[i], Z) * nb1;
-				if (win && i >= MPC_RB_MAXN) sum += s.wv_off[r + e1[i]] - s.wv_off[r + e0[i]] + 1u;
-				else sum += ovf_off[r + e1[i]] - ovf_off[r + e0[i]];
-			}
-			best = sum > best ? sum : best;
+		for (u32 Z = par; Z < n + par; Z += 2u) { // (every lane runs the same number of turns: the shuffles below are wave-wide)
+			const u32 Zc = Z < n ? Z : n - 1u;
+			const u32 v = tab[(mpc_rec_index(n, S, Zc)) * nb1 + e];
+			const u32 lo = __shfl(v, (int)(lane & ~16u)), hb = __shfl(v, (int)(lane | 16u));
+			u32 d = (e1 != e0) ? hb - lo + (wrec ? 1u : 0u) : 0u;
+			for (int k = 1; k < 16; k <<= 1) d += __shfl(d, (int)((lane & ~15u) | ((li + (u32)k) & 15u))); // sum over the 16 records (rotation inside the row)
+			best = d > best ? d : best;
 		}
-		for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_down(best, d); best = o > best ? o : best; }
-		if (lane == 0u) out[q] = best;
+		for (int k = 32; k >= 1; k >>= 1) { const u32 o = __shfl(best, (int)(lane ^ (u32)k)); best = o > best ? o : best; }
+		if (lane == 0u) out[q] = first + best;
 	}
 }
 

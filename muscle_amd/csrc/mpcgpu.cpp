@@ -732,6 +732,12 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			for (u32 t = 0; t < nt; ++t)
 				if (out[4 * t] <= max_slots && words[(size_t)t * MPC_RB_TILE_WORDS + 6] <= MPC_RB_MAXFIRST && out[4 * t + 2] > cap_blocks) need.push_back(t);
 			if (!need.empty()) {
+				if (trace_on()) {
+					u64 bsum = 0, esum = 0;
+					for (u32 t : need) { bsum += out[4 * t + 2]; esum += out[4 * t + 1]; }
+					fprintf(stderr, "[mpcgpu] band tiles: %zu of %u tiles need the exact worst step (mean bound %.0f blocks, mean step %.0f, area %u)\n",
+						need.size(), nt, (double)bsum / need.size(), (double)esum / need.size(), cap_blocks);
+				}
 				if (upload(c, c->d_bt_list, need)) return 1;
 				HIPCHK(c, c->d_bt_count.ensure(need.size() * 4));
 				MPC_LAUNCH(band_fit_kernel, std::min<u32>((u32)need.size(), cus * 32), 64, 0, c->stream, sp, c->d_ovf_off.as<u32>(), nb1,
@@ -2140,7 +2146,17 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	fill_store_params(c, sp);
 	if (c->have_pad) {
 		if (c->band_ok) {
-			const int r = relax_band(c, sp, k0, k1);
+			int r = relax_band(c, sp, k0, k1);
+			if (r == 2 && c->win_ok) {
+				// no band fits with the Y rows as windows (one wide row can be most of the LDS): the same tiles with the Y rows as block
+				// lists, i.e. the two-list walk; the window records are dropped
+				c->win_ok = false;
+				c->d_win.release(); c->d_pos_w.release();
+				{ const size_t at = c->store_desc.find(" + window records"); if (at != std::string::npos) c->store_desc.erase(at); }
+				c->btiles_k0 = c->btiles_k1 = ~0ull;
+				fill_store_params(c, sp);
+				r = relax_band(c, sp, k0, k1);
+			}
 			if (r != 2) return r;
 			c->band_ok = false; // this store's rows do not cut into band tiles that fit: whole-record tiles from here on
 		}

@@ -528,6 +528,11 @@ def test_emu_relax_two_geometries(emu):
     {"MPCGPU_RELAX_LDS_KB": "8"},                                    # one 16-row band of the (18, 70)-residue pair needs 7.2 KB: no tiling -> CSR slabs + gather kernel
     {"MPCGPU_RELAX_LDS_KB": "12", "MPCGPU_RELAX_SHAPE": "2,2,5"},   # target 5 KB of 9.5: most steps prefetched, the large ones late
     {"MPCGPU_RELAX_TILES": "pairs"},                                 # the whole-record tiles of relax_var_kernel (A/B)
+    {"MPCGPU_RELAX_FORM": "walk"},                                   # the two-list walk on block records for the Y operand too (no window records)
+    {"MPCGPU_RELAX_FORM": "walk", "MPCGPU_RELAX_SHAPE": "4,2", "MPCGPU_RELAX_SLOTS": "2"},
+    {"MPCGPU_RELAX_WIN_PCT": "100000"},                              # window records whatever they cost (the unrelated 70-residue sequence has wide rows)
+    {"MPCGPU_RELAX_WIN_PCT": "100000", "MPCGPU_RELAX_SHAPE": "2,2,8", "MPCGPU_RELAX_LDS_KB": "20"},
+    {"MPCGPU_RELAX_WIN_PCT": "100000", "MPCGPU_RELAX_LDS_KB": "9"},  # no band fits with windows: the store drops them and walks block lists
 ])
 def test_emu_relax_band_tiles(emu, env):
     """relax_band_kernel over forced tile shapes, slot budgets and staging areas: row bands of 16..80 rows, Y ranges that start
@@ -537,6 +542,12 @@ def test_emu_relax_band_tiles(emu, env):
     info = {}
     got = _with_env(env, lambda: P.run_lib(seqs, lib_path=emu, info=info))
     P.assert_same(got, P.run_oracle(seqs), "band tiles %s" % env)
+    if env.get("MPCGPU_RELAX_LDS_KB") == "9":
+        assert "relax_band_kernel" in info["relax_info"] and "MpcRbBlocks" in info["relax_info"], info["relax_info"]
+    elif "MPCGPU_RELAX_WIN_PCT" in env:
+        assert "MpcRbWin" in info["relax_info"] and "window records" in info["relax_info"], info["relax_info"]
+    elif env.get("MPCGPU_RELAX_FORM") == "walk":
+        assert "MpcRbBlocks" in info["relax_info"] and "window records" not in info["relax_info"], info["relax_info"]
     if env.get("MPCGPU_RELAX_TILES") == "pairs":
         assert "relax_var_kernel" in info["relax_info"], info["relax_info"]
     elif env.get("MPCGPU_RELAX_LDS_KB") == "8":
@@ -551,7 +562,10 @@ def test_emu_relax_band_tiles_races(emu, mode):
     destination poisoned meanwhile) with step Z+1 prefetched beside step Z, and threads run in reverse / random order between
     synchronisation points"""
     seqs = make_family(6, 40, seed=3) + make_family(3, 18, seed=5)
-    env = {"MPCGPU_RELAX_SHAPE": "4,4,3", "MPCGPU_RELAX_LDS_KB": "10"}
-    env.update({"EMU_DMA": "late"} if mode == "late" else {"EMU_SCHED": mode})
-    got = _with_env(env, lambda: P.run_lib(seqs, lib_path=emu))
-    P.assert_same(got, P.run_oracle(seqs), "band tiles, %s" % mode)
+    want = P.run_oracle(seqs)
+    for form in ({"MPCGPU_RELAX_WIN_PCT": "100000"}, {"MPCGPU_RELAX_FORM": "walk"}):  # the direct-index merge / the two-list walk
+        env = {"MPCGPU_RELAX_SHAPE": "4,4,3", "MPCGPU_RELAX_LDS_KB": "10"}
+        env.update(form)
+        env.update({"EMU_DMA": "late"} if mode == "late" else {"EMU_SCHED": mode})
+        got = _with_env(env, lambda: P.run_lib(seqs, lib_path=emu))
+        P.assert_same(got, want, "band tiles, %s, %s" % (mode, form))

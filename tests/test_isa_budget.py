@@ -38,7 +38,8 @@ def _scratch(lines):
     return [k for k, l in enumerate(lines) if re.search(r"\bscratch_(load|store)|\bbuffer_(load|store)", l)]
 
 
-BAND = "_Z17relax_band_kernelILi1024ELi13ELi2ELi0E14MpcRbBlocksAsmEv15RelaxBandParams"
+BAND = "_Z17relax_band_kernelILi1024ELi13ELi2ELi0E14MpcRbBlocksAsmEv15RelaxBandParams"   # the two-list walk (wide rows)
+BAND_WIN = "_Z17relax_band_kernelILi1024ELi13ELi2ELi0E11MpcRbWinAsmEv15RelaxBandParams"  # the direct-index merge (narrow rows: the bench's default)
 
 
 def _walk(body):
@@ -46,12 +47,13 @@ def _walk(body):
     return merges
 
 
-def test_default_relax_walk_has_no_spill_reloads(isa):
+@pytest.mark.parametrize("kernel", [BAND_WIN, BAND])
+def test_default_relax_walk_has_no_spill_reloads(isa, kernel):
     """relax_band_kernel, the instantiation relax_band launches by default (kBandSlots cells per lane). A reload inside the walk is
     worse here than in relax_var_kernel: its wait is vmcnt(0), and the prefetch of the next step is in flight on the same counter."""
     src = open(os.path.join(CSRC, "mpcgpu.cpp")).read()
     assert re.search(r"kBandThreads = 1024, kBandSlots = 13;", src), "default geometry of relax_band changed: update this test"
-    body = _body(isa, BAND)
+    body = _body(isa, kernel)
     merges = _walk(body)
     assert len(merges) == 13, len(merges)  # one hand-scheduled merge loop per cell slot
     inside = [k for k in _scratch(body) if merges[0] <= k <= merges[-1]]
@@ -64,12 +66,14 @@ def test_default_relax_walk_has_no_spill_reloads(isa):
     assert not waits, "; ".join(body[k].strip() for k in waits[:5])
 
 
-def test_band_merge_registers_are_not_touched_between_statements(isa):
+@pytest.mark.parametrize("kernel", [BAND_WIN, BAND])
+def test_band_merge_registers_are_not_touched_between_statements(isa, kernel):
     """The hand-scheduled merge leaves LDS reads in flight into v24..v40 (the next slot's first blocks, its Y bias) when a
     statement ends; the compiler does not know. Between the end of one merge statement and the opening wait of the next
     (or the drain after the last slot) no compiler-generated instruction may read or write those registers."""
-    body = _body(isa, BAND)
-    pinned = set(range(24, 41))
+    body = _body(isa, kernel)
+    # the walk pins v24..v40; the direct-index merge v24..v29, v32..v37 and v40 (its descriptor pairs are two registers each)
+    pinned = set(range(24, 41)) if kernel == BAND else (set(range(24, 30)) | set(range(32, 38)) | {40})
 
     def regs(line):
         out = set()
@@ -82,7 +86,7 @@ def test_band_merge_registers_are_not_touched_between_statements(isa):
     in_gap, bad = False, []
     for k, l in enumerate(body):
         t = l.strip()
-        if re.match(r"\.Lrv_done_\d+:", t):
+        if re.match(r"\.Lrv_(done|last)_\d+:", t):
             in_gap = "armed"  # the statement's last instruction (restore exec) follows, then ;;#ASMEND
         elif in_gap == "armed" and t.startswith(";;#ASMEND"):
             in_gap = True
