@@ -318,7 +318,7 @@ def main():
                          "launch time: a progress figure, NOT a fraction of a roof (the LDS tiling serves up to 64 pairs' row bands from 16 partial records, so "
                          "far fewer bytes cross the fabric). null = no committed PMC pass for this workload and this kernel."}
             cost_key = kname + "/MpcRbBlocksAsm" if kname == "relax_band_kernel" and launched and "MpcRbBlocks" in launched else kname
-            return measured_roof(r, pmc_entry(kname, *fixture_shape), avg_s, cost_key, 1.20, launched)
+            return measured_roof(r, pmc_entry(cost_key, *fixture_shape) or pmc_entry(kname, *fixture_shape), avg_s, cost_key, 1.20, launched)
 
         def fb_roof():
             ms, launches = timers["fb"]
