@@ -132,6 +132,11 @@ def cpu_baseline(seqs, n_full, budget_s=20.0):
             "stage_a_s": m["timed"]["stage_a_s"], "relax_2it_s": m["timed"]["relax_2it_s"], "extrapolated": False,
             "extrapolation_formula_error_at_this_size": m["extrapolation_error"],
             "source": "profiles/%s (diag/ref_time.py on an MI355X box: EPYC 9575F, 16-core quota)" % src}
+        # beside `value`: how far the extrapolation formula was off where it could be checked against a TIMED run of the same size,
+        # and how far this run's live figure is from that timed run's (box to box, core quota to core quota)
+        out["extrapolation_error"] = m["extrapolation_error"]
+        if m["timed"]["n"] == n_full:
+            out["live_vs_timed_run"] = out["value"] / m["timed"]["pairs_per_s"] - 1.0
     except (OSError, ValueError, KeyError):
         pass
     return out

@@ -1325,13 +1325,18 @@ static int set_seqs_impl(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, 
 		if (lens[i] == 0) return fail(c, "mpcgpu_set_seqs: sequence %u is empty", i);
 		if (lens[i] > MPC_KEY_COL_MASK) return fail(c, "mpcgpu_set_seqs: sequence %u is longer than %u", i, MPC_KEY_COL_MASK);
 		c->raw[i].assign(seqs[i], seqs[i] + lens[i]);
-		for (u8 b : c->raw[i]) {
+		for (u32 at = 0; at < lens[i]; ++at) {
+			const u8 b = c->raw[i][at];
 			if (b >= 128) return fail(c, "mpcgpu_set_seqs: sequence %u holds non-ASCII byte %u", i, (unsigned)b);
-			if (c->code_of[b] < 0) c->code_of[b] = c->A++;
+			if (c->code_of[b] < 0) {
+				if (c->A == 64) return fail(c, "mpcgpu_set_seqs: more than 64 distinct byte values: byte %u ('%c') at position %u of sequence %u is the 65th "
+					"(the emission tables live in LDS as a compacted A x A matrix; the reference indexes all 256)", (unsigned)b, (b >= 32 && b < 127) ? (char)b : '?',
+					at, i);
+				c->code_of[b] = c->A++;
+			}
 		}
 		if (lens[i] > maxl) { max2 = maxl; maxl = lens[i]; } else if (lens[i] > max2) max2 = lens[i];
 	}
-	if (c->A > 64) return fail(c, "mpcgpu_set_seqs: %d distinct letters; this build supports at most 64", c->A);
 	// calcposteriorflat.cpp:54-61
 	if (double(maxl) * double(max2) * 5 + 100 > double(INT_MAX))
 		return fail(c, "HMM overflow, sequence lengths %u, %u (max ~21k)", maxl, max2);

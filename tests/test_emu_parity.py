@@ -289,6 +289,20 @@ def test_emu_mega_rejects_bad_input(emu):
     g.close()
 
 
+def test_emu_set_seqs_names_the_65th_byte(emu):
+    """the build's alphabet limit: the message says which byte overflowed it and where it stands"""
+    from muscle_amd._lib import MpcGpu
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, emu)
+    g.set_hmm(s, t, m, i, thr)
+    first = bytes(range(33, 33 + 40))
+    second = bytes(range(73, 73 + 24)) + b"~" + b"A"  # '~' (126) is the 65th distinct value, at position 24 of sequence 1
+    g.set_seqs([first, second[:-2]])  # exactly 64: accepted
+    with pytest.raises(RuntimeError, match=r"byte 126 .* position 24 of sequence 1"):
+        g.set_seqs([first, second])
+    g.close()
+
+
 def test_emu_mega_then_letters_on_one_context(emu):
     """set_seqs drops the profiles: the same context goes back to letter emissions"""
     from muscle_amd._lib import MpcGpu
