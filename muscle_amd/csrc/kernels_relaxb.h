@@ -99,6 +99,12 @@ struct MpcRbWinCxx {
 typedef MpcRbWinCxx MpcRbWinAsm;
 #endif
 
+// Wave scans of the walk kernel's prologue through ds_bpermute with the lane number passed in: the caller passes a lane number
+// that went through MPC_OPAQUE inside the tile loop — __shfl_up's own lane number (and the byte index made of it) is a loop
+// invariant the compiler keeps in two VGPRs across the walk.
+__device__ __forceinline__ u32 rb_lane_up(u32 v, u32 d, u32 ln) { return mpc_lane_gather(v, 4u * ((ln - d) & 63u)); } // value of lane ln - d
+__device__ __forceinline__ u32 rb_lane_at(u32 v, u32 l) { return mpc_lane_gather(v, 4u * l); }
+
 struct RelaxBandParams {
 	StoreParams s;
 	const u32 *ovf_off;  // [(Z*n + A) * nb1 + b]: block index (in `pad`) where the overflow blocks of rows >= b*HB of record (A,Z) start; the record's end for b*HB >= len(A)
@@ -109,6 +115,7 @@ struct RelaxBandParams {
 	u64 k0, k1;          // only pairs in [k0,k1) are relaxed (multi-GPU shard)
 	u32 cap_bytes;       // staging area (after the tables)
 	u32 *tile_next;      // 8 counters, zeroed before the launch: next tile of each XCD's range
+	u32 by_rows;         // cell order inside an X group: G > 0 = blocks of G rows, a block's cells pair after pair; 0 = pair after pair
 };
 
 // ---- band tables -------------------------------------------------------------------------------------------------------------
@@ -412,12 +419,12 @@ __global__ void __launch_bounds__(64) band_eval_kernel(StoreParams s, RbTileTabs
 // record (*blk0), its blocks (*blocks; 0: nothing is staged), the index bands [e0, e1) whose dynamic blocks belong to the piece,
 // and *arow: the row the piece's first block starts with. Block form: one block per row. Window form (win, Y records only): the
 // static piece is the descriptors of rows [ylo & ~3, yhi] — 4 per block, the pair a cell reads ends with row yhi's successor.
-__device__ __forceinline__ void rb_record(const StoreParams &s, const u32 *tw, u32 i, u32 win, u32 *S, u32 *blk0, u32 *blocks, u32 *e0, u32 *e1, u32 *arow)
+__device__ __forceinline__ void rb_record(const u32 *seq_len, const u32 *tw, u32 i, u32 win, u32 *S, u32 *blk0, u32 *blocks, u32 *e0, u32 *e1, u32 *arow)
 {
 	const u32 x0 = tw[0], nx = tw[1], y0 = tw[2], ny = tw[3], r0 = tw[4], r1 = tw[5];
 	u32 a0 = 0, a1 = 0, A = x0;
 	if (i < MPC_RB_MAXN) {
-		if (i < nx) { A = x0 + i; const u32 LA = s.seq_len[A]; a0 = r0; a1 = r1 < LA ? r1 : LA; }
+		if (i < nx) { A = x0 + i; const u32 LA = seq_len[A]; a0 = r0; a1 = r1 < LA ? r1 : LA; }
 	} else if (i - MPC_RB_MAXN < ny) {
 		A = y0 + (i - MPC_RB_MAXN);
 		const u32 w = tw[8 + (i - MPC_RB_MAXN)];
@@ -442,7 +449,7 @@ __global__ void __launch_bounds__(64) band_fit_kernel(StoreParams s, const u32 *
 	for (u32 q = blockIdx.x; q < nlist; q += gridDim.x) {
 		const u32 *tw = tiles + (u64)MPC_RB_TILE_WORDS * list[q];
 		u32 S, blk0, blocks, e0, e1, arow;
-		rb_record(s, tw, li, win, &S, &blk0, &blocks, &e0, &e1, &arow);
+		rb_record(s.seq_len, tw, li, win, &S, &blk0, &blocks, &e0, &e1, &arow);
 		u32 first = (lane < 16u) ? blocks : 0u;
 		first = rb_wave_sum(first);
 		const bool wrec = win && li >= MPC_RB_MAXN;
@@ -509,7 +516,10 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 		__syncthreads();
 		const u32 tl = mpc_wave_first(misc[0]);
 		if (tl == 0xffffffffu) break;
-		const u32 *tw = p.tiles + (u64)MPC_RB_TILE_WORDS * tl;
+		// the prologue's pointers come from the kernarg segment again, tile by tile: held in scalar registers across the walk (they
+		// were: 70 of them spilled into lanes of two VGPRs) they cost the walk an accumulator
+		const auto pa = MPC_KERNARG_AGAIN(p);
+		const u32 *tw = pa->tiles + (u64)MPC_RB_TILE_WORDS * tl;
 		const u32 x0 = mpc_wave_first(tw[0]), nx = mpc_wave_first(tw[1]), y0 = mpc_wave_first(tw[2]), ny = mpc_wave_first(tw[3]);
 		const u32 r0 = mpc_wave_first(tw[4]), r1 = mpc_wave_first(tw[5]);
 
@@ -520,31 +530,33 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			u32 cnt = 0, e0 = 0, kk = 0;
 			if (ix < nx && iy < ny && X < Y) {
 				const u64 k = mpc_pair_index(n, X, Y);
-				if (k >= p.k0 && k < p.k1) {
-					const u32 b0 = r0 / MPC_RB_HB, b1r = (r1 + MPC_RB_HB - 1u) / MPC_RB_HB, b1 = b1r < p.nb1 - 1u ? b1r : p.nb1 - 1u;
-					e0 = p.cell_off[k * p.nb1 + b0];
-					cnt = p.cell_off[k * p.nb1 + b1] - e0;
+				if (k >= pa->k0 && k < pa->k1) {
+					const u32 b0 = r0 / MPC_RB_HB, b1r = (r1 + MPC_RB_HB - 1u) / MPC_RB_HB, b1 = b1r < pa->nb1 - 1u ? b1r : pa->nb1 - 1u;
+					e0 = pa->cell_off[k * pa->nb1 + b0];
+					cnt = pa->cell_off[k * pa->nb1 + b1] - e0;
 					kk = (u32)k;
 				}
 			}
 			// cells laid end to end pair after pair inside an X group; every group rounded up to whole waves
+			u32 ln = lane;
+			MPC_OPAQUE(ln);
 			u32 w = cnt;
-			for (int d = 1; d < 8; d <<= 1) { const u32 o = __shfl_up(w, d); if (iy >= (u32)d) w += o; }
-			const u32 gtot = __shfl(w, (int)(lane | 7u));
+			for (u32 d = 1; d < 8; d <<= 1) { const u32 o = rb_lane_up(w, d, ln); if (iy >= d) w += o; }
+			const u32 gtot = rb_lane_at(w, ln | 7u);
 			const u32 grnd = (gtot + MPC_RV_WAVE - 1u) & ~(MPC_RV_WAVE - 1u);
 			u32 gi = iy == 0u ? grnd : 0u;
-			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(gi, d); if (lane >= (u32)d) gi += o; }
-			const u32 gbase = __shfl(gi, (int)(lane & ~7u)) - grnd;
-			const u32 total = __shfl(gi, 63);
+			for (u32 d = 1; d < 64; d <<= 1) { const u32 o = rb_lane_up(gi, d, ln); if (ln >= d) gi += o; }
+			const u32 gbase = rb_lane_at(gi, ln & ~7u) - grnd;
+			const u32 total = rb_lane_at(gi, 63u);
 			u32 *e = ptab + 4 * lane;
 			e[0] = gbase + w - cnt; e[1] = cnt; e[2] = kk; e[3] = e0;
 			if (iy == 0u) { gtab[2 * ix] = gbase; gtab[2 * ix + 1] = gbase + gtot; }
 			// pieces
 			u32 S, row0, rows, b0, b1, arow;
-			rb_record(s, tw, lane & 15u, WIN ? 1u : 0u, &S, &row0, &rows, &b0, &b1, &arow);
+			rb_record(pa->s.seq_len, tw, lane & 15u, WIN ? 1u : 0u, &S, &row0, &rows, &b0, &b1, &arow);
 			u32 fi = lane < 16u ? rows : 0u;
-			for (int d = 1; d < 16; d <<= 1) { const u32 o = __shfl_up(fi, d); if (lane >= (u32)d) fi += o; }
-			const u32 ftot = __shfl(fi, 15);
+			for (u32 d = 1; d < 16; d <<= 1) { const u32 o = rb_lane_up(fi, d, ln); if (ln >= d) fi += o; }
+			const u32 ftot = rb_lane_at(fi, 15u);
 			if (lane < 16u) {
 				u32 *r = rtab + 8 * lane;
 				const u32 fst = fi - rows;
@@ -552,7 +564,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 				// [3] sequence, [4] / [5] index bands of the dynamic piece, [6] first row of the static piece, [7] the record's bias
 				// constant: [2] again for block records (hop bias), the descriptor blocks of a window record (its value area starts there)
 				r[0] = fst; r[1] = rows; r[2] = row0 - fst; r[3] = S; r[4] = b0; r[5] = b1; r[6] = arow;
-				r[7] = (WIN && lane >= MPC_RB_MAXN) ? (s.seq_len[S] + 1u + 3u) / 4u : row0 - fst;
+				r[7] = (WIN && lane >= MPC_RB_MAXN) ? (pa->s.seq_len[S] + 1u + 3u) / 4u : row0 - fst;
 			}
 			if (lane == 0u) { misc[1] = total; misc[2] = ftot; }
 		}
@@ -572,7 +584,70 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 		for (int j = 0; j < (MAXSLOTS + 9) / 10; ++j) sel_a[j] = 0u;
 #pragma unroll
 		for (int j = 0; j < (int)YREGS; ++j) yreg[j] = 0u;
-		auto find_cell = [&](u32 q, u32 *kout, u32 *eout, u32 *ixo, u32 *iyo) -> bool { // the cell of (slot q, this lane); false: a repeat
+		// ---- cell order inside an X group. The 64 cells of a (wave, slot) run their merge loop as often as the LONGEST X row among
+		// them has blocks, and at r ~ 2 a fifth of the rows of a record have a second block: laid out pair after pair, 64 consecutive
+		// cells are ~35 different rows of X and nearly every (wave, slot) pays two or three rounds for the few lanes that need them
+		// (40 x 400 synthetic posteriors: 2.0 - 2.2 rounds per slot). Laid out ROW BY ROW — row x of all the group's pairs, then row
+		// x + 1 — the same 64 cells are ~5 rows of X: 1.4 - 1.5 rounds, 21 % fewer LDS and VALU instructions on the device
+		// (SQ_INSTS_LDS 1.13e11 -> 0.90e11 per two launches) — and slower: the 32 lanes of a half wave then read descriptors and
+		// values of 8 different Y records, SQ_LDS_BANK_CONFLICT 1.0e11 -> 2.3e11 cycles. In between: BLOCKS of G rows, the cells of
+		// a block pair after pair (G = 8: runs of ~14 cells of one pair, ~10 X rows per slot, 1.6 rounds) keep the conflicts of the
+		// pair order and most of the saved rounds: relax per step 880 ms (pairs), 929 (G = 1), 849 (G = 8), 851 (16), 886 (32).
+		// Which lane owns which cell changes nothing in any sum. The order needs, per group, the cells before row r (T) and per pair
+		// (PJ): prefix sums of the packed records' row counts over the band, built in the staging area before the walk and again
+		// after it (13 cells per lane look themselves up twice per tile; the table does not live across the walk).
+		u32 rows_g, gx0, gnx, band0, R1, tstride, gbytes; // rows_g: rows per block of the cell order; gx0, gnx: the tile's X sequences; R1: prefix entries per group (rows of the band + 1); tstride: bytes of a group's T array (u16); gbytes: + its PJ array, 8 x u16 per row
+		bool by_rows;
+		auto row_geometry = [&](auto P) { // (computed where it is used, from the tile's words: five values that would otherwise live across the walk)
+			u32 t = misc[0];
+			MPC_OPAQUE(t);
+			const u32 *w = P->tiles + (u64)MPC_RB_TILE_WORDS * mpc_wave_first(t);
+			const u32 ra = mpc_wave_first(w[4]), rb = mpc_wave_first(w[5]);
+			gx0 = mpc_wave_first(w[0]); gnx = mpc_wave_first(w[1]);
+			const u32 bb = (rb + MPC_RB_HB - 1u) / MPC_RB_HB;
+			band0 = ra / MPC_RB_HB;
+			R1 = ((bb < P->nb1 - 1u ? bb : P->nb1 - 1u) - band0) * MPC_RB_HB + 1u;
+			tstride = (2u * R1 + 15u) & ~15u;
+			gbytes = tstride + 16u * R1;
+			rows_g = P->by_rows;
+			by_rows = rows_g != 0u && MPC_RB_MAXN * gbytes <= P->cap_bytes;
+		};
+		row_geometry(pa);
+		auto build_rows = [&](auto P) { // P: the kernel's argument (the epilogue reads it from the kernarg segment again)
+			constexpr u32 PPW = 64u / NWAVES; // pairs of the tile per wave; lanes = rows
+			static_assert(64u % NWAVES == 0u, "relax_band_kernel: 64 pairs are dealt over the waves");
+			for (u32 pp = 0; pp < PPW; ++pp) {
+				const u32 pr = wave * PPW + pp, gx = pr >> 3, j = pr & 7u;
+				const u32 cnt = mpc_wave_first(ptab[4 * pr + 1]), k = mpc_wave_first(ptab[4 * pr + 2]);
+				unsigned short *PJ = (unsigned short *)(stage + gx * gbytes + tstride);
+				const u32 *rec = P->s.packed + P->s.pbase[k]; // rowcnt: the first LX words of the packed record (kernels_post.h)
+				const u32 LX = P->s.seq_len[gx0 + (gx < gnx ? gx : 0u)];
+				u32 carry = 0;
+				u32 ln = lane;
+				MPC_OPAQUE(ln);
+				if (ln == 0u) PJ[j] = 0;
+				for (u32 c0 = 0; c0 + 1u < R1; c0 += 64u) {
+					const u32 r = c0 + ln, x = band0 * MPC_RB_HB + r;
+					const u32 v = (cnt != 0u && r + 1u < R1 && x < LX) ? rec[x] : 0u;
+					u32 incl = v;
+					for (u32 d = 1; d < 64; d <<= 1) { const u32 o = rb_lane_up(incl, d, ln); if (ln >= d) incl += o; }
+					if (r + 1u < R1) PJ[8u * (r + 1u) + j] = (unsigned short)(carry + incl);
+					carry += mpc_wave_first(rb_lane_at(incl, 63u));
+				}
+			}
+			__syncthreads();
+			for (u32 i = tid; i < MPC_RB_MAXN * R1; i += THREADS) {
+				const u32 gx = i / R1, r = i % R1;
+				const unsigned short *PJ = (const unsigned short *)(stage + gx * gbytes + tstride) + 8u * r;
+				u32 t = 0;
+				for (u32 j = 0; j < MPC_RB_MAXN; ++j) t += PJ[j];
+				((unsigned short *)(stage + gx * gbytes))[r] = (unsigned short)t;
+			}
+			__syncthreads();
+		};
+		if (by_rows) build_rows(pa);
+		// the cell of (slot q, this lane); false: a repeat. *rowo: the cell's row when the order knows it, else 0xffffffff
+		auto find_cell = [&](u32 q, u32 *kout, u32 *eout, u32 *ixo, u32 *iyo, u32 *rowo) -> bool {
 			const u32 g0 = q * THREADS + wave_first;
 			u32 ix = 0;
 			for (u32 j = 1; j < MPC_RB_MAXN; ++j) if (mpc_wave_first(gtab[2 * j]) <= g0 && mpc_wave_first(gtab[2 * j + 1]) > mpc_wave_first(gtab[2 * j])) ix = j;
@@ -582,12 +657,39 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			const u32 g = g0 + ln;
 			const u32 ge = g < gend ? g : gend - 1u;
 			u32 iy = 0;
+			if (by_rows) {
+				const u32 d = ge - mpc_wave_first(gtab[2 * ix]);
+				const unsigned short *T = (const unsigned short *)(stage + ix * gbytes);
+				const unsigned short *PJ = (const unsigned short *)(stage + ix * gbytes + tstride);
+				const u32 rows = R1 - 1u, nblk = (rows + rows_g - 1u) / rows_g;
+				u32 lo = 0, hi = nblk; // blocks of rows_g rows: cells before block lo <= d < cells before block hi
+				while (hi - lo > 1u) {
+					const u32 mid = (lo + hi) >> 1;
+					if ((u32)T[mid * rows_g] <= d) lo = mid; else hi = mid;
+				}
+				const u32 ra = lo * rows_g, rb = ra + rows_g < rows ? ra + rows_g : rows;
+				const unsigned short *A = PJ + 8u * ra, *B = PJ + 8u * rb;
+				u32 dd = d - (u32)T[ra], before = 0;
+				bool found = false;
+				for (u32 j = 0; j < MPC_RB_MAXN; ++j) { // inside a block: pair after pair
+					const u32 a = A[j], c = (u32)B[j] - a;
+					if (!found) {
+						if (dd < c) { iy = j; before = a; found = true; }
+						else dd -= c;
+					}
+				}
+				u32 r = ra; // the row inside the pair's run
+				while (r + 1u < rb && (u32)PJ[8u * (r + 1u) + iy] - before <= dd) ++r;
+				const u32 *e = ptab + 4 * (8 * ix + iy);
+				*kout = e[2]; *eout = e[3] + before + dd; *ixo = ix; *iyo = iy; *rowo = band0 * MPC_RB_HB + r;
+				return g < gend;
+			}
 			for (u32 j = 0; j < MPC_RB_MAXN; ++j) {
 				const u32 b = ptab[4 * (8 * ix + j)], c = ptab[4 * (8 * ix + j) + 1];
 				if (c != 0u && b <= ge && ge - b < c) iy = j;
 			}
 			const u32 *e = ptab + 4 * (8 * ix + iy);
-			*kout = e[2]; *eout = e[3] + (ge - e[0]); *ixo = ix; *iyo = iy;
+			*kout = e[2]; *eout = e[3] + (ge - e[0]); *ixo = ix; *iyo = iy; *rowo = 0xffffffffu;
 			return g < gend;
 		};
 #pragma unroll
@@ -595,12 +697,12 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			MPC_SCHED_BARRIER();
 			acc[q] = 1.0f; xy[q] = 0u;
 			if ((u32)q < nact) {
-				u32 k, e, ix, iy;
-				find_cell((u32)q, &k, &e, &ix, &iy);
-				const u32 nnz = (u32)(s.vbase[(u64)k + 1] - s.vbase[k]);
-				const u32 *ent = s.packed + s.pbase[k] + s.seq_len[s.pair_x[k]] + s.seq_len[s.pair_y[k]];
+				u32 k, e, ix, iy, rw;
+				find_cell((u32)q, &k, &e, &ix, &iy, &rw);
+				const u32 nnz = (u32)(pa->s.vbase[(u64)k + 1] - pa->s.vbase[k]);
+				const u32 *ent = pa->s.packed + pa->s.pbase[k] + pa->s.seq_len[pa->s.pair_x[k]] + pa->s.seq_len[pa->s.pair_y[k]];
 				acc[q] = __uint_as_float(ent[2 * (u64)e]) * 2.0f; // conspairflat.cpp:29-30
-				const u32 col = ent[2 * (u64)e + 1], row = ent[2 * (u64)nnz + e];
+				const u32 col = ent[2 * (u64)e + 1], row = rw != 0xffffffffu ? rw : ent[2 * (u64)nnz + e];
 				// row - row0 + first-piece offset, in bytes (rtab[..][2] = row0 - offset)
 				const u32 xo = (row - rtab[8 * ix + 2]) << 4;
 				const u32 yo = WIN ? (rtab[8 * (MPC_RB_MAXN + iy)] << 4) + ((col - rtab[8 * (MPC_RB_MAXN + iy) + 6]) << 2) // the row's descriptor
@@ -782,13 +884,19 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			atomicAdd(tt + 0, tm_all); atomicAdd(tt + 1, tm_bar); atomicAdd(tt + 2, tm_stage); atomicAdd(tt + 3, tm_wait);
 		}
 		// ---- UpdateFromPost (mysparsemx.cpp:87-113): P' = acc / N on the frozen pattern
+		const auto pk = MPC_KERNARG_AGAIN(p);
+		row_geometry(pk);
+		if (by_rows) {
+			__syncthreads(); // the last step's readers are done with the staging area
+			build_rows(pk);
+		}
 #pragma unroll
 		for (int q = 0; q < MAXSLOTS; ++q) {
 			MPC_SCHED_BARRIER();
 			if ((u32)q < nact) {
-				u32 k, e, ix, iy;
-				if (find_cell((u32)q, &k, &e, &ix, &iy))
-					s.vnext[s.vbase[k] + e] = acc[q] / (float)n; // uint -> float, IEEE divide (mysparsemx.cpp:108)
+				u32 k, e, ix, iy, rw;
+				if (find_cell((u32)q, &k, &e, &ix, &iy, &rw))
+					pk->s.vnext[pk->s.vbase[k] + e] = acc[q] / (float)pk->s.n; // uint -> float, IEEE divide (mysparsemx.cpp:108)
 			}
 		}
 	}

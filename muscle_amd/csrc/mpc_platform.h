@@ -99,6 +99,16 @@ __device__ __forceinline__ unsigned mpc_lane_gather(unsigned v, unsigned byte_in
 // optimisation barrier on one VGPR value (no code): stops hoisting of what is derived from it
 #define MPC_OPAQUE(v) asm volatile("" : "+v"(v))
 #define MPC_OPAQUE_S(v) asm volatile("" : "+s"(v)) // the same for a wave-uniform value in a scalar register
+// The kernel's (single, struct) argument read from the kernarg segment AGAIN, through a pointer the compiler cannot connect with
+// the argument it already loaded: pointers an epilogue needs are then scalar loads there instead of registers held across the
+// kernel's main loop. Use as MPC_KERNARG_AGAIN(p)->field.
+template <class T> __device__ __forceinline__ const __attribute__((address_space(4))) T *mpc_kernarg_again(const T &)
+{
+	unsigned long long k = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(k));
+	return (const __attribute__((address_space(4))) T *)k;
+}
+#define MPC_KERNARG_AGAIN(p) mpc_kernarg_again(p)
 // orders this wave's earlier global stores before its later global loads (other lanes' data): s_waitcnt only,
 // the waves of a workgroup share the CU's L1
 #define MPC_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")

@@ -102,6 +102,7 @@ template <class T> static inline T __shfl_down(T v, unsigned d) { return emu_xch
 template <class T> static inline T __shfl(T v, int src) { return emu_xchg(v, src, true); }
 #define MPC_OPAQUE(v) ((void)0)
 #define MPC_OPAQUE_S(v) ((void)0)
+#define MPC_KERNARG_AGAIN(p) (&(p))
 #define MPC_SCHED_BARRIER() ((void)0)
 #define MPC_WAVE_LDS_ORDER() ((void)__shfl(0, 0)) // a rendezvous of the WAVE (any collective is one): the emulator runs lanes one after the other between synchronisation points
 #define MPC_WAVE_FENCE() ((void)0) // emulated lanes meet at every shuffle

@@ -547,6 +547,10 @@ def test_emu_relax_two_geometries(emu):
     {"MPCGPU_RELAX_WIN_PCT": "100000"},                              # window records whatever they cost (the unrelated 70-residue sequence has wide rows)
     {"MPCGPU_RELAX_WIN_PCT": "100000", "MPCGPU_RELAX_SHAPE": "2,2,8", "MPCGPU_RELAX_LDS_KB": "20"},
     {"MPCGPU_RELAX_WIN_PCT": "100000", "MPCGPU_RELAX_LDS_KB": "9"},  # no band fits with windows: the store drops them and walks block lists
+    {"MPCGPU_RELAX_ORDER": "pairs"},                                 # cells of an X group pair after pair (the default: blocks of 8 rows, a block's cells pair after pair)
+    {"MPCGPU_RELAX_ORDER": "1"},                                     # row by row
+    {"MPCGPU_RELAX_ORDER": "3", "MPCGPU_RELAX_SHAPE": "8,8", "MPCGPU_RELAX_SLOTS": "1"},  # blocks that do not divide the band
+    {"MPCGPU_RELAX_ORDER": "pairs", "MPCGPU_RELAX_FORM": "walk", "MPCGPU_RELAX_SHAPE": "4,2", "MPCGPU_RELAX_SLOTS": "2"},
 ])
 def test_emu_relax_band_tiles(emu, env):
     """relax_band_kernel over forced tile shapes, slot budgets and staging areas: row bands of 16..80 rows, Y ranges that start

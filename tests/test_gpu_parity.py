@@ -288,7 +288,7 @@ def test_relax_gather_equals_tiled():
     # four-workgroups-per-CU geometry; relax_var_kernel (whole-record tiles) in its geometries
     variants = [{"MPCGPU_RELAX_SHAPE": "8,8"}, {"MPCGPU_RELAX_SHAPE": "4,2,12"}, {"MPCGPU_RELAX_SHAPE": "1,1"},
                 {"MPCGPU_RELAX_SHAPE": "8,8", "MPCGPU_RELAX_SLOTS": "2"}, {"MPCGPU_RELAX_LDS_KB": "24"},
-                {"MPCGPU_RELAX_MERGE": "cxx"}, {"MPCGPU_RELAX_WG": "512"},
+                {"MPCGPU_RELAX_MERGE": "cxx"}, {"MPCGPU_RELAX_WG": "512"}, {"MPCGPU_RELAX_ORDER": "pairs"}, {"MPCGPU_RELAX_ORDER": "pairs", "MPCGPU_RELAX_FORM": "walk"}, {"MPCGPU_RELAX_ORDER": "1"}, {"MPCGPU_RELAX_ORDER": "5", "MPCGPU_RELAX_FORM": "walk"},
                 # the default above looks the Y rows up in window records (narrow rows); the two-list walk on block records, and both merges of it
                 {"MPCGPU_RELAX_FORM": "walk"}, {"MPCGPU_RELAX_FORM": "walk", "MPCGPU_RELAX_MERGE": "cxx"}, {"MPCGPU_RELAX_FORM": "walk", "MPCGPU_RELAX_SHAPE": "4,2,12"}]
     variants += [{"MPCGPU_RELAX_TILES": "pairs", "MPCGPU_RELAX_WG": geo, "MPCGPU_RELAX_NBUF": nbuf}
