@@ -66,22 +66,24 @@ typedef MpcRbBlocksCxx MpcRbBlocksAsm; // the emulator has the C++ statement onl
 // every X entry (z, P) looks its partner up in the Y row's WINDOW (StoreParams::win): value = val[off + min(z - c0, span)] — a
 // column the row does not store reads 0.0f (inside the window) or the 0.0f guard at off + span (outside, also below c0: the
 // unsigned difference wraps). P * 0.0f = +0.0f leaves the strictly positive sum unchanged, so the additions that count are those of
-// the reference, in z order. yd: LDS address of the Y row's descriptor (the next row's follows it); hb: LDS address of the value
+// the reference, in z order. yd: LDS address of the Y row's descriptor word (this slot's: read again only for a wide row); hb: LDS address of the value
 // area of the cell's Y record as it lies in this step's buffer (gathered one slot ahead).
 struct MpcRbWinCxx {
 	static constexpr bool WINDOW = true;
 	MpcQuad a[2];
-	u32 d0[2], d1[2];
+	u32 d0[2];
 	u32 hb;
-	__device__ __forceinline__ void load(u32 ia, u32 yd, u32 hb_addr) { a[0] = mpc_lds_load16(ia); d0[0] = mpc_lds_load4(yd); d1[0] = mpc_lds_load4(yd + 4u); hb = mpc_lds_load4(hb_addr); }
+	__device__ __forceinline__ void load(u32 ia, u32 yd, u32 hb_addr) { a[0] = mpc_lds_load16(ia); d0[0] = mpc_lds_load4(yd); hb = mpc_lds_load4(hb_addr); }
 	__device__ __forceinline__ void drain() {}
-	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32, u32 nia, u32 nyd, u32 nidx, u32 bias_y)
+	template <int SET> __device__ __forceinline__ void merge(float &sum, u32 ia, u32 yd, u32 nia, u32 nyd, u32 nidx, u32 bias_y)
 	{
 		MpcQuad va = a[SET];
-		const u32 D0 = d0[SET], D1 = d1[SET], base = hb;
-		a[SET ^ 1] = mpc_lds_load16(nia); d0[SET ^ 1] = mpc_lds_load4(nyd); d1[SET ^ 1] = mpc_lds_load4(nyd + 4u);
+		const u32 D0 = d0[SET], base = hb;
+		a[SET ^ 1] = mpc_lds_load16(nia); d0[SET ^ 1] = mpc_lds_load4(nyd);
 		hb = mpc_lane_gather(bias_y, nidx);
-		const u32 c0 = D0 & 0xfffu, off = D0 >> 12, span = (D1 >> 12) - off - 1u, vb = base + 4u * off;
+		const u32 c0 = D0 & 0xfffu, vb = base + 4u * (D0 >> 17); // kernels_store.h: c0 | span << 12 | off << 17
+		u32 span = (D0 >> 12) & 31u;
+		if (span == MPC_WIN_MAXSPAN) span = (mpc_lds_load4(yd + 4u) >> 17) - (D0 >> 17) - 1u; // the escape: a wide row
 		for (;;) {
 			u32 j0 = (va.z & 0xffffu) - c0, j1 = va.w - c0;
 			j0 = j0 < span ? j0 : span; j1 = j1 < span ? j1 : span;

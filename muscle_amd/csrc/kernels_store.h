@@ -67,8 +67,13 @@ struct StoreParams {
 	// WINDOW records (kernels_relaxb.h, the direct-index merge; null: not built): a second copy of every ordered pair's matrix for
 	// the role of the Y operand, in which a row is looked up BY COLUMN instead of being walked:
 	//   record (A,Z) = [desc: len(A)+1 words, padded to 16 bytes][values, + one spare block], at block wrec_off[Z*n+A] of `win`
-	//   desc[a] = c0 | off << 12: first stored column of row a (0: none) and the dword offset of its values in the value area;
-	//   desc[len(A)] = total << 12. Row a owns dwords off .. off + span (span = last - first + 1 columns, 0 for an empty row):
+	//   desc[a] = c0 | span << 12 | off << 17: first stored column of row a (0: none; 12 bits), span = last - first + 1 columns (0 for
+	//   an empty row; 5 bits) and the dword offset of its values in the value area (15 bits) — ONE word per row, one LDS read per
+	//   (cell, Z) (until round 4's last profile: c0 | off << 12, the span taken from the next row's word: a two-word read whose
+	//   bank conflicts the row-block cell order doubled). A span field of 31 is an ESCAPE: the span is then off(a + 1) - off - 1,
+	//   one more read for the lanes that meet such a row (a fragment against a full-length sequence: spans of 60). Stores with a
+	//   value area > 32767 dwords keep block records for the Y operand (win_size_kernel's flag). desc[len(A)] = total << 17. Row a
+	//   owns dwords off .. off + span:
 	//   the probability of column c0 + j at off + j (0.0f where that column is not stored), and 0.0f at off + span — the GUARD that
 	//   every column outside the window is clamped to: value(z) = val[off + min(z - c0 (unsigned), span)].
 	// wv_off[(Z*n+A)*nb1 + b] = block of `win` that holds the first value of row MPC_RB_HB*b (the record's end beyond the last row).
@@ -80,6 +85,8 @@ struct StoreParams {
 };
 
 #define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128)
+#define MPC_WIN_MAXSPAN 31u   // window records: a row's span field (5 bits); 31 = look at the next row's offset
+#define MPC_WIN_MAXOFF 32767u  // and its value offset (15 bits)
 #define MPC_RB_HB 8u  // rows per index band of the band tables (overflow offsets here; cell offsets, y ranges: kernels_relaxb.h)
 #define MPC_PAD_SENTINEL 0x1fffu // larger than any column: sequences in the padded layout are <= 8191 long
 
@@ -147,7 +154,7 @@ __global__ void __launch_bounds__(64) var_size_kernel(StoreParams s, u32 *sizes)
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
 		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n); // b == mpc_rec_index(n, A, Z)
 		const u32 LA = s.seq_len[A];
-		u32 mine = 0;
+		u32 mine = 0, wide = 0;
 		if (A != Z) {
 			const bool fwd = A < Z;
 			const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
@@ -239,7 +246,7 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 
 // ---- window records (see StoreParams::win) -----------------------------------------------------------------------------------
 // value dwords of window record (A,Z): sum over rows of (span + 1); sizes[b] = blocks of the record = desc blocks + value blocks
-// + 1 spare; *too_wide is set when a record's value area does not fit the 16-bit positions. One wave per record.
+// + 1 spare; *too_wide is set when a record does not fit the descriptor word (a value area > MPC_WIN_MAXOFF dwords). One wave per record.
 __global__ void __launch_bounds__(64) win_size_kernel(StoreParams s, u32 *sizes, u32 *vals_total, u32 *too_wide)
 {
 	const int t = threadIdx.x;
@@ -247,7 +254,7 @@ __global__ void __launch_bounds__(64) win_size_kernel(StoreParams s, u32 *sizes,
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
 		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n);
 		const u32 LA = s.seq_len[A];
-		u32 mine = 0;
+		u32 mine = 0, wide = 0;
 		if (A != Z) {
 			const bool fwd = A < Z;
 			const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
@@ -264,13 +271,13 @@ __global__ void __launch_bounds__(64) win_size_kernel(StoreParams s, u32 *sizes,
 				}
 				mine += span + 1u;
 			}
-			for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
+			for (int d = 32; d >= 1; d >>= 1) { mine += __shfl_down(mine, d); wide |= __shfl_down(wide, d); }
 			(void)k;
 		} else mine = LA; // empty matrix: every row is its guard alone
 		if (t == 0) {
 			sizes[b] = (LA + 1u + 3u) / 4u + (mine + 3u) / 4u + 1u;
 			vals_total[b] = mine;
-			if (mine > 0xffffu) atomicOr(too_wide, 1u);
+			if (mine > MPC_WIN_MAXOFF || wide) atomicOr(too_wide, 1u);
 		}
 	}
 }
@@ -310,10 +317,10 @@ __global__ void __launch_bounds__(64) win_build_kernel(StoreParams s)
 				if (t >= (u32)d) incl += o;
 			}
 			const u32 off = carry + incl - v;
-			if (a <= LA) { desc[a] = c_first | (off << 12); s_off[a] = off; }
+			if (a <= LA) { desc[a] = c_first | ((span < MPC_WIN_MAXSPAN ? span : MPC_WIN_MAXSPAN) << 12) | (off << 17); s_off[a] = off; }
 			carry += __shfl(incl, 63);
 		}
-		for (u32 q = LA + 1u + t; q < 4u * dblocks; q += 64) desc[q] = carry << 12; // padding words repeat the end marker
+		for (u32 q = LA + 1u + t; q < 4u * dblocks; q += 64) desc[q] = carry << 17; // padding words repeat the end marker
 		__syncthreads();
 		const u32 vtotal = carry, vblocks = (vtotal + 3u) / 4u + 1u;
 		for (u32 q = t; q < 4u * vblocks; q += 64) vals[q] = 0u; // 0.0f everywhere: guards and the gaps inside the windows
@@ -355,8 +362,8 @@ __global__ void __launch_bounds__(64) win_pos_kernel(StoreParams s)
 		for (u32 q = t; q < nnz; q += 64) {
 			const u32 col = ent[2 * (u64)q + 1], row = ent[2 * (u64)nnz + q];
 			const u32 wf = dxy[row], wt = dyx[col];
-			s.pos_wf[s.vbase[k] + q] = (unsigned short)((wf >> 12) + (col - (wf & 0xfffu)));
-			s.pos_wt[s.vbase[k] + q] = (unsigned short)((wt >> 12) + (row - (wt & 0xfffu)));
+			s.pos_wf[s.vbase[k] + q] = (unsigned short)((wf >> 17) + (col - (wf & 0xfffu)));
+			s.pos_wt[s.vbase[k] + q] = (unsigned short)((wt >> 17) + (row - (wt & 0xfffu)));
 		}
 	}
 }

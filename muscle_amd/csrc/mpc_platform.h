@@ -309,7 +309,7 @@ struct MpcRbBlocksAsm {
 };
 #define MPC_RB_HAVE_ASM 1
 // ---- the DIRECT-INDEX merge of relax_band_kernel (kernels_relaxb.h: MpcRbWinCxx is its C++ statement). The X row is walked block by
-// block as before; the Y row is not walked: it is a WINDOW record's row — descriptor pair {c0 | off << 12, next row's} and
+// block as before; the Y row is not walked: it is a WINDOW record's row — descriptor word c0 | span << 12 | off << 17 and
 // values val[off + j] for column c0 + j, with a 0.0f guard at off + span (StoreParams::win) — and every X entry (z, P) looks its
 // partner up: value = val[off + min(z - c0, span)]. Per X block: 2 x (sub, min, address, ds_read_b32, mul, add) instead of a
 // 2 x 2 compare-select step on two block lists, and the number of steps is that of the X row alone. Registers: set 0 = X block
@@ -317,26 +317,35 @@ struct MpcRbBlocksAsm {
 struct MpcRbWinAsm {
 	static constexpr bool WINDOW = true;
 	mpc_uint4v a0, a1;
-	unsigned long long d0, d1;
+	unsigned d0, d1;
 	unsigned hb;
 	__device__ __forceinline__ void load(unsigned ia, unsigned yd, unsigned hb_addr)
 	{
-		asm volatile("ds_read_b128 %0, %3\n\tds_read2_b32 %1, %4 offset1:1\n\tds_read_b32 %2, %5"
-			: "={v[24:27]}"(a0), "={v[28:29]}"(d0), "={v40}"(hb) : "v"(ia), "v"(yd), "v"(hb_addr) : "memory");
+		asm volatile("ds_read_b128 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5"
+			: "={v[24:27]}"(a0), "={v28}"(d0), "={v40}"(hb) : "v"(ia), "v"(yd), "v"(hb_addr) : "memory");
 	}
-	__device__ __forceinline__ void drain() { asm volatile("s_waitcnt lgkmcnt(0)" : "+{v[24:27]}"(a0), "+{v[28:29]}"(d0), "+{v[32:35]}"(a1), "+{v[36:37]}"(d1), "+{v40}"(hb) : : "memory"); }
-#define MPC_RW_MERGE_ASM(A0_, A1_, A2_, A3_, D0_, D1_, CURA_, NXTA_, NXTD_)                                              \
-	"s_waitcnt lgkmcnt(0)\n\t" /* this slot's X block, descriptor pair and value base have landed */                     \
+	__device__ __forceinline__ void drain() { asm volatile("s_waitcnt lgkmcnt(0)" : "+{v[24:27]}"(a0), "+{v28}"(d0), "+{v[32:35]}"(a1), "+{v36}"(d1), "+{v40}"(hb) : : "memory"); }
+#define MPC_RW_MERGE_ASM(A0_, A1_, A2_, A3_, D0_, CURA_, NXTA_, NXTD_)                                                   \
+	"s_waitcnt lgkmcnt(0)\n\t" /* this slot's X block, descriptor and value base have landed */                          \
 	"ds_read_b128 " NXTA_ ", %[nia]\n\t"                                                                                 \
-	"ds_read2_b32 " NXTD_ ", %[nyd] offset1:1\n\t"                                                                       \
-	"v_and_b32_e32 %[c0], 0xfff, " D0_ "\n\t"                                                                            \
-	"v_lshrrev_b32_e32 %[vb], 12, " D0_ "\n\t"                                                                           \
-	"v_lshrrev_b32_e32 %[sp], 12, " D1_ "\n\t"                                                                           \
-	"v_sub_u32_e32 %[sp], %[sp], %[vb]\n\t"                                                                              \
-	"v_add_u32_e32 %[sp], -1, %[sp]\n\t" /* span = off(next row) - off - 1: where the guard sits */                       \
+	"ds_read_b32 " NXTD_ ", %[nyd]\n\t"                                                                                  \
+	"v_and_b32_e32 %[c0], 0xfff, " D0_ "\n\t"                  /* descriptor: c0 | span << 12 | off << 17 */             \
+	"v_bfe_u32 %[sp], " D0_ ", 12, 5\n\t"                      /* span: where the guard sits */                          \
+	"v_lshrrev_b32_e32 %[vb], 17, " D0_ "\n\t"                                                                           \
 	"v_lshl_add_u32 %[vb], %[vb], 2, %[hb]\n\t" /* LDS address of the row's first value */                               \
 	"ds_bpermute_b32 %[hb], %[nidx], %[by]\n\t" /* the next slot's value base, into the register this slot's just left */ \
-	"s_mov_b64 %[sv], exec\n"                                                                                            \
+	"s_mov_b64 %[sv], exec\n\t"                                                                                          \
+	"v_cmp_eq_u32_e32 vcc, 31, %[sp]\n\t"       /* the escape: a row wider than the field — its span from the next row's offset */ \
+	"s_cbranch_vccz .Lrv_narrow_%=\n\t"                                                                                  \
+	"s_mov_b64 exec, vcc\n\t"                                                                                            \
+	"ds_read_b32 %[j0], %[yd] offset:4\n\t"                                                                              \
+	"v_lshrrev_b32_e32 %[j1], 17, " D0_ "\n\t"                                                                           \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                           \
+	"v_lshrrev_b32_e32 %[j0], 17, %[j0]\n\t"                                                                             \
+	"v_sub_u32_e32 %[j0], %[j0], %[j1]\n\t"                                                                              \
+	"v_add_u32_e32 %[sp], -1, %[j0]\n\t"                                                                                 \
+	"s_mov_b64 exec, %[sv]\n"                                                                                            \
+	".Lrv_narrow_%=:\n"                                                                                                  \
 	".Lrv_step_%=:\n\t"                                                                                                  \
 	"v_sub_u32_sdwa %[j0], " A2_ ", %[c0] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"        \
 	"v_sub_u32_e32 %[j1], " A3_ ", %[c0]\n\t"                                                                            \
@@ -371,28 +380,27 @@ struct MpcRbWinAsm {
 	"v_add_f32_e32 %[sum], %[sum], %[t0]\n\t"                                                                            \
 	"v_add_f32_e32 %[sum], %[sum], %[t1]\n\t"                                                                            \
 	"s_mov_b64 exec, %[sv]"
-	// merges the slot whose X block and descriptor pair are in set SET (ia: address of the X row's first block + the X record's hop
-	// bias) onto sum; reads the next slot's X block (nia) and descriptor pair (nyd) into the other set and gathers its value base
-	template <int SET> __device__ __forceinline__ void merge(float &sum, unsigned ia, unsigned ib, unsigned nia, unsigned nyd, unsigned nidx, unsigned bias_y)
+	// merges the slot whose X block and descriptor are in set SET (ia: address of the X row's first block + the X record's hop
+	// bias) onto sum; reads the next slot's X block (nia) and descriptor (nyd) into the other set and gathers its value base
+	template <int SET> __device__ __forceinline__ void merge(float &sum, unsigned ia, unsigned yd, unsigned nia, unsigned nyd, unsigned nidx, unsigned bias_y)
 	{
-		(void)ib;
 		mpc_u64s sv, more, keep;
 		float t0, t1, p0, p1;
 		unsigned c0, sp, vb, j0, j1;
 		const unsigned kf = 0xffffu;
 		if (SET == 0)
-			asm volatile(MPC_RW_MERGE_ASM("v24", "v25", "v26", "v27", "v28", "v29", "v[24:27]", "v[32:35]", "v[36:37]")
-				: [sum] "+v"(sum), [ia] "+v"(ia), [hb] "+{v40}"(hb), "+{v[24:27]}"(a0), "+{v[28:29]}"(d0), "=&{v[32:35]}"(a1), "=&{v[36:37]}"(d1),
+			asm volatile(MPC_RW_MERGE_ASM("v24", "v25", "v26", "v27", "v28", "v[24:27]", "v[32:35]", "v36")
+				: [sum] "+v"(sum), [ia] "+v"(ia), [hb] "+{v40}"(hb), "+{v[24:27]}"(a0), "+{v28}"(d0), "=&{v[32:35]}"(a1), "=&{v36}"(d1),
 				  [t0] "=&v"(t0), [t1] "=&v"(t1), [p0] "=&v"(p0), [p1] "=&v"(p1), [c0] "=&v"(c0), [sp] "=&v"(sp), [vb] "=&v"(vb), [j0] "=&v"(j0), [j1] "=&v"(j1),
 				  [sv] "=&s"(sv), [more] "=&s"(more), [keep] "=&s"(keep)
-				: [nia] "v"(nia), [nyd] "v"(nyd), [nidx] "v"(nidx), [by] "v"(bias_y), [kf] "s"(kf)
+				: [nia] "v"(nia), [nyd] "v"(nyd), [yd] "v"(yd), [nidx] "v"(nidx), [by] "v"(bias_y), [kf] "s"(kf)
 				: "vcc", "scc", "memory");
 		else
-			asm volatile(MPC_RW_MERGE_ASM("v32", "v33", "v34", "v35", "v36", "v37", "v[32:35]", "v[24:27]", "v[28:29]")
-				: [sum] "+v"(sum), [ia] "+v"(ia), [hb] "+{v40}"(hb), "+{v[32:35]}"(a1), "+{v[36:37]}"(d1), "=&{v[24:27]}"(a0), "=&{v[28:29]}"(d0),
+			asm volatile(MPC_RW_MERGE_ASM("v32", "v33", "v34", "v35", "v36", "v[32:35]", "v[24:27]", "v28")
+				: [sum] "+v"(sum), [ia] "+v"(ia), [hb] "+{v40}"(hb), "+{v[32:35]}"(a1), "+{v36}"(d1), "=&{v[24:27]}"(a0), "=&{v28}"(d0),
 				  [t0] "=&v"(t0), [t1] "=&v"(t1), [p0] "=&v"(p0), [p1] "=&v"(p1), [c0] "=&v"(c0), [sp] "=&v"(sp), [vb] "=&v"(vb), [j0] "=&v"(j0), [j1] "=&v"(j1),
 				  [sv] "=&s"(sv), [more] "=&s"(more), [keep] "=&s"(keep)
-				: [nia] "v"(nia), [nyd] "v"(nyd), [nidx] "v"(nidx), [by] "v"(bias_y), [kf] "s"(kf)
+				: [nia] "v"(nia), [nyd] "v"(nyd), [yd] "v"(yd), [nidx] "v"(nidx), [by] "v"(bias_y), [kf] "s"(kf)
 				: "vcc", "scc", "memory");
 	}
 #undef MPC_RW_MERGE_ASM

@@ -808,9 +808,11 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	rp.tile_next = c->d_tile_next.as<u32>();
 	{ // cell order inside an X group (kernels_relaxb.h): blocks of G rows, a block's cells pair after pair. MPCGPU_RELAX_ORDER = G, or "pairs"
 		// (no blocks: the layout until round 4's last profile). 1000 x 400, relax per step: pairs 880 ms, G = 1: 929, 2: 920, 4: 885,
-		// 8: 849, 16: 851, 32: 886 (profiles/r09b_order_sweep.log)
+		// 8: 849, 16: 851, 32: 886 (profiles/r09b_order_sweep.log). The two-list walk on wide rows (rdrp, <= 4x2 pairs, 3 cells per lane) gains nothing from
+		// blocks: 12 577 ms against 12 280 pair after pair (profiles/r09c) — its default stays "pairs".
 		const char *order_env = getenv("MPCGPU_RELAX_ORDER");
-		rp.by_rows = !order_env ? 8u : !strcmp(order_env, "pairs") ? 0u : (u32)atoi(order_env) > 0 ? (u32)atoi(order_env) : 8u;
+		const u32 order_default = use_win ? 8u : 0u;
+		rp.by_rows = !order_env ? order_default : !strcmp(order_env, "pairs") ? 0u : (u32)atoi(order_env) > 0 ? (u32)atoi(order_env) : order_default;
 	}
 	const size_t smem = MPC_RB_TAB_BYTES + (size_t)cap;
 	const int diag = env_int("MPCGPU_RELAX_DIAG", 0); // measurement only (results wrong): needs a library built with -DMPC_RELAX_DIAG_BUILD

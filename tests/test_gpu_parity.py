@@ -305,6 +305,24 @@ def test_relax_gather_equals_tiled():
         assert ("relax_var_kernel" if "MPCGPU_RELAX_TILES" in env else "relax_band_kernel") in info["relax_info"], (env, info["relax_info"])
 
 
+def test_relax_window_rows_wider_than_the_span_field(monkeypatch):
+    """the direct-index merge's escape (a window descriptor's 5-bit span field is 31: the span comes from the next row's offset) in
+    its hand-scheduled form: ragged unrelated sequences — a 3-residue row against 75 columns — with window records forced"""
+    seqs = make_family(7, 75, seed=11) + make_family(3, 18, seed=5) + [make_family(1, 70, seed=9)[0], "MKV"]
+    want = P.run_oracle(seqs)
+    assert max(int(v[1::2][o[i + 1] - 1]) - int(v[1::2][o[i]]) + 1 for o, v in want[0][0] for i in range(len(o) - 1) if o[i + 1] > o[i]) > 31
+    monkeypatch.setenv("MPCGPU_RELAX_WIN_PCT", "100000")
+    for extra in ({}, {"MPCGPU_RELAX_ORDER": "1"}, {"MPCGPU_RELAX_SHAPE": "4,2", "MPCGPU_RELAX_SLOTS": "2"}, {"MPCGPU_RELAX_MERGE": "cxx"}):
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        info = {}
+        got = P.run_lib(seqs, info=info)
+        for k in extra:
+            monkeypatch.delenv(k)
+        assert "MpcRbWin" in info["relax_info"], info["relax_info"]
+        P.assert_same(got, want, "window escape %s" % extra)
+
+
 @pytest.mark.parametrize("kernel", ["by size", "one wave", "waves", "lds rows"])
 def test_calc_aln_paths(kernel, monkeypatch):
     """CalcAlnFlat + TraceBackFlat on the device: integer traceback bit-for-bit (path string) and
