@@ -541,6 +541,7 @@ static int relax_var_launch(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1
 #else
 #define MPC_RB_DIAG_CASES(TH, SL)
 #endif
+constexpr u32 kBandSlotsWin = 15; // cells per lane of the direct-index merge (its two-word descriptor sets became one word each: registers for two more cells)
 constexpr u32 kBandThreads = 1024, kBandSlots = 13; // two 1024-thread workgroups per CU (8 waves per SIMD, 64 VGPRs), 13 cells per lane (14: spill reloads inside the walk, and every reload waits for vmcnt(0) - the prefetch)
 
 // 0 = launched (or nothing to do), 1 = error, 2 = not for band tiles (the caller runs relax_var)
@@ -552,11 +553,12 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	const u32 bthreads = env_int("MPCGPU_RELAX_WG", 1024) == 512 ? 512u : 1024u;
 	const u32 lds_bytes = (u32)std::max(env_int("MPCGPU_RELAX_LDS_KB", bthreads == 512 ? 40 : 80), 3) * 1024u;
 	const u32 cap = (lds_bytes - MPC_RB_TAB_BYTES) & ~15u, cap_blocks = cap / 16;
-	const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)kBandSlots), 1), (int)kBandSlots);
 	const u32 cus = (u32)c->prop.multiProcessorCount;
 	// the direct-index merge (window records for the Y operand) where the store has them; the 512-thread geometry and the
 	// measurement kernels exist for the block walk only
 	const bool use_win = c->win_ok && bthreads == 1024 && !env_int("MPCGPU_RELAX_DIAG", 0);
+	const u32 kernel_slots = use_win ? kBandSlotsWin : kBandSlots;
+	const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)kernel_slots), 1), (int)kernel_slots);
 	if (c->btiles_k0 != k0 || c->btiles_k1 != k1) {
 		c->btiles_k0 = c->btiles_k1 = ~0ull;
 		RbTileTabs tb;
@@ -829,8 +831,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		TimedSpan ts;
 		if (go && span_begin(c, 3, &ts)) return 1;
 		if (use_win) { // window records for the Y operand: the direct-index merge
-			if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbWinCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbWinCxx>), grid, kBandThreads, smem, c->stream, rp); }
-			else { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbWinAsm>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlots, 2, 0, MpcRbWinAsm>), grid, kBandThreads, smem, c->stream, rp); }
+			if (merge_cxx) { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlotsWin, 2, 0, MpcRbWinCxx>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlotsWin, 2, 0, MpcRbWinCxx>), grid, kBandThreads, smem, c->stream, rp); }
+			else { fn = (const void *)relax_band_kernel<kBandThreads, kBandSlotsWin, 2, 0, MpcRbWinAsm>; if (go) MPC_LAUNCH((relax_band_kernel<kBandThreads, kBandSlotsWin, 2, 0, MpcRbWinAsm>), grid, kBandThreads, smem, c->stream, rp); }
 		}
 		else if (bthreads == 512) { fn = (const void *)relax_band_kernel<512, kBandSlots, 4>; if (go) MPC_LAUNCH((relax_band_kernel<512, kBandSlots, 4>), grid, 512, smem, c->stream, rp); }
 		else
@@ -849,7 +851,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			}
 			grid = std::max(std::min<u32>(ntiles, cus * (u32)occ), 1u);
 			char kn[128];
-			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, %u, %d, %s>", bthreads, kBandSlots, bthreads == 512 ? 4u : 2u, bthreads == 512 ? 0 : diag,
+			snprintf(kn, sizeof(kn), "relax_band_kernel<%u, %u, %u, %d, %s>", bthreads, kernel_slots, bthreads == 512 ? 4u : 2u, bthreads == 512 ? 0 : diag,
 				use_win ? (merge_cxx ? "MpcRbWinCxx" : "MpcRbWinAsm") : merge_cxx && !diag && bthreads == 1024 ? "MpcRbBlocksCxx" : "MpcRbBlocksAsm");
 			c->relax_kernel_name = kn;
 			if (trace_on()) { fprintf(stderr, "[mpcgpu] relax band: %s; lds=%zu B occ=%d grid=%u\n", c->tiles_desc.c_str(), smem, occ, grid); fflush(stderr); }

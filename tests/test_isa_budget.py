@@ -39,7 +39,7 @@ def _scratch(lines):
 
 
 BAND = "_Z17relax_band_kernelILi1024ELi13ELi2ELi0E14MpcRbBlocksAsmEv15RelaxBandParams"   # the two-list walk (wide rows)
-BAND_WIN = "_Z17relax_band_kernelILi1024ELi13ELi2ELi0E11MpcRbWinAsmEv15RelaxBandParams"  # the direct-index merge (narrow rows: the bench's default)
+BAND_WIN = "_Z17relax_band_kernelILi1024ELi15ELi2ELi0E11MpcRbWinAsmEv15RelaxBandParams"  # the direct-index merge (narrow rows: the bench's default), 15 cells per lane (16: two accumulators reloaded per step)
 
 
 def _walk(body):
@@ -52,10 +52,10 @@ def test_default_relax_walk_has_no_spill_reloads(isa, kernel):
     """relax_band_kernel, the instantiation relax_band launches by default (kBandSlots cells per lane). A reload inside the walk is
     worse here than in relax_var_kernel: its wait is vmcnt(0), and the prefetch of the next step is in flight on the same counter."""
     src = open(os.path.join(CSRC, "mpcgpu.cpp")).read()
-    assert re.search(r"kBandThreads = 1024, kBandSlots = 13;", src), "default geometry of relax_band changed: update this test"
+    assert re.search(r"kBandThreads = 1024, kBandSlots = 13;", src) and re.search(r"kBandSlotsWin = 15;", src), "default geometry of relax_band changed: update this test"
     body = _body(isa, kernel)
     merges = _walk(body)
-    assert len(merges) == 13, len(merges)  # one hand-scheduled merge loop per cell slot
+    assert len(merges) == (15 if kernel == BAND_WIN else 13), len(merges)  # one hand-scheduled merge loop per cell slot
     inside = [k for k in _scratch(body) if merges[0] <= k <= merges[-1]]
     assert not inside, "spill code between the merges of a step: " + "; ".join(body[k].strip() for k in inside[:5])
     # no wait for the VMEM counter between the prefetch (the staging block sits between the first and the second merge) and the last
@@ -72,8 +72,8 @@ def test_band_merge_registers_are_not_touched_between_statements(isa, kernel):
     statement ends; the compiler does not know. Between the end of one merge statement and the opening wait of the next
     (or the drain after the last slot) no compiler-generated instruction may read or write those registers."""
     body = _body(isa, kernel)
-    # the walk pins v24..v40; the direct-index merge v24..v29, v32..v37 and v40 (its descriptor pairs are two registers each)
-    pinned = set(range(24, 41)) if kernel == BAND else (set(range(24, 30)) | set(range(32, 38)) | {40})
+    # the walk pins v24..v40; the direct-index merge v24..v28, v32..v36 and v40 (X block + descriptor word per set, the value base)
+    pinned = set(range(24, 41)) if kernel == BAND else (set(range(24, 29)) | set(range(32, 37)) | {40})
 
     def regs(line):
         out = set()
