@@ -70,7 +70,7 @@ def main():
         import json
         path, out = sys.argv[2], sys.argv[3]
         res = {}
-        for name, key, walk in (("relax_band_kernel", "relax_band_kernelILi1024ELi13ELi2ELi0E11MpcRbWinAsm", True),
+        for name, key, walk in (("relax_band_kernel", "relax_band_kernelILi1024ELi15ELi2ELi0E11MpcRbWinAsm", True),
                                 ("relax_band_kernel/MpcRbBlocksAsm", "relax_band_kernelILi1024ELi13ELi2ELi0E14MpcRbBlocksAsm", True),
                                 ("relax_var_kernel", "relax_var_kernelILi1024ELi13ELi2ELi0E14MpcRvBlocksAsm", True),
                                 ("fb_chain_kernel", "fb_chain_kernelILi7E", False), ("fb_kernel", "fb_kernelILi7ELb0ELb0E", False)):
