@@ -305,6 +305,24 @@ def test_relax_gather_equals_tiled():
         assert ("relax_var_kernel" if "MPCGPU_RELAX_TILES" in env else "relax_band_kernel") in info["relax_info"], (env, info["relax_info"])
 
 
+def test_relax_cell_order_on_long_row_bands(monkeypatch):
+    """the row-block cell order where a tile's band is the whole sequence (few pairs: 500 rows, the order's tables take 72 KB of the
+    staging area) and where the tables do not fit (800 rows: the kernel falls back to the pair order by itself) — against the
+    oracle, and the orders against each other"""
+    for n, length in ((12, 500), (6, 800)):
+        seqs = make_family(n, length, seed=7)
+        want = P.run_oracle(seqs)
+        for order in (None, "1", "pairs"):
+            if order:
+                monkeypatch.setenv("MPCGPU_RELAX_ORDER", order)
+            info = {}
+            got = P.run_lib(seqs, info=info)
+            if order:
+                monkeypatch.delenv("MPCGPU_RELAX_ORDER")
+            assert "relax_band_kernel" in info["relax_info"], info["relax_info"]
+            P.assert_same(got, want, "%d x %d, order %s" % (n, length, order))
+
+
 def test_relax_window_rows_wider_than_the_span_field(monkeypatch):
     """the direct-index merge's escape (a window descriptor's 5-bit span field is 31: the span comes from the next row's offset) in
     its hand-scheduled form: ragged unrelated sequences — a 3-residue row against 75 columns — with window records forced"""
