@@ -305,6 +305,29 @@ def test_relax_gather_equals_tiled():
         assert ("relax_var_kernel" if "MPCGPU_RELAX_TILES" in env else "relax_band_kernel") in info["relax_info"], (env, info["relax_info"])
 
 
+def test_random_ragged_stores_against_the_oracle():
+    """seeded random inputs through the default path (band tiles, window records where they pay, row-block cell order): mixes of
+    families of different lengths, unrelated sequences, fragments of 1..5 residues — every stage bit-identical to the oracle.
+    MPCGPU_TEST_FUZZ_CASES widens the sweep (default 40 cases: 2 s on the GPU box)."""
+    import random
+    cases = int(os.environ.get("MPCGPU_TEST_FUZZ_CASES", "40"))
+    for case in range(cases):
+        rng = random.Random(1000 + case)
+        seqs = []
+        for _ in range(rng.randint(1, 3)):
+            seqs += make_family(rng.randint(2, 14), rng.choice([12, 30, 60, 90, 150, 240]), seed=rng.randint(1, 10 ** 6),
+                                p_del=rng.choice([0.03, 0.1]), p_ins=rng.choice([0.03, 0.1]), p_sub=rng.choice([0.2, 0.5]))
+        for _ in range(rng.randint(0, 3)):
+            seqs.append(make_family(1, rng.randint(1, 5), seed=rng.randint(1, 10 ** 6))[0])
+        if rng.random() < 0.5:  # fragments of a family member: one-sided overlaps, wide rows against the full-length ones
+            t = seqs[0]
+            seqs += [t[: max(1, len(t) // 3)], t[len(t) // 2:]]
+        rng.shuffle(seqs)
+        info = {}
+        got = P.run_lib(seqs, info=info)
+        P.assert_same(got, P.run_oracle(seqs), "fuzz case %d (%d sequences, lengths %s; %s)" % (case, len(seqs), [len(t) for t in seqs], info.get("relax_info", "")[-80:]))
+
+
 def test_relax_cell_order_on_long_row_bands(monkeypatch):
     """the row-block cell order where a tile's band is the whole sequence (few pairs: 500 rows, the order's tables take 72 KB of the
     staging area) and where the tables do not fit (800 rows: the kernel falls back to the pair order by itself) — against the
