@@ -493,13 +493,15 @@ def test_errors_are_loud():
     g.close()
 
 
-@pytest.mark.parametrize("name", ["n256_L300", "n1000_L400", "rdrp256"])
+@pytest.mark.parametrize("name", ["n256_L300", "n1000_L400", "rdrp256", "rdrp384"])
 def test_baseline_configs_vs_reference_digests(name):
     """BASELINE configs 2 (256 x L~300) and 3 (1000 x L~400, the benchmarked workload) in full through the default
     kernels: EA bits and all three stage snapshots (after CalcPosteriors, after each ConsIter) against digests
     generated by the compiled reference (tests/golden/mpcbig_*.npz; mpcflat.cpp:313,328, mysparsemx.cpp:87-113).
     rdrp256: real data (first 256 records of the reference's test_data/rdrp), ~7 stored cells per row: records of tens of KB,
-    the 160 KB single-buffer relax geometry with the 4x1 / 2x1 tile mix the 1000-record bench run uses."""
+    band tiles of <= 4x2 pairs with the two-list walk, as the 1000-record bench run uses. rdrp384: the first 384 records (73 536
+    pairs, 202.8 M stored entries; 2.5 h of the compiled reference on 6 threads): more than 256 sequences put more than one tile
+    row of X groups and several shapes of band tiles under the digests."""
     import _bigdigest as D
     if D.fixture_for(*D.BIG_SETS[name]) is None:
         pytest.skip("fixture tests/golden/mpcbig_%s.npz not generated" % name)
