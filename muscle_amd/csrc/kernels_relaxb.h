@@ -21,6 +21,10 @@
 // relative to the record as it lies in HBM; (address of the first block in LDS) + bias + distance is its overflow block in
 // LDS. The bias of a slot's X record is a scalar (cells are laid out X-major and every X group is rounded up to whole waves,
 // so the 64 cells of a (wave, slot) share their X record); the Y record differs per lane: one cross-lane gather per slot.
+// Inside an X group the cells go in blocks of 8 rows, a block's cells pair after pair (see "cell order" in the kernel).
+//
+// The Y operand comes in one of two forms: block records walked with the X row (two-list merge, MpcRbBlocksAsm), or WINDOW
+// records looked up by column (direct-index merge, MpcRbWinAsm: the default where rows are narrow) — same tiles, same staging.
 //
 // Buffers: a step's pieces are placed at the bottom or at the top of the staging area, alternating; the next step is
 // prefetched when both fit (the host cuts the bands so that they do on average), otherwise — wide-row data: one step fills most
