@@ -585,7 +585,9 @@ def test_emu_relax_band_tiles_races(emu, mode):
     synchronisation points"""
     seqs = make_family(6, 40, seed=3) + make_family(3, 18, seed=5)
     want = P.run_oracle(seqs)
-    for form in ({"MPCGPU_RELAX_WIN_PCT": "100000"}, {"MPCGPU_RELAX_FORM": "walk"}):  # the direct-index merge / the two-list walk
+    # the direct-index merge / the two-list walk / the row-by-row cell order (its tables are built in the staging area before the walk and
+    # again after it: between the last step's readers and the epilogue's searches)
+    for form in ({"MPCGPU_RELAX_WIN_PCT": "100000"}, {"MPCGPU_RELAX_FORM": "walk"}, {"MPCGPU_RELAX_WIN_PCT": "100000", "MPCGPU_RELAX_ORDER": "1"}):
         env = {"MPCGPU_RELAX_SHAPE": "4,4,3", "MPCGPU_RELAX_LDS_KB": "10"}
         env.update(form)
         env.update({"EMU_DMA": "late"} if mode == "late" else {"EMU_SCHED": mode})
