@@ -729,12 +729,12 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			MPC_OPAQUE(ln);
 			const u32 li = ln & 15u, role = ln >> 4;
 			const u32 S = rtab[8 * li + 3], b0 = rtab[8 * li + 4], b1 = rtab[8 * li + 5];
-			const u32 rec = Zt * n + S; // (32-bit: the store has fewer than 2^32 blocks, and more blocks than table entries)
+			const u32 rec = Zt * n + S; // (n * n < 2^32: build_var_store; the PRODUCT with nb1 is formed in 64 bits — a store of skewed lengths has more table entries than blocks)
 			// one base pointer and an element offset (a select between two POINTERS became a two-entry table in scratch memory, read
 			// back with a load whose wait — vmcnt(0) — also waited for the prefetch the wave had just issued)
 			const bool wide = role == 1u || role == 2u;
 			const bool wrec = WIN && li >= MPC_RB_MAXN; // a window record: its own record table and band table
-			const long long off = (wide ? (long long)((wrec ? s.wv_off : p.ovf_off) - s.rec_off) + (long long)(rec * p.nb1 + (role == 1u ? b0 : b1))
+			const long long off = (wide ? (long long)((wrec ? s.wv_off : p.ovf_off) - s.rec_off) + (long long)rec * (long long)p.nb1 + (long long)(role == 1u ? b0 : b1)
 			                            : (wrec ? (long long)(s.wrec_off - s.rec_off) : 0ll) + (long long)rec);
 			if (ln < 48u) mpc_dma4(s.rec_off + off, ttab + 64u * (Zt & 1u));
 		};

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64) var_size_kernel(StoreParams s, u32 *sizes)
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
 		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n); // b == mpc_rec_index(n, A, Z)
 		const u32 LA = s.seq_len[A];
-		u32 mine = 0, wide = 0;
+		u32 mine = 0;
 		if (A != Z) {
 			const bool fwd = A < Z;
 			const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64) win_size_kernel(StoreParams s, u32 *sizes,
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
 		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n);
 		const u32 LA = s.seq_len[A];
-		u32 mine = 0, wide = 0;
+		u32 mine = 0;
 		if (A != Z) {
 			const bool fwd = A < Z;
 			const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
@@ -271,13 +271,13 @@ __global__ void __launch_bounds__(64) win_size_kernel(StoreParams s, u32 *sizes,
 				}
 				mine += span + 1u;
 			}
-			for (int d = 32; d >= 1; d >>= 1) { mine += __shfl_down(mine, d); wide |= __shfl_down(wide, d); }
+			for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
 			(void)k;
 		} else mine = LA; // empty matrix: every row is its guard alone
 		if (t == 0) {
 			sizes[b] = (LA + 1u + 3u) / 4u + (mine + 3u) / 4u + 1u;
 			vals_total[b] = mine;
-			if (mine > MPC_WIN_MAXOFF || wide) atomicOr(too_wide, 1u);
+			if (mine > MPC_WIN_MAXOFF) atomicOr(too_wide, 1u);
 		}
 	}
 }

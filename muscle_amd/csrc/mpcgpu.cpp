@@ -186,6 +186,11 @@ struct mpcgpu_ctx {
 	u32 sa_capc = 0, sa_long_min = 0;
 	bool sa_post_rows = false;
 	std::vector<u32> list_x, list_y; // the pairs of the last list stage
+	// mpcgpu_align_pairs runs its list in chunks (and halves a chunk that stage A had to split): the caller's WHOLE list and the
+	// index of the first pair of the chunk the last stage A ran on — mpcgpu_get_list_sparse(q) indexes the caller's list
+	std::vector<u32> ap_x, ap_y;
+	u32 list_q0 = 0;
+	bool ap_keep = false; // set around the stage_a calls that serve the align-pairs list (every other list stage forgets it)
 	HostBuf h_ap;             // mpcgpu_align_pairs: kernel parameters and results, page-locked
 	DevBuf d_ap_off;
 	DevBuf d_chain_first, d_chain_cnt; // fb_chain_kernel's work list (kernels_fbc.h)
@@ -551,6 +556,9 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	// geometry: 2 x 1024 threads per CU (default) or 4 x 512 (MPCGPU_RELAX_WG=512): 8 waves per SIMD either way; a barrier of the
 	// walk then holds 8 waves instead of 16, and three other workgroups fill a waiting one's issue slots
 	const u32 bthreads = env_int("MPCGPU_RELAX_WG", 1024) == 512 ? 512u : 1024u;
+	// (measured and removed again, profiles/r10a_rdrp_geometry_sweep.log: ONE 1024-thread workgroup per CU with the CU's 160 KB and 26 cells per
+	// lane — 8x4 bands, 10.7 cells per lane, every step prefetched, 6.6 B per cell-step instead of 11.7 — is 18 % SLOWER on real data
+	// (rdrp-500: 1818 against 1545 ms per two iterations): the walk's merges are chains of dependent LDS reads and want 8 waves per SIMD)
 	const u32 lds_bytes = (u32)std::max(env_int("MPCGPU_RELAX_LDS_KB", bthreads == 512 ? 40 : 80), 3) * 1024u;
 	const u32 cap = (lds_bytes - MPC_RB_TAB_BYTES) & ~15u, cap_blocks = cap / 16;
 	const u32 cus = (u32)c->prop.multiProcessorCount;
@@ -1182,6 +1190,11 @@ static int build_slab_store(mpcgpu_ctx *c)
 	TimedSpan ts;
 	c->d_pad.release();
 	c->d_pos.release();
+	// the band and window tables of a dense-record store that turned out not to tile go with it (nn * nb1 words each: GBs)
+	c->win_ok = false;
+	c->d_ovf_off.release(); c->d_cell_off.release(); c->d_yr.release(); c->d_ovf_sum.release(); c->d_ovf_maxc.release();
+	c->d_win.release(); c->d_pos_w.release(); c->d_wv_off.release(); c->d_wsum.release(); c->d_wmaxc.release(); c->d_wrec_off.release(); c->d_rec_off.release();
+	c->d_btiles.release();
 	{
 		const char *rm = getenv("MPCGPU_RELAX");
 		c->store_desc = "CSR slabs per sequence; relax_kernel (one thread per stored cell gathers its rows from HBM: the slow path, ~5x the LDS-tiled kernels)";
@@ -1503,6 +1516,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	c->have_shard = c->have_store = false;
 	c->shard_is_list = true;
 	c->list_x.assign(px, px + np); c->list_y.assign(py, py + np); // mpcgpu_get_list_sparse
+	c->list_q0 = 0;
+	if (!c->ap_keep) { c->ap_x.clear(); c->ap_y.clear(); }
 	c->sh_k0 = 0; c->sh_k1 = np;
 	c->sh_nnz.assign(np, 0);
 	c->sh_ea.assign(np, 0.0f);
@@ -2166,7 +2181,7 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 				// no band fits with the Y rows as windows (one wide row can be most of the LDS): the same tiles with the Y rows as block
 				// lists, i.e. the two-list walk; the window records are dropped
 				c->win_ok = false;
-				c->d_win.release(); c->d_pos_w.release();
+				c->d_win.release(); c->d_pos_w.release(); c->d_wv_off.release(); c->d_wsum.release(); c->d_wmaxc.release(); c->d_wrec_off.release();
 				{ const size_t at = c->store_desc.find(" + window records"); if (at != std::string::npos) c->store_desc.erase(at); }
 				c->btiles_k0 = c->btiles_k1 = ~0ull;
 				fill_store_params(c, sp);
@@ -2756,6 +2771,7 @@ static int align_pairs_small(mpcgpu_ctx *c, u32 np, const u32 *px, const u32 *py
 	c->have_shard = c->have_store = false;
 	c->shard_is_list = true;
 	c->list_x.assign(px, px + np); c->list_y.assign(py, py + np);
+	c->list_q0 = 0; c->ap_x.clear(); c->ap_y.clear();
 	c->sh_k0 = 0; c->sh_k1 = np;
 	// ---- the page-locked record
 	std::vector<u64> off(np + 1, 0);
@@ -2894,12 +2910,16 @@ int mpcgpu_align_pairs(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, con
 		if (rc != 2) return rc;
 	}
 	u32 chunk = 256; // pairs per stage-A call: their dense matrices (LX*LY floats each) live together
+	struct KeepList { mpcgpu_ctx *c; ~KeepList() { c->ap_keep = false; } } keep_guard{c};
+	c->ap_keep = true;
+	c->ap_x.assign(seq1, seq1 + npairs); c->ap_y.assign(seq2, seq2 + npairs);
 	for (u32 q0 = 0; q0 < npairs;) {
 		u32 nq = std::min<u32>(chunk, npairs - q0);
 		// the dense matrices below are rebuilt from the candidate lists ONE stage-A batch leaves behind: a chunk that stage A had to
 		// cut into several batches (long sequences, little free memory) is halved and run again, down to a single pair
 		for (;;) {
 			if (stage_a(c, nq, seq1 + q0, seq2 + q0)) return 1;
+			c->list_q0 = q0; // what the last stage holds is pairs [q0, q0 + nq) of the caller's list
 			if (c->sa_b0 == 0 && c->sa_B == nq) break;
 			if (nq == 1) return fail(c, "mpcgpu_align_pairs: pair %u (%u x %u residues) does not fit one stage-A batch", q0, c->len[seq1[q0]], c->len[seq2[q0]]);
 			nq = (nq + 1) / 2;
@@ -2983,20 +3003,41 @@ int mpcgpu_align_pairs(mpcgpu_ctx *c, uint32_t npairs, const uint32_t *seq1, con
 int mpcgpu_get_list_sparse(mpcgpu_ctx *c, uint32_t q, uint32_t *nnz, uint32_t *offsets, void *values)
 {
 	if (!c) return 1;
-	if (!c->shard_is_list || q >= c->list_x.size()) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
+	if (!c->shard_is_list) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
 	HIPCHK(c, hipSetDevice(c->device));
-	if (q >= c->sh_nnz.size()) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
-	if (!c->have_shard && offsets && values) { // the short-list path of mpcgpu_align_pairs packs nothing: the general stage on the same list does
-		const std::vector<u32> lx = c->list_x, ly = c->list_y;
-		if (lx.size() > 256) return fail(c, "mpcgpu_get_list_sparse: the last list stage is gone");
-		if (stage_a(c, lx.size(), lx.data(), ly.data())) return 1;
+	// q indexes the list the CALLER passed. mpcgpu_align_pairs may have run that list in chunks (256 pairs, halved when stage A had to
+	// split one): the last stage then holds pairs [list_q0, list_q0 + list_x.size()) of it. A pair outside that window gets a stage
+	// of its own (same kernels, same bits) — never another pair's record.
+	const bool want_record = offsets && values;
+	if (c->ap_x.empty() && !c->have_shard && want_record) { c->ap_x = c->list_x; c->ap_y = c->list_y; c->list_q0 = 0; } // the short-list path packed nothing
+	u32 ql = q;
+	if (!c->ap_x.empty()) {
+		if (q >= c->ap_x.size()) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
+		struct KeepList { mpcgpu_ctx *c; ~KeepList() { c->ap_keep = false; } } keep_guard{c};
+		c->ap_keep = true;
+		bool inside = q >= c->list_q0 && q - c->list_q0 < c->list_x.size();
+		if (inside && !c->have_shard && want_record) { // the general stage on the window's list packs the records
+			const std::vector<u32> lx = c->list_x, ly = c->list_y;
+			const u32 q0 = c->list_q0;
+			if (stage_a(c, lx.size(), lx.data(), ly.data())) return 1;
+			c->list_q0 = q0;
+			inside = c->sa_b0 == 0 && c->sa_B == lx.size(); // (split into batches: the shard holds the last batch only)
+		}
+		if (!inside) {
+			const u32 x = c->ap_x[q], y = c->ap_y[q];
+			if (stage_a(c, 1, &x, &y)) return 1;
+			c->list_q0 = q;
+		}
+		ql = q - c->list_q0;
 	}
+	if (ql >= c->list_x.size() || ql >= c->sh_nnz.size()) return fail(c, "mpcgpu_get_list_sparse: no list stage holds pair %u", q);
 	const u64 np = c->list_x.size();
 	u64 w = shard_header_bytes(np) / 4;
-	for (u32 k = 0; k < q; ++k) w += rec_words(c->len[c->list_x[k]], c->len[c->list_y[k]], c->sh_nnz[k]);
-	const u32 LX = c->len[c->list_x[q]], LY = c->len[c->list_y[q]], nz = c->sh_nnz[q];
+	for (u32 k = 0; k < ql; ++k) w += rec_words(c->len[c->list_x[k]], c->len[c->list_y[k]], c->sh_nnz[k]);
+	const u32 LX = c->len[c->list_x[ql]], LY = c->len[c->list_y[ql]], nz = c->sh_nnz[ql];
 	if (nnz) *nnz = nz;
-	if (!offsets || !values) return 0;
+	if (!want_record) return 0;
+	if (!c->have_shard) return fail(c, "mpcgpu_get_list_sparse: the list stage of pair %u left no packed records (internal error)", q);
 	std::vector<u32> rowcnt(LX);
 	HIPCHK(c, hipMemcpyAsync(rowcnt.data(), c->d_shard.as<u32>() + w, (size_t)LX * 4, hipMemcpyDeviceToHost, c->stream));
 	if (nz) HIPCHK(c, hipMemcpyAsync(values, c->d_shard.as<u32>() + w + LX + LY, (size_t)nz * 8, hipMemcpyDeviceToHost, c->stream));

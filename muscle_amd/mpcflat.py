@@ -58,11 +58,13 @@ class TorchExchange:
         cols = [[int(host[r, j]) for r in range(self.world)] for j in range(k)]
         return cols[0] if k == 1 else cols
 
-    def buffer(self, key, count, dtype):
+    def buffer(self, key, count, dtype, owner=None):
         """a persistent 1-D device buffer of at least `count` elements (grown geometrically, reused by every step: the gathered
-        shards are gigabytes and must not be allocated inside the timed loop)"""
+        shards are gigabytes and must not be allocated inside the timed loop). The buffers live ON `owner` (the engine whose store
+        they feed; default: this exchange) and die with it — keyed by id(engine) here they were never evicted, and a recycled id
+        aliased another engine's buffers."""
         import torch
-        bufs = self.__dict__.setdefault("_bufs", {})
+        bufs = (self if owner is None else owner).__dict__.setdefault("_xbufs", {})
         b = bufs.get(key)
         if b is None or b.numel() < count or b.dtype != dtype:
             b = torch.empty(max(int(count + count // 16), 1), dtype=dtype, device=self.device)
@@ -129,8 +131,8 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
     # shard bytes and value counts of every rank in one exchange (the stored cells of a shard are known once its stage A is done)
     sizes, counts = exchange.all_sizes(nbytes, engine.shard_entries())
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    # (the buffers belong to this engine's store: an exchange that serves several engines keeps one set per engine)
-    full = exchange.buffer(("shards", id(engine)), int(offs[-1]), torch.uint8)
+    # (the buffers belong to this engine's store and are kept on the engine: one set per engine, freed with it)
+    full = exchange.buffer("shards", int(offs[-1]), torch.uint8, owner=engine)
     engine.shard_export(full.data_ptr() + int(offs[exchange.rank]))
     full = exchange.all_gather_segments(full, sizes)
     _sync(torch, exchange.device)
@@ -142,7 +144,7 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
         first, count = engine.values_slice(k0, k1)
         assert count == counts[exchange.rank], (count, counts)
         voffs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        allv = exchange.buffer(("values", id(engine)), int(voffs[-1]), torch.float32)
+        allv = exchange.buffer("values", int(voffs[-1]), torch.float32, owner=engine)
         for _ in range(iters):
             engine.cons_iter(k0, k1)
             t0 = time.perf_counter()

@@ -197,6 +197,24 @@ void ref_mega_bwd(uint idx1, uint idx2, float *Flat) { Mega::CalcBwdFlat_mega(Me
 
 void ref_mpc_calc_posteriors() { g_M->CalcPosteriors(); }     // mpcflat.cpp:214
 void ref_mpc_cons_iter(uint iter) { g_M->ConsIter(iter); }     // consflat.cpp:5
+// MPCFlat::ConsPair (conspairflat.cpp:10-110) of SOME pairs of the current iteration: reads *m_ptrSparsePosts of all pairs, writes the
+// listed pairs' matrices of *m_ptrUpdatedSparsePosts; NO swap (consflat.cpp:22) — the store stays at the stage it was. For sampled pins
+// of stores whose full ConsIter takes days (rdrp, N = 1000: tests/golden/make_golden.py big-sampled). OpenMP over the list as
+// consflat.cpp:13-20 runs it over all pairs.
+void ref_mpc_cons_pairs(const uint *ks, uint count)
+	{
+	const unsigned ThreadCount = GetRequestedThreadCount();
+#pragma omp parallel for num_threads(ThreadCount) schedule(dynamic, 1)
+	for (int i = 0; i < (int) count; ++i)
+		g_M->ConsPair(ks[i]);
+	}
+uint ref_mpc_updated_nnz(uint k) { const MySparseMx &S = g_M->GetUpdatedSparsePost(k); return S.m_Offsets[S.m_LX]; }
+void ref_mpc_updated_sparse(uint k, uint *offsets, byte *values)
+	{
+	const MySparseMx &S = g_M->GetUpdatedSparsePost(k);
+	memcpy(offsets, S.m_Offsets, sizeof(uint)*(S.m_LX+1));
+	memcpy(values, S.m_ValueVec, 8*(size_t)S.m_Offsets[S.m_LX]);
+	}
 uint ref_mpc_pair_count() { return (uint) g_M->m_Pairs.size(); }
 void ref_mpc_pair(uint k, uint *i, uint *j) { *i = g_M->m_Pairs[k].first; *j = g_M->m_Pairs[k].second; }
 float ref_mpc_ea(uint i, uint j) { return g_M->m_DistMx[i][j]; }

@@ -240,6 +240,77 @@ def gen_mpc_big(names, threads):
             print(pool.map(_mpc_big_worker, [(name, n, length, seed, threads)])[0], flush=True)
 
 
+def _mpc_sampled_worker(args):
+    """SAMPLED pin of a store whose full ConsIter takes days on the CPU (rdrp, N = 1000: RelaxFlat_XZ_YZ's linear search at ~7
+    stored cells per row): the compiled reference runs stage A for ALL pairs (EA + stage-0 digests per block of 1000 pairs, as the
+    full fixtures hold them) and MPCFlat::ConsPair (conspairflat.cpp:10-110) of iteration 1 for `nsample` seeded pairs; per sampled
+    pair the sha256 of (offsets || values) of its UPDATED matrix. The store is not swapped (no iteration 2)."""
+    name, n, nsample, threads = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import time
+    import _ref as R
+    from muscle_amd.synth import read_fasta
+    seqs = read_fasta(os.path.join(HERE, "rdrp_first1000.fa.gz"))[:n]
+    assert len(seqs) == n
+    R.init_hmm(False, 0)
+    L = R.lib()
+    L.ref_mpc_updated_nnz.restype = C.c_uint
+    arr = (C.c_char_p * len(seqs))(*[s.encode() for s in seqs])
+    if L.ref_mpc_begin(len(seqs), arr, threads) != 0:
+        raise RuntimeError("ref_mpc_begin may only be called once per process")
+    lens = [len(s) for s in seqs]
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    u32p, u8p = R.u32p, R.u8p
+    t0 = time.time()
+    L.ref_mpc_calc_posteriors()
+    tA = time.time() - t0
+    print("stage A: %.1f s" % tA, flush=True)
+    ea = np.array([L.ref_mpc_ea(i, j) for (i, j) in pairs], np.float32)
+    eab = [hashlib.sha256(ea[b:b + BLOCK].tobytes()).digest() for b in range(0, len(ea), BLOCK)]
+    whole, blocks, blk, tot = hashlib.sha256(), [], hashlib.sha256(), 0
+    for k, (i, j) in enumerate(pairs):
+        nnz = L.ref_mpc_nnz(k)
+        off = np.empty(lens[i] + 1, np.uint32)
+        val = np.empty(max(nnz, 1) * 2, np.uint32)
+        L.ref_mpc_sparse(k, off.ctypes.data_as(u32p), val.ctypes.data_as(u8p))
+        b = off.tobytes() + val[:2 * nnz].tobytes()
+        whole.update(b); blk.update(b); tot += nnz
+        if (k + 1) % BLOCK == 0 or k + 1 == len(pairs):
+            blocks.append(blk.digest()); blk = hashlib.sha256()
+    rng = np.random.default_rng(20260927)
+    ks = np.sort(rng.choice(len(pairs), size=min(nsample, len(pairs)), replace=False)).astype(np.uint32)
+    t0 = time.time()
+    L.ref_mpc_cons_pairs(ks.ctypes.data_as(u32p), len(ks))
+    tB = time.time() - t0
+    print("ConsPair x %d: %.1f s" % (len(ks), tB), flush=True)
+    shas, snnz = [], []
+    for k in ks:
+        i, j = pairs[int(k)]
+        nnz = L.ref_mpc_updated_nnz(int(k))
+        off = np.empty(lens[i] + 1, np.uint32)
+        val = np.empty(max(nnz, 1) * 2, np.uint32)
+        L.ref_mpc_updated_sparse(int(k), off.ctypes.data_as(u32p), val.ctypes.data_as(u8p))
+        shas.append(hashlib.sha256(off.tobytes() + val[:2 * nnz].tobytes()).digest()); snnz.append(nnz)
+    d = {"n": np.int32(n), "length": np.int32(0), "seed": np.int32(0), "block": np.int32(BLOCK),
+         "seqs_sha": np.array(hashlib.sha256("\n".join(seqs).encode()).hexdigest()),
+         "ea_sha": np.array(hashlib.sha256(ea.tobytes()).hexdigest()),
+         "ea_blocks": np.frombuffer(b"".join(eab), np.uint8).reshape(-1, 32),
+         "nstages": np.int32(1), "digest0": np.array(whole.hexdigest()),
+         "blocks0": np.frombuffer(b"".join(blocks), np.uint8).reshape(-1, 32), "nnz_total0": np.int64(tot),
+         "sample_k": ks, "sample_nnz": np.array(snnz, np.uint32),
+         "sample_sha1": np.frombuffer(b"".join(shas), np.uint8).reshape(-1, 32),
+         "ref_seconds": np.array([tA, tB]), "ref_threads": np.int32(threads)}
+    np.savez_compressed(os.path.join(HERE, "mpcbig_%s_sampled.npz" % name), **d)
+    return name, n, tot, len(ks), [tA, tB]
+
+
+def gen_mpc_sampled(name, n, nsample, threads):
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        print(pool.map(_mpc_sampled_worker, [(name, n, nsample, threads)])[0], flush=True)
+
+
 def _mega_worker(name):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import tempfile
@@ -433,6 +504,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:2] == ["big"]:  # python make_golden.py big <threads> <name> ...: digest-only BASELINE-size sets (CPU-hours)
         gen_mpc_big(sys.argv[3:], int(sys.argv[2]))
+        sys.exit(0)
+    if sys.argv[1:2] == ["big-sampled"]:  # python make_golden.py big-sampled <threads> <n> [nsample]: rdrp prefix, stage A of all pairs + ConsPair of a sample
+        gen_mpc_sampled("rdrp%d" % int(sys.argv[3]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 2048, int(sys.argv[2]))
         sys.exit(0)
     if sys.argv[1:2] == ["mpc"]:  # python make_golden.py mpc <name> ...: only these whole-stage sets
         gen_mpc(set(sys.argv[2:]))

@@ -66,14 +66,18 @@ def test_default_relax_walk_has_no_spill_reloads(isa, kernel):
     assert not waits, "; ".join(body[k].strip() for k in waits[:5])
 
 
-@pytest.mark.parametrize("kernel", [BAND_WIN, BAND])
+BAND_512 = "_Z17relax_band_kernelILi512ELi13ELi4ELi0E14MpcRbBlocksAsmEv15RelaxBandParams"  # MPCGPU_RELAX_WG=512: four 512-thread workgroups per CU
+
+
+@pytest.mark.parametrize("kernel", [BAND_WIN, BAND, BAND_512])
 def test_band_merge_registers_are_not_touched_between_statements(isa, kernel):
     """The hand-scheduled merge leaves LDS reads in flight into v24..v40 (the next slot's first blocks, its Y bias) when a
     statement ends; the compiler does not know. Between the end of one merge statement and the opening wait of the next
     (or the drain after the last slot) no compiler-generated instruction may read or write those registers."""
     body = _body(isa, kernel)
     # the walk pins v24..v40; the direct-index merge v24..v28, v32..v36 and v40 (X block + descriptor word per set, the value base)
-    pinned = set(range(24, 41)) if kernel == BAND else (set(range(24, 29)) | set(range(32, 37)) | {40})
+    # (every hand-scheduled instantiation relax_band can launch is checked: ADVICE r4)
+    pinned = set(range(24, 41)) if kernel != BAND_WIN else (set(range(24, 29)) | set(range(32, 37)) | {40})
 
     def regs(line):
         out = set()
