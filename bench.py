@@ -81,6 +81,77 @@ def parity_check(g, a):
             "reference's: tests/golden/mpcbig_%s.npz" % name) if err is None else ("MISMATCH", err)
 
 
+def real_data_leg(g, torch, run_stage, steps=1):
+    """The realistic input beside the synthetic headline ("also report one realistic set"): the first 1000 records of the
+    reference's test_data/rdrp/rdrp.fa (tests/golden/rdrp_first1000.fa.gz; ~6.8 stored cells per row against ~2). One pass that doubles
+    as warm-up and SAMPLED parity pin (tests/golden/mpcbig_rdrp1000_sampled.npz: the compiled reference's stage A for all 499 500
+    pairs — EA and stage-0 digests — and ConsPair of iteration 1 for 2048 seeded pairs), then `steps` timed steps. -> dict."""
+    import _bigdigest as D
+    from muscle_amd.mpcflat import CONSISTENCY_ITERS
+    from muscle_amd.synth import read_fasta
+    path = os.path.join(ROOT, "tests", "golden", "rdrp_first1000.fa.gz")
+    n = 1000
+    seqs = read_fasta(path)[:n]
+    lens = [len(s) for s in seqs]
+    npairs = n * (n - 1) // 2
+    g.set_seqs(seqs)
+    # pass 1 (untimed): the stage step by step, checked against the reference where a pin exists
+    parity, detail = None, "no sampled fixture (tests/golden/make_golden.py big-sampled)"
+    name = D.sampled_fixture_for_fasta(path, n)
+    g.calc_posteriors(0, npairs)
+    g.build_store()
+    if name is not None:
+        z = D.load(name)
+        err = D.compare_ea(z, g.get_ea()) or D.compare_stage(z, 0, g)
+    g.cons_iter(0, npairs)
+    g.cons_commit()
+    if name is not None:
+        err = err or D.compare_sample(z, g)
+        parity = "match" if err is None else "MISMATCH"
+        detail = ("EA bits and stage-0 sparse posteriors of ALL %d pairs, and the stage-1 matrices (one relax iteration) of %d seeded pairs, equal the "
+                  "compiled reference's: tests/golden/mpcbig_%s.npz" % (npairs, len(z["sample_k"]), name)) if err is None else err
+    g.cons_iter(0, npairs)
+    g.cons_commit()
+    g.synchronize()
+    g.timers_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_stage(g, lens, None, torch_mod=torch)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    timers = g.timers_get()
+    geo, fallback = g.relax_info()
+    nnz = g.get_nnz()
+    iters = max(steps * CONSISTENCY_ITERS, 1)
+    relax_ms = timers["relax"][0] / iters
+    launched = geo.split("kernel=")[1].split(";")[0].strip() if "kernel=" in geo else None
+    out = {"workload": "first %d records of rdrp_first1000.fa.gz (real proteins, mean L %.0f): %d pairs, %d stored posteriors (%.1f per row)"
+                       % (n, float(np.mean(lens)), npairs, int(nnz.sum()), float(nnz.sum()) / max(sum(lens[i] * (n - 1 - i) for i in range(n)), 1)),
+           "value": npairs * steps / el, "unit": "pairs/s", "steps": steps, "ms_per_step": 1000.0 * el / steps,
+           "relax_ms_per_iteration": relax_ms, "kernel_ms_per_step": {k: v[0] / steps for k, v in timers.items()},
+           "relax_geometry": {"layout": geo, "fallback": fallback},
+           "parity_sample": parity, "parity_detail": detail}
+    pmc = None
+    for key in (("relax_band_kernel/MpcRbBlocksAsm" if launched and "MpcRbBlocks" in launched else "relax_band_kernel"), "relax_band_kernel"):
+        pmc = pmc or pmc_entry(key, n, 0)
+    if pmc is not None and launched is not None and launched in pmc.get("kernel", ""):
+        avg_s = relax_ms * 1e-3
+        clock = float(pmc.get("clock_hz") or 2.1e9)
+        fr = {"hbm": float(pmc["hbm_bytes_per_launch"]) / avg_s / 1e9 / HBM_PEAK_GBS}
+        sq = pmc.get("sq_per_launch", {})
+        if "SQ_LDS_IDX_ACTIVE" in sq:
+            fr["lds"] = sq["SQ_LDS_IDX_ACTIVE"] / (256 * clock) / avg_s
+            if "SQ_LDS_BANK_CONFLICT" in sq:
+                fr["lds_net_of_conflicts"] = (sq["SQ_LDS_IDX_ACTIVE"] - sq["SQ_LDS_BANK_CONFLICT"]) / (256 * clock) / avg_s
+        out["measured_fractions"] = fr
+        out["counter_source"] = pmc.get("source")
+    else:
+        out["measured_fractions"] = None
+        out["pmc_rejected"] = "no committed PMC pass of %r for this input" % launched
+    return out
+
+
 def cpu_baseline(seqs, n_full, budget_s=20.0):
     """Reference (oracle/_ref/libmuscle_ref.so = the reference's own MPCFlat::CalcPosteriors +
     ConsIter, OpenMP over all host cores) on a bounded sample of the same family, extrapolated to
@@ -154,6 +225,7 @@ def main():
                     "(.gz accepted), e.g. tests/golden/rdrp_first1000.fa.gz (first 1000 records of the reference's test_data/rdrp/rdrp.fa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the digest self-check after the timed region")
+    ap.add_argument("--no-real-data", action="store_true", help="skip the real-data leg (rdrp, first 1000 records) after the synthetic timed region")
     a = ap.parse_args()
 
     from muscle_amd.hostinfo import pin_openmp_team
@@ -367,10 +439,16 @@ def main():
             out["dry_run"] = True
         elif not a.no_parity:
             out["parity_digest"], out["parity_detail"] = parity_check(g, a)
+        # the realistic input, after the synthetic timed region and its self-check (one GPU, the default workload only)
+        if world == 1 and not dry and not a.fasta and not a.no_real_data and a.n == 1000 and a.len == 400:
+            try:
+                out["real_data"] = real_data_leg(g, torch, run_stage)
+            except Exception as e:  # noqa: BLE001 - the headline line must still be printed
+                out["real_data"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not a.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(seqs, a.n)
         print(json.dumps(out), flush=True)
-        if out.get("parity_digest") == "MISMATCH":
+        if out.get("parity_digest") == "MISMATCH" or (out.get("real_data") or {}).get("parity_sample") == "MISMATCH":
             rc = 3  # a fast wrong answer is not a result
     g.close()
     if world > 1:

@@ -51,8 +51,10 @@ int mpcgpu_set_hmm(mpcgpu_ctx *ctx, const float start[5], const float trans[25],
 
 /* Input sequences. Replaces MPCFlat::InitSeqs + GetBytePtr/GetSeqLength (mpcflat.cpp:41-57,
  * 121-137): n raw ASCII byte strings (already upper-cased by the loader, sequence.cpp:87-88).
- * The bytes are copied; at most 64 distinct byte values may occur over all sequences (the error names the 65th byte and
- * where it stands).
+ * The bytes are copied; every seven-bit byte value is taken (the emission tables are compacted to the A distinct values that
+ * occur, A <= 128, and live in LDS: (A*A + A) floats — beyond the 64 KB default the library asks for the larger dynamic LDS).
+ * Bytes >= 128 are refused: the reference indexes m_MatchScore[256][256] by a plain `char` (fwdflat3.cpp:102-109), a negative
+ * index there.
  * Also performs MPCFlat::InitPairs (all i<j pairs). Length overflow check of
  * calcposteriorflat.cpp:54-61 (LX*LY*5+100 > INT_MAX) is preserved as an error. Build limits beyond
  * the reference's: a pair whose row sequence is longer than 768 takes the row-block kernels (a choice up to

@@ -24,6 +24,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -304,15 +306,31 @@ int env_int(const char *name, int dflt)
 	return (s && *s) ? atoi(s) : dflt;
 }
 
+// Dynamic LDS beyond the default 64 KB (alphabets of more than ~125 compacted letters: (A*A + A) floats; gfx950 has 160 KB per CU)
+// has to be asked for per kernel function; asked once per function and size (the call costs a good fraction of a millisecond).
+void ensure_dyn_smem(const void *fn, size_t smem)
+{
+	if (smem <= 64u * 1024u) return;
+	static std::mutex mu;
+	static std::map<const void *, size_t> have;
+	std::lock_guard<std::mutex> lk(mu);
+	size_t &h = have[fn];
+	if (h >= smem) return;
+	if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess) h = smem;
+	else (void)hipGetLastError();
+}
+
 template <int H, bool MEGA, bool LONG = false> void launch_fb(const FbParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
 	auto kern = fb_kernel<H, MEGA, LONG>;
+	ensure_dyn_smem((const void *)kern, smem);
 	MPC_LAUNCH(kern, grid, block, smem, st, p);
 }
 
 template <int H, bool MEGA, bool LONG = false> int occ_fb(u32 block, size_t smem)
 {
 	int nb = 0;
+	ensure_dyn_smem((const void *)fb_kernel<H, MEGA, LONG>, smem);
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_kernel<H, MEGA, LONG>, (int)block, smem) != hipSuccess || nb < 1)
 		nb = 1;
 	return nb;
@@ -363,12 +381,14 @@ void launch_fb_h(int H, bool mega, const FbParams &p, u32 grid, u32 block, size_
 template <int H> void launch_fbc(const FbChainParams &p, u32 grid, u32 block, size_t smem, hipStream_t st)
 {
 	auto kern = fb_chain_kernel<H>;
+	ensure_dyn_smem((const void *)kern, smem);
 	MPC_LAUNCH(kern, grid, block, smem, st, p);
 }
 
 template <int H> int occ_fbc(u32 block, size_t smem)
 {
 	int nb = 0;
+	ensure_dyn_smem((const void *)fb_chain_kernel<H>, smem);
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)fb_chain_kernel<H>, (int)block, smem) != hipSuccess || nb < 1)
 		nb = 1;
 	return nb;
@@ -1350,11 +1370,10 @@ static int set_seqs_impl(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, 
 		c->raw[i].assign(seqs[i], seqs[i] + lens[i]);
 		for (u32 at = 0; at < lens[i]; ++at) {
 			const u8 b = c->raw[i][at];
-			if (b >= 128) return fail(c, "mpcgpu_set_seqs: sequence %u holds non-ASCII byte %u", i, (unsigned)b);
+			// (the reference indexes m_MatchScore[256][256] by a plain `char`, fwdflat3.cpp:102-109: bytes >= 128 are negative indices
+			// there — undefined behaviour, not a feature; all 128 seven-bit values are taken)
+			if (b >= 128) return fail(c, "mpcgpu_set_seqs: sequence %u holds non-ASCII byte %u at position %u", i, (unsigned)b, at);
 			if (c->code_of[b] < 0) {
-				if (c->A == 64) return fail(c, "mpcgpu_set_seqs: more than 64 distinct byte values: byte %u ('%c') at position %u of sequence %u is the 65th "
-					"(the emission tables live in LDS as a compacted A x A matrix; the reference indexes all 256)", (unsigned)b, (b >= 32 && b < 127) ? (char)b : '?',
-					at, i);
 				c->code_of[b] = c->A++;
 			}
 		}
@@ -1371,7 +1390,7 @@ static int set_seqs_impl(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, 
 	}
 	off[n] = code.size();
 	std::vector<float> cm((size_t)c->A * c->A), ci(c->A);
-	int byte_of[64];
+	int byte_of[128];
 	for (int b = 0; b < 256; ++b) if (c->code_of[b] >= 0) byte_of[c->code_of[b]] = b;
 	for (int a = 0; a < c->A; ++a) {
 		ci[a] = c->ins256[byte_of[a]];

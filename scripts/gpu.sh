@@ -24,7 +24,7 @@ RDRP=$R/tests/golden/rdrp_first1000.fa.gz
 prof() { # prof <dir> <rocprof args...> -- <bench args...>
 	local d=$1; shift; rm -rf $OUT/$d
 	local pa=(); while [ "$1" != "--" ]; do pa+=("$1"); shift; done; shift
-	( cd /tmp && TAILN=3 step timeout 600 rocprofv3 "${pa[@]}" --output-format csv -d $OUT/$d -o r -- python -u $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-parity )
+	( cd /tmp && TAILN=3 step timeout 600 rocprofv3 "${pa[@]}" --output-format csv -d $OUT/$d -o r -- python -u $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-real-data )
 }
 for s in "$@"; do
 	IFS=: read -r name a1 a2 a3 <<< "$s"
@@ -35,7 +35,7 @@ for s in "$@"; do
 	tests) if [ -n "${a1:-}" ]; then TAILN=15 step timeout 1500 python -u -m pytest tests -m gpu -q -x -k "${s#tests:}"; else TAILN=15 step timeout 1500 python -u -m pytest tests -m gpu -q -x; fi;;
 	smoke) step timeout 120 python -u -c "import __graft_entry__ as g; g.smoke()";;
 	bench) N=${a1:-1000}; L=${a2:-400}; K=${a3:-2}
-		step timeout 900 python -u bench.py --n $N --len $L --steps $K --warmup 1 --no-cpu-baseline
+		step timeout 900 python -u bench.py --n $N --len $L --steps $K --warmup 1 --no-cpu-baseline --no-real-data
 		grep '^{"metric"' $LOG | tail -1 > $OUT/${TAG}_bench_${N}x${L}${LABEL}.json;;
 	benchcpu) step timeout 900 python -u bench.py
 		grep '^{"metric"' $LOG | tail -1 > $OUT/${TAG}_bench_default${LABEL}.json;;

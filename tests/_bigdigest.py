@@ -81,3 +81,25 @@ def compare_ea(z, ea):
     want = z["ea_blocks"]
     bad = [b for b in range(len(blocks)) if blocks[b] != want[b].tobytes()]
     return "EA: %d of %d blocks differ, first = block %d" % (len(bad), len(blocks), bad[0] if bad else -1)
+
+
+# ---- SAMPLED pin of the real-data bench size (rdrp, N = 1000): the compiled reference's stage A for ALL pairs (EA + stage-0 block
+# digests) and MPCFlat::ConsPair of iteration 1 for 2048 seeded pairs (tests/golden/make_golden.py big-sampled; a full ConsIter at
+# this size is days of RelaxFlat_XZ_YZ's linear search). A fixture of its own: mpcbig_rdrp<n>_sampled.npz.
+def sampled_fixture_for_fasta(path, n):
+    if os.path.basename(path) != "rdrp_first1000.fa.gz":
+        return None
+    name = "rdrp%d_sampled" % n
+    return name if os.path.exists(os.path.join(GDIR, "mpcbig_%s.npz" % name)) else None
+
+
+def compare_sample(z, g):
+    """the library's CURRENT store (after one relax iteration + commit) against the sampled pairs' reference digests -> None | text"""
+    import hashlib as H
+    ks, want = z["sample_k"], z["sample_sha1"]
+    bad = []
+    for q, k in enumerate(ks):
+        (off, val), = g.get_sparse_range(int(k), int(k) + 1)
+        if H.sha256(off.tobytes() + val.tobytes()).digest() != want[q].tobytes():
+            bad.append(int(k))
+    return None if not bad else "stage 1 sample: %d of %d sampled pairs differ, first = pair %d" % (len(bad), len(ks), bad[0])

@@ -31,7 +31,7 @@ def stage_digest(stage):
     return h.hexdigest()
 
 
-MPC_SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "bb11001", "n32_L150", "bb11005", "n48_L260", "n3_L1100"]
+MPC_SETS = ["n2_L40", "n3_L30", "n8_L60", "ragged", "alpha82", "bb11001", "n32_L150", "bb11005", "n48_L260", "n3_L1100"]
 # GPU suite only (minutes of CPU for the oracle): real data, ~7 stored cells per row: records of tens of KB, the 160 KB relax geometry
 MPC_SETS_GPU = MPC_SETS + ["rdrp128"]
 

@@ -126,6 +126,24 @@ def _mpc_worker(args):
     return name, len(seqs), [int(sum(len(v) // 2 for _, v in st)) for st in stages]
 
 
+def odd_alphabet_family():
+    """5 sequences of L~70 in which a third of the residues are replaced by arbitrary printable bytes (lower case, digits,
+    punctuation): 82 distinct byte values — more than the 64 a compacted LDS table of the first rounds took."""
+    import random
+    from muscle_amd.synth import make_family
+    rnd = random.Random(11)
+    odd = [chr(b) for b in range(33, 127) if chr(b) not in ">-." and not chr(b).isupper() or chr(b) in "BJOUXZ"]
+    seqs = []
+    for s in make_family(5, 70, seed=4):
+        t = list(s)
+        for i in range(len(t)):
+            if rnd.random() < 0.35:
+                t[i] = rnd.choice(odd)
+        seqs.append("".join(t))
+    assert len(set("".join(seqs))) == 82
+    return seqs
+
+
 def gen_mpc(only=None):
     from muscle_amd.synth import make_family
     jobs = [
@@ -134,6 +152,7 @@ def gen_mpc(only=None):
         ("n8_L60", make_family(8, 60, seed=2), True),
         ("ragged", ["M", "MKVLA", make_family(1, 90, seed=9)[0], "ACDEFGHIKLMNPQRSTVWY" * 2,
                     make_family(1, 33, seed=10)[0], "WWWWWWWW"], True),
+        ("alpha82", odd_alphabet_family(), True),           # 82 distinct byte values: the reference indexes its tables by raw byte (pairhmm.h:28-29)
         ("n32_L150", make_family(32, 150, seed=1), False),  # BASELINE config 0 shape
         ("n48_L260", make_family(48, 260, seed=1), False),
         ("n3_L1100", make_family(3, 1100, seed=7), False),  # X longer than 1024: the row-block fb kernel's shape
