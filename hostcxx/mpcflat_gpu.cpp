@@ -208,6 +208,10 @@ bool TimingEnv()
 	return s != 0 && *s != 0 && *s != '0';
 	}
 const std::chrono::steady_clock::time_point g_ProcessStart = std::chrono::steady_clock::now(); // static initialisation of this object file
+// Small stores (the <= 32-sequence shrubs of -super7, the clusters of -super5) take whole-record relax tiles: no window records or band
+// tables to build and no tiles to cut per store (MPCGPU_RELAX_SMALL_PAIRS, muscle_amd/csrc/mpcgpu.cpp: build_var_store; 4.6 ms of host
+// round trips per store otherwise, 412 stores in a 10 000-sequence run). Set here, before any thread exists; the user's own setting wins.
+const int g_SmallStoreDefault = setenv("MPCGPU_RELAX_SMALL_PAIRS", "40", 0);
 double g_CtxSeconds = 0; // MUSCLE_GPU_TIMING: creating contexts (the first one pays for the HIP runtime's start-up)
 struct CtxClock
 	{

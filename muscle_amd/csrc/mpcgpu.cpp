@@ -1052,8 +1052,15 @@ int build_var_store(mpcgpu_ctx *c)
 	size_t smem = 0;
 	var_lds_geometry(threads, nbuf, &buf_bytes, &smem);
 	c->var_mixed = false;
-	const char *tiles_mode = getenv("MPCGPU_RELAX_TILES"); // "pairs": whole-record tiles of relax_var_kernel only
-	const bool want_band = !(tiles_mode && !strcmp(tiles_mode, "pairs")) && c->npairs < 0xffffffffull;
+	const char *tiles_mode = getenv("MPCGPU_RELAX_TILES"); // "pairs": whole-record tiles of relax_var_kernel only; "band": band tiles whatever the size
+	// MPCGPU_RELAX_SMALL_PAIRS=<n> (default 0 = never; the drop-in binary sets 40): stores of <= n sequences whose pairs fit the
+	// whole-record tiles take those. A shrub of -super7 (<= 32 sequences, 412 of them in a 10 000-sequence run) is relaxed in 0.3 ms
+	// either way, but the band path builds window records and band tables and cuts its tiles on the device first: 4.6 ms of launches
+	// and round trips per store against 0.06 (profiles/r10d_small_store_time.log) — the 0.7 s that run lost in round 4.
+	const int small_n = env_int("MPCGPU_RELAX_SMALL_PAIRS", 0);
+	const bool small_pairs = small_n > 0 && n <= (u32)small_n && 2ull * max_rec * 16 <= buf_bytes && slots_ok(threads) &&
+		!(tiles_mode && !strcmp(tiles_mode, "band"));
+	const bool want_band = !(tiles_mode && !strcmp(tiles_mode, "pairs")) && !small_pairs && c->npairs < 0xffffffffull;
 	bool pairs_ok = true;
 	if (2ull * max_rec * 16 > buf_bytes || !slots_ok(threads)) { // not every single pair (two records, its cells) fits a tile of this geometry
 		u32 bb1 = 0;

@@ -524,6 +524,37 @@ def test_baseline_configs_vs_reference_digests(name):
     g.close()
 
 
+def test_rdrp1000_sampled_reference_pin():
+    """The real-data BENCH size (first 1000 rdrp records: 499 500 pairs, ~1.4e9 stored entries, relax through the band tiles the bench run
+    cuts) against the compiled reference where a full reference run is days: stage A of ALL pairs (EA bits, stage-0 digests per 1000
+    pairs) and MPCFlat::ConsPair (conspairflat.cpp:10-110) of iteration 1 for 2048 seeded pairs
+    (tests/golden/mpcbig_rdrp1000_sampled.npz, tests/golden/make_golden.py big-sampled). bench.py repeats this check in its real_data leg."""
+    import hashlib
+    import _bigdigest as D
+    from muscle_amd.synth import read_fasta
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rdrp_first1000.fa.gz")
+    name = D.sampled_fixture_for_fasta(path, 1000)
+    if name is None:
+        pytest.skip("fixture tests/golden/mpcbig_rdrp1000_sampled.npz not generated")
+    z = D.load(name)
+    seqs = read_fasta(path)[:1000]
+    assert hashlib.sha256("\n".join(seqs).encode()).hexdigest() == str(z["seqs_sha"])
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    assert D.compare_ea(z, g.get_ea()) is None
+    g.build_store()
+    assert D.compare_stage(z, 0, g) is None
+    g.cons_iter()
+    g.cons_commit()
+    assert D.compare_sample(z, g) is None
+    info = g.relax_info()[0]
+    assert "relax_band_kernel" in info, info
+    g.close()
+
+
 @pytest.mark.parametrize("nctx", [2, 3])
 def test_group_of_contexts_equals_reference(nctx):
     """mpcgpu_group_* (several GPUs inside one process; here nctx contexts on device 0, peer-copy transport): after the
