@@ -140,6 +140,13 @@ def real_data_leg(g, torch, run_stage, steps=1):
         clock = float(pmc.get("clock_hz") or 2.1e9)
         fr = {"hbm": float(pmc["hbm_bytes_per_launch"]) / avg_s / 1e9 / HBM_PEAK_GBS}
         sq = pmc.get("sq_per_launch", {})
+        if "SQ_INSTS_VALU" in sq:
+            try:
+                with open(os.path.join(ROOT, "muscle_amd", "csrc", "isa_cost.json")) as f:
+                    cost = float(json.load(f)["relax_band_kernel/MpcRbBlocksAsm" if "MpcRbBlocks" in launched else "relax_band_kernel"]["mean_issue_cost"])
+            except (OSError, ValueError, KeyError):
+                cost = 1.19
+            fr["valu_issue"] = sq["SQ_INSTS_VALU"] * cost * 2.0 / (1024 * clock) / avg_s
         if "SQ_LDS_IDX_ACTIVE" in sq:
             fr["lds"] = sq["SQ_LDS_IDX_ACTIVE"] / (256 * clock) / avg_s
             if "SQ_LDS_BANK_CONFLICT" in sq:
@@ -358,6 +365,11 @@ def main():
             r["traffic"] = traffic
             r["measured_fractions"] = fr
             known = {k: v for k, v in fr.items() if v is not None}
+            # beside `lds` (LDS-array cycles, bank conflicts included — a kernel that wasted more cycles on conflicts would score higher):
+            # the same without the conflict cycles; not a candidate for `bound`
+            sq = (pmc or {}).get("sq_per_launch", {})
+            if fr["lds"] is not None and "SQ_LDS_BANK_CONFLICT" in sq:
+                fr["lds_net_of_conflicts"] = (sq["SQ_LDS_IDX_ACTIVE"] - sq["SQ_LDS_BANK_CONFLICT"]) / (CHIP_CUS * clock_of(pmc)[0]) / avg_s
             if known:
                 b = max(known, key=known.get)
                 r["bound"], r["frac"] = b, known[b]

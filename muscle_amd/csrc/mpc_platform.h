@@ -242,7 +242,7 @@ struct MpcRbBlocksAsm {
 			: "={v[24:27]}"(a0), "={v[28:31]}"(b0), "={v40}"(hb) : "v"(ia), "v"(ib), "v"(hb_addr) : "memory");
 	}
 	__device__ __forceinline__ void drain() { asm volatile("s_waitcnt lgkmcnt(0)" : "+{v[24:27]}"(a0), "+{v[28:31]}"(b0), "+{v[32:35]}"(a1), "+{v[36:39]}"(b1), "+{v40}"(hb) : : "memory"); }
-#define MPC_RB_MERGE_ASM(A0_, A1_, A2_, A3_, B0_, B1_, B2_, B3_, CURA_, CURB_, NXTA_, NXTB_)                           \
+#define MPC_RB_MERGE_HEAD(A0_, A1_, A2_, A3_, B0_, B1_, B2_, B3_, CURA_, CURB_, NXTA_, NXTB_)                           \
 	"s_waitcnt lgkmcnt(0)\n\t" /* this slot's first blocks and its Y bias (issued during the previous slot) have landed */ \
 	"v_add_u32_e32 %[ib], %[ib], %[hb]\n\t"                                                                              \
 	"ds_read_b128 " NXTA_ ", %[nia]\n\t"                                                                                 \
@@ -257,7 +257,8 @@ struct MpcRbBlocksAsm {
 	"v_cmp_le_u32_e64 %[ada], " A3_ ", " B3_ "\n\t"                                                                      \
 	"v_cmp_le_u32_e64 %[adb], " B3_ ", " A3_ "\n\t"                                                                      \
 	"v_cmp_lt_u32_e64 %[nla], %[kf], " A2_ "\n\t"                                                                        \
-	"v_cmp_lt_u32_e64 %[nlb], %[kf], " B2_ "\n\t"                                                                        \
+	"v_cmp_lt_u32_e64 %[nlb], %[kf], " B2_ "\n\t"
+#define MPC_RB_MERGE_ARITH(A0_, A1_, A2_, A3_, B0_, B1_, B2_, B3_, CURA_, CURB_, NXTA_, NXTB_) \
 	"v_cndmask_b32_e64 %[t0], 0, " B1_ ", %[e01]\n\t"                                                                    \
 	"v_cndmask_b32_e64 %[t1], 0, " B1_ ", %[e11]\n\t"                                                                    \
 	"v_cndmask_b32_e64 %[t0], %[t0], " B0_ ", %[e00]\n\t" /* of two equal columns in B the first wins */                 \
@@ -265,7 +266,8 @@ struct MpcRbBlocksAsm {
 	"v_mul_f32_e32 %[t0], " A0_ ", %[t0]\n\t"                                                                            \
 	"v_mul_f32_e32 %[t1], " A1_ ", %[t1]\n\t"                                                                            \
 	"v_add_f32_e32 %[sum], %[sum], %[t0]\n\t" /* z ascending: relaxflat.cpp:27, product rounded, then added */           \
-	"v_add_f32_e32 %[sum], %[sum], %[t1]\n\t"                                                                            \
+	"v_add_f32_e32 %[sum], %[sum], %[t1]\n\t"
+#define MPC_RB_MERGE_TAIL(A0_, A1_, A2_, A3_, B0_, B1_, B2_, B3_, CURA_, CURB_, NXTA_, NXTB_) \
 	"s_orn2_b64 %[nla], %[nla], %[ada]\n\t"                                                                              \
 	"s_orn2_b64 %[nlb], %[nlb], %[adb]\n\t"                                                                              \
 	"s_and_b64 %[nla], %[nla], %[nlb]\n\t"                                                                               \
@@ -283,6 +285,11 @@ struct MpcRbBlocksAsm {
 	"s_branch .Lrv_step_%=\n"                                                                                            \
 	".Lrv_done_%=:\n\t"                                                                                                  \
 	"s_mov_b64 exec, %[sv]"
+#ifdef MPC_RB_NOARITH /* measurement build only (MPCGPU_RELAX_DIAG=5): the walk without its selects, products and sums - wrong results */
+#define MPC_RB_MERGE_ASM(...) MPC_RB_MERGE_HEAD(__VA_ARGS__) MPC_RB_MERGE_TAIL(__VA_ARGS__)
+#else
+#define MPC_RB_MERGE_ASM(...) MPC_RB_MERGE_HEAD(__VA_ARGS__) MPC_RB_MERGE_ARITH(__VA_ARGS__) MPC_RB_MERGE_TAIL(__VA_ARGS__)
+#endif
 	// merges the slot whose first blocks are in set SET (first-block addresses + X bias in ia, Y first-block address in ib) onto
 	// sum; reads the blocks at nia, nib into the other set and gathers lane nidx/4 of bias_y for the next slot
 	template <int SET> __device__ __forceinline__ void merge(float &sum, unsigned ia, unsigned ib, unsigned nia, unsigned nib, unsigned nidx, unsigned bias_y)
@@ -306,6 +313,9 @@ struct MpcRbBlocksAsm {
 				: "vcc", "scc", "memory");
 	}
 #undef MPC_RB_MERGE_ASM
+#undef MPC_RB_MERGE_HEAD
+#undef MPC_RB_MERGE_ARITH
+#undef MPC_RB_MERGE_TAIL
 };
 #define MPC_RB_HAVE_ASM 1
 // ---- the DIRECT-INDEX merge of relax_band_kernel (kernels_relaxb.h: MpcRbWinCxx is its C++ statement). The X row is walked block by
