@@ -194,6 +194,8 @@ struct mpcgpu_ctx {
 	u32 list_q0 = 0;
 	bool ap_keep = false; // set around the stage_a calls that serve the align-pairs list (every other list stage forgets it)
 	HostBuf h_ap;             // mpcgpu_align_pairs: kernel parameters and results, page-locked
+	HostBuf h_bt;             // relax_band's tile cutter: the small host <-> device transfers of a cut, page-locked (a copy into pageable memory
+	                          // right after a launch was measured at 24 ms on an otherwise idle device: profiles/r10k)
 	DevBuf d_ap_off;
 	DevBuf d_chain_first, d_chain_cnt; // fb_chain_kernel's work list (kernels_fbc.h)
 	u64 sa_pairs = 0, sa_chained = 0, sa_chains = 0; // last stage A: pairs, pairs that ran in chains, chains
@@ -589,6 +591,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 	const u32 max_slots = (u32)std::min<int>(std::max(env_int("MPCGPU_RELAX_SLOTS", (int)kernel_slots), 1), (int)kernel_slots);
 	if (c->btiles_k0 != k0 || c->btiles_k1 != k1) {
 		c->btiles_k0 = c->btiles_k1 = ~0ull;
+		const auto t_cut0 = std::chrono::steady_clock::now();
+		auto lap_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cut0).count(); };
 		RbTileTabs tb;
 		tb.cell_off = c->d_cell_off.as<u32>(); tb.yr = c->d_yr.as<u32>(); tb.ovf_sum = c->d_ovf_sum.as<u32>(); tb.ovf_maxc = c->d_ovf_maxc.as<u32>();
 		tb.nb1 = nb1; tb.threads = bthreads; tb.k0 = k0; tb.k1 = k1;
@@ -608,6 +612,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			return 0;
 		};
+		auto pair_index = [&](u32 X, u32 Y) -> u64 { return (u64)X * n - ((u64)X * (X + 1)) / 2 + (Y - X - 1); }; // InitPairs order (mpcflat.cpp:145-155), X < Y
 		u64 last_cut_candidates = 0; // super-tiles with cells in the last cut
 		// super-tiles of nx x ny sequences cut into row bands of <= max_slots cells per lane and <= target blocks per step (mean)
 		auto cut = [&](u32 nx, u32 ny, u32 target, std::vector<u32> &words, std::vector<u32> &out) -> int {
@@ -617,20 +622,26 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 				for (u32 yb = 0; yb < nby; ++yb) {
 					const u32 x0 = xb * nx, cx = std::min(nx, n - x0), y0 = yb * ny, cy = std::min(ny, n - y0);
 					if (y0 + cy <= x0 + 1) continue; // no pair X < Y in this block
+					// a rank of a sharded run relaxes [k0, k1) only: blocks whose pairs all lie outside that range are not candidates
+					// (pair indices grow with X first: the block's pairs lie between its first row's first and its last row's last pair)
+					const u32 xl = std::min(x0 + cx - 1, y0 + cy - 2);
+					if (pair_index(x0, std::max(y0, x0 + 1)) >= k1 || pair_index(xl, y0 + cy - 1) < k0) continue;
 					cand.insert(cand.end(), {x0, cx, y0, cy});
 				}
 			const u32 nc = (u32)(cand.size() / 4);
 			words.clear();
 			if (!nc) { out.clear(); return 0; }
-			if (upload(c, c->d_bt_cand, cand)) return 1;
-			HIPCHK(c, c->d_bt_count.ensure((size_t)nc * 4));
-			HIPCHK(c, c->d_bt_list.ensure((size_t)nc * 4));
+			// The cut's small inputs and outputs (candidates in, bands per candidate out, list bases in) live in ONE page-locked record that
+			// the kernels read and write in place: three transfers and a wait fewer per cut. (The FIRST wait of a cut ends 16 - 27 ms late in
+			// some processes, every or every other step, whatever is queued first — copy or kernel, polled or blocking wait; not under
+			// rocprofv3, not with torch initialised before the context: profiles/r10k_rank_time.log. Not understood, not fixed by this.)
+			HIPCHK(c, c->h_bt.ensure(cand.size() * 4 + (size_t)nc * 8));
+			u32 *cnt = c->h_bt.as<u32>(), *base = cnt + nc, *hcand = base + nc; // [cnt nc][base nc][cand 4 nc]
+			memcpy(hcand, cand.data(), cand.size() * 4);
 			const u32 grid = std::min<u32>(nc, cus * 32);
-			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 8, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 0, c->d_bt_count.as<u32>(),
+			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 8, c->stream, sp, tb, (const u32 *)hcand, nc, max_slots, target, 0, cnt,
 				(const u32 *)nullptr, (u32 *)nullptr);
 			HIPCHK(c, hipGetLastError());
-			std::vector<u32> cnt(nc), base(nc);
-			HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_bt_count.p, (size_t)nc * 4, hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			u64 tot = 0;
 			last_cut_candidates = 0;
@@ -638,16 +649,16 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			if (tot > 0x7fffffffull / MPC_RB_TILE_WORDS) return fail(c, "mpcgpu_cons_iter: too many band tiles");
 			words.assign((size_t)tot * MPC_RB_TILE_WORDS, 0u);
 			if (!tot) { out.clear(); return 0; }
-			HIPCHK(c, hipMemcpyAsync(c->d_bt_list.p, base.data(), (size_t)nc * 4, hipMemcpyHostToDevice, c->stream));
+
 			HIPCHK(c, c->d_btiles.ensure(words.size() * 4));
-			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 8, c->stream, sp, tb, c->d_bt_cand.as<u32>(), nc, max_slots, target, 1, (u32 *)nullptr,
-				c->d_bt_list.as<u32>(), c->d_btiles.as<u32>());
+			MPC_LAUNCH(band_cut_kernel, grid, 64, (size_t)(nb1 + 1) * 8, c->stream, sp, tb, (const u32 *)hcand, nc, max_slots, target, 1, (u32 *)nullptr,
+				(const u32 *)base, c->d_btiles.as<u32>());
 			HIPCHK(c, hipGetLastError());
 			HIPCHK(c, hipMemcpyAsync(words.data(), c->d_btiles.p, words.size() * 4, hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(c, hipStreamSynchronize(c->stream)); // `base` dies with this frame
 			return eval_tiles(words, out);
 		};
-		struct Score { double fill, bytes_per_cell, in_target; u64 tiles; };
+	struct Score { double fill, bytes_per_cell, in_target; u64 tiles; };
 		auto score = [&](const std::vector<u32> &out, u32 target) {
 			Score sc = {0, 0, 0, out.size() / 4};
 			u64 cells = 0, est = 0, ok = 0;
@@ -826,6 +837,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			}
 		if (upload(c, c->d_btiles, c->h_btiles)) return 1;
 		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles: cut, checked and uploaded in %.2f ms\n", lap_ms());
 		c->btiles_k0 = k0; c->btiles_k1 = k1;
 	}
 	const u32 ntiles = (u32)(c->h_btiles.size() / MPC_RB_TILE_WORDS);
