@@ -35,7 +35,9 @@
 #include "mpcflat.h"
 #include "pairhmm.h"
 #include "pprog.h"
+#include <memory>
 #include "mega.h"
+#include "mpcflat_mega.h"
 #include "super7.h"
 #include "uclust.h"
 #include "mpcgpu.h"
@@ -1063,7 +1065,7 @@ uint UClust::Search(uint SeqIndex, string &Path)
 // share the shrubs. Results land in m_ShrubMSAs by shrub index; the one process-wide input of MPCFlat::Run that depends on
 // the order of the shrubs, the rand() stream of RefineIter (refineflat.cpp:14: one draw per sequence per refinement round,
 // Derep is off in -super7: super7.cpp:11), is positioned per shrub where the sequential loop would have had it.
-// (.mega inputs: Super7_mega::IntraAlignShrub hands per-shrub profile tables to its MPCFlat — kept sequential.)
+// (.mega inputs: Super7_mega::IntraAlignShrub differs only in the MPCFlat_mega object — the worker threads make one each.)
 void Super7::IntraAlignShrubs()
 	{
 	asserta(m_ShrubMSAs.empty());
@@ -1076,7 +1078,8 @@ void Super7::IntraAlignShrubs()
 		Workers = MAX_SLOTS - 1;
 	if (Workers > ShrubCount)
 		Workers = ShrubCount;
-	if (Workers <= 1 || dynamic_cast<Super7_mega *>(this) != 0)
+	const bool IsMega = dynamic_cast<Super7_mega *>(this) != 0; // Super7_mega::IntraAlignShrub (super7_mega.cpp:9-24) = the same with an MPCFlat_mega
+	if (Workers <= 1)
 		{
 		for (uint ShrubIndex = 0; ShrubIndex < ShrubCount; ++ShrubIndex)
 			{
@@ -1113,7 +1116,10 @@ void Super7::IntraAlignShrubs()
 	for (uint w = 0; w < Workers; ++w)
 		Threads.emplace_back([&, w]()
 			{
-			MPCFlat Local;
+// (.mega inputs: the profiles are process-wide statics found by label, Mega::GetProfileByLabel — read-only here — and which emissions
+// a run takes is decided by Mega::m_Loaded (calcpost.cpp:14-22, SetMega above); the object is an MPCFlat_mega as in the reference's loop)
+			std::unique_ptr<MPCFlat> LocalObj(IsMega ? (MPCFlat *) new MPCFlat_mega : new MPCFlat);
+			MPCFlat &Local = *LocalObj;
 			Local.m_ConsistencyIterCount = m_MPC->m_ConsistencyIterCount;
 			Local.m_RefineIterCount = m_MPC->m_RefineIterCount;
 			Local.m_D.m_Disable = m_MPC->m_D.m_Disable; // super7.cpp:11
