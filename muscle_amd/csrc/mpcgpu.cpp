@@ -194,6 +194,19 @@ struct mpcgpu_ctx {
 	u32 list_q0 = 0;
 	bool ap_keep = false; // set around the stage_a calls that serve the align-pairs list (every other list stage forgets it)
 	HostBuf h_ap;             // mpcgpu_align_pairs: kernel parameters and results, page-locked
+	// Host vectors of megabytes that take part in device copies are KEPT (members, not locals). glibc gives such a block back to the
+	// kernel when it is freed (munmap above the mmap threshold, or a trim of the heap's top: both thresholds move at run time), the
+	// runtime had it registered for DMA (a pageable source / destination of hipMemcpyAsync), and the kernel driver answers the MMU
+	// invalidation by EVICTING and later restoring the process's queues: the next dispatch starts 10 - 30 ms late. Measured with
+	// in-kernel clocks (profiles/r10k_rank_time.log): the first kernel after the store build ran 12 - 27 ms after its launch in some
+	// processes, every or every other step — the 4 MB offset tables of build_var_store died at its return. (Telling the allocator
+	// to keep everything mapped — mallopt — removes it too, but slows the reference's own host code down: -align 4.37 -> 4.62 s.)
+	std::vector<u32> v_flags;               // stage A: per-pair flags of a batch as they are read back
+	std::vector<u64> v_dstbase, v_recw;     // stage A: where a batch's records go in the shard
+	std::vector<u8> v_shdr;                 // stage A: the shard's header as it is uploaded
+	std::vector<u8> v_hdr;                  // mpcgpu_store_import: a shard's header as it is read back
+	std::vector<u32> v_off, v_woff;         // build_var_store: block offsets of the n x n records / window records
+	std::vector<u32> v_words, v_out, v_w2, v_o2, v_okw; // relax_band: tile words and their statistics while the tiles are cut
 	HostBuf h_bt;             // relax_band's tile cutter: the small host <-> device transfers of a cut, page-locked (a copy into pageable memory
 	                          // right after a launch was measured at 24 ms on an otherwise idle device: profiles/r10k)
 	DevBuf d_ap_off;
@@ -675,7 +688,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		// transfer when the next step cannot be prefetched) and a part per cell slot. Shapes with more X than Y sequences are on the
 		// menu because the X pieces are the band's rows only, the Y pieces the whole range those rows' cells reach.
 		static const u32 menu[10][2] = {{8, 8}, {8, 4}, {8, 2}, {8, 1}, {4, 4}, {4, 2}, {4, 1}, {2, 2}, {2, 1}, {1, 1}};
-		std::vector<u32> words, out;
+		std::vector<u32> &words = c->v_words, &out = c->v_out; // (kept: see mpcgpu_ctx)
+		words.clear(); out.clear();
 		u32 use_nx = 0, use_ny = 0, use_target = 0;
 		const u32 margin = std::min<u32>(cap_blocks / 16, 64); // blocks: steps vary around the mean
 		const u32 half = cap_blocks / 2 > margin ? cap_blocks / 2 - margin : cap_blocks / 2, full = cap_blocks > 2 * margin ? cap_blocks - 2 * margin : cap_blocks;
@@ -690,7 +704,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		if (!use_nx && n <= 64) {
 			// few sequences (the shrubs of -super7, the clusters of -super5): the 8 x 8 super-tiles with ALL their rows as one band
 			// each, evaluated in one pass; taken when every one of them fits the cell slots and leaves room for the next step
-			std::vector<u32> w2, o2;
+			std::vector<u32> &w2 = c->v_w2, &o2 = c->v_o2; // (kept: see mpcgpu_ctx)
+			w2.clear(); o2.clear();
 			for (u32 x0 = 0; x0 < n; x0 += 8)
 				for (u32 y0 = x0; y0 < n; y0 += 8) {
 					u32 nw[MPC_RB_TILE_WORDS] = {x0, std::min(8u, n - x0), y0, std::min(8u, n - y0), 0u, (nb1 - 1) * (u32)MPC_RB_HB};
@@ -744,7 +759,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			if (trace_on()) fprintf(stderr, "[mpcgpu] band tiles: %.1f cells per row; worst step / mean step = %.3f (95th percentile): one step resident = %u blocks mean\n", per_row, r95, single);
 			double best = 0;
 			bool have = false;
-			std::vector<u32> w2, o2;
+			std::vector<u32> &w2 = c->v_w2, &o2 = c->v_o2; // (kept: see mpcgpu_ctx)
+			w2.clear(); o2.clear();
 			for (u32 mode = 0; mode < 2; ++mode)
 				for (u32 m = 0; m < 10; ++m) {
 					const u32 target = mode == 0 ? half : single;
@@ -764,7 +780,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		}
 		// every tile must fit: cells per lane, 16-bit first-piece offsets, and its WORST step in the staging area (upper bound
 		// first; the exact maximum over Z only where the bound does not settle it). What does not fit is halved: band, then Y, then X.
-		std::vector<u32> okw;
+		std::vector<u32> &okw = c->v_okw;
+		okw.clear();
 		u64 nsplit = 0;
 		if (!words.empty() && upload(c, c->d_btiles, words)) return 1; // (the device copy is that of the last shape tried)
 		for (int round = 0; round < 24 && !words.empty(); ++round) {
@@ -816,8 +833,8 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		if (!words.empty()) return 2;
 		{
 			u64 cells = 0, est = 0;
-			std::vector<u32> o2;
-			std::vector<u32> w2 = okw;
+			std::vector<u32> &o2 = c->v_o2, &w2 = c->v_w2; // (kept: see mpcgpu_ctx)
+			w2 = okw;
 			if (eval_tiles(w2, o2)) return 1; // (also leaves the final list's statistics for the description)
 			for (size_t t = 0; t + 3 < o2.size(); t += 4) { cells += o2[t + 3]; est += o2[t + 1]; }
 			const size_t nt = okw.size() / MPC_RB_TILE_WORDS;
@@ -1046,7 +1063,8 @@ int build_var_store(mpcgpu_ctx *c)
 	HIPCHK(c, c->d_sizes.ensure(nn * 4));
 	MPC_LAUNCH(var_size_kernel, (u32)std::min<u64>(nn, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp0, c->d_sizes.as<u32>());
 	HIPCHK(c, hipGetLastError());
-	std::vector<u32> off(nn + 1);
+	std::vector<u32> &off = c->v_off; // (kept: see mpcgpu_ctx)
+	off.resize(nn + 1);
 	HIPCHK(c, hipMemcpyAsync(off.data() + 1, c->d_sizes.p, nn * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	off[0] = 0;
@@ -1165,7 +1183,8 @@ int build_var_store(mpcgpu_ctx *c)
 			MPC_LAUNCH(win_size_kernel, (u32)std::min<u64>(nn, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp, c->d_sizes.as<u32>(),
 				c->d_tilefit.as<u32>(), c->d_wflag.as<u32>());
 			HIPCHK(c, hipGetLastError());
-			std::vector<u32> woff(nn + 1);
+			std::vector<u32> &woff = c->v_woff; // (kept: see mpcgpu_ctx)
+			woff.resize(nn + 1);
 			u32 wide = 0;
 			HIPCHK(c, hipMemcpyAsync(woff.data() + 1, c->d_sizes.p, nn * 4, hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(c, hipMemcpyAsync(&wide, c->d_wflag.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1973,7 +1992,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		if (done + B < np && prepare(done + B, nxt)) return 1;
 		lap(2);
 		// ---- sizes back, overflow check, pack
-		std::vector<u32> flags(B);
+		std::vector<u32> &flags = c->v_flags; // (kept: see mpcgpu_ctx)
+		flags.resize(B);
 		HIPCHK(c, hipMemcpyAsync(&c->sh_nnz[done], c->d_nnz.p, B * 4, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(&c->sh_ea[done], c->d_ea.p, B * 4, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipMemcpyAsync(flags.data(), c->d_flags.p, B * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1987,7 +2007,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 			capc = (u32)std::min<u64>((u64)capc * 2, (u64)LXmax * LYmax);
 			continue; // redo this batch with a larger candidate capacity
 		}
-		std::vector<u64> dstbase(B), recw(B);
+		std::vector<u64> &dstbase = c->v_dstbase, &recw = c->v_recw; // (kept: see mpcgpu_ctx)
+		dstbase.resize(B); recw.resize(B);
 		u64 w = words_done;
 		for (u64 q = 0; q < B; ++q) {
 			recw[q] = rec_words(c->len[bx[q]], c->len[by[q]], c->sh_nnz[done + q]);
@@ -2017,7 +2038,8 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 		fprintf(stderr, "[mpcgpu] stage A host seconds: prepare (first batch / retries) %.4f, uploads + launches %.4f, next batch prepared %.4f, "
 			"waiting for the device %.4f, sizes -> pack -> wait %.4f\n", lap_t[0], lap_t[1], lap_t[2], lap_t[3], lap_t[4]);
 	// header
-	std::vector<u8> h(hdr, 0);
+	std::vector<u8> &h = c->v_shdr; // (kept: see mpcgpu_ctx)
+	h.assign(hdr, 0);
 	u64 h2[2] = {np, words_done};
 	memcpy(h.data(), h2, 16);
 	memcpy(h.data() + 16, c->sh_nnz.data(), np * 4);
@@ -2100,7 +2122,8 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 		const u64 np = k1[s] - k0[s];
 		const u64 hdr = shard_header_bytes(np);
 		if (bytes[s] < hdr) return fail(c, "mpcgpu_store_import: shard %u too small", s);
-		std::vector<u8> h(hdr);
+		std::vector<u8> &h = c->v_hdr; // (kept: see mpcgpu_ctx — 8 bytes per pair of the shard)
+		h.resize(hdr);
 		HIPCHK(c, hipMemcpyAsync(h.data(), (const u8 *)dev_all + byte_off, hdr, hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		u64 h2[2];
