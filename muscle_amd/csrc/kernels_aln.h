@@ -108,32 +108,33 @@ __global__ void __launch_bounds__(MPC_ALN_THREADS) calc_aln_kernel(AlnParams p)
 #define MPC_ALNW_ROWBYTES (MPC_ALNW_MAXW / 2)
 #define MPC_ALNW_PF 4                      // rows of Post in flight
 
-__device__ __forceinline__ void calc_aln_wave_body(const AlnParams &p, unsigned char *smem_raw) // smem_raw: (LX+1) rows of MPC_ALNW_ROWBYTES traceback nibbles
+template <int C> // columns per lane: 64 * C >= LY + 1
+__device__ __forceinline__ void calc_aln_wave_body_c(const AlnParams &p, unsigned char *smem_raw) // smem_raw: (LX+1) rows of MPC_ALNW_ROWBYTES traceback nibbles
 {
 	const u32 LX = p.LX, LY = p.LY, W = LY + 1;
 	const u32 lane = threadIdx.x & 63u;
-	const u32 j0 = lane * MPC_ALNW_C; // my columns [j0, j0 + C)
-	float oldr[MPC_ALNW_C];
+	const u32 j0 = lane * C; // my columns [j0, j0 + C)
+	float oldr[C];
 	u32 code0 = 0; // row 0: 'Y' everywhere (calcalnflat.cpp:15-19); codes: 0 = 'B', 1 = 'X', 2 = 'Y'
 #pragma unroll
-	for (int c = 0; c < MPC_ALNW_C; ++c) { oldr[c] = 0.0f; code0 |= 2u << (4 * c); }
+	for (int c = 0; c < C; ++c) { oldr[c] = 0.0f; code0 |= 2u << (4 * c); }
 	((u32 *)smem_raw)[lane] = code0;
 	// Post(i-1, j-1) of my columns, MPC_ALNW_PF rows ahead: the row loop is a dependent chain of ~0.2 us per row and a load from
 	// HBM/L2 takes ~1-2 us, so one row of lookahead leaves the chain waiting on memory every row (measured: 1.5 us per row).
 	// The loads are unconditional (a branch around a load makes the compiler wait for ALL loads in flight, vmcnt(0), at the
 	// next use): rows past LX and columns outside 1..LY read a clamped in-range address instead, and what they read is never
 	// used (column 0 and the columns past LY get their S and letter without it and stay out of the row maximum).
-	float ring[MPC_ALNW_PF][MPC_ALNW_C];
-	u32 coff[MPC_ALNW_C]; // clamped column offsets: the same for every row
+	float ring[MPC_ALNW_PF][C];
+	u32 coff[C]; // clamped column offsets: the same for every row
 #pragma unroll
-	for (int c = 0; c < MPC_ALNW_C; ++c) {
+	for (int c = 0; c < C; ++c) {
 		const u32 j = j0 + c;
 		coff[c] = (j < 1u ? 1u : (j > LY ? LY : j)) - 1u;
 	}
 	auto load_row = [&](float *dst, u32 i) {
 		const float *prow = p.post + (u64)((i <= LX ? i : LX) - 1u) * LY;
 #pragma unroll
-		for (int c = 0; c < MPC_ALNW_C; ++c) dst[c] = prow[coff[c]];
+		for (int c = 0; c < C; ++c) dst[c] = prow[coff[c]];
 	};
 #pragma unroll
 	for (int r = 0; r < MPC_ALNW_PF; ++r) { load_row(ring[r], 1u + r); MPC_SCHED_BARRIER(); } // issued oldest row first: the waits count loads in order
@@ -142,19 +143,19 @@ __device__ __forceinline__ void calc_aln_wave_body(const AlnParams &p, unsigned 
 	for (int r = 0; r < MPC_ALNW_PF; ++r) {
 		const u32 i = ib + r;
 		if (i > LX) break; // wave-uniform
-		float pvc[MPC_ALNW_C];
+		float pvc[C];
 #pragma unroll
-		for (int c = 0; c < MPC_ALNW_C; ++c) pvc[c] = ring[r][c];
+		for (int c = 0; c < C; ++c) pvc[c] = ring[r][c];
 		load_row(ring[r], i + MPC_ALNW_PF);
 		MPC_SCHED_BARRIER();
 		// S(i-1, j0-1): the previous lane's last column of the previous row
-		float left_old = mpc_lane_up1(oldr[MPC_ALNW_C - 1]);
+		float left_old = mpc_lane_up1(oldr[C - 1]);
 		if (lane == 0) left_old = 0.0f; // unused (column 0 has no B)
-		float T[MPC_ALNW_C];
-		bool bx[MPC_ALNW_C];
+		float T[C];
+		bool bx[C];
 		float run = 0.0f; // T_j >= 0 always (X >= 0), and S(i,0) = 0
 #pragma unroll
-		for (int c = 0; c < MPC_ALNW_C; ++c) {
+		for (int c = 0; c < C; ++c) {
 			const u32 j = j0 + c;
 			const float diag = c == 0 ? left_old : oldr[c - 1];
 			const float B = diag + pvc[c];
@@ -169,7 +170,7 @@ __device__ __forceinline__ void calc_aln_wave_body(const AlnParams &p, unsigned 
 		if (lane == 0) Y = 0.0f;
 		u32 codes = 0;
 #pragma unroll
-		for (int c = 0; c < MPC_ALNW_C; ++c) {
+		for (int c = 0; c < C; ++c) {
 			const u32 j = j0 + c;
 			float S;
 			u32 code;
@@ -190,8 +191,8 @@ __device__ __forceinline__ void calc_aln_wave_body(const AlnParams &p, unsigned 
 	// score = S(LX, LY): lane LY / C, register LY % C
 	float sc = 0.0f;
 #pragma unroll
-	for (int c = 0; c < MPC_ALNW_C; ++c) if ((u32)c == (LY % MPC_ALNW_C)) sc = oldr[c];
-	sc = mpc_read_lane(sc, LY / MPC_ALNW_C);
+	for (int c = 0; c < C; ++c) if ((u32)c == (LY % C)) sc = oldr[c];
+	sc = mpc_read_lane(sc, LY / C);
 	__syncthreads(); // one wave: orders the LDS writes above before the walk below
 	// TraceBackFlat (tracebackflat.cpp:3-37) out of LDS
 	u32 *s_n = (u32 *)(smem_raw + (u64)(LX + 1) * MPC_ALNW_ROWBYTES);
@@ -200,8 +201,9 @@ __device__ __forceinline__ void calc_aln_wave_body(const AlnParams &p, unsigned 
 		int i = (int)LX, j = (int)LY;
 		u32 n = 0;
 		while (i != 0 || j != 0) {
-			const u32 byte = smem_raw[(u64)i * MPC_ALNW_ROWBYTES + (j >> 1)];
-			const u32 code = (byte >> (4 * (j & 1))) & 0xfu;
+			const u32 jl = (u32)j / (u32)C, jc = (u32)j % (u32)C; // lane and register of column j: a lane's C codes are the low nibbles of its word of the row
+			const u32 byte = smem_raw[(u64)i * MPC_ALNW_ROWBYTES + 4u * jl + (jc >> 1)];
+			const u32 code = (byte >> (4 * (jc & 1))) & 0xfu;
 			const char ch = code == 0u ? 'B' : (code == 1u ? 'X' : 'Y');
 			p.rev[n++] = ch;
 			if (code == 0u) { --i; --j; } else if (code == 1u) --i; else --j;
@@ -213,6 +215,20 @@ __device__ __forceinline__ void calc_aln_wave_body(const AlnParams &p, unsigned 
 	const u32 n = *s_n;
 	for (u32 k = lane; k < n; k += 64) p.path[k] = p.rev[n - 1 - k];
 	(void)W;
+}
+
+// Columns per lane by the matrix's width: the row loop is a dependent chain whose length grows with the columns a lane owns (two
+// passes over them around the wave scan), and the joins of a -super7 shrub are ~300 columns wide, those of a 400-residue family ~450:
+// 5 / 7 columns per lane instead of 8 (51 148 one-wave alignments are 61 % of that run's kernel time: profiles/r10j). Same cells, same
+// comparisons, same tie order; a row of codes stays one word per lane (256 bytes) whatever C is.
+__device__ __forceinline__ void calc_aln_wave_body(const AlnParams &p, unsigned char *smem_raw)
+{
+	const u32 W = p.LY + 1; // wave-uniform
+	if (W <= 64u * 4u) calc_aln_wave_body_c<4>(p, smem_raw);
+	else if (W <= 64u * 5u) calc_aln_wave_body_c<5>(p, smem_raw);
+	else if (W <= 64u * 6u) calc_aln_wave_body_c<6>(p, smem_raw);
+	else if (W <= 64u * 7u) calc_aln_wave_body_c<7>(p, smem_raw);
+	else calc_aln_wave_body_c<8>(p, smem_raw);
 }
 
 __global__ void __launch_bounds__(64) calc_aln_wave_kernel(AlnParams p)

@@ -104,6 +104,10 @@ def test_emu_calc_aln(emu, kernel, monkeypatch):
         P0 = (rng.random((LX, LY)) < 0.15) * rng.random((LX, LY))
         mats.append(P0.astype(np.float32))
         mats.append(np.round(P0 * 4).astype(np.float32) / 4)  # many exact ties
+    # the one-wave kernel picks its columns per lane by width (4 .. 8: kernels_aln.h): both sides of every class boundary, with ties
+    for LY in (255, 256, 319, 320, 383, 384, 447, 448, 511):
+        P0 = (rng.random((11, LY)) < 0.1) * rng.random((11, LY))
+        mats.append((np.round(P0 * 4) / 4).astype(np.float32))
     mats.append(np.zeros((5, 6), np.float32))                 # all ties: every cell equal
     mats.append((rng.random((30, 1100)) * 3).astype(np.float32))  # more columns than threads
     if kernel == "waves":  # more rows than one staged traceback block holds (150 KB / 320 bytes per row)

@@ -380,7 +380,9 @@ def test_calc_aln_paths(kernel, monkeypatch):
         assert path == str(z["path%d" % k])
         assert P.bits(sc) == P.bits(z["calcaln_score%d" % k])
     rng = np.random.default_rng(11)
-    for LX, LY in ((1, 1), (1, 9), (7, 1), (150, 170), (620, 580), (300, 2500), (1010, 990), (2000, 4000), (40, 4500)):
+    # (255 .. 511 columns: both sides of every columns-per-lane class of the one-wave kernel, 4 .. 8)
+    for LX, LY in ((1, 1), (1, 9), (7, 1), (150, 170), (620, 580), (300, 2500), (1010, 990), (2000, 4000), (40, 4500),
+                   (90, 255), (90, 256), (310, 319), (90, 320), (400, 383), (90, 384), (450, 447), (90, 448), (500, 511)):
         M = ((rng.random((LX, LY)) < 0.02) * rng.random((LX, LY)) * 3).astype(np.float32)
         for Q in (M, np.round(M * 2) / 2):
             path, sc = g.calc_aln(Q.astype(np.float32))
