@@ -270,3 +270,29 @@ def check_fb_chains(lib_path=None):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def check_align_pairs_chunked(lib_path=None):
+    """a list of 300 pairs (two stage-A chunks: 256 + 44) through mpcgpu_align_pairs + mpcgpu_get_list_sparse: every entry equals what the
+    same ordered pair gives as a list of one — paths, score / EA bits, sparse matrices"""
+    import _golden as G
+    from muscle_amd._lib import MpcGpu
+    from muscle_amd.synth import make_family
+    seqs = make_family(6, 14, seed=21)
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, lib_path) if lib_path else MpcGpu(0)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    ordered = [(a, b) for a in range(6) for b in range(6) if a != b]
+    lst = [ordered[q % len(ordered)] for q in range(300)]
+    res, sp = g.align_pairs([a for a, _ in lst], [b for _, b in lst], sparse=True)
+    assert len(sp) == 300
+    one = {}
+    for (a, b) in ordered:
+        r1, s1 = g.align_pairs([a], [b], sparse=True)
+        one[(a, b)] = (r1[0], s1[0])
+    for q, (a, b) in enumerate(lst):
+        (path, sc, ea), (off, val) = one[(a, b)]
+        assert res[q][0] == path and bits(res[q][1]) == bits(sc) and bits(res[q][2]) == bits(ea), q
+        assert np.array_equal(sp[q][0], off) and np.array_equal(sp[q][1], val), (q, a, b)
+    g.close()

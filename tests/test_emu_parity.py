@@ -505,6 +505,12 @@ def test_emu_align_pairs_vs_reference_golden(emu):
     P.check_align_pairs_golden("ap_ragged", emu)
 
 
+def test_emu_align_pairs_list_longer_than_a_chunk(emu):
+    """mpcgpu_get_list_sparse indexes the CALLER'S list: a list of 300 pairs runs in two stage-A chunks (256 + 44), and the matrix of a pair
+    of the first chunk must still be that pair's (the index used to address the last chunk — another pair's record, or an error)"""
+    P.check_align_pairs_chunked(emu)
+
+
 def test_emu_fb_chains(emu):
     """pairs that share their row sequence swept back to back (kernels_fbc.h) == one pair per sweep == the oracle"""
     P.check_fb_chains(emu)

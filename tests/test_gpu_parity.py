@@ -666,6 +666,11 @@ def test_two_gpus_rccl_group_and_torchrun_bench():
     assert rec["exchange_ms"] > 0
 
 
+def test_align_pairs_list_longer_than_a_chunk():
+    """mpcgpu_get_list_sparse after a list that ran in two stage-A chunks: the caller's index, not the last chunk's"""
+    P.check_align_pairs_chunked()
+
+
 def test_align_pairs_vs_reference_golden():
     """mpcgpu_align_pairs / mpcgpu_get_list_sparse against the compiled reference's AlignPairFlat_SparsePost
     (alignpairflat.cpp:3-27; callers uclust.cpp:14, transaln.cpp:787, eadistmx.cpp:54): path, EA bits, FromPost matrix."""
