@@ -42,10 +42,12 @@
 #include "uclust.h"
 #include "mpcgpu.h"
 
+#include <malloc.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <map>
+#include <set>
 #include <mutex>
 #include <thread>
 
@@ -124,6 +126,9 @@ enum { MAX_JOIN_CTX = 64 };
 JoinCtx g_Join[MAX_JOIN_CTX];
 std::atomic<unsigned> g_JoinNext(0);
 thread_local int t_JoinIndex = -1;
+// join contexts beyond one per device: the worker threads of PProg::Run2 below run independent joins side by side, each on a context
+// of its own (context i lives on device i mod #devices)
+std::atomic<unsigned> g_JoinCtxWanted(0);
 
 int SlotIndexOf(const MPCFlat *M)
 	{
@@ -189,14 +194,14 @@ vector<int> DeviceList()
 JoinCtx &JoinOfThisThread()
 	{
 	const vector<int> Devs = DeviceList();
-	const unsigned N = (unsigned) std::min<size_t>(Devs.size(), MAX_JOIN_CTX);
+	const unsigned N = (unsigned) std::min<size_t>(std::max<size_t>(Devs.size(), g_JoinCtxWanted.load()), MAX_JOIN_CTX);
 	if (t_JoinIndex < 0 || (unsigned) t_JoinIndex >= N)
 		t_JoinIndex = (int) (g_JoinNext.fetch_add(1) % N);
 	JoinCtx &J = g_Join[t_JoinIndex];
 	std::lock_guard<std::mutex> Guard(J.m_Mu);
 	if (J.m_Ctx == 0)
 		{
-		if (mpcgpu_create(&J.m_Ctx, Devs[t_JoinIndex]) != 0)
+		if (mpcgpu_create(&J.m_Ctx, Devs[(size_t) t_JoinIndex % Devs.size()]) != 0)
 			Die("GPU posterior stage: %s", mpcgpu_last_error(0));
 		}
 	return J;
@@ -214,6 +219,21 @@ const std::chrono::steady_clock::time_point g_ProcessStart = std::chrono::steady
 // tables to build and no tiles to cut per store (MPCGPU_RELAX_SMALL_PAIRS, muscle_amd/csrc/mpcgpu.cpp: build_var_store; 4.6 ms of host
 // round trips per store otherwise, 412 stores in a 10 000-sequence run). Set here, before any thread exists; the user's own setting wins.
 const int g_SmallStoreDefault = setenv("MPCGPU_RELAX_SMALL_PAIRS", "40", 0);
+// The allocator keeps freed memory mapped (blocks below 1 GB come from the heap, the heap's top is not trimmed). Host memory that the HIP
+// runtime has touched for a copy is registered for DMA; when glibc hands such a block back to the kernel (munmap above its moving mmap
+// threshold, or a trim), the kernel driver answers the invalidation by EVICTING the process's device queues and restoring them later:
+// every queue of the process stops for 10 - 30 ms (profiles/r10k). One thread's joins lose little to that; six threads
+// running joins side by side (PProg::Run2 below) freed such blocks all the time: 11.4 s for the run that takes 7.7 s on one thread and
+// 6.4 s with the memory kept (profiles/r11d). MUSCLE_GPU_MALLOC=default leaves the allocator alone.
+const int g_KeepFreedMemoryMapped = []
+	{
+	const char *e = getenv("MUSCLE_GPU_MALLOC");
+	if (e != 0 && strcmp(e, "default") == 0)
+		return 0;
+	mallopt(M_MMAP_THRESHOLD, 1 << 30);
+	mallopt(M_TRIM_THRESHOLD, 1 << 30);
+	return 1;
+	}();
 double g_CtxSeconds = 0; // MUSCLE_GPU_TIMING: creating contexts (the first one pays for the HIP runtime's start-up)
 struct CtxClock
 	{
@@ -758,28 +778,25 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 	return result;
 	}
 
-float PProg::AlignMSAsFlat(const string &ProgressStr,
-  const MultiSequence &MSA1, const MultiSequence &MSA2,
-  uint TargetPairCount, string &Path)
+namespace
+{
+// PProg::AlignMSAsFlat (alnmsasflat.cpp:4-50) behind its pair sampling: the pairs are given. Split off so that PProg::Run2 below can
+// draw every join's pairs in join order on one thread (GetPairs consumes the process-wide randu32 stream) and run the joins side by side.
+float AlignMSAsWithPairs(const string &ProgressStr, const MultiSequence &MSA1, const MultiSequence &MSA2,
+  const vector<uint> &SeqIndexes1, const vector<uint> &SeqIndexes2, string &Path, bool Progress)
 	{
-// alnmsasflat.cpp:8-25
 	const uint SeqCount1 = MSA1.GetNumSequences();
 	const uint SeqCount2 = MSA2.GetNumSequences();
-	asserta(SeqCount1 > 0);
-	asserta(SeqCount2 > 0);
 	asserta(MSA1.IsAligned());
 	asserta(MSA2.IsAligned());
 	const uint ColCount1 = MSA1.GetColCount();
 	const uint ColCount2 = MSA2.GetColCount();
-
-	vector<uint> SeqIndexes1;
-	vector<uint> SeqIndexes2;
-	GetPairs(SeqCount1, SeqCount2, TargetPairCount, SeqIndexes1, SeqIndexes2);
 	const uint PairCount = SIZE(SeqIndexes1);
 	asserta(SIZE(SeqIndexes2) == PairCount);
 	asserta(PairCount > 0);
-	ProgressStep(0, 1, "%s [%u x %u, %u pairs]", ProgressStr.substr(0, 20).c_str(),
-	  min(SeqCount1, SeqCount2), max(SeqCount1, SeqCount2), PairCount);
+	if (Progress) // (ProgressStep keeps its state in unguarded process globals: the worker threads of Run2 run without it)
+		ProgressStep(0, 1, "%s [%u x %u, %u pairs]", ProgressStr.substr(0, 20).c_str(),
+		  min(SeqCount1, SeqCount2), max(SeqCount1, SeqCount2), PairCount);
 
 // The ungapped sequences come from the global input registry by label, like CalcPost does
 // (calcpost.cpp:4-36, getpostpairsalignedflat.cpp:43-46); the ones this join touches are handed to
@@ -850,6 +867,154 @@ float PProg::AlignMSAsFlat(const string &ProgressStr,
 	for (uint PairIndex = 0; PairIndex < PairCount; ++PairIndex)
 		SumEA += EA[PairIndex];
 	return SumEA/PairCount;
+	}
+}
+
+float PProg::AlignMSAsFlat(const string &ProgressStr,
+  const MultiSequence &MSA1, const MultiSequence &MSA2,
+  uint TargetPairCount, string &Path)
+	{
+// alnmsasflat.cpp:8-25
+	const uint SeqCount1 = MSA1.GetNumSequences();
+	const uint SeqCount2 = MSA2.GetNumSequences();
+	asserta(SeqCount1 > 0);
+	asserta(SeqCount2 > 0);
+	vector<uint> SeqIndexes1;
+	vector<uint> SeqIndexes2;
+	GetPairs(SeqCount1, SeqCount2, TargetPairCount, SeqIndexes1, SeqIndexes2);
+	return AlignMSAsWithPairs(ProgressStr, MSA1, MSA2, SeqIndexes1, SeqIndexes2, Path, true);
+	}
+
+// PProg::Run2 (pprog2.cpp:58-76): the joins of a guide tree in join order, one after the other in the reference. A join needs its two
+// children and nothing else, so the joins of different subtrees are independent — and one join is a few milliseconds of latency
+// (stage A on <= 2000 sampled pairs, one BuildPost, one alignment; the 411 joins of a 10 000-sequence -super7 run: 2.2 of its 7.7 s).
+// Here MUSCLE_GPU_JOIN_WORKERS threads (default 6; 1 = the reference's loop) take ready joins, lowest join index first, each on a join
+// context of its own. What the sequential order decides besides the result is kept: every join's pair sample is drawn on THIS thread
+// in join order before any join runs (GetPairs, getpairs.cpp:33-69, draws from the process-wide randu32 stream; the sequence counts it
+// needs follow from the tree), m_JoinMSAIndexes1/2 are filled in join order, and a join does what PProg::AlignAndJoin
+// (pprog2.cpp:7-56) does. With -savedir (a file per join, named by m_JoinIndex) the reference's loop runs.
+void PProg::Run2(const vector<uint> &Indexes1,
+  const vector<uint> &Indexes2)
+	{
+	asserta(m_InputMSACount > 0);
+	m_JoinCount = m_InputMSACount - 1;
+	m_NodeCount = m_InputMSACount + m_JoinCount;
+	asserta(SIZE(Indexes1) == m_JoinCount);
+	asserta(SIZE(Indexes2) == m_JoinCount);
+	ValidateJoinOrder(Indexes1, Indexes2);
+
+	uint Workers = 6;
+	const char *EnvWorkers = getenv("MUSCLE_GPU_JOIN_WORKERS");
+	if (EnvWorkers != 0 && *EnvWorkers != 0)
+		Workers = (uint) atoi(EnvWorkers);
+	if (Workers > MAX_JOIN_CTX)
+		Workers = MAX_JOIN_CTX;
+	if (Workers <= 1 || m_JoinCount < 2 || optset_savedir)
+		{
+		for (m_JoinIndex = 0; m_JoinIndex < m_JoinCount; ++m_JoinIndex)
+			AlignAndJoin(Indexes1[m_JoinIndex], Indexes2[m_JoinIndex]);
+		return;
+		}
+
+// sequence counts of every node, and every join's pairs, in join order
+	vector<uint> SeqCounts(m_NodeCount, 0);
+	for (uint i = 0; i < m_InputMSACount; ++i)
+		SeqCounts[i] = GetMSA(i).GetNumSequences();
+	vector<vector<uint> > Pairs1(m_JoinCount), Pairs2(m_JoinCount);
+	for (uint k = 0; k < m_JoinCount; ++k)
+		{
+		const uint n1 = SeqCounts[Indexes1[k]], n2 = SeqCounts[Indexes2[k]];
+		asserta(n1 > 0 && n2 > 0);
+		SeqCounts[m_InputMSACount + k] = n1 + n2;
+		GetPairs(n1, n2, m_TargetPairCount, Pairs1[k], Pairs2[k]);
+		m_JoinMSAIndexes1.push_back(Indexes1[k]);
+		m_JoinMSAIndexes2.push_back(Indexes2[k]);
+		}
+
+// which join waits for which: join k produces node m_InputMSACount + k
+	vector<int> Waiting(m_JoinCount, 0);
+	vector<vector<uint> > Users(m_NodeCount);
+	for (uint k = 0; k < m_JoinCount; ++k)
+		{
+		const uint Ins[2] = { Indexes1[k], Indexes2[k] };
+		for (int q = 0; q < 2; ++q)
+			if (Ins[q] >= m_InputMSACount)
+				{
+				++Waiting[k];
+				Users[Ins[q]].push_back(k);
+				}
+		}
+	std::mutex Mu;
+	std::condition_variable Cv;
+	std::set<uint> Ready;
+	for (uint k = 0; k < m_JoinCount; ++k)
+		if (Waiting[k] == 0)
+			Ready.insert(k);
+	uint Done = 0;
+	const bool SavedQuiet = opt_quiet;
+	ProgressLog("Joining %u alignments on %u join contexts\n", m_InputMSACount, Workers);
+	opt_quiet = true; // (ProgressStep is not thread-safe: as for the shrub workers of Super7::IntraAlignShrubs)
+	g_JoinCtxWanted.store(std::max<unsigned>(g_JoinCtxWanted.load(), Workers));
+	vector<std::thread> Threads;
+	for (uint w = 0; w < Workers; ++w)
+		Threads.emplace_back([&, w]()
+			{
+			t_JoinIndex = (int) w;
+			for (;;)
+				{
+				uint k;
+					{
+					std::unique_lock<std::mutex> Lock(Mu);
+					Cv.wait(Lock, [&] { return !Ready.empty() || Done == m_JoinCount; });
+					if (Ready.empty())
+						return;
+					k = *Ready.begin();
+					Ready.erase(Ready.begin());
+					}
+// PProg::AlignAndJoin (pprog2.cpp:7-56) for join k
+				const uint Index1 = Indexes1[k], Index2 = Indexes2[k];
+				const MultiSequence &MSA1 = GetMSA(Index1);
+				const MultiSequence &MSA2 = GetMSA(Index2);
+				AssertSameLabels(MSA1);
+				AssertSameLabels(MSA2);
+				string ProgressStr;
+				Ps(ProgressStr, "Join %u / %u", k+1, m_JoinCount);
+				string Path;
+				AlignMSAsWithPairs(ProgressStr, MSA1, MSA2, Pairs1[k], Pairs2[k], Path, false);
+				MultiSequence *MSA12 = new MultiSequence;
+				AlignMSAsByPath(MSA1, MSA2, Path, *MSA12);
+				AssertSeqsEq(MSA1, *MSA12);
+				AssertSeqsEq(MSA2, *MSA12);
+				AssertSameSeqsJoin(MSA1, MSA2, *MSA12);
+				AssertSameLabels(*MSA12);
+				vector<uint>().swap(Pairs1[k]);
+				vector<uint>().swap(Pairs2[k]);
+					{
+					std::lock_guard<std::mutex> Lock(Mu);
+					if (Index1 >= m_InputMSACount)
+						{
+						delete &MSA1;
+						m_MSAs[Index1] = 0;
+						}
+					if (Index2 >= m_InputMSACount)
+						{
+						delete &MSA2;
+						m_MSAs[Index2] = 0;
+						}
+					const uint NewMSAIndex = m_InputMSACount + k;
+					SetMSA(NewMSAIndex, *MSA12);
+					for (size_t u = 0; u < Users[NewMSAIndex].size(); ++u)
+						if (--Waiting[Users[NewMSAIndex][u]] == 0)
+							Ready.insert(Users[NewMSAIndex][u]);
+					++Done;
+					}
+				Cv.notify_all();
+				}
+			});
+	for (size_t t = 0; t < Threads.size(); ++t)
+		Threads[t].join();
+	opt_quiet = SavedQuiet;
+	m_JoinIndex = m_JoinCount;
 	}
 
 // AlignPairFlat (alignpairflat.cpp:3-27) and its sequential caller in -super5, UClust::Search (uclust.cpp:26-56): the same

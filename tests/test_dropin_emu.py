@@ -52,6 +52,15 @@ def test_final_msa_identical_sharded_over_contexts(emu_muscle, name, devices):
     assert md5 == _msa.golden_md5()[name]
 
 
+@pytest.mark.parametrize("workers", ["1", "2", "6"])
+def test_super7_joins_side_by_side(emu_muscle, workers):
+    """-super7 on 24 sequences in shrubs of 3: eight shrubs, seven PProg joins along the shrub tree (pprog2.cpp:58-76) — run by
+    MUSCLE_GPU_JOIN_WORKERS threads on join contexts of their own (hostcxx: PProg::Run2), independent subtrees side by side; 1 = the
+    reference's loop. The final MSA is the reference's whatever the number of workers."""
+    md5, _ = _msa.run_muscle(emu_muscle, "super7_24x14_b3", threads=2, env={"MUSCLE_GPU_JOIN_WORKERS": workers, "MUSCLE_GPU_SHRUB_CONTEXTS": "3"})
+    assert md5 == _msa.golden_md5()["super7_24x14_b3"]
+
+
 @pytest.mark.parametrize("name,workers", [("super7_8x18_b4", "1"), ("super7_8x18_b4", "2"), ("super7_8x18_b4", "5")])
 def test_super7_shrubs_over_worker_contexts(emu_muscle, name, workers):
     """-super7: the shrub loop (super7.cpp:127-137) run by MUSCLE_GPU_SHRUB_CONTEXTS worker threads, each with its own MPCFlat and
