@@ -234,6 +234,11 @@ const int g_KeepFreedMemoryMapped = []
 	mallopt(M_TRIM_THRESHOLD, 1 << 30);
 	return 1;
 	}();
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise), and streams that share a
+// queue run one after the other: the 8 shrub workers and 6 join workers, each with a stream of one-wave kernels, were 4 wide on the
+// device (-super7 10 000 x 250: 6.5 -> 6.0 s with 8 queues, 5.9 with 16; profiles/r11f). The runtime reads the variable when its first
+// call initialises it — after this object's static initialisation; the user's own setting wins.
+const int g_HwQueuesDefault = setenv("GPU_MAX_HW_QUEUES", "16", 0);
 double g_CtxSeconds = 0; // MUSCLE_GPU_TIMING: creating contexts (the first one pays for the HIP runtime's start-up)
 struct CtxClock
 	{

@@ -106,7 +106,9 @@ __global__ void __launch_bounds__(MPC_ALN_THREADS) calc_aln_kernel(AlnParams p)
 #define MPC_ALNW_C 8                       // columns per lane
 #define MPC_ALNW_MAXW (64 * MPC_ALNW_C)    // W = LY + 1 <= 512
 #define MPC_ALNW_ROWBYTES (MPC_ALNW_MAXW / 2)
+#ifndef MPC_ALNW_PF
 #define MPC_ALNW_PF 4                      // rows of Post in flight
+#endif
 
 template <int C> // columns per lane: 64 * C >= LY + 1
 __device__ __forceinline__ void calc_aln_wave_body_c(const AlnParams &p, unsigned char *smem_raw) // smem_raw: (LX+1) rows of MPC_ALNW_ROWBYTES traceback nibbles
