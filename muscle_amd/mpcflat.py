@@ -36,9 +36,10 @@ def shard_bounds(lens, world):
 
 class TorchExchange:
     """The two collectives of the sharded stage, over torch.distributed (backend nccl == RCCL on
-    ROCm; gloo in the CPU tests). Shards differ in size, so the all-gather is `world` broadcasts,
-    each of one rank's exact segment straight into its final place in ONE preallocated buffer
-    (queued together, waited for once): no padding to the largest shard and no concatenation copy."""
+    ROCm; gloo in the CPU tests). Shards differ in size, so the all-gather is one grouped set of
+    exact-size point-to-point transfers, each segment straight into its final place in ONE
+    preallocated buffer (queued together, waited for once): no padding to the largest shard and no
+    concatenation copy."""
 
     def __init__(self, dist, device):
         self.dist = dist
@@ -73,18 +74,33 @@ class TorchExchange:
 
     def all_gather_segments(self, full, sizes):
         """full: 1-D tensor that already holds THIS rank's segment at its final place (offset = sum of the sizes before it);
-        every other rank's segment is received straight into its own place: `world` broadcasts of exact sizes, queued
-        together and waited for once — no padding to the largest shard, no staging copy."""
+        every other rank's segment is received straight into its own place: exact sizes, queued together and waited for
+        once — no padding to the largest shard, no staging copy."""
         works = self.start_gather_segments(full, sizes)
         return self.finish_gather_segments(full, sizes, works)
 
     def start_gather_segments(self, full, sizes):
-        """queues the `world` broadcasts of all_gather_segments and returns their handles: the caller has its own device work
-        (the commit of its own slice) run under the transfers before it waits for them"""
+        """queues the transfers of all_gather_segments and returns their handles: the caller has its own device work (the commit
+        of its own slice) run under them before it waits. ONE grouped set of point-to-point transfers (batch_isend_irecv: on RCCL
+        one ncclGroupStart/End): a rank sends its segment to each peer and receives each peer's segment straight into its place —
+        on xGMI's full mesh the 7 sends of a rank leave over 7 links at once, where `world` broadcasts on one communicator run one
+        after the other (the same pattern as the one-process group, muscle_amd/csrc/mpcgpu_group.cpp). MPC_EXCHANGE=bcast: the
+        `world` broadcasts of rounds 2-4."""
+        import os
         offs = [0]
         for sz in sizes:
             offs.append(offs[-1] + int(sz))
-        return [self.dist.broadcast(full[offs[r]:offs[r + 1]], src=r, async_op=True) for r in range(self.world) if sizes[r]]
+        if os.environ.get("MPC_EXCHANGE", "p2p") == "bcast":
+            return [self.dist.broadcast(full[offs[r]:offs[r + 1]], src=r, async_op=True) for r in range(self.world) if sizes[r]]
+        mine = full[offs[self.rank]:offs[self.rank + 1]]
+        ops = []
+        for d in range(1, self.world):  # peer at distance d: receive from the rank d behind, send to the rank d ahead
+            src, dst = (self.rank - d) % self.world, (self.rank + d) % self.world
+            if sizes[src]:
+                ops.append(self.dist.P2POp(self.dist.irecv, full[offs[src]:offs[src + 1]], src))
+            if sizes[self.rank]:
+                ops.append(self.dist.P2POp(self.dist.isend, mine, dst))
+        return list(self.dist.batch_isend_irecv(ops)) if ops else []
 
     def finish_gather_segments(self, full, sizes, works):
         for w in works:

@@ -26,7 +26,7 @@ LIB = os.environ.get("TEC_LIB") or None
 
 
 class ThreadDist:
-    """all_gather_into_tensor / rank / world of torch.distributed for WORLD threads of one process"""
+    """all_gather_into_tensor / batch_isend_irecv / broadcast / rank / world of torch.distributed for WORLD threads of one process"""
 
     def __init__(self):
         self.bar = threading.Barrier(WORLD)
@@ -47,6 +47,24 @@ class ThreadDist:
         _sync()
         self.bar.wait()
 
+
+    # the grouped point-to-point form of the exchange (TorchExchange.start_gather_segments): P2POp / isend / irecv / batch_isend_irecv
+    isend, irecv = "isend", "irecv"
+
+    def P2POp(self, op, tensor, peer):
+        return (op, tensor, peer)
+
+    def batch_isend_irecv(self, ops):
+        _sync()
+        me = self.tl.rank
+        self.slots[me] = {peer: t for (op, t, peer) in ops if op == "isend"}
+        self.bar.wait()
+        for op, t, peer in ops:
+            if op == "irecv":
+                t.copy_(self.slots[peer][me])
+        _sync()
+        self.bar.wait()
+        return []
 
     def broadcast(self, t, src, async_op=False):
         _sync()
