@@ -9,7 +9,8 @@
 #                        MPCFlat::AlignAlns, PProg::AlignMSAsFlat, MPCFlat::BuildPost and AlignPairFlat(_SparsePost) are ours)
 #                      - calcposteriorflat.o's CalcPosterior symbol, weakened with objcopy so that
 #                        hostcxx/mpcflat_gpu.cpp's strong definition wins while CalcPostFlat and the
-#                        two vestigial virtuals in the same object stay available
+#                        two vestigial virtuals in the same object stay available; likewise one member each of
+#                        super7.o, uclust.o, pprog2.o and mpcflat.o (MPCFlat::CalcPosteriors) - see below
 #   + hostcxx/mpcflat_gpu.cpp (g++, against the reference headers) + hostcxx/rand_isolate.cpp
 #     (-Wl,--wrap=rand) + -lmpcgpu
 set -euo pipefail
@@ -36,7 +37,9 @@ objcopy --weaken-symbol=_ZN6Super716IntraAlignShrubsEv "$REFOBJ/super7.o" "$OUT/
 objcopy --weaken-symbol=_ZN6UClust6SearchEjRNSt7__cxx1112basic_stringIcSt11char_traitsIcESaIcEEE "$REFOBJ/uclust.o" "$OUT/uclust_weak.o"
 # PProg::Run2: ours (independent joins of the guide tree side by side); AlignAndJoin and the rest of pprog2.o stay
 objcopy --weaken-symbol=_ZN5PProg4Run2ERKSt6vectorIjSaIjEES4_ "$REFOBJ/pprog2.o" "$OUT/pprog2_weak.o"
-OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' -e '/uclust\.o$' -e '/alignpairflat\.o$' -e '/pprog2\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$')
+# MPCFlat::CalcPosteriors: ours (a plain loop: the work of all pairs happens inside the first CalcPosterior call); the rest of mpcflat.o stays
+objcopy --weaken-symbol=_ZN7MPCFlat14CalcPosteriorsEv "$REFOBJ/mpcflat.o" "$OUT/mpcflat_weak.o"
+OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' -e '/uclust\.o$' -e '/alignpairflat\.o$' -e '/pprog2\.o$' -e '/mpcflat\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$')
 # The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
 # MPCGPU_LIBDIR/MPCGPU_LIBNAME pointing at the SIMT-emulator build of the same library sources
 # (tests/emu, test infrastructure) to check the host-side plumbing of this file without a GPU.
@@ -45,6 +48,6 @@ LIBNAME="${MPCGPU_LIBNAME:-mpcgpu}"
 BIN="${MPCGPU_BIN:-muscle_gpu}"
 # --wrap=rand: the reference's rand() (refineflat.cpp:14) gets a private copy of glibc's default
 # stream; the HIP runtime in the same process otherwise consumes it (hostcxx/rand_isolate.cpp)
-g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/super7_weak.o" "$OUT/uclust_weak.o" "$OUT/pprog2_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
+g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/super7_weak.o" "$OUT/uclust_weak.o" "$OUT/pprog2_weak.o" "$OUT/mpcflat_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
   -L"$LIBDIR" -l"$LIBNAME" -Wl,-rpath,"$LIBDIR" -Wl,-rpath,'$ORIGIN/../../muscle_amd/csrc' -Wl,-rpath,/opt/rocm/lib -o "$OUT/$BIN"
 echo "built: $OUT/$BIN"

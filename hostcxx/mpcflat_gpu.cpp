@@ -565,6 +565,22 @@ void StartBatch(MPCFlat &M, Batch &B, int SlotIndex)
 	}
 } // namespace
 
+// MPCFlat::CalcPosteriors (mpcflat.cpp:239-251): the reference's OpenMP loop over the pairs. Here the first CalcPosterior call of a run
+// computes every pair on the device and the others copy their EA, so the loop is plain: an OpenMP team per call bought nothing and cost
+// the -super7 shrub workers their cores — each worker thread owns a team of its own, libgomp's idle team threads spin after a region,
+// and 8 workers x 15 spinners starved the threads that feed the device (AlignAlns 0.22 ms per call with one worker, 0.35 with eight;
+// profiles/r11j, r11l). Same calls in the same order as one thread of the reference's loop makes them.
+void MPCFlat::CalcPosteriors()
+	{
+	const uint PairCount = SIZE(m_Pairs);
+	asserta(PairCount > 0);
+	for (uint PairIndex = 0; PairIndex < PairCount; ++PairIndex)
+		{
+		ProgressStep(PairIndex, PairCount, "Calc posteriors");
+		CalcPosterior(PairIndex);
+		}
+	}
+
 void MPCFlat::CalcPosterior(uint PairIndex)
 	{
 	const pair<uint, uint> &Pair = GetPair(PairIndex);
@@ -1230,7 +1246,8 @@ uint UClust::Search(uint SeqIndex, string &Path)
 // Super7::IntraAlignShrubs (super7.cpp:127-137): one MPCFlat::Run per shrub of <= shrub_size sequences. The reference runs
 // them one after the other; a shrub is far too small to fill a GPU (496 pairs, then 131 small alignments-of-alignments whose
 // cost is launch and synchronisation latency), and the shrubs are independent. Here MUSCLE_GPU_SHRUB_CONTEXTS worker threads
-// (default 8; 1 = the reference's loop) take shrubs from a counter, each with its own MPCFlat object and its own device
+// (default 16 — 8 until MPCFlat::CalcPosteriors above stopped spawning an OpenMP team per worker: profiles/r11m —; 1 = the reference's
+// loop) take shrubs from a counter, each with its own MPCFlat object and its own device
 // context (dealt round-robin over MUSCLE_GPU_DEVICES), so the small launches of different shrubs overlap and several GPUs
 // share the shrubs. Results land in m_ShrubMSAs by shrub index; the one process-wide input of MPCFlat::Run that depends on
 // the order of the shrubs, the rand() stream of RefineIter (refineflat.cpp:14: one draw per sequence per refinement round,
@@ -1240,7 +1257,7 @@ void Super7::IntraAlignShrubs()
 	{
 	asserta(m_ShrubMSAs.empty());
 	const uint ShrubCount = GetShrubCount();
-	uint Workers = 8;
+	uint Workers = 16;
 	const char *EnvWorkers = getenv("MUSCLE_GPU_SHRUB_CONTEXTS");
 	if (EnvWorkers != 0 && *EnvWorkers != 0)
 		Workers = (uint) atoi(EnvWorkers);
