@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 // alignment path receive a contribution from almost every (s,t) pair — 250 000 terms at the root of a 1000-sequence tree — so
 // the work cannot be one thread per cell (round 1: a serial load -> add chain per thread, 7.7 of the 11.8 s of the
 // progressive + refinement tail at 1000 x L~400, profiles/r02g_e2e_timing.log). Here the wave loads 64 consecutive terms at
-// once (coalesced) and runs the chain through its lanes (mpc_wave_chain_add, mpc_platform.h: one wave instruction per term,
+// once (coalesced) and runs the chain through its lanes (mpc_wave_chain_add, mpc_platform.h: one DPP add per term,
 // every term added exactly once in sequence; lanes past the end of the run add +0.0f, exact for these non-negative sums).
 //
 // Run boundaries of the sorted records: record q opens a run when its cell differs from record q-1's. The opener appends
@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(256) build_post_heads_kernel(const u32 *keys, 
 
 #define MPC_BP_GROUP 8
 // The launch is as long as its slowest SIMD: nearly all records of a join near the root sit in the ~1000-2000 cells along the
-// alignment path (~10^5 terms each), a lone wave adds a term every ~13 cycles (two wait states + the dependent add; two waves
-// on a SIMD overlap perfectly, four already share its issue: diag/chain_time.hip), and runs dealt out statically pile several
+// alignment path (~10^5 terms each), a lone wave adds a term every ~7 cycles (round 5's row-broadcast chain; ~14 with the shifted
+// partial sums of rounds 1-4; with two waves on a SIMD 12.6 per wave, four share its issue: diag/chain_time.hip), and runs dealt out statically pile several
 // heavy ones onto one SIMD (measured: 4.6 ms for a 1.4 ms critical path). So: few resident waves (the host launches two per
 // SIMD) that PULL runs from a queue — whichever wave finishes takes the next run.
 __global__ void __launch_bounds__(256) build_post_reduce_kernel(const float *vals, const u32 *run_end, const u32 *heads, const u32 *nheads,

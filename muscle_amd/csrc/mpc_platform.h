@@ -50,13 +50,32 @@ __device__ __forceinline__ float mpc_lane_up1_fill(float v, float fill)
 {
 	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
 }
-// ((((total + v[0]) + v[1]) + ...) + v[63]) over the wave's 64 lane values, strictly left to right, as a wave-uniform result.
-// Lane 0's term is replaced by w[0] = total + v[0]; then 64 steps of p = shift_up(p) + w, a lane without a source (lane 0)
-// reading 0.0f (0 + w[0] == w[0] exactly: the sums here are non-negative): after step j lane k holds
-// ((w[k-j+1] + ...) + w[k]) added in order, so after 64 steps lane 63 holds the whole chain. ONE instruction per term
-// (v_add_f32 with a DPP source; the two wait states a DPP read of a just-written register needs are spelled out because the
-// hazard recognizer does not look into inline asm); every term is added exactly once, in sequence, each add rounded on its own.
+// ((((total + v[0]) + v[1]) + ...) + v[63]) over the wave's 64 lane values, strictly left to right, as a wave-uniform result
+// (`total` is wave-uniform). The accumulator lives in every lane of a DPP row of 16 lanes; term k of the row is added with
+// v_add_f32_dpp acc, v, acc row_newbcast:k — the DPP operand is v (lane k of the row, broadcast to the row), the accumulator is an
+// ordinary operand, so consecutive adds depend on each other through a plain register read and issue back to back: ~5 cycles per term.
+// After a row's 16 terms its lane 15 hands the accumulator to the next row (v_mov_b32_dpp row_bcast:15 — a DPP read of a register just
+// written: the two wait states that needs are spelled out, the hazard recognizer does not look into inline asm). Rounds 1-4 shifted the
+// partial sums instead (p = wave_shr:1(p) + w): a DPP read of the just-written register and two wait states PER TERM, ~13 cycles
+// (diag/chain_time.hip measures both). Every term is added exactly once, in sequence, each add rounded on its own; a + b == b + a bit for bit.
 __device__ __forceinline__ float mpc_wave_chain_add(float total, float v)
+{
+	float acc = total;
+	asm volatile(
+		"s_nop 1\n\t"
+		".irp k,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:\\k row_mask:0x1 bank_mask:0xf\n\t.endr\n\t"
+		"s_nop 1\n\tv_mov_b32_dpp %0, %0 row_bcast:15 row_mask:0x2 bank_mask:0xf\n\t"
+		".irp k,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:\\k row_mask:0x2 bank_mask:0xf\n\t.endr\n\t"
+		"s_nop 1\n\tv_mov_b32_dpp %0, %0 row_bcast:15 row_mask:0x4 bank_mask:0xf\n\t"
+		".irp k,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:\\k row_mask:0x4 bank_mask:0xf\n\t.endr\n\t"
+		"s_nop 1\n\tv_mov_b32_dpp %0, %0 row_bcast:15 row_mask:0x8 bank_mask:0xf\n\t"
+		".irp k,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15\n\tv_add_f32_dpp %0, %1, %0 row_newbcast:\\k row_mask:0x8 bank_mask:0xf\n\t.endr"
+		: "+v"(acc) : "v"(v));
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
+}
+// the form of rounds 1-4 (kept for diag/chain_time.hip's comparison): lane 0's term becomes total + v[0], then 64 steps of
+// p = shift_up(p) + w, a lane without a source reading 0.0f; after 64 steps lane 63 holds the whole chain
+__device__ __forceinline__ float mpc_wave_chain_add_shift(float total, float v)
 {
 	const float w = (threadIdx.x & 63u) == 0u ? total + v : v;
 	float p = 0.0f;
