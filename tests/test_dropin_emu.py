@@ -36,8 +36,10 @@ def emu_muscle():
                                   "mega_bb11001+r2", "mega_synth_6x40_s2+r2", "mega_super7_6x16_b3",
                                   # full runs (100 refinement rounds): affordable since the emulator runs GPU threads as fibers
                                   "n8_L60", "bb11001", "mega_bb11001", "perturb",
-                                  # sequences longer than 1024: row-block fb kernel + gather relax fallback
-                                  "synth_5x1300_s3"])
+                                  # sequences longer than 1024: the row-block fb kernels (H = 7, three blocks) and the multi-wave alignment kernel. The
+                                  # same paths as synth_5x1300_s3 with its 100 refinement rounds (108 s on the emulator; that set runs on the GPU:
+                                  # tests/test_gpu_dropin.py) in 6 s
+                                  "synth_3x1100_s3+r2"])
 def test_final_msa_identical(emu_muscle, name):
     md5, _ = _msa.run_muscle(emu_muscle, name, threads=3)
     assert md5 == _msa.golden_md5()[name]
