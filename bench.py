@@ -292,6 +292,7 @@ def main():
         run_stage(g, lens, exchange, torch_mod=torch)
     g.timers_reset()
     g._exchange_seconds = 0.0
+    g._phase = {}  # host seconds per phase of a sharded step (muscle_amd/mpcflat.py: run_stage)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -304,6 +305,15 @@ def main():
         el = float(t.item())
     timers = g.timers_get()
     rc = 0
+    # every rank's phases (host seconds between the points where run_stage waits for the device anyway), and how many ranks the
+    # collective backend really connected: rank 0 prints the maximum over ranks and the list
+    per_rank = None
+    if world > 1:
+        mine = {k: 1000.0 * v / a.steps for k, v in getattr(g, "_phase", {}).items()}
+        mine["kernels"] = {k: v[0] / a.steps for k, v in timers.items() if v[0]}
+        mine["rank"], mine["device"] = rank, ("cpu" if dry else torch.cuda.get_device_name(local))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         nnz = g.get_nnz()
@@ -447,6 +457,25 @@ def main():
             "roofline": roof,
             "roofline_stage_a" if roof["kernel"].startswith("relax") else "roofline_relax": roof_other,
         }
+        if world > 1:
+            from muscle_amd.mpcflat import PIECES, plan
+            rects, pos, px, py = plan(g, lens, world)
+            phases = sorted({k for pr in per_rank for k in pr if k not in ("kernels", "rank", "device")})
+            out["multi_gpu"] = {
+                "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "transport": "gloo (dry run)" if dry else "RCCL point-to-point (torch.distributed nccl backend), one process per GPU",
+                "partition": ("%d blocks of the pair triangle (mpcgpu_plan_partition), a rank's store holds the matrices of its blocks' sequences" % len(rects))
+                             if len(rects) else "contiguous InitPairs ranges",
+                "stage_a_pieces": int(os.environ.get("MPC_PIECES", PIECES)),
+                "pairs_per_rank": [int(pos[r + 1] - pos[r]) for r in range(world)],
+                "sequences_held_per_rank": [int(len(set(px[pos[r]:pos[r + 1]].tolist()) | set(py[pos[r]:pos[r + 1]].tolist()))) for r in range(world)],
+                "phase_ms_max_over_ranks": {k: max(pr.get(k, 0.0) for pr in per_rank) for k in phases},
+                "phase_ms_per_rank": [{k: round(pr.get(k, 0.0), 3) for k in phases} for pr in per_rank],
+                "kernel_ms_per_rank": [pr["kernels"] for pr in per_rank],
+                "devices": [pr["device"] for pr in per_rank],
+                "note": "phase_ms: host wall time of rank r between the points where a step waits for the device anyway (stage_a: its pieces; "
+                        "exchange_shards: size exchange, copy of the own piece, and what of the all-gather is NOT hidden under the next piece; "
+                        "import_store; relax: kernel + the copy of the own slice; exchange_values: all-gather of the values with the own slice's "
+                        "commit under it; commit: the other ranks' slices)"}
         if dry:
             out["dry_run"] = True
         elif not a.no_parity:

@@ -83,6 +83,32 @@ int mpcgpu_set_mega(mpcgpu_ctx *ctx, uint32_t nfeat, const uint32_t *alpha, cons
 
 uint64_t mpcgpu_pair_count(const mpcgpu_ctx *ctx); /* n(n-1)/2 */
 
+/* ---- pair order of a block-partitioned multi-GPU run -------------------------------
+ * MPCFlat::InitPairs (mpcflat.cpp:139-159) enumerates the pairs row-major, and a contiguous range of that order holds pairs
+ * (X, Y) with Y anywhere behind X: a rank that owns such a range needs the sparse matrices of nearly every sequence for
+ * MPCFlat::ConsPair (conspairflat.cpp:37-92). A rank that owns BLOCKS of the pair triangle (sequence group i x group j) needs
+ * those of a few groups only. mpcgpu_set_pair_order makes the context enumerate its pairs rectangle by rectangle (row-major
+ * inside each): rects[4 r ..] = {xa, xb, ya, yb} is either off the diagonal (ya >= xb: every (x, y) of [xa,xb) x [ya,yb)) or a
+ * triangle (xa == ya, xb == yb: the pairs x < y inside [xa,xb)); together they must hold every pair exactly once. nrects == 0:
+ * back to InitPairs order. Call after mpcgpu_set_seqs (which resets it), before stage A.
+ * From then on the SHARDING calls — mpcgpu_calc_posteriors, mpcgpu_store_import(_part), mpcgpu_values_slice, mpcgpu_cons_iter —
+ * take POSITIONS in this order ("[k0,k1)" = the k0-th to k1-th pair of the enumeration), and the values array is in position
+ * order; the RESULT getters (mpcgpu_get_ea, _get_nnz, _get_sparse, _get_sparse_range) and everything that names sequences
+ * (mpcgpu_align_alns ...) keep speaking InitPairs pair numbers / sequence indices. */
+int mpcgpu_set_pair_order(mpcgpu_ctx *ctx, uint32_t nrects, const uint32_t *rects);
+/* position of pair (x, y), x < y, in the context's pair order */
+int mpcgpu_pair_position(mpcgpu_ctx *ctx, uint32_t x, uint32_t y, uint64_t *pos);
+/* The partition itself (host only, no context): n sequences of the given lengths over `world` ranks. Sequences fall into g groups
+ * of equal weight (sum of L + 1), the pair triangle into g (g + 1) / 2 blocks, a rank owns whole blocks: world = g (g - 1) / 2 +
+ * g / 2 with g even (2, 8, 18 ...) — one off-diagonal block per rank and one rank per two diagonal blocks (8 ranks: every rank
+ * touches 2 of 4 groups, half of the store); any other world — g = world, rank i owns the triangle of group i and the blocks
+ * {i, i + d}, d < g / 2, the antipodal blocks of an even g cut in two by rows. rects (capacity max_rects x 4 words) receives the
+ * rectangles in rank order, rank_pos[world + 1] the positions where each rank's pairs begin: rank r owns [rank_pos[r],
+ * rank_pos[r + 1]). *nrects == 0: no block cut (one rank, too few sequences, or MPCGPU_PARTITION=contiguous): InitPairs order,
+ * contiguous ranges balanced by DP cells — the partition of rounds 1-5. Returns 0, or 2 when max_rects is too small. */
+int mpcgpu_plan_partition(uint32_t n, const uint32_t *lens, uint32_t world, uint32_t max_rects, uint32_t *rects,
+                          uint32_t *nrects, uint64_t *rank_pos);
+
 /* Stage A for the pair range [k0,k1): replaces MPCFlat::CalcPosteriors' OpenMP loop
  * (mpcflat.cpp:239-251) over MPCFlat::CalcPosterior (calcposteriorflat.cpp:45-92), i.e.
  * CalcFwdFlat (fwdflat3.cpp:12) + CalcBwdFlat (bwdflat3.cpp:10) + CalcTotalProbFlat
@@ -112,6 +138,19 @@ int mpcgpu_shard_export(mpcgpu_ctx *ctx, void *dev_dst);
  * new probabilities into it (the swap of consflat.cpp:22) — hence not const. */
 int mpcgpu_store_import(mpcgpu_ctx *ctx, uint32_t nshards, const uint64_t *k0, const uint64_t *k1,
                         const uint64_t *bytes, void *dev_all);
+/* The same for a rank of a pair-sharded run whose stage A ran in pieces: the shards may come in any order and lie anywhere in
+ * dev_all (offsets[s], multiples of 4; NULL: back to back in the order given); sorted by k0 they must tile [0, pair_count).
+ * [own_k0, own_k1) = the positions this context will relax (mpcgpu_cons_iter): the store is PARTIAL — it holds the row-indexed
+ * matrices (A, Z) of the sequences A that those pairs touch and of no other (the block partition: half of the store at 8 ranks;
+ * what a ConsPair of the range reads, conspairflat.cpp:49-89), while everything per pair (packed matrices, values, EA) is
+ * complete. mpcgpu_cons_iter outside the range is refused; mpcgpu_cons_commit(_range) commits every entry into what exists.
+ * own = [0, pair_count) is mpcgpu_store_import. */
+int mpcgpu_store_import_part(mpcgpu_ctx *ctx, uint32_t nshards, const uint64_t *k0, const uint64_t *k1, const uint64_t *bytes,
+                             const uint64_t *offsets, void *dev_all, uint64_t own_k0, uint64_t own_k1);
+/* Makes a partial store whole (the matrices of every sequence, from the packed ones, which hold the current values): what the
+ * host that reads results — progressive alignment, MPCFlat::BuildPost — needs after the last mpcgpu_cons_iter. mpcgpu_align_alns
+ * and mpcgpu_build_post call it themselves; a no-op on a complete store. */
+int mpcgpu_store_complete(mpcgpu_ctx *ctx);
 /* Device address + element count of the float array holding the next-iteration probabilities of
  * ALL pairs in canonical order (pair ascending, entries row-major), and the [first, first+count)
  * slice that cons_iter(k0,k1) writes. The caller all-gathers the slices in place, then commits. */

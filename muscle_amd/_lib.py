@@ -21,6 +21,7 @@ SYMBOLS = [
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_cons_commit_range", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
     "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_align_pairs", "mpcgpu_get_list_sparse", "mpcgpu_stage_a_info", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info", "mpcgpu_shard_entries",
+    "mpcgpu_set_pair_order", "mpcgpu_pair_position", "mpcgpu_plan_partition", "mpcgpu_store_import_part", "mpcgpu_store_complete",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
     "mpcgpu_group_calc_posteriors", "mpcgpu_group_cons_iter",
@@ -63,6 +64,11 @@ def load(lib_path=None):
     L.mpcgpu_values_import.argtypes = [vp, u64, u64, vp]
     L.mpcgpu_store_import.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mpcgpu_values_info.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.mpcgpu_set_pair_order.argtypes = [vp, u32, vp]
+    L.mpcgpu_pair_position.argtypes = [vp, u32, u32, C.POINTER(u64)]
+    L.mpcgpu_plan_partition.argtypes = [u32, vp, u32, u32, vp, C.POINTER(u32), vp]
+    L.mpcgpu_store_import_part.argtypes = [vp, u32, vp, vp, vp, vp, vp, u64, u64]
+    L.mpcgpu_store_complete.argtypes = [vp]
     L.mpcgpu_values_slice.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(u64)]
     L.mpcgpu_cons_iter.argtypes = [vp, u64, u64]
     L.mpcgpu_cons_commit.argtypes = [vp]
@@ -106,6 +112,21 @@ def load(lib_path=None):
     L.mpcgpu_group_cons_iter.argtypes = [vp]
     _libs[path] = L
     return L
+
+
+def plan_partition(lens, world, lib_path=None, L=None):
+    """The block partition of the all-pairs schedule (include/mpcgpu.h: mpcgpu_plan_partition; host only, no device):
+    -> (rects (nrects, 4) uint32 — empty: InitPairs order —, rank_pos list of world + 1 positions)."""
+    L = L or load(lib_path)
+    lens = np.ascontiguousarray(lens, np.uint32)
+    cap = world * (world // 2 + 3) + 4
+    rects = np.zeros((cap, 4), np.uint32)
+    nr = C.c_uint32()
+    pos = np.zeros(world + 1, np.uint64)
+    rc = L.mpcgpu_plan_partition(len(lens), lens.ctypes.data, world, cap, rects.ctypes.data, C.byref(nr), pos.ctypes.data)
+    if rc != 0:
+        raise MpcGpuError("mpcgpu_plan_partition failed (%d)" % rc)
+    return rects[:nr.value].copy(), [int(x) for x in pos]
 
 
 class MpcGroup:
@@ -295,6 +316,30 @@ class MpcGpu:
     def store_import(self, k0s, k1s, nbytes, dev_ptr):
         a, b, c = (np.ascontiguousarray(x, np.uint64) for x in (k0s, k1s, nbytes))
         self._ck(self.L.mpcgpu_store_import(self.h, len(a), a.ctypes.data, b.ctypes.data, c.ctypes.data, dev_ptr))
+
+    def store_import_part(self, k0s, k1s, nbytes, offsets, dev_ptr, own_k0, own_k1):
+        """shards anywhere in the buffer (offsets; None: back to back), any order; a PARTIAL store for the positions
+        [own_k0, own_k1) this context will relax (include/mpcgpu.h: mpcgpu_store_import_part)"""
+        a, b, c = (np.ascontiguousarray(x, np.uint64) for x in (k0s, k1s, nbytes))
+        o = None if offsets is None else np.ascontiguousarray(offsets, np.uint64)
+        self._ck(self.L.mpcgpu_store_import_part(self.h, len(a), a.ctypes.data, b.ctypes.data, c.ctypes.data,
+                                                 None if o is None else o.ctypes.data, dev_ptr, own_k0, own_k1))
+
+    def store_complete(self):
+        self._ck(self.L.mpcgpu_store_complete(self.h))
+
+    def set_pair_order(self, rects):
+        """rects: (nrects, 4) array of {xa, xb, ya, yb}, or None / empty for InitPairs order (include/mpcgpu.h: mpcgpu_set_pair_order)"""
+        r = np.zeros((0, 4), np.uint32) if rects is None else np.ascontiguousarray(rects, np.uint32).reshape(-1, 4)
+        self._ck(self.L.mpcgpu_set_pair_order(self.h, len(r), r.ctypes.data if len(r) else None))
+
+    def plan_partition(self, lens, world):
+        return plan_partition(lens, world, L=self.L)
+
+    def pair_position(self, x, y):
+        p = C.c_uint64()
+        self._ck(self.L.mpcgpu_pair_position(self.h, x, y, C.byref(p)))
+        return p.value
 
     def values_info(self):
         p, n = C.c_void_p(), C.c_uint64()

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(64) build_post_gen_kernel(BuildPostParams p)
 		const u32 a = (u32)(ab / p.n2), b = (u32)(ab % p.n2);
 		const u32 S = p.seq1[a], T = p.seq2[b];
 		const bool fwd = S < T;
-		const u64 k = fwd ? mpc_pair_index(p.s.n, S, T) : mpc_pair_index(p.s.n, T, S);
+		const u64 k = fwd ? mpc_pair_pos(p.s, S, T) : mpc_pair_pos(p.s, T, S);
 		const u32 LX = p.s.seq_len[fwd ? S : T], LY = p.s.seq_len[fwd ? T : S];
 		const u32 *rec = p.s.packed + p.s.pbase[k];
 		const u32 nnz = (u32)(p.s.vbase[k + 1] - p.s.vbase[k]);

@@ -34,7 +34,7 @@
 
 // MPC_RB_HB (kernels_store.h): rows per index band — overflow offsets, cell offsets and y ranges are kept per band
 #define MPC_RB_MAXN 8u          // sequences per side of a tile
-#define MPC_RB_TILE_WORDS 16u   // x0, nx, y0, ny, r0, r1, first-piece blocks, slots, then ylo | yhi << 16 per Y (yhi exclusive)
+#define MPC_RB_TILE_WORDS 16u   // x0, nx, y0, ny, r0, r1, first-piece blocks, slots | (X records with cells) << 8, then ylo | yhi << 16 per Y (yhi exclusive)
 #define MPC_RB_TAB_BYTES 2560u  // tables at the head of the dynamic LDS: pairs 64 x 16 B, records 16 x 32 B, groups, misc, step tables, biases
 #define MPC_RB_PTAB 0u
 #define MPC_RB_RTAB 1024u
@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(64) band_index_kernel(StoreParams s, u32 nb1, 
 {
 	const u32 t = threadIdx.x;
 	for (u64 k = blockIdx.x; k < s.npairs; k += gridDim.x) {
+		if (!mpc_need(s, s.pair_x[k]) || !mpc_need(s, s.pair_y[k])) continue; // a partial store relaxes pairs of its own sequences only
 		const u32 LX = s.seq_len[s.pair_x[k]], LY = s.seq_len[s.pair_y[k]];
 		const u32 *rec = s.packed + s.pbase[k];
 		const u32 *ent = rec + LX + LY;
@@ -174,6 +175,7 @@ __global__ void __launch_bounds__(64) ovf_stats_kernel(StoreParams s, const u32 
 	const u32 t = threadIdx.x, n = s.n;
 	const u32 *rstart = win ? s.wrec_off : s.rec_off;
 	for (u32 A = blockIdx.x; A < n; A += gridDim.x) {
+		if (!mpc_need(s, A)) continue; // a partial store: no records of this sequence
 		const u32 LA = win ? (s.seq_len[A] + 1u + 3u) / 4u : s.seq_len[A]; // blocks of the static part of a record
 		for (u32 b = t; b < nb1; b += 64) {
 			u32 sum = 0;
@@ -223,6 +225,9 @@ struct RbTileStats {
 	u32 first;       // blocks of the first pieces
 	u32 est, bound;  // blocks per step: mean over Z (rounded up) / upper bound
 	u32 yr;          // lane iy (< 8): ylo | yhi << 16 of Y record iy (yhi exclusive; 0 when it has no cell)
+	u32 xmask;       // bit ix: X record ix has cells in the band (an X sequence without any is not staged: the last one of a tile on
+	                 // the diagonal, the sequences of a neighbouring block at the ragged edge of a rank's blocks — whose records a
+	                 // partial store does not even hold)
 };
 __device__ __forceinline__ u32 rb_wave_sum(u32 v) { for (int d = 1; d < 64; d <<= 1) v += __shfl(v, (int)((threadIdx.x & 63u) ^ (u32)d)); return v; }
 
@@ -249,7 +254,8 @@ __device__ __forceinline__ RbTileStats rb_tile_stats(const StoreParams &s, const
 	r.slots = (rounded + tb.threads - 1u) / tb.threads;
 	// pieces: lane ix*8 speaks for X record ix, lane iy (ix == 0) for Y record iy
 	u32 first = 0, sum = 0, mxc = 0;
-	if (iy == 0u && ix < nx) {
+	r.xmask = rb_wave_sum((iy == 0u && ix < nx && g != 0u) ? 1u << ix : 0u);
+	if (iy == 0u && ix < nx && g != 0u) {
 		const u32 A = x0 + ix, LA = s.seq_len[A];
 		const u32 a0 = b0 * MPC_RB_HB, a1 = (b1 * MPC_RB_HB < LA) ? b1 * MPC_RB_HB : LA;
 		if (a1 > a0) {
@@ -281,7 +287,7 @@ __device__ __forceinline__ u64 rb_lane_pair(const StoreParams &s, const RbTileTa
 	const u32 lane = threadIdx.x & 63u, ix = lane >> 3, iy = lane & 7u;
 	const u32 X = x0 + ix, Y = y0 + iy;
 	if (ix >= nx || iy >= ny || X >= Y) return ~0ull;
-	const u64 k = mpc_pair_index(s.n, X, Y);
+	const u64 k = mpc_pair_pos(s, X, Y);
 	return (k >= tb.k0 && k < tb.k1) ? k : ~0ull;
 }
 
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(64) band_eval_kernel(StoreParams s, RbTileTabs
 		const RbTileStats st = rb_tile_stats(s, tb, x0, nx, y0, ny, b0, b1, c, lo, hi);
 		if (lane < 8u) tw[8 + lane] = st.yr;
 		if (lane == 0u) {
-			tw[6] = st.first; tw[7] = st.slots;
+			tw[6] = st.first; tw[7] = st.slots | (st.xmask << 8);
 			out[4 * t] = st.slots; out[4 * t + 1] = st.est; out[4 * t + 2] = st.bound; out[4 * t + 3] = st.cells;
 		}
 	}
@@ -430,7 +436,7 @@ __device__ __forceinline__ void rb_record(const u32 *seq_len, const u32 *tw, u32
 	const u32 x0 = tw[0], nx = tw[1], y0 = tw[2], ny = tw[3], r0 = tw[4], r1 = tw[5];
 	u32 a0 = 0, a1 = 0, A = x0;
 	if (i < MPC_RB_MAXN) {
-		if (i < nx) { A = x0 + i; const u32 LA = seq_len[A]; a0 = r0; a1 = r1 < LA ? r1 : LA; }
+		if (i < nx && ((tw[7] >> (8u + i)) & 1u)) { A = x0 + i; const u32 LA = seq_len[A]; a0 = r0; a1 = r1 < LA ? r1 : LA; } // (word 7: slots | X mask << 8, band_eval_kernel)
 	} else if (i - MPC_RB_MAXN < ny) {
 		A = y0 + (i - MPC_RB_MAXN);
 		const u32 w = tw[8 + (i - MPC_RB_MAXN)];
@@ -535,7 +541,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_band_kerne
 			const u32 X = x0 + ix, Y = y0 + iy;
 			u32 cnt = 0, e0 = 0, kk = 0;
 			if (ix < nx && iy < ny && X < Y) {
-				const u64 k = mpc_pair_index(n, X, Y);
+				const u64 k = mpc_pair_pos_f(n, pa->s.nrect, pa->s.rects, X, Y);
 				if (k >= pa->k0 && k < pa->k1) {
 					const u32 b0 = r0 / MPC_RB_HB, b1r = (r1 + MPC_RB_HB - 1u) / MPC_RB_HB, b1 = b1r < pa->nb1 - 1u ? b1r : pa->nb1 - 1u;
 					e0 = pa->cell_off[k * pa->nb1 + b0];

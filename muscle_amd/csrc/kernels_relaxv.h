@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(THREADS, WGS * THREADS / 256) relax_var_kernel
 			u32 nnz = 0, sel = 0;
 			u64 k = 0;
 			if (lane < 16u && ix < nx && iy < ny && X < Y) {
-				k = mpc_pair_index(n, X, Y);
+				k = mpc_pair_pos(s, X, Y);
 				if (k >= p.k0 && k < p.k1) nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
 				const u32 mb = (Y < x0 + nx) ? Y - x0 : MPC_RV_YLANE + (Y - ys); // Y >= x0 here (X < Y), so Y is in one of the runs
 				sel = ix | (mb << 8);

@@ -82,6 +82,16 @@ struct StoreParams {
 	const u32 *wrec_off;
 	u32 *wv_off;
 	unsigned short *pos_wf, *pos_wt;
+	// PAIR ORDER (mpcgpu_set_pair_order; multi-GPU block partition): the position k of pair (X,Y) in every per-pair array
+	// above. nrect == 0: MPCFlat::InitPairs order (mpcflat.cpp:145-155, closed form). Otherwise the pairs are enumerated rectangle by
+	// rectangle, row-major inside each: rects[6 r ..] = {xa, xb, ya, yb, base lo, base hi}; a rectangle is either off the diagonal
+	// (ya >= xb: all (x,y) of [xa,xb) x [ya,yb)) or a triangle (xa == ya, xb == yb: the pairs x < y inside [xa,xb)). A rank of a
+	// block-partitioned run owns consecutive rectangles, i.e. ONE contiguous range of positions.
+	u32 nrect;
+	const u32 *rects;
+	// PARTIAL STORE (mpcgpu_store_import_part): need[A] != 0 where the records (A, Z) of sequence A exist — a rank whose pairs touch
+	// only the sequences of its blocks builds, reads and commits the records of those sequences only. null: every sequence.
+	const u8 *need;
 };
 
 #define MPC_PAD_ROW 2 // entries per block (16 bytes = one ds_read_b128)
@@ -94,6 +104,22 @@ __device__ __forceinline__ u64 mpc_pair_index(u32 n, u32 i, u32 j) // i<j, mpcfl
 {
 	return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1);
 }
+
+// position of pair (X,Y), X < Y, in the store's pair order (StoreParams::rects)
+__device__ __forceinline__ u64 mpc_pair_pos_f(u32 n, u32 nrect, const u32 *rects, u32 X, u32 Y)
+{
+	if (nrect == 0u) return mpc_pair_index(n, X, Y);
+	for (u32 r = 0; r < nrect; ++r) {
+		const u32 *q = rects + 6u * r;
+		const u32 xa = q[0], xb = q[1], ya = q[2], yb = q[3];
+		if (X < xa || X >= xb || Y < ya || Y >= yb) continue;
+		const u64 base = (u64)q[4] | ((u64)q[5] << 32);
+		return ya >= xb ? base + (u64)(X - xa) * (yb - ya) + (Y - ya) : base + mpc_pair_index(xb - xa, X - xa, Y - xa);
+	}
+	return ~0ull; // (mpcgpu_set_pair_order checks that the rectangles cover every pair)
+}
+__device__ __forceinline__ u64 mpc_pair_pos(const StoreParams &s, u32 X, u32 Y) { return mpc_pair_pos_f(s.n, s.nrect, s.rects, X, Y); }
+__device__ __forceinline__ bool mpc_need(const StoreParams &s, u32 A) { return s.need == nullptr || s.need[A] != 0; }
 
 // index of record (A,Z) in rec_off: Z-major (see StoreParams::pad)
 __device__ __forceinline__ u64 mpc_rec_index(u32 n, u32 A, u32 Z) { return (u64)Z * n + A; }
@@ -114,7 +140,7 @@ __global__ void __launch_bounds__(64) slab_build_kernel(StoreParams s)
 			continue;
 		}
 		const bool fwd = A < Z;
-		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+		const u64 k = fwd ? mpc_pair_pos(s, A, Z) : mpc_pair_pos(s, Z, A);
 		const u32 *rec = s.packed + s.pbase[k];
 		const u32 LX = fwd ? LA : s.seq_len[Z]; // rows of the stored (unordered) pair
 		const u32 LY = fwd ? s.seq_len[Z] : LA;
@@ -155,9 +181,10 @@ __global__ void __launch_bounds__(64) var_size_kernel(StoreParams s, u32 *sizes)
 		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n); // b == mpc_rec_index(n, A, Z)
 		const u32 LA = s.seq_len[A];
 		u32 mine = 0;
+		if (!mpc_need(s, A)) { if (t == 0) sizes[b] = 0u; continue; } // a partial store: no record for this sequence
 		if (A != Z) {
 			const bool fwd = A < Z;
-			const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+			const u64 k = fwd ? mpc_pair_pos(s, A, Z) : mpc_pair_pos(s, Z, A);
 			const u32 *rec = s.packed + s.pbase[k];
 			const u32 *cnt = fwd ? rec : rec + s.seq_len[Z];
 			for (u32 a = t; a < LA; a += 64) {
@@ -181,6 +208,7 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
 		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n); // b == mpc_rec_index(n, A, Z)
 		const u32 LA = s.seq_len[A];
+		if (!mpc_need(s, A)) continue; // (wave-uniform) a partial store: this sequence has no records, no band entries, no positions
 		u32 *rec_out = s.pad + 4 * (u64)s.rec_off[b];
 		const u32 units = s.rec_off[b + 1] - s.rec_off[b];
 		for (u32 q = t; q < units; q += 64) { // every block starts as an empty one
@@ -191,7 +219,7 @@ __global__ void __launch_bounds__(64) var_build_kernel(StoreParams s)
 			continue;
 		}
 		const bool fwd = A < Z;
-		const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
+		const u64 k = fwd ? mpc_pair_pos(s, A, Z) : mpc_pair_pos(s, Z, A);
 		const u32 *rec = s.packed + s.pbase[k];
 		const u32 LX = fwd ? LA : s.seq_len[Z]; // rows of the stored (unordered) pair
 		const u32 LY = fwd ? s.seq_len[Z] : LA;
@@ -255,9 +283,8 @@ __global__ void __launch_bounds__(64) win_size_kernel(StoreParams s, u32 *sizes,
 		const u32 Z = (u32)(b / s.n), A = (u32)(b % s.n);
 		const u32 LA = s.seq_len[A];
 		u32 mine = 0;
+		if (!mpc_need(s, A)) { if (t == 0) { sizes[b] = 0u; vals_total[b] = 0u; } continue; } // a partial store
 		if (A != Z) {
-			const bool fwd = A < Z;
-			const u64 k = fwd ? mpc_pair_index(s.n, A, Z) : mpc_pair_index(s.n, Z, A);
 			// the span of row a of M(A,Z) = last - first + 1 of the stored columns: from the record of (A,Z) in block form (first block
 			// of the row: its first column; the row's last block: its last column) — already built
 			const u32 *rec = s.pad + 4 * (u64)s.rec_off[b];
@@ -272,7 +299,6 @@ __global__ void __launch_bounds__(64) win_size_kernel(StoreParams s, u32 *sizes,
 				mine += span + 1u;
 			}
 			for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d);
-			(void)k;
 		} else mine = LA; // empty matrix: every row is its guard alone
 		if (t == 0) {
 			sizes[b] = (LA + 1u + 3u) / 4u + (mine + 3u) / 4u + 1u;
@@ -293,6 +319,7 @@ __global__ void __launch_bounds__(64) win_build_kernel(StoreParams s)
 	for (u64 b = blockIdx.x; b < total; b += gridDim.x) {
 		const u32 A = (u32)(b % s.n);
 		const u32 LA = s.seq_len[A];
+		if (!mpc_need(s, A)) continue; // (wave-uniform) a partial store
 		const u32 *rec = s.pad + 4 * (u64)s.rec_off[b];
 		u32 *wrec = s.win + 4 * (u64)s.wrec_off[b];
 		const u32 dblocks = (LA + 1u + 3u) / 4u;
@@ -359,11 +386,12 @@ __global__ void __launch_bounds__(64) win_pos_kernel(StoreParams s)
 		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
 		const u32 *dxy = s.win + 4 * (u64)s.wrec_off[mpc_rec_index(s.n, X, Y)];
 		const u32 *dyx = s.win + 4 * (u64)s.wrec_off[mpc_rec_index(s.n, Y, X)];
+		const bool nx = mpc_need(s, X), ny = mpc_need(s, Y); // (a partial store has the records of the needed sequences only)
+		if (!nx && !ny) continue;
 		for (u32 q = t; q < nnz; q += 64) {
 			const u32 col = ent[2 * (u64)q + 1], row = ent[2 * (u64)nnz + q];
-			const u32 wf = dxy[row], wt = dyx[col];
-			s.pos_wf[s.vbase[k] + q] = (unsigned short)((wf >> 17) + (col - (wf & 0xfffu)));
-			s.pos_wt[s.vbase[k] + q] = (unsigned short)((wt >> 17) + (row - (wt & 0xfffu)));
+			if (nx) { const u32 wf = dxy[row]; s.pos_wf[s.vbase[k] + q] = (unsigned short)((wf >> 17) + (col - (wf & 0xfffu))); }
+			if (ny) { const u32 wt = dyx[col]; s.pos_wt[s.vbase[k] + q] = (unsigned short)((wt >> 17) + (row - (wt & 0xfffu))); }
 		}
 	}
 }
@@ -488,13 +516,57 @@ __global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s, u64 e0, 
 		const u32 pb = __float_as_uint(s.vnext[e]);
 		ent[2 * (u64)idx] = pb;
 		// entry `pos` of a record = block pos / 2, slot pos % 2: its probability is dword block * 4 + slot
-		const u32 pf = s.pos_f[e], pt = s.pos_t[e];
-		s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, X, Y)] + (pf >> 1) * 4u + (pf & 1u)] = pb;
-		s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, Y, X)] + (pt >> 1) * 4u + (pt & 1u)] = pb;
+		const bool nx = mpc_need(s, X), ny = mpc_need(s, Y); // a partial store holds the records of the needed sequences only
+		if (nx) { const u32 pf = s.pos_f[e]; s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, X, Y)] + (pf >> 1) * 4u + (pf & 1u)] = pb; }
+		if (ny) { const u32 pt = s.pos_t[e]; s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, Y, X)] + (pt >> 1) * 4u + (pt & 1u)] = pb; }
 		if (s.win) { // the window copies of both orientations
-			s.win[4 * ((u64)s.wrec_off[mpc_rec_index(s.n, X, Y)] + (LX + 1u + 3u) / 4u) + s.pos_wf[e]] = pb;
-			s.win[4 * ((u64)s.wrec_off[mpc_rec_index(s.n, Y, X)] + (LY + 1u + 3u) / 4u) + s.pos_wt[e]] = pb;
+			if (nx) s.win[4 * ((u64)s.wrec_off[mpc_rec_index(s.n, X, Y)] + (LX + 1u + 3u) / 4u) + s.pos_wf[e]] = pb;
+			if (ny) s.win[4 * ((u64)s.wrec_off[mpc_rec_index(s.n, Y, X)] + (LY + 1u + 3u) / 4u) + s.pos_wt[e]] = pb;
 		}
+	}
+}
+
+// The same commit, one WAVE PER PAIR (round 6): the per-entry form above finds its pair by a binary search over vbase — 19 dependent
+// loads per thread at 499 500 pairs — and visits every entry even where nothing is to be written. Here a wave takes pair k of
+// [k0, k1) and walks its entries inside [e0, e1) (coalesced reads of vnext and the position arrays); a PARTIAL store skips the pairs
+// that touch none of its sequences and are not its own, and writes the packed record only for its own pairs [own0, own1) — the relax
+// kernel reads P_XY of its own pairs there; everyone else's packed values are refreshed from vnext when somebody asks for them
+// (packed_refresh_kernel: mpcgpu.cpp, refresh_packed).
+__global__ void __launch_bounds__(64) commit_pairs_kernel(StoreParams s, u64 k0, u64 k1, u64 e0, u64 e1, u64 own0, u64 own1, int lazy_packed)
+{
+	const u32 t = threadIdx.x;
+	for (u64 k = k0 + blockIdx.x; k < k1; k += gridDim.x) {
+		const u32 X = s.pair_x[k], Y = s.pair_y[k];
+		const bool nx = mpc_need(s, X), ny = mpc_need(s, Y);
+		const bool pk = !lazy_packed || (k >= own0 && k < own1);
+		if (!nx && !ny && !pk) continue;
+		const u64 vb = s.vbase[k], ve = s.vbase[k + 1];
+		const u64 a = vb > e0 ? vb : e0, b = ve < e1 ? ve : e1;
+		if (a >= b) continue;
+		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];
+		u32 *ent = s.packed + s.pbase[k] + LX + LY;
+		u32 *rx = s.pad + 4 * (u64)s.rec_off[mpc_rec_index(s.n, X, Y)], *ry = s.pad + 4 * (u64)s.rec_off[mpc_rec_index(s.n, Y, X)];
+		u32 *wx = s.win ? s.win + 4 * ((u64)s.wrec_off[mpc_rec_index(s.n, X, Y)] + (LX + 1u + 3u) / 4u) : nullptr;
+		u32 *wy = s.win ? s.win + 4 * ((u64)s.wrec_off[mpc_rec_index(s.n, Y, X)] + (LY + 1u + 3u) / 4u) : nullptr;
+		for (u64 e = a + t; e < b; e += 64) {
+			const u32 pb = __float_as_uint(s.vnext[e]);
+			if (pk) ent[2 * (e - vb)] = pb;
+			// entry `pos` of a record = block pos / 2, slot pos % 2: its probability is dword block * 4 + slot
+			if (nx) { const u32 pf = s.pos_f[e]; rx[(pf >> 1) * 4u + (pf & 1u)] = pb; if (wx) wx[s.pos_wf[e]] = pb; }
+			if (ny) { const u32 pt = s.pos_t[e]; ry[(pt >> 1) * 4u + (pt & 1u)] = pb; if (wy) wy[s.pos_wt[e]] = pb; }
+		}
+	}
+}
+
+// packed P of the pairs OUTSIDE [own0, own1) from vnext (a partial store commits those lazily: commit_pairs_kernel)
+__global__ void __launch_bounds__(64) packed_refresh_kernel(StoreParams s, u64 own0, u64 own1)
+{
+	const u32 t = threadIdx.x;
+	for (u64 k = blockIdx.x; k < s.npairs; k += gridDim.x) {
+		if (k >= own0 && k < own1) continue;
+		const u64 vb = s.vbase[k], ve = s.vbase[k + 1];
+		u32 *ent = s.packed + s.pbase[k] + s.seq_len[s.pair_x[k]] + s.seq_len[s.pair_y[k]];
+		for (u64 e = vb + t; e < ve; e += 64) ent[2 * (e - vb)] = __float_as_uint(s.vnext[e]);
 	}
 }
 
@@ -511,16 +583,18 @@ __global__ void __launch_bounds__(256) pack_kernel(const u32 *res, u64 res_strid
 }
 
 // Export pairs [k0,k1) in MySparseMx layout: offsets (LX+1 per pair, exclusive scan of rowcnt) and
-// values ({P,col} per entry) into two contiguous staging arrays.
+// values ({P,col} per entry) into two contiguous staging arrays. klist != null: the pairs are klist[q], q in [k0,k1), and their
+// values go to entry val_base[q] (a custom pair order: an InitPairs range is a list of positions).
 __global__ void __launch_bounds__(64) export_kernel(StoreParams s, u64 k0, u64 k1, const u64 *off_base,
-	u32 *out_off, u32 *out_val)
+	u32 *out_off, u32 *out_val, const u64 *klist, const u64 *val_base)
 {
 	const int t = threadIdx.x;
-	for (u64 k = k0 + blockIdx.x; k < k1; k += gridDim.x) {
+	for (u64 q = k0 + blockIdx.x; q < k1; q += gridDim.x) {
+		const u64 k = klist ? klist[q] : q;
 		const u32 LX = s.seq_len[s.pair_x[k]], LY = s.seq_len[s.pair_y[k]];
 		const u32 *rec = s.packed + s.pbase[k];
 		const u32 nnz = (u32)(s.vbase[k + 1] - s.vbase[k]);
-		u32 *oo = out_off + off_base[k - k0];
+		u32 *oo = out_off + off_base[q - k0];
 		u32 carry = 0;
 		for (u32 a0 = 0; a0 <= LX; a0 += 64) {
 			const u32 a = a0 + t;
@@ -534,7 +608,7 @@ __global__ void __launch_bounds__(64) export_kernel(StoreParams s, u64 k0, u64 k
 			carry += __shfl(incl, 63);
 		}
 		const u32 *ent = rec + LX + LY;
-		u32 *ov = out_val + 2 * (s.vbase[k] - s.vbase[k0]);
-		for (u32 q = t; q < 2 * nnz; q += 64) ov[q] = ent[q];
+		u32 *ov = out_val + 2 * (klist ? val_base[q] : s.vbase[k] - s.vbase[k0]);
+		for (u32 i = t; i < 2 * nnz; i += 64) ov[i] = ent[i];
 	}
 }

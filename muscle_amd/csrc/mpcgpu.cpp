@@ -120,6 +120,19 @@ struct mpcgpu_ctx {
 	u64 npairs = 0;
 	DevBuf d_pair_x, d_pair_y; // all pairs
 	std::vector<u32> h_pair_x, h_pair_y;
+	// pair order (mpcgpu_set_pair_order): empty = MPCFlat::InitPairs order. order_rects: 4 words per rectangle {xa, xb, ya, yb},
+	// order_base[r] = position of its first pair; d_rects: 6 words per rectangle for the kernels (StoreParams::rects); ext2pos[k] =
+	// position of InitPairs pair k (the getters speak InitPairs numbers, the sharding calls positions)
+	std::vector<u32> order_rects;
+	std::vector<u64> order_base;
+	std::vector<u32> ext2pos;
+	DevBuf d_rects;
+	// partial store (mpcgpu_store_import_part): the sequences whose records exist, and the positions this context relaxes
+	bool partial = false;
+	bool packed_stale = false; // commits since the import wrote the packed records of the own pairs only (refresh_packed)
+	std::vector<u8> need;
+	DevBuf d_need;
+	u64 own_k0 = 0, own_k1 = 0;
 
 	// shard state (stage A output of this context)
 	bool have_shard = false;
@@ -175,7 +188,7 @@ struct mpcgpu_ctx {
 	// scratch
 	DevBuf d_bnd;
 	DevBuf d_queue, d_order, d_bx, d_by, d_fm, d_cand, d_cand_cnt, d_total, d_res, d_nnz, d_ea, d_flags,
-		d_sort_scratch, d_srow_scratch, d_dstbase, d_recwords, d_exp_off, d_exp_val, d_exp_offbase;
+		d_sort_scratch, d_srow_scratch, d_dstbase, d_recwords, d_exp_off, d_exp_val, d_exp_offbase, d_exp_klist, d_exp_valbase;
 
 	// measurement
 	std::vector<TimedSpan> spans;
@@ -463,6 +476,23 @@ void fill_store_params(mpcgpu_ctx *c, StoreParams &s)
 	s.wv_off = c->win_ok ? c->d_wv_off.as<u32>() : nullptr;
 	s.pos_wf = c->d_pos_w.as<unsigned short>();
 	s.pos_wt = c->d_pos_w.as<unsigned short>() + c->total_entries;
+	s.nrect = (u32)(c->order_rects.size() / 4);
+	s.rects = s.nrect ? c->d_rects.as<u32>() : nullptr;
+	s.need = c->partial ? c->d_need.as<u8>() : nullptr;
+}
+
+// position of pair (X,Y), X < Y, in the context's pair order (the host twin of mpc_pair_pos, kernels_store.h)
+u64 pair_pos(const mpcgpu_ctx *c, u32 X, u32 Y)
+{
+	const u32 n = c->n;
+	auto tri = [](u32 m, u32 i, u32 j) { return (u64)i * m - ((u64)i * (i + 1)) / 2 + (j - i - 1); }; // InitPairs order (mpcflat.cpp:145-155)
+	if (c->order_rects.empty()) return tri(n, X, Y);
+	for (size_t r = 0; r < c->order_rects.size() / 4; ++r) {
+		const u32 *q = &c->order_rects[4 * r];
+		if (X < q[0] || X >= q[1] || Y < q[2] || Y >= q[3]) continue;
+		return q[2] >= q[1] ? c->order_base[r] + (u64)(X - q[0]) * (q[3] - q[2]) + (Y - q[2]) : c->order_base[r] + tri(q[1] - q[0], X - q[0], Y - q[0]);
+	}
+	return ~0ull;
 }
 
 // ---- variable-size records + relax_var_kernel (kernels_relaxv.h) -------------------------------------------------------
@@ -626,6 +656,22 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			return 0;
 		};
 		auto pair_index = [&](u32 X, u32 Y) -> u64 { return (u64)X * n - ((u64)X * (X + 1)) / 2 + (Y - X - 1); }; // InitPairs order (mpcflat.cpp:145-155), X < Y
+		// does the block of sequences [x0, x0+cx) x [y0, y0+cy) hold a pair whose position may lie in [k0, k1)? (a conservative test: the
+		// kernels check every pair's own position)
+		auto block_in_range = [&](u32 x0, u32 cx, u32 y0, u32 cy) -> bool {
+			if (c->order_rects.empty()) {
+				// InitPairs order: pair indices grow with X first — the block's pairs lie between its first row's first and its last row's last pair
+				const u32 xl = std::min(x0 + cx - 1, y0 + cy - 2);
+				return !(pair_index(x0, std::max(y0, x0 + 1)) >= k1 || pair_index(xl, y0 + cy - 1) < k0);
+			}
+			for (size_t r = 0; r < c->order_rects.size() / 4; ++r) { // block order: the rectangles whose positions meet [k0, k1) and whose sequences meet the block's
+				const u32 *q = &c->order_rects[4 * r];
+				const u64 cnt = q[2] >= q[1] ? (u64)(q[1] - q[0]) * (q[3] - q[2]) : (u64)(q[1] - q[0]) * (q[1] - q[0] - 1) / 2;
+				if (c->order_base[r] >= k1 || c->order_base[r] + cnt <= k0) continue;
+				if (x0 < q[1] && x0 + cx > q[0] && y0 < q[3] && y0 + cy > q[2]) return true;
+			}
+			return false;
+		};
 		u64 last_cut_candidates = 0; // super-tiles with cells in the last cut
 		// super-tiles of nx x ny sequences cut into row bands of <= max_slots cells per lane and <= target blocks per step (mean)
 		auto cut = [&](u32 nx, u32 ny, u32 target, std::vector<u32> &words, std::vector<u32> &out) -> int {
@@ -636,9 +682,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 					const u32 x0 = xb * nx, cx = std::min(nx, n - x0), y0 = yb * ny, cy = std::min(ny, n - y0);
 					if (y0 + cy <= x0 + 1) continue; // no pair X < Y in this block
 					// a rank of a sharded run relaxes [k0, k1) only: blocks whose pairs all lie outside that range are not candidates
-					// (pair indices grow with X first: the block's pairs lie between its first row's first and its last row's last pair)
-					const u32 xl = std::min(x0 + cx - 1, y0 + cy - 2);
-					if (pair_index(x0, std::max(y0, x0 + 1)) >= k1 || pair_index(xl, y0 + cy - 1) < k0) continue;
+					if (!block_in_range(x0, cx, y0, cy)) continue;
 					cand.insert(cand.end(), {x0, cx, y0, cy});
 				}
 			const u32 nc = (u32)(cand.size() / 4);
@@ -831,11 +875,46 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 			if (eval_tiles(words, out)) return 1;
 		}
 		if (!words.empty()) return 2;
+		u64 ntail_split = 0;
+		{
+			// The tail of the launch: the kernel deals the list to the 8 XCDs in contiguous chunks (a counter each), and a chunk's
+			// LAST tiles — one per resident workgroup of the XCD — are the ones that finish alone. They are cut in two by rows (any
+			// part of a tile is a valid tile): half the tail, which is one tile of ~62 per workgroup on one GPU and one of ~8 on a rank
+			// of eight. MPCGPU_RELAX_TAIL=0: off.
+			const u32 W = MPC_RB_TILE_WORDS;
+			const size_t nt = okw.size() / W;
+			const u32 per_xcd = std::max(cus * 2u / 8u, 1u); // resident workgroups of an XCD (two per CU)
+			if (env_int("MPCGPU_RELAX_TAIL", 1) != 0 && nt >= (size_t)per_xcd * 8u * 3u) {
+				const size_t chunk = (nt + 7) / 8;
+				std::vector<u32> split;
+				split.reserve(okw.size() + (size_t)per_xcd * 8u * W);
+				for (size_t c0 = 0; c0 < nt; c0 += chunk) {
+					const size_t c1 = std::min(c0 + chunk, nt), body = c1 - c0 > per_xcd ? c1 - per_xcd : c0;
+					split.insert(split.end(), okw.begin() + c0 * W, okw.begin() + body * W);
+					for (size_t t = body; t < c1; ++t) {
+						const u32 *w = &okw[t * W];
+						const u32 hb = (w[5] - w[4] + MPC_RB_HB - 1) / MPC_RB_HB;
+						if (hb < 2) { split.insert(split.end(), w, w + W); continue; }
+						const u32 mid = w[4] + (hb / 2) * MPC_RB_HB;
+						u32 a[MPC_RB_TILE_WORDS] = {w[0], w[1], w[2], w[3], w[4], mid}, b[MPC_RB_TILE_WORDS] = {w[0], w[1], w[2], w[3], mid, w[5]};
+						split.insert(split.end(), a, a + W);
+						split.insert(split.end(), b, b + W);
+						++ntail_split;
+					}
+				}
+				okw.swap(split);
+			}
+		}
 		{
 			u64 cells = 0, est = 0;
 			std::vector<u32> &o2 = c->v_o2, &w2 = c->v_w2; // (kept: see mpcgpu_ctx)
 			w2 = okw;
-			if (eval_tiles(w2, o2)) return 1; // (also leaves the final list's statistics for the description)
+			if (eval_tiles(w2, o2)) return 1; // (fills words 6.. of the halves; also leaves the final list's statistics for the description)
+			if (ntail_split) { // halves without a cell go; the others are tiles like any other
+				okw.clear();
+				for (size_t t = 0; t < w2.size() / MPC_RB_TILE_WORDS; ++t)
+					if (o2[4 * t + 3]) okw.insert(okw.end(), w2.begin() + t * MPC_RB_TILE_WORDS, w2.begin() + (t + 1) * MPC_RB_TILE_WORDS);
+			}
 			for (size_t t = 0; t + 3 < o2.size(); t += 4) { cells += o2[t + 3]; est += o2[t + 1]; }
 			const size_t nt = okw.size() / MPC_RB_TILE_WORDS;
 			char b[320];
@@ -848,7 +927,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 		if (trace_on() && env_int("MPCGPU_TRACE_TILES", 0))
 			for (size_t t = 0; t < c->h_btiles.size() / MPC_RB_TILE_WORDS && t < (size_t)env_int("MPCGPU_TRACE_TILES", 0); ++t) {
 				const u32 *w = &c->h_btiles[t * MPC_RB_TILE_WORDS];
-				fprintf(stderr, "[mpcgpu] tile %zu: X %u+%u Y %u+%u rows [%u,%u) first %u slots %u; Y rows", t, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+				fprintf(stderr, "[mpcgpu] tile %zu: X %u+%u Y %u+%u rows [%u,%u) first %u slots %u; Y rows", t, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7] & 0xffu);
 				for (u32 j = 0; j < w[3]; ++j) fprintf(stderr, " [%u,%u)", w[8 + j] & 0xffffu, w[8 + j] >> 16);
 				fprintf(stderr, "\n");
 			}
@@ -938,7 +1017,7 @@ int relax_band(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 int relax_var(mpcgpu_ctx *c, const StoreParams &sp, u64 k0, u64 k1)
 {
 	const u32 n = c->n;
-	auto pidx = [&](u32 i, u32 j) { return (u64)i * n - ((u64)i * (i + 1)) / 2 + (j - i - 1); };
+	auto pidx = [&](u32 i, u32 j) { return pair_pos(c, i, j); };
 	// Tiles of geometry (geo, nbuf) out of a list of candidate tiles: a tile is kept when its cells fit the register slots and its
 	// records of one step, packed back to back, fit one staging buffer at EVERY step (the worst step of every tile is measured on
 	// the device); others are split (Y first, then X) and measured again. Single pairs that still do not fit go to `leftover`
@@ -1240,11 +1319,28 @@ int build_var_store(mpcgpu_ctx *c)
 
 // The fallback layout: compact CSR slabs per sequence + the gather kernel (relax_kernel). Built from the packed records, which
 // always hold the current values: also the way out when a store of dense records turns out not to tile (mpcgpu_cons_iter).
+// The packed records of the pairs a sharded context does not relax itself are committed lazily (commit_pairs_kernel): before anything
+// reads them — the getters, a rebuild of the records — they take their values from the values array, which holds the committed
+// probability of every such pair from the last exchange on (mpcgpu_cons_iter writes the context's own slice only).
+static int refresh_packed(mpcgpu_ctx *c)
+{
+	if (!c->packed_stale) return 0;
+	StoreParams sp;
+	fill_store_params(c, sp);
+	MPC_LAUNCH(packed_refresh_kernel, (u32)std::min<u64>(std::max<u64>(c->npairs, 1), (u64)c->prop.multiProcessorCount * 64), 64, 0, c->stream, sp, c->own_k0, c->own_k1);
+	HIPCHK(c, hipGetLastError());
+	c->packed_stale = false;
+	return 0;
+}
+
 static int build_slab_store(mpcgpu_ctx *c)
 {
 	const u32 n = c->n;
+	if (refresh_packed(c)) return 1; // (the slabs are built from the packed records)
+	c->own_k0 = 0; c->own_k1 = c->npairs; // (and hold everything: commits are complete from here on)
 	c->have_pad = false;
 	c->band_ok = false;
+	c->partial = false; // (the slabs hold every sequence: a partial store that falls back here is a complete one)
 	TimedSpan ts;
 	c->d_pad.release();
 	c->d_pos.release();
@@ -1272,8 +1368,7 @@ static int build_slab_store(mpcgpu_ctx *c)
 				if (run > 0xffffffffull) return fail(c, "mpcgpu_store_import: slab of sequence %u exceeds 2^32 entries", A);
 				mbase[(size_t)A * (n + 1) + Z] = (u32)run;
 				if (Z != A) {
-					const u64 k = A < Z ? (u64)A * n - ((u64)A * (A + 1)) / 2 + (Z - A - 1)
-					                    : (u64)Z * n - ((u64)Z * (Z + 1)) / 2 + (A - Z - 1);
+					const u64 k = A < Z ? pair_pos(c, A, Z) : pair_pos(c, Z, A);
 					run += c->all_nnz[k];
 				}
 			}
@@ -1439,6 +1534,8 @@ static int set_seqs_impl(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, 
 		return 1;
 	c->npairs = 0;
 	c->h_pair_x.clear(); c->h_pair_y.clear();
+	c->order_rects.clear(); c->order_base.clear(); c->ext2pos.clear(); // (a pair order belongs to one set of sequences)
+	c->partial = false;
 	if (!with_pairs) { // explicit pair lists only (mpcgpu_align_msas)
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		return 0;
@@ -1463,6 +1560,66 @@ int mpcgpu_set_seqs(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const
 int mpcgpu_set_seqs_registry(mpcgpu_ctx *c, uint32_t n, const uint8_t *const *seqs, const uint32_t *lens)
 {
 	return set_seqs_impl(c, n, seqs, lens, false);
+}
+
+int mpcgpu_set_pair_order(mpcgpu_ctx *c, uint32_t nrects, const uint32_t *rects)
+{
+	if (!c) return 1;
+	if (c->n == 0 || c->npairs == 0) return fail(c, "mpcgpu_set_pair_order: call mpcgpu_set_seqs first");
+	if (nrects && !rects) return fail(c, "mpcgpu_set_pair_order: no rectangles");
+	HIPCHK(c, hipSetDevice(c->device));
+	const u32 n = c->n;
+	c->have_shard = c->have_store = false;
+	c->partial = false;
+	c->order_rects.clear(); c->order_base.clear(); c->ext2pos.clear();
+	u64 k = 0;
+	if (nrects == 0) { // back to MPCFlat::InitPairs order (mpcflat.cpp:145-155)
+		for (u32 i = 0; i < n; ++i)
+			for (u32 j = i + 1; j < n; ++j) { c->h_pair_x[k] = i; c->h_pair_y[k] = j; ++k; }
+	} else {
+		std::vector<u8> seen(((u64)n * n + 7) / 8, 0); // every pair exactly once
+		std::vector<u64> base(nrects);
+		for (u32 r = 0; r < nrects; ++r) {
+			const u32 xa = rects[4 * r], xb = rects[4 * r + 1], ya = rects[4 * r + 2], yb = rects[4 * r + 3];
+			const bool tri = xa == ya && xb == yb;
+			if (xa > xb || ya > yb || xb > n || yb > n || (!tri && ya < xb))
+				return fail(c, "mpcgpu_set_pair_order: rectangle %u = [%u,%u) x [%u,%u) is neither off the diagonal nor a triangle", r, xa, xb, ya, yb);
+			base[r] = k;
+			for (u32 x = xa; x < xb; ++x)
+				for (u32 y = tri ? x + 1 : ya; y < yb; ++y) {
+					const u64 bit = (u64)x * n + y;
+					if (k >= c->npairs || (seen[bit >> 3] >> (bit & 7)) & 1) return fail(c, "mpcgpu_set_pair_order: pair (%u,%u) is listed twice", x, y);
+					seen[bit >> 3] |= (u8)(1u << (bit & 7));
+					c->h_pair_x[k] = x; c->h_pair_y[k] = y; ++k;
+				}
+		}
+		if (k != c->npairs) return fail(c, "mpcgpu_set_pair_order: the rectangles hold %llu of %llu pairs", (u64)k, (u64)c->npairs);
+		c->order_rects.assign(rects, rects + 4 * (size_t)nrects);
+		c->order_base = base;
+		std::vector<u32> dev(6 * (size_t)nrects);
+		for (u32 r = 0; r < nrects; ++r) {
+			for (u32 q = 0; q < 4; ++q) dev[6 * r + q] = rects[4 * r + q];
+			dev[6 * r + 4] = (u32)(base[r] & 0xffffffffull); dev[6 * r + 5] = (u32)(base[r] >> 32);
+		}
+		if (upload(c, c->d_rects, dev)) return 1;
+		HIPCHK(c, hipStreamSynchronize(c->stream)); // `dev` dies with this block
+		c->ext2pos.resize(c->npairs);
+		for (u64 q = 0; q < c->npairs; ++q) {
+			const u32 x = c->h_pair_x[q], y = c->h_pair_y[q];
+			c->ext2pos[(u64)x * n - ((u64)x * (x + 1)) / 2 + (y - x - 1)] = (u32)q;
+		}
+	}
+	if (upload(c, c->d_pair_x, c->h_pair_x) || upload(c, c->d_pair_y, c->h_pair_y)) return 1;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+int mpcgpu_pair_position(mpcgpu_ctx *c, uint32_t x, uint32_t y, uint64_t *pos)
+{
+	if (!c) return 1;
+	if (x >= y || y >= c->n) return fail(c, "mpcgpu_pair_position: need x < y < n");
+	if (pos) *pos = pair_pos(c, x, y);
+	return 0;
 }
 
 int mpcgpu_set_mega(mpcgpu_ctx *c, uint32_t nfeat, const uint32_t *alpha, const float *weight,
@@ -2091,11 +2248,12 @@ int mpcgpu_shard_export(mpcgpu_ctx *c, void *dev_dst)
 	return 0;
 }
 
-int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, const uint64_t *k1,
-	const uint64_t *bytes, void *dev_all)
+int mpcgpu_store_import_part(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, const uint64_t *k1, const uint64_t *bytes,
+	const uint64_t *offsets, void *dev_all, uint64_t own_k0, uint64_t own_k1)
 {
 	if (!c) return 1;
 	if (c->n == 0) return fail(c, "mpcgpu_store_import: call mpcgpu_set_seqs first");
+	if (own_k0 > own_k1 || own_k1 > c->npairs) return fail(c, "mpcgpu_store_import_part: bad own range [%llu,%llu)", (u64)own_k0, (u64)own_k1);
 	HIPCHK(c, hipSetDevice(c->device));
 	c->have_store = false;
 	c->tiles_k0 = c->tiles_k1 = ~0ull;
@@ -2109,41 +2267,62 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 		HIPCHK(c, hipMemGetInfo(&free_now, &total_now));
 		if ((u64)free_now < 5 * packed_bytes + (4ull << 30)) c->d_fm.release();
 	}
-	// ---- read shard headers, check coverage
+	// ---- read shard headers, check coverage. The shards may lie anywhere in dev_all (offsets[s]; null: back to back in the order
+	// given) and come in any order: sorted by their first position they must tile [0, pairs)
+	std::vector<u32> by_k(nshards);
+	for (u32 s = 0; s < nshards; ++s) by_k[s] = s;
+	std::sort(by_k.begin(), by_k.end(), [&](u32 a, u32 b) { return k0[a] != k0[b] ? k0[a] < k0[b] : k1[a] < k1[b]; });
+	std::vector<u64> at(nshards, 0);
+	{
+		u64 run = 0;
+		for (u32 s = 0; s < nshards; ++s) { at[s] = offsets ? offsets[s] : run; run += bytes[s]; if (at[s] & 3) return fail(c, "mpcgpu_store_import: shard %u is not word-aligned", s); }
+	}
 	c->all_nnz.assign(c->npairs, 0);
 	c->all_ea.assign(c->npairs, 0.0f);
 	c->h_pbase.assign(c->npairs + 1, 0);
 	c->h_vbase.assign(c->npairs + 1, 0);
-	u64 expect = 0, byte_off = 0;
+	u64 expect = 0, end_max = 0;
+	// all headers are read back with ONE wait (a pair-sharded run with stage A in pieces imports world x pieces shards)
+	std::vector<u64> hoff(nshards + 1, 0);
 	for (u32 s = 0; s < nshards; ++s) {
-		if (k0[s] != expect || k1[s] < k0[s] || k1[s] > c->npairs)
-			return fail(c, "mpcgpu_store_import: shards must tile [0,%llu) in order (shard %u is [%llu,%llu))",
-				(u64)c->npairs, s, (u64)k0[s], (u64)k1[s]);
-		const u64 np = k1[s] - k0[s];
-		const u64 hdr = shard_header_bytes(np);
+		if (k1[s] < k0[s] || k1[s] > c->npairs) return fail(c, "mpcgpu_store_import: shard %u is [%llu,%llu)", s, (u64)k0[s], (u64)k1[s]);
+		const u64 hdr = shard_header_bytes(k1[s] - k0[s]);
 		if (bytes[s] < hdr) return fail(c, "mpcgpu_store_import: shard %u too small", s);
-		std::vector<u8> &h = c->v_hdr; // (kept: see mpcgpu_ctx — 8 bytes per pair of the shard)
-		h.resize(hdr);
-		HIPCHK(c, hipMemcpyAsync(h.data(), (const u8 *)dev_all + byte_off, hdr, hipMemcpyDeviceToHost, c->stream));
-		HIPCHK(c, hipStreamSynchronize(c->stream));
+		hoff[s + 1] = hoff[s] + hdr;
+	}
+	std::vector<u8> &h = c->v_hdr; // (kept: see mpcgpu_ctx — 8 bytes per pair)
+	h.resize(hoff[nshards]);
+	for (u32 s = 0; s < nshards; ++s)
+		HIPCHK(c, hipMemcpyAsync(h.data() + hoff[s], (const u8 *)dev_all + at[s], hoff[s + 1] - hoff[s], hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	for (u32 q = 0; q < nshards; ++q) {
+		const u32 s = by_k[q];
+		if (k0[s] != expect)
+			return fail(c, "mpcgpu_store_import: shards must tile [0,%llu) (shard %u is [%llu,%llu), expected one that starts at %llu)",
+				(u64)c->npairs, s, (u64)k0[s], (u64)k1[s], (u64)expect);
+		const u64 np = k1[s] - k0[s];
+		const u64 hdr = hoff[s + 1] - hoff[s];
+		const u8 *hs = h.data() + hoff[s];
 		u64 h2[2];
-		memcpy(h2, h.data(), 16);
+		memcpy(h2, hs, 16);
 		if (h2[0] != np || hdr + h2[1] * 4 != bytes[s])
 			return fail(c, "mpcgpu_store_import: shard %u header mismatch (pairs %llu vs %llu, bytes %llu vs %llu)", s,
 				(u64)h2[0], (u64)np, (u64)(hdr + h2[1] * 4), (u64)bytes[s]);
-		memcpy(&c->all_nnz[k0[s]], h.data() + 16, np * 4);
-		memcpy(&c->all_ea[k0[s]], h.data() + 16 + np * 4, np * 4);
-		u64 w = (byte_off + hdr) / 4;
+		if (np) {
+			memcpy(&c->all_nnz[k0[s]], hs + 16, np * 4);
+			memcpy(&c->all_ea[k0[s]], hs + 16 + np * 4, np * 4);
+		}
+		u64 w = (at[s] + hdr) / 4;
 		for (u64 k = k0[s]; k < k1[s]; ++k) {
 			c->h_pbase[k] = w;
 			w += rec_words(c->len[c->h_pair_x[k]], c->len[c->h_pair_y[k]], c->all_nnz[k]);
 		}
-		if (w * 4 != byte_off + bytes[s]) return fail(c, "mpcgpu_store_import: shard %u record sizes do not add up", s);
-		byte_off += bytes[s];
+		if (w * 4 != at[s] + bytes[s]) return fail(c, "mpcgpu_store_import: shard %u record sizes do not add up", s);
+		end_max = std::max(end_max, at[s] + bytes[s]);
 		expect = k1[s];
 	}
 	if (expect != c->npairs) return fail(c, "mpcgpu_store_import: shards cover %llu of %llu pairs", (u64)expect, (u64)c->npairs);
-	c->h_pbase[c->npairs] = byte_off / 4;
+	c->h_pbase[c->npairs] = end_max / 4; // (a sentinel only: a pair's record length follows from its lengths and its entry count)
 	for (u64 k = 0; k < c->npairs; ++k) c->h_vbase[k + 1] = c->h_vbase[k] + c->all_nnz[k];
 	c->total_entries = c->h_vbase[c->npairs];
 	c->max_nnz = 0;
@@ -2153,6 +2332,20 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 	c->st_packed = (const u32 *)dev_all;
 	HIPCHK(c, c->d_vnext.ensure(std::max<u64>(c->total_entries, 1) * 4));
 	if (upload(c, c->d_pbase, c->h_pbase) || upload(c, c->d_vbase, c->h_vbase)) return 1;
+	// ---- a PARTIAL store: this context relaxes the positions [own_k0, own_k1) only, so it needs the records (A, Z) of the
+	// sequences A those pairs touch and of no other (a rank of a block-partitioned run: the sequences of its blocks — half of the
+	// store at 8 ranks). Everything per pair (packed records, values) stays complete.
+	c->own_k0 = own_k0; c->own_k1 = own_k1;
+	c->packed_stale = false;
+	c->partial = !(own_k0 == 0 && own_k1 == c->npairs);
+	if (c->partial) {
+		c->need.assign(n, 0);
+		for (u64 k = own_k0; k < own_k1; ++k) { c->need[c->h_pair_x[k]] = 1; c->need[c->h_pair_y[k]] = 1; }
+		u32 cnt = 0;
+		for (u32 i = 0; i < n; ++i) cnt += c->need[i];
+		if (cnt == n) c->partial = false; // (the rank's pairs touch every sequence: nothing to leave out)
+		else if (upload(c, c->d_need, c->need)) return 1;
+	}
 	// ---- layout for relax: padded records + LDS-tiled kernel when a tile fits the LDS and the
 	// records fit HBM; otherwise compact slabs + the gather kernel (MPCGPU_RELAX=gather forces it).
 	// Both are device paths with identical results.
@@ -2168,6 +2361,31 @@ int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, con
 			if (rc == 0) { c->have_store = true; return 0; }
 		}
 	}
+	return build_slab_store(c);
+}
+
+int mpcgpu_store_import(mpcgpu_ctx *c, uint32_t nshards, const uint64_t *k0, const uint64_t *k1,
+	const uint64_t *bytes, void *dev_all)
+{
+	if (!c) return 1;
+	return mpcgpu_store_import_part(c, nshards, k0, k1, bytes, nullptr, dev_all, 0, c->npairs);
+}
+
+int mpcgpu_store_complete(mpcgpu_ctx *c)
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_store_complete: no store");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (refresh_packed(c)) return 1;
+	if (!c->partial) { c->own_k0 = 0; c->own_k1 = c->npairs; return 0; }
+	// the packed records hold the current values (every commit writes them): the records of ALL sequences are built from them
+	c->partial = false;
+	c->own_k0 = 0; c->own_k1 = c->npairs;
+	c->have_store = false;
+	c->tiles_k0 = c->tiles_k1 = ~0ull;
+	const int rc = build_var_store(c);
+	if (rc == 1) return 1;
+	if (rc == 0) { c->have_store = true; return 0; }
 	return build_slab_store(c);
 }
 
@@ -2229,6 +2447,9 @@ int mpcgpu_cons_iter(mpcgpu_ctx *c, uint64_t k0, uint64_t k1)
 	if (!c) return 1;
 	if (!c->have_store) return fail(c, "mpcgpu_cons_iter: no store (call mpcgpu_build_store / mpcgpu_store_import)");
 	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_cons_iter: bad pair range");
+	if (c->partial && k0 != k1 && (k0 < c->own_k0 || k1 > c->own_k1))
+		return fail(c, "mpcgpu_cons_iter: [%llu,%llu) is outside the range [%llu,%llu) this partial store was imported for (mpcgpu_store_import_part)",
+			(u64)k0, (u64)k1, (u64)c->own_k0, (u64)c->own_k1);
 	HIPCHK(c, hipSetDevice(c->device));
 	const u64 cnt = c->h_vbase[k1] - c->h_vbase[k0];
 	c->work_entry_z = cnt * c->n;
@@ -2280,7 +2501,19 @@ int mpcgpu_cons_commit_range(mpcgpu_ctx *c, uint64_t first, uint64_t count)
 	const u32 block = 256;
 	const u64 blocks = (count + block - 1) / block;
 	const u32 grid = (u32)std::min<u64>(blocks, (u64)c->prop.multiProcessorCount * 64);
-	if (c->have_pad) MPC_LAUNCH(commit_pad_kernel, grid, block, 0, c->stream, sp, (u64)first, (u64)(first + count));
+	if (c->have_pad && env_int("MPCGPU_COMMIT", 1) != 0) {
+		// one wave per pair (kernels_store.h: commit_pairs_kernel): the pairs whose entries meet [first, first + count)
+		const u64 ka = (u64)(std::upper_bound(c->h_vbase.begin(), c->h_vbase.end(), (u64)first) - c->h_vbase.begin()) - 1;
+		const u64 kb = (u64)(std::lower_bound(c->h_vbase.begin(), c->h_vbase.end(), (u64)(first + count)) - c->h_vbase.begin());
+		// a context that relaxes a part of the pairs only (a rank of a sharded run) writes the packed records of ITS pairs — what its
+		// relax reads — and leaves the others' to refresh_packed (whoever reads them asks for it)
+		const bool lazy = !(c->own_k0 == 0 && c->own_k1 == c->npairs);
+		if (lazy) c->packed_stale = true;
+		const u64 pairs = std::min<u64>(kb, c->npairs) - ka;
+		MPC_LAUNCH(commit_pairs_kernel, (u32)std::min<u64>(std::max<u64>(pairs, 1), (u64)c->prop.multiProcessorCount * 64), 64, 0, c->stream, sp, ka,
+			std::min<u64>(kb, c->npairs), (u64)first, (u64)(first + count), c->own_k0, c->own_k1, lazy ? 1 : 0);
+	}
+	else if (c->have_pad) MPC_LAUNCH(commit_pad_kernel, grid, block, 0, c->stream, sp, (u64)first, (u64)(first + count));
 	else MPC_LAUNCH(commit_kernel, grid, block, 0, c->stream, sp, (u64)first, (u64)(first + count));
 	HIPCHK(c, hipGetLastError());
 	if (span_end(c, &ts)) return 1;
@@ -2294,22 +2527,46 @@ int mpcgpu_cons_commit(mpcgpu_ctx *c)
 	return mpcgpu_cons_commit_range(c, 0, c->total_entries);
 }
 
+// The getters speak MPCFlat::InitPairs pair numbers (mpcflat.cpp:145-155) whatever order the context keeps its pairs in
+// (mpcgpu_set_pair_order): position of InitPairs pair k
+static inline u64 pos_of(const mpcgpu_ctx *c, u64 k) { return c->ext2pos.empty() ? k : (u64)c->ext2pos[k]; }
+
 int mpcgpu_get_ea(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, float *ea)
 {
 	if (!c) return 1;
 	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_get_ea: bad pair range");
-	if (c->have_store) { memcpy(ea, &c->all_ea[k0], (k1 - k0) * 4); return 0; }
-	if (c->have_shard && !c->shard_is_list && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(ea, &c->sh_ea[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
-	return fail(c, "mpcgpu_get_ea: range [%llu,%llu) not available", (u64)k0, (u64)k1);
+	const bool shard_ok = c->have_shard && !c->shard_is_list;
+	if (c->ext2pos.empty()) {
+		if (c->have_store) { memcpy(ea, &c->all_ea[k0], (k1 - k0) * 4); return 0; }
+		if (shard_ok && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(ea, &c->sh_ea[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
+		return fail(c, "mpcgpu_get_ea: range [%llu,%llu) not available", (u64)k0, (u64)k1);
+	}
+	for (u64 k = k0; k < k1; ++k) {
+		const u64 q = pos_of(c, k);
+		if (c->have_store) ea[k - k0] = c->all_ea[q];
+		else if (shard_ok && q >= c->sh_k0 && q < c->sh_k1) ea[k - k0] = c->sh_ea[q - c->sh_k0];
+		else return fail(c, "mpcgpu_get_ea: pair %llu not available", (u64)k);
+	}
+	return 0;
 }
 
 int mpcgpu_get_nnz(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, uint32_t *nnz)
 {
 	if (!c) return 1;
 	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_get_nnz: bad pair range");
-	if (c->have_store) { memcpy(nnz, &c->all_nnz[k0], (k1 - k0) * 4); return 0; }
-	if (c->have_shard && !c->shard_is_list && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(nnz, &c->sh_nnz[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
-	return fail(c, "mpcgpu_get_nnz: range [%llu,%llu) not available", (u64)k0, (u64)k1);
+	const bool shard_ok = c->have_shard && !c->shard_is_list;
+	if (c->ext2pos.empty()) {
+		if (c->have_store) { memcpy(nnz, &c->all_nnz[k0], (k1 - k0) * 4); return 0; }
+		if (shard_ok && k0 >= c->sh_k0 && k1 <= c->sh_k1) { memcpy(nnz, &c->sh_nnz[k0 - c->sh_k0], (k1 - k0) * 4); return 0; }
+		return fail(c, "mpcgpu_get_nnz: range [%llu,%llu) not available", (u64)k0, (u64)k1);
+	}
+	for (u64 k = k0; k < k1; ++k) {
+		const u64 q = pos_of(c, k);
+		if (c->have_store) nnz[k - k0] = c->all_nnz[q];
+		else if (shard_ok && q >= c->sh_k0 && q < c->sh_k1) nnz[k - k0] = c->sh_nnz[q - c->sh_k0];
+		else return fail(c, "mpcgpu_get_nnz: pair %llu not available", (u64)k);
+	}
+	return 0;
 }
 
 int mpcgpu_get_sparse_range(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, uint32_t *offsets, void *values)
@@ -2319,17 +2576,26 @@ int mpcgpu_get_sparse_range(mpcgpu_ctx *c, uint64_t k0, uint64_t k1, uint32_t *o
 	if (k0 > k1 || k1 > c->npairs) return fail(c, "mpcgpu_get_sparse_range: bad pair range");
 	if (k0 == k1) return 0;
 	HIPCHK(c, hipSetDevice(c->device));
-	std::vector<u64> offbase(k1 - k0);
-	u64 o = 0;
-	for (u64 k = k0; k < k1; ++k) { offbase[k - k0] = o; o += c->len[c->h_pair_x[k]] + 1; }
-	const u64 nval = c->h_vbase[k1] - c->h_vbase[k0];
+	if (refresh_packed(c)) return 1;
+	const bool listed = !c->ext2pos.empty(); // a custom pair order: the InitPairs range is a list of positions
+	std::vector<u64> offbase(k1 - k0), valbase, klist;
+	if (listed) { valbase.resize(k1 - k0); klist.resize(k1 - k0); }
+	u64 o = 0, nval = 0;
+	for (u64 k = k0; k < k1; ++k) {
+		const u64 q = pos_of(c, k);
+		offbase[k - k0] = o; o += c->len[c->h_pair_x[q]] + 1;
+		if (listed) { klist[k - k0] = q; valbase[k - k0] = nval; }
+		nval += c->all_nnz[q];
+	}
 	HIPCHK(c, c->d_exp_off.ensure(o * 4));
 	HIPCHK(c, c->d_exp_val.ensure(std::max<u64>(nval, 1) * 8));
 	if (upload(c, c->d_exp_offbase, offbase)) return 1;
+	if (listed && (upload(c, c->d_exp_klist, klist) || upload(c, c->d_exp_valbase, valbase))) return 1;
 	StoreParams sp;
 	fill_store_params(c, sp);
 	MPC_LAUNCH(export_kernel, (u32)std::min<u64>(k1 - k0, (u64)c->prop.multiProcessorCount * 32), 64, 0, c->stream, sp,
-		(u64)k0, (u64)k1, c->d_exp_offbase.as<u64>(), c->d_exp_off.as<u32>(), c->d_exp_val.as<u32>());
+		(u64)(listed ? 0 : k0), (u64)(listed ? k1 - k0 : k1), c->d_exp_offbase.as<u64>(), c->d_exp_off.as<u32>(), c->d_exp_val.as<u32>(),
+		listed ? c->d_exp_klist.as<u64>() : (const u64 *)nullptr, listed ? c->d_exp_valbase.as<u64>() : (const u64 *)nullptr);
 	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipMemcpyAsync(offsets, c->d_exp_off.p, o * 4, hipMemcpyDeviceToHost, c->stream));
 	if (nval) HIPCHK(c, hipMemcpyAsync(values, c->d_exp_val.p, nval * 8, hipMemcpyDeviceToHost, c->stream));
@@ -2531,6 +2797,9 @@ static int build_post_impl(mpcgpu_ctx *c, uint32_t n1, const uint32_t *seq1, uin
 {
 	if (!c) return 1;
 	if (!c->have_store) return fail(c, "mpcgpu_align_alns: no store (call mpcgpu_build_store / mpcgpu_store_import)");
+	// BuildPost reads the records of any sequence: a partial store (a rank of a block-partitioned run) is completed first — once,
+	// from the packed records, which hold the current values
+	if ((c->partial || c->packed_stale) && mpcgpu_store_complete(c)) return 1;
 	if (!seq1 || !seq2 || !pos2col1 || !pos2col2 || (path && !pathlen)) return fail(c, "mpcgpu_align_alns: NULL argument");
 	if (n1 == 0 || n2 == 0 || C1 == 0 || C2 == 0) return fail(c, "mpcgpu_align_alns: empty alignment");
 	HIPCHK(c, hipSetDevice(c->device));

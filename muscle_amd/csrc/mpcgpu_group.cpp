@@ -174,6 +174,64 @@ void shard_bounds(const std::vector<uint32_t> &len, uint32_t world, std::vector<
 	for (size_t r = 1; r < cuts.size(); ++r) cuts[r] = std::max(cuts[r], cuts[r - 1]);
 }
 
+// ---- block partition -------------------------------------------------------------------------------------------------
+// A rank that owns a contiguous range of InitPairs pairs relaxes pairs (X, Y) with Y anywhere behind X: it reads the records of
+// (nearly) every sequence, so every rank imports, builds and commits the WHOLE store — the part of a rank's step that does not
+// shrink with the number of ranks. Cut in two dimensions instead: the sequences fall into g groups of equal weight (sum of L + 1),
+// the pair triangle into g (g + 1) / 2 blocks (group i x group j), and a rank owns whole blocks — its pairs then touch the
+// sequences of a few groups only, and it needs the records of those (mpcgpu_store_import_part).
+//   world = g (g - 1) / 2 + g / 2, g even (2, 8, 18 ...): one off-diagonal block per rank, and one rank per two diagonal blocks
+//     (a triangle weighs half a square): at 8 ranks every rank touches 2 of 4 groups — HALF of the store.
+//   any other world: g = world groups, rank i owns the triangle of group i and the blocks {i, i + d}, d = 1 .. (g - 1) / 2 (indices
+//     mod g); for even g the g / 2 antipodal blocks {i, i + g / 2} are cut in two by rows, one half for either rank.
+// The pairs are enumerated rank by rank, block by block (mpcgpu_set_pair_order), so that a rank's pairs are one contiguous range
+// of positions and everything per pair — shards, values — stays one segment per rank.
+struct PlanRect { uint32_t xa, xb, ya, yb; };
+
+static uint64_t rect_pairs(const PlanRect &q) { return q.ya >= q.xb ? (uint64_t)(q.xb - q.xa) * (q.yb - q.ya) : (uint64_t)(q.xb - q.xa) * (q.xb - q.xa - 1) / 2; }
+
+static bool plan_blocks(const std::vector<uint32_t> &len, uint32_t world, std::vector<std::vector<PlanRect>> &per_rank)
+{
+	const uint32_t n = (uint32_t)len.size();
+	uint32_t g = 0;
+	bool paired = false;
+	for (uint32_t e = 2; e * (e - 1) / 2 + e / 2 <= world; e += 2) if (e * (e - 1) / 2 + e / 2 == world) { g = e; paired = true; }
+	if (!g) g = world;
+	if (world < 2 || n < 4 * g) return false; // too few sequences for groups: contiguous ranges
+	std::vector<uint64_t> cum(n + 1, 0);
+	for (uint32_t i = 0; i < n; ++i) cum[i + 1] = cum[i] + len[i] + 1;
+	auto cut_at = [&](uint32_t lo, uint32_t hi, uint64_t num, uint64_t den) { // first index in [lo, hi] whose prefix weight reaches num / den of the range's
+		const uint64_t target = cum[lo] + (cum[hi] - cum[lo]) * num / den;
+		return (uint32_t)(std::lower_bound(cum.begin() + lo, cum.begin() + hi + 1, target) - cum.begin());
+	};
+	std::vector<uint32_t> gb(g + 1, 0);
+	for (uint32_t j = 1; j < g; ++j) gb[j] = std::max(cut_at(0, n, j, g), gb[j - 1] + 1);
+	gb[g] = n;
+	for (uint32_t j = g; j-- > 1;) if (gb[j] >= gb[j + 1]) gb[j] = gb[j + 1] - 1; // (every group keeps at least one sequence)
+	auto tri = [&](uint32_t i) { return PlanRect{gb[i], gb[i + 1], gb[i], gb[i + 1]}; };
+	auto blk = [&](uint32_t i, uint32_t j) { if (i > j) std::swap(i, j); return PlanRect{gb[i], gb[i + 1], gb[j], gb[j + 1]}; };
+	per_rank.assign(world, {});
+	if (paired) {
+		uint32_t r = 0;
+		for (uint32_t t = 0; t < g; t += 2) { per_rank[r].push_back(tri(t)); per_rank[r].push_back(tri(t + 1)); ++r; }
+		for (uint32_t i = 0; i < g; ++i)
+			for (uint32_t j = i + 1; j < g; ++j) per_rank[r++].push_back(blk(i, j));
+		return true;
+	}
+	for (uint32_t i = 0; i < g; ++i) {
+		per_rank[i].push_back(tri(i));
+		for (uint32_t d = 1; d <= (g - 1) / 2; ++d) per_rank[i].push_back(blk(i, (i + d) % g));
+	}
+	if (g % 2 == 0)
+		for (uint32_t i = 0; i < g / 2; ++i) { // the antipodal block, cut by rows at half of its weight
+			PlanRect b = blk(i, i + g / 2);
+			const uint32_t mid = std::min(std::max(cut_at(b.xa, b.xb, 1, 2), b.xa), b.xb);
+			if (mid > b.xa) per_rank[i].push_back(PlanRect{b.xa, mid, b.ya, b.yb});
+			if (b.xb > mid) per_rank[i + g / 2].push_back(PlanRect{mid, b.xb, b.ya, b.yb});
+		}
+	return true;
+}
+
 #define GHIP(g, call)                                                                                           \
 	do {                                                                                                        \
 		hipError_t e_ = (call);                                                                                 \
@@ -182,8 +240,10 @@ void shard_bounds(const std::vector<uint32_t> &len, uint32_t world, std::vector<
 
 // Segment r (seg_bytes[r] bytes at src[r] on rank r's device) goes to dst[d] + seg_off[r] on every rank d. With
 // in_place the segment already sits at its final place on its owner (dst[r] + seg_off[r] == src[r]).
+// wait == false: the transfers are queued on the exchange streams and the caller synchronises those later (the next piece of
+// stage A runs meanwhile).
 int all_gather_segments(mpcgpu_group *g, const std::vector<const void *> &src, const std::vector<void *> &dst,
-	const std::vector<uint64_t> &seg_off, const std::vector<uint64_t> &seg_bytes, bool in_place)
+	const std::vector<uint64_t> &seg_off, const std::vector<uint64_t> &seg_bytes, bool in_place, bool wait = true)
 {
 	const uint32_t R = (uint32_t)g->ctx.size();
 	if (g->use_rccl) {
@@ -205,7 +265,7 @@ int all_gather_segments(mpcgpu_group *g, const std::vector<const void *> &src, c
 		const int rc2 = g->rccl.GroupEnd();
 		if (herr != hipSuccess) return gfail(g, "exchange: %s", hipGetErrorString(herr));
 		if (rc || rc2) return gfail(g, "RCCL exchange: %s", g->rccl.GetErrorString(rc ? rc : rc2));
-		for (uint32_t r = 0; r < R; ++r) {
+		for (uint32_t r = 0; r < R && wait; ++r) {
 			GHIP(g, hipSetDevice(g->dev[r]));
 			GHIP(g, hipStreamSynchronize(g->xs[r]));
 		}
@@ -218,7 +278,7 @@ int all_gather_segments(mpcgpu_group *g, const std::vector<const void *> &src, c
 			if (!seg_bytes[r] || (d == r && in_place)) continue;
 			GHIP(g, hipMemcpyPeerAsync((char *)dst[d] + seg_off[r], g->dev[d], src[r], g->dev[r], seg_bytes[r], g->xs[r]));
 		}
-		GHIP(g, hipStreamSynchronize(g->xs[r]));
+		if (wait) GHIP(g, hipStreamSynchronize(g->xs[r]));
 		return 0;
 	});
 }
@@ -226,6 +286,37 @@ int all_gather_segments(mpcgpu_group *g, const std::vector<const void *> &src, c
 } // namespace
 
 extern "C" {
+
+int mpcgpu_plan_partition(uint32_t n, const uint32_t *lens, uint32_t world, uint32_t max_rects, uint32_t *rects, uint32_t *nrects,
+	uint64_t *rank_pos)
+{
+	if (!lens || !nrects || !rank_pos || world == 0 || n < 2) return 1;
+	const std::vector<uint32_t> len(lens, lens + n);
+	std::vector<std::vector<PlanRect>> per_rank;
+	const char *mode = getenv("MPCGPU_PARTITION"); // "contiguous": the contiguous InitPairs ranges of rounds 1-5 (A/B, tests)
+	if ((mode && !strcmp(mode, "contiguous")) || !plan_blocks(len, world, per_rank)) {
+		std::vector<uint64_t> cuts;
+		shard_bounds(len, world, cuts);
+		*nrects = 0;
+		for (uint32_t r = 0; r <= world; ++r) rank_pos[r] = cuts[r];
+		return 0;
+	}
+	uint32_t nr = 0;
+	uint64_t pos = 0;
+	for (uint32_t r = 0; r < world; ++r) {
+		rank_pos[r] = pos;
+		for (const PlanRect &q : per_rank[r]) {
+			if (rect_pairs(q) == 0) continue;
+			if (nr >= max_rects || !rects) return 2; // the caller's array is too small
+			rects[4 * nr] = q.xa; rects[4 * nr + 1] = q.xb; rects[4 * nr + 2] = q.ya; rects[4 * nr + 3] = q.yb;
+			++nr;
+			pos += rect_pairs(q);
+		}
+	}
+	rank_pos[world] = pos;
+	*nrects = nr;
+	return pos == (uint64_t)n * (n - 1) / 2 ? 0 : 3;
+}
 
 const char *mpcgpu_group_last_error(const mpcgpu_group *g) { return g ? g->err.c_str() : g_group_create_err.c_str(); }
 uint32_t mpcgpu_group_size(const mpcgpu_group *g) { return g ? (uint32_t)g->ctx.size() : 0; }
@@ -331,47 +422,107 @@ int mpcgpu_group_calc_posteriors(mpcgpu_group *g)
 	if (g->n < 2) return gfail(g, "mpcgpu_group_calc_posteriors: call mpcgpu_group_set_seqs first");
 	const uint32_t R = (uint32_t)g->ctx.size();
 	g->have_store = false;
-	std::vector<uint64_t> cuts;
-	shard_bounds(g->len, R, cuts);
-	g->k0.assign(cuts.begin(), cuts.end() - 1);
-	g->k1.assign(cuts.begin() + 1, cuts.end());
+	// ---- the partition: blocks of the pair triangle (mpcgpu_plan_partition), every context enumerates its pairs rank by rank
+	std::vector<uint32_t> rects(4 * (size_t)(R * (R / 2 + 3) + 4));
+	std::vector<uint64_t> pos(R + 1, 0);
+	uint32_t nrects = 0;
+	if (mpcgpu_plan_partition(g->n, g->len.data(), R, (uint32_t)(rects.size() / 4), rects.data(), &nrects, pos.data()))
+		return gfail(g, "mpcgpu_group_calc_posteriors: no partition of %u sequences over %u ranks", g->n, R);
+	g->k0.assign(pos.begin(), pos.end() - 1);
+	g->k1.assign(pos.begin() + 1, pos.end());
+	for (uint32_t r = 0; r < R; ++r)
+		if (mpcgpu_set_pair_order(g->ctx[r], nrects, rects.data())) return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
 	if (R == 1) { // nothing to exchange
 		if (mpcgpu_calc_posteriors(g->ctx[0], g->k0[0], g->k1[0]) || mpcgpu_build_store(g->ctx[0]))
 			return gfail(g, "%s", mpcgpu_last_error(g->ctx[0]));
 		g->have_store = true;
 		return 0;
 	}
-	// ---- stage A on every device's shard
-	std::vector<uint64_t> bytes(R, 0);
-	std::vector<const void *> src(R, nullptr);
-	int rc = per_rank(g, [&](uint32_t r) -> int {
-		void *p = nullptr;
-		if (mpcgpu_calc_posteriors(g->ctx[r], g->k0[r], g->k1[r]) || mpcgpu_shard_info(g->ctx[r], &bytes[r], &p) ||
-			mpcgpu_synchronize(g->ctx[r]))
-			return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
-		src[r] = p;
-		return 0;
-	});
-	if (rc) return rc;
-	// ---- all-gather of the packed shards: every device gets [shard 0 | shard 1 | ...]
-	std::vector<uint64_t> off(R, 0);
-	uint64_t total = 0;
-	for (uint32_t r = 0; r < R; ++r) { off[r] = total; total += bytes[r]; }
-	for (uint32_t r = 0; r < R; ++r) {
-		GHIP(g, hipSetDevice(g->dev[r]));
-		if (g->gcap[r] < total) {
-			if (g->gbuf[r]) GHIP(g, hipFree(g->gbuf[r]));
-			g->gbuf[r] = nullptr; g->gcap[r] = 0;
-			GHIP(g, hipMalloc(&g->gbuf[r], total + total / 16 + 256));
-			g->gcap[r] = total + total / 16 + 256;
+	// ---- stage A in PIECES (MPCGPU_GROUP_PIECES, default 1: at 8 ranks two pieces cost more stage-A time — small launches of fb_chain_kernel — than the exchange they hide, profiles/r12b): a rank's range is cut by DP cells, and the all-gather of piece p
+	// travels (exchange streams) while piece p + 1 is computed (library streams) — only the last piece's exchange is exposed
+	const uint32_t P = (uint32_t)std::min(std::max(getenv("MPCGPU_GROUP_PIECES") ? atoi(getenv("MPCGPU_GROUP_PIECES")) : 1, 1), 16);
+	std::vector<uint64_t> cutp((size_t)R * (P + 1), 0); // cutp[r * (P + 1) + p]: first position of piece p of rank r
+	{
+		// DP cells per position, in position order: the pairs of the rectangles (or InitPairs order)
+		std::vector<uint64_t> cum(1, 0);
+		cum.reserve((size_t)g->n * (g->n - 1) / 2 + 1);
+		auto add = [&](uint32_t x, uint32_t y) { cum.push_back(cum.back() + (uint64_t)(g->len[x] + 1) * (g->len[y] + 1)); };
+		if (!nrects) { for (uint32_t i = 0; i < g->n; ++i) for (uint32_t j = i + 1; j < g->n; ++j) add(i, j); }
+		else
+			for (uint32_t q = 0; q < nrects; ++q) {
+				const uint32_t xa = rects[4 * q], xb = rects[4 * q + 1], ya = rects[4 * q + 2], yb = rects[4 * q + 3];
+				for (uint32_t x = xa; x < xb; ++x) for (uint32_t y = ya >= xb ? ya : x + 1; y < yb; ++y) add(x, y);
+			}
+		for (uint32_t r = 0; r < R; ++r) {
+			uint64_t *cp = &cutp[(size_t)r * (P + 1)];
+			cp[0] = g->k0[r]; cp[P] = g->k1[r];
+			for (uint32_t p = 1; p < P; ++p) {
+				const uint64_t target = cum[g->k0[r]] + (cum[g->k1[r]] - cum[g->k0[r]]) * p / P;
+				cp[p] = (uint64_t)(std::lower_bound(cum.begin() + g->k0[r], cum.begin() + g->k1[r] + 1, target) - cum.begin());
+				cp[p] = std::min(std::max(cp[p], cp[p - 1]), g->k1[r]);
+			}
 		}
 	}
-	std::vector<void *> dst(g->gbuf.begin(), g->gbuf.end());
-	rc = all_gather_segments(g, src, dst, off, bytes, false);
+	std::vector<uint64_t> sk0, sk1, sbytes, soff; // the shards as they lie in every rank's gather buffer: piece after piece, rank after rank
+	uint64_t total = 0;
+	bool pending = false; // an exchange is in flight on the exchange streams
+	auto finish_exchange = [&]() -> int {
+		if (!pending) return 0;
+		pending = false;
+		for (uint32_t r = 0; r < R; ++r) { GHIP(g, hipSetDevice(g->dev[r])); GHIP(g, hipStreamSynchronize(g->xs[r])); }
+		return 0;
+	};
+	for (uint32_t p = 0; p < P; ++p) {
+		std::vector<uint64_t> bytes(R, 0);
+		std::vector<const void *> src(R, nullptr);
+		int rc = per_rank(g, [&](uint32_t r) -> int {
+			void *ptr = nullptr;
+			const uint64_t *cp = &cutp[(size_t)r * (P + 1)];
+			if (mpcgpu_calc_posteriors(g->ctx[r], cp[p], cp[p + 1]) || mpcgpu_shard_info(g->ctx[r], &bytes[r], &ptr) || mpcgpu_synchronize(g->ctx[r]))
+				return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
+			src[r] = ptr;
+			return 0;
+		});
+		if (rc) return rc;
+		uint64_t piece = 0;
+		std::vector<uint64_t> off(R, 0);
+		for (uint32_t r = 0; r < R; ++r) { off[r] = total + piece; piece += (bytes[r] + 15) & ~15ull; }
+		// room for this piece and, by its size, for the ones to come (a buffer that turns out too small is replaced: its content is copied)
+		const uint64_t want = total + piece, guess = total + piece * (P - p) + (piece * (P - p)) / 8 + 4096;
+		for (uint32_t r = 0; r < R; ++r) {
+			if (g->gcap[r] >= want) continue;
+			if ((rc = finish_exchange())) return rc;
+			GHIP(g, hipSetDevice(g->dev[r]));
+			void *nb = nullptr;
+			GHIP(g, hipMalloc(&nb, guess));
+			if (g->gbuf[r] && total) GHIP(g, hipMemcpy(nb, g->gbuf[r], total, hipMemcpyDeviceToDevice));
+			if (g->gbuf[r]) GHIP(g, hipFree(g->gbuf[r]));
+			g->gbuf[r] = nb; g->gcap[r] = guess;
+		}
+		// the own piece leaves the context's shard buffer now (the next stage A overwrites it): a device-local copy on the exchange
+		// stream, then the sends read the gather buffer
+		if ((rc = finish_exchange())) return rc;
+		for (uint32_t r = 0; r < R; ++r) {
+			GHIP(g, hipSetDevice(g->dev[r]));
+			if (bytes[r]) GHIP(g, hipMemcpyAsync((char *)g->gbuf[r] + off[r], src[r], bytes[r], hipMemcpyDeviceToDevice, g->xs[r]));
+			GHIP(g, hipStreamSynchronize(g->xs[r]));
+			src[r] = (const char *)g->gbuf[r] + off[r];
+		}
+		std::vector<void *> dst(g->gbuf.begin(), g->gbuf.end());
+		rc = all_gather_segments(g, src, dst, off, bytes, true, false);
+		if (rc) return rc;
+		pending = true;
+		for (uint32_t r = 0; r < R; ++r) {
+			const uint64_t *cp = &cutp[(size_t)r * (P + 1)];
+			sk0.push_back(cp[p]); sk1.push_back(cp[p + 1]); sbytes.push_back(bytes[r]); soff.push_back(off[r]);
+		}
+		total += piece;
+	}
+	int rc = finish_exchange();
 	if (rc) return rc;
-	// ---- every device builds its store from the gathered shards
+	// ---- every device builds its store from the gathered shards: the records of the sequences its own pairs touch
 	rc = per_rank(g, [&](uint32_t r) -> int {
-		if (mpcgpu_store_import(g->ctx[r], R, g->k0.data(), g->k1.data(), bytes.data(), g->gbuf[r]))
+		if (mpcgpu_store_import_part(g->ctx[r], (uint32_t)sk0.size(), sk0.data(), sk1.data(), sbytes.data(), soff.data(), g->gbuf[r], g->k0[r], g->k1[r]))
 			return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
 		return 0;
 	});

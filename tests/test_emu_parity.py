@@ -462,6 +462,52 @@ def test_emu_group_of_contexts(nctx):
     grp.close()
 
 
+@pytest.mark.parametrize("nctx,n,pieces", [(3, 12, 2), (4, 16, 3), (8, 16, 2), (5, 20, 1)])
+def test_emu_group_block_partition_partial_stores(nctx, n, pieces, monkeypatch):
+    """The block partition with real kernels: every context owns blocks of the pair triangle, enumerates the pairs
+    block by block, runs stage A in pieces, imports the shards piece by piece and builds a PARTIAL store (the records of its
+    blocks' sequences only). After every stage every rank's packed matrices — read back in InitPairs order — equal the oracle's;
+    afterwards BuildPost on rank 0 (which completes its store first) equals BuildPost on a single context."""
+    from muscle_amd._lib import MpcGroup, MpcGpu, plan_partition
+    monkeypatch.setenv("MPCGPU_GROUP_PIECES", str(pieces))
+    seqs = make_family(n - 3, 44, seed=5) + make_family(3, 70, seed=6)
+    rects, pos = plan_partition([len(s) for s in seqs], nctx, EMU_LIB)
+    assert len(rects) > 0  # blocks, not the contiguous fallback
+    want = P.run_oracle(seqs)
+    grp = MpcGroup([0] * nctx, EMU_LIB)
+    grp.set_hmm(*G.hmm_tables())
+    grp.set_seqs(seqs)
+    grp.calc_posteriors()
+    views = [grp.ctx(r) for r in range(nctx)]
+    st = [[v.get_sparse_range()] for v in views]
+    ea = [v.get_ea().copy() for v in views]
+    for _ in range(2):
+        grp.cons_iter()
+        for r, v in enumerate(views):
+            st[r].append(v.get_sparse_range())
+    for r in range(nctx):
+        P.assert_same((st[r], ea[r]), want, "block partition over %d, rank %d" % (nctx, r))
+    # a join on rank 0's (partial, then completed) store against the same join on one context
+    one = MpcGpu(0, EMU_LIB)
+    one.set_hmm(*G.hmm_tables())
+    one.set_seqs(seqs)
+    one.calc_posteriors()
+    one.build_store()
+    for _ in range(2):
+        one.cons_iter()
+        one.cons_commit()
+    s1, s2 = [0, n - 1, 3], [5, 1, n - 2, 7]
+    p2c1 = [np.arange(len(seqs[i]), dtype=np.uint32) for i in s1]
+    p2c2 = [np.arange(len(seqs[i]), dtype=np.uint32) for i in s2]
+    C1, C2 = max(len(seqs[i]) for i in s1), max(len(seqs[i]) for i in s2)
+    a = views[0].build_post(s1, s2, p2c1, p2c2, C1, C2)
+    b = one.build_post(s1, s2, p2c1, p2c2, C1, C2)
+    assert np.array_equal(P.bits(a.ravel()), P.bits(b.ravel()))
+    one.close()
+    del views
+    grp.close()
+
+
 @pytest.mark.parametrize("n,nctx", [(3, 4), (2, 2), (4, 3)])
 def test_emu_group_more_contexts_than_work(n, nctx):
     """mpcgpu_group_* when shards are empty or tiny (more contexts than pairs; two sequences: no consistency stage)"""
