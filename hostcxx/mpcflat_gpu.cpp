@@ -300,8 +300,29 @@ bool DebugOn()
 // MUSCLE_GPU_TIMING=1: wall time spent inside the replaced functions, printed at exit (where does an
 // end-to-end run spend its time once the stage itself takes a few seconds).
 enum { T_STAGE_A, T_CONS_ITER, T_ALN_PREP, T_ALN_LIB, T_ALN_POST, T_JOIN_PREP, T_JOIN_LIB, T_PAIRS_PREP, T_PAIRS_LIB, T_COUNT };
-double g_Seconds[T_COUNT];
-unsigned long long g_Calls[T_COUNT];
+// (atomics: the shrub and join workers of -super7 stop their watches concurrently — round-5 advisor finding)
+std::atomic<unsigned long long> g_Nanos[T_COUNT];
+std::atomic<unsigned long long> g_Calls[T_COUNT];
+// The timeline of ONE MPCFlat::Run (muscle -align): when the replaced functions were entered first / left last, in ns since process
+// start. What lies BETWEEN them is the reference's own host code — the row f4 of SURVEY.md 8 (CalcGuideTree = UPGMA5,
+// upgma5.cpp:87-..., ClustalWeights, CalcJoinOrder, the bookkeeping of ProgAln / RefineIter, SortMSA, output) — which this file does
+// not replace and could not time from inside.
+enum { M_POST_ENTER, M_POST_EXIT, M_CONS_ENTER, M_CONS_EXIT, M_ALN_ENTER, M_ALN_EXIT, M_COUNT };
+std::atomic<unsigned long long> g_Mark[M_COUNT];
+bool TimingOn();
+void PhaseMark(int Which, bool First)
+	{
+	if (!TimingOn())
+		return;
+	const unsigned long long t = (unsigned long long) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - g_ProcessStart).count() + 1;
+	unsigned long long Old = g_Mark[Which].load();
+	if (First)
+		{
+		while (Old == 0 && !g_Mark[Which].compare_exchange_weak(Old, t)) {}
+		}
+	else
+		g_Mark[Which].store(t);
+	}
 bool TimingOn()
 	{
 	static int On = -1;
@@ -319,7 +340,29 @@ bool TimingOn()
 				  "process", std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count());
 				fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  (inside the first call below that needed it)\n", "context creation, HIP init", g_CtxSeconds);
 				for (int i = 0; i < T_COUNT; ++i)
-					fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  %8llu calls\n", Names[i], g_Seconds[i], g_Calls[i]);
+					fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  %8llu calls\n", Names[i], g_Nanos[i].load()*1e-9, g_Calls[i].load());
+				if (g_Mark[M_POST_ENTER].load() != 0)
+					{
+					const double End = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count();
+					auto At = [](int m) { return g_Mark[m].load()*1e-9; };
+					fprintf(stderr, "[muscle_gpu] timeline of the first MPCFlat::Run (s since process start; the gaps are the REFERENCE's host code, SURVEY.md 8 row f4):\n");
+					fprintf(stderr, "[muscle_gpu]   %8.3f  start .. CalcPosteriors entered: options, input, Derep, InitSeqs / InitPairs / InitDistMx   %7.3f s\n", At(M_POST_ENTER), At(M_POST_ENTER));
+					fprintf(stderr, "[muscle_gpu]   %8.3f  CalcPosteriors (replaced)                                                                   %7.3f s\n", At(M_POST_EXIT), At(M_POST_EXIT) - At(M_POST_ENTER));
+					if (g_Mark[M_CONS_ENTER].load() != 0)
+						{
+						fprintf(stderr, "[muscle_gpu]   %8.3f  .. first ConsIter: CalcGuideTree = UPGMA5 (upgma5.cpp) + PermTree + ClustalWeights                %7.3f s\n", At(M_CONS_ENTER), At(M_CONS_ENTER) - At(M_POST_EXIT));
+						fprintf(stderr, "[muscle_gpu]   %8.3f  ConsIter x n (replaced; queues the relax, does not wait for it)                              %7.3f s\n", At(M_CONS_EXIT), At(M_CONS_EXIT) - At(M_CONS_ENTER));
+						}
+					if (g_Mark[M_ALN_ENTER].load() != 0)
+						{
+						const double From = g_Mark[M_CONS_EXIT].load() != 0 ? At(M_CONS_EXIT) : At(M_POST_EXIT);
+						fprintf(stderr, "[muscle_gpu]   %8.3f  .. first AlignAlns: CalcJoinOrder, ProgressiveAlign's leaf MSAs                                  %7.3f s\n", At(M_ALN_ENTER), At(M_ALN_ENTER) - From);
+						const double In = (g_Nanos[T_ALN_PREP].load() + g_Nanos[T_ALN_LIB].load() + g_Nanos[T_ALN_POST].load())*1e-9;
+						fprintf(stderr, "[muscle_gpu]   %8.3f  first .. last AlignAlns: %.3f s inside the calls (rows above), between them ProgAln / RefineIter: rand(), Project, delete   %7.3f s\n",
+						  At(M_ALN_EXIT), In, At(M_ALN_EXIT) - At(M_ALN_ENTER) - In);
+						fprintf(stderr, "[muscle_gpu]   %8.3f  .. exit handlers: SortMSA, InsertDupes, output                                                   %7.3f s\n", End, End - At(M_ALN_EXIT));
+						}
+					}
 // device time per kernel family of the library (hipEvents on its stream): where the library seconds above go
 				static const char *Fam[MPCGPU_NKERNELS] = { "fwd/bwd", "posterior finish", "store build", "relax", "commit",
 				  "BuildPost: records", "BuildPost: sort", "BuildPost: reduce", "CalcAlnFlat+traceback" };
@@ -332,6 +375,7 @@ bool TimingOn()
 		}
 	return On == 1;
 	}
+const bool g_TimingAtStart = TimingOn(); // (decided during static initialisation: before any worker thread can race for the lazy static)
 struct Stopwatch
 	{
 	int m_Slot;
@@ -347,7 +391,7 @@ struct Stopwatch
 		{
 		if (m_Slot < 0 || !TimingOn())
 			return;
-		g_Seconds[m_Slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - m_T0).count();
+		g_Nanos[m_Slot] += (unsigned long long) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - m_T0).count();
 		++g_Calls[m_Slot];
 		m_Slot = -1;
 		}
@@ -574,11 +618,13 @@ void MPCFlat::CalcPosteriors()
 	{
 	const uint PairCount = SIZE(m_Pairs);
 	asserta(PairCount > 0);
+	PhaseMark(M_POST_ENTER, true);
 	for (uint PairIndex = 0; PairIndex < PairCount; ++PairIndex)
 		{
 		ProgressStep(PairIndex, PairCount, "Calc posteriors");
 		CalcPosterior(PairIndex);
 		}
+	PhaseMark(M_POST_EXIT, false);
 	}
 
 void MPCFlat::CalcPosterior(uint PairIndex)
@@ -632,6 +678,8 @@ void MPCFlat::ConsIter(uint Iter)
 	uint PairCount = SIZE(m_Pairs);
 	asserta(PairCount > 0);
 	ProgressStep(0, 1, "Consistency (%u/%u)", Iter+1, m_ConsistencyIterCount);
+	PhaseMark(M_CONS_ENTER, true);
+	struct ExitMark { ~ExitMark() { PhaseMark(M_CONS_EXIT, false); } } MarkAtExit;
 	Stopwatch SW(T_CONS_ITER);
 		{
 		const int SlotIndex = SlotIndexOf(this);
@@ -719,6 +767,8 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 	const uint SeqCount2 = MSA2.GetSeqCount();
 	const uint ColCount1 = MSA1.GetColCount();
 	const uint ColCount2 = MSA2.GetColCount();
+	PhaseMark(M_ALN_ENTER, true);
+	struct ExitMark { ~ExitMark() { PhaseMark(M_ALN_EXIT, false); } } MarkAtExit;
 
 // alnalnsflat.cpp:16-20
 	const uint SeqCount = GetSeqCount();
@@ -1305,8 +1355,10 @@ void Super7::IntraAlignShrubs()
 			{
 // (.mega inputs: the profiles are process-wide statics found by label, Mega::GetProfileByLabel — read-only here — and which emissions
 // a run takes is decided by Mega::m_Loaded (calcpost.cpp:14-22, SetMega above); the object is an MPCFlat_mega as in the reference's loop)
-			std::unique_ptr<MPCFlat> LocalObj(IsMega ? (MPCFlat *) new MPCFlat_mega : new MPCFlat);
-			MPCFlat &Local = *LocalObj;
+// (two owners of exact type: ~MPCFlat is not virtual, mpcflat.h:52 — deleting an MPCFlat_mega through an MPCFlat pointer is undefined)
+			std::unique_ptr<MPCFlat_mega> LocalMega(IsMega ? new MPCFlat_mega : 0);
+			std::unique_ptr<MPCFlat> LocalPlain(IsMega ? 0 : new MPCFlat);
+			MPCFlat &Local = IsMega ? (MPCFlat &) *LocalMega : *LocalPlain;
 			Local.m_ConsistencyIterCount = m_MPC->m_ConsistencyIterCount;
 			Local.m_RefineIterCount = m_MPC->m_RefineIterCount;
 			Local.m_D.m_Disable = m_MPC->m_D.m_Disable; // super7.cpp:11

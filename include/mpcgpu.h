@@ -307,6 +307,11 @@ int mpcgpu_work_get(mpcgpu_ctx *ctx, uint64_t *dp_cells, uint64_t *relax_entry_z
  * ran as members of chains (consecutive pairs with the same row sequence swept back to back by one wavefront, no systolic
  * fill/drain in between: kernels_fbc.h), and the number of chains. Same cells, same results; MPCGPU_FB_CHAIN=0 turns chains off. */
 int mpcgpu_stage_a_info(mpcgpu_ctx *ctx, uint64_t *pairs, uint64_t *chained_pairs, uint64_t *chains);
+/* Sizes of the current store, for the measurement's lower bounds (bench.py: min_bytes_per_launch): out[0] bytes of the row-indexed
+ * block records, out[1] of the window records (0: not built), out[2] of the packed matrices of all pairs, out[3] stored posteriors
+ * of all pairs, out[4] of the pairs this context relaxes, out[5] sequences whose records the store holds (all of them unless the
+ * store is partial: mpcgpu_store_import_part). */
+int mpcgpu_store_info(mpcgpu_ctx *ctx, uint64_t out[6]);
 int mpcgpu_synchronize(mpcgpu_ctx *ctx);
 /* Which store layout and relax kernel the current store uses, in words (record sizes, workgroup geometry, the tile shapes
  * once a relax iteration has built them), and whether that is a FALLBACK this build chose because the run exceeds the default

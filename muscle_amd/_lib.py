@@ -21,7 +21,7 @@ SYMBOLS = [
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_cons_commit_range", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
     "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_align_pairs", "mpcgpu_get_list_sparse", "mpcgpu_stage_a_info", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info", "mpcgpu_shard_entries",
-    "mpcgpu_set_pair_order", "mpcgpu_pair_position", "mpcgpu_plan_partition", "mpcgpu_store_import_part", "mpcgpu_store_complete",
+    "mpcgpu_set_pair_order", "mpcgpu_pair_position", "mpcgpu_plan_partition", "mpcgpu_store_import_part", "mpcgpu_store_complete", "mpcgpu_store_info",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
     "mpcgpu_group_calc_posteriors", "mpcgpu_group_cons_iter",
@@ -69,6 +69,7 @@ def load(lib_path=None):
     L.mpcgpu_plan_partition.argtypes = [u32, vp, u32, u32, vp, C.POINTER(u32), vp]
     L.mpcgpu_store_import_part.argtypes = [vp, u32, vp, vp, vp, vp, vp, u64, u64]
     L.mpcgpu_store_complete.argtypes = [vp]
+    L.mpcgpu_store_info.argtypes = [vp, vp]
     L.mpcgpu_values_slice.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(u64)]
     L.mpcgpu_cons_iter.argtypes = [vp, u64, u64]
     L.mpcgpu_cons_commit.argtypes = [vp]
@@ -324,6 +325,12 @@ class MpcGpu:
         o = None if offsets is None else np.ascontiguousarray(offsets, np.uint64)
         self._ck(self.L.mpcgpu_store_import_part(self.h, len(a), a.ctypes.data, b.ctypes.data, c.ctypes.data,
                                                  None if o is None else o.ctypes.data, dev_ptr, own_k0, own_k1))
+
+    def store_info(self):
+        """sizes of the current store (include/mpcgpu.h: mpcgpu_store_info)"""
+        o = np.zeros(6, np.uint64)
+        self._ck(self.L.mpcgpu_store_info(self.h, o.ctypes.data))
+        return dict(zip(("record_bytes", "window_bytes", "packed_bytes", "entries", "own_entries", "sequences_held"), (int(x) for x in o)))
 
     def store_complete(self):
         self._ck(self.L.mpcgpu_store_complete(self.h))

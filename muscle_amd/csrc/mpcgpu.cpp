@@ -175,7 +175,7 @@ struct mpcgpu_ctx {
 	bool band_ok = false;      // the band tables exist for this store
 	bool var_pairs_ok = true;  // every pair's two whole records fit a tile of relax_var_kernel (else: band tiles or nothing)
 	u32 band_nb1 = 0;
-	DevBuf d_ovf_off, d_cell_off, d_yr, d_ovf_sum, d_ovf_maxc, d_btiles, d_bt_out, d_bt_cand, d_bt_count, d_bt_list;
+	DevBuf d_ovf_off, d_cell_off, d_yr, d_ovf_sum, d_ovf_maxc, d_btiles, d_bt_out, d_bt_count, d_bt_list;
 	std::vector<u32> h_btiles;
 	u64 btiles_k0 = ~0ull, btiles_k1 = ~0ull;
 	bool win_ok = false;       // window records exist for this store (the direct-index merge: kernels_relaxb.h)
@@ -213,7 +213,8 @@ struct mpcgpu_ctx {
 	// invalidation by EVICTING and later restoring the process's queues: the next dispatch starts 10 - 30 ms late. Measured with
 	// in-kernel clocks (profiles/r10k_rank_time.log): the first kernel after the store build ran 12 - 27 ms after its launch in some
 	// processes, every or every other step — the 4 MB offset tables of build_var_store died at its return. (Telling the allocator
-	// to keep everything mapped — mallopt — removes it too, but slows the reference's own host code down: -align 4.37 -> 4.62 s.)
+	// to keep everything mapped — mallopt — removes it too; the library leaves the allocator to its host program, the drop-in binary
+	// sets it: no cost to -align, profiles/r11i_align_malloc_ab.log.)
 	std::vector<u32> v_flags;               // stage A: per-pair flags of a batch as they are read back
 	std::vector<u64> v_dstbase, v_recw;     // stage A: where a batch's records go in the shard
 	std::vector<u8> v_shdr;                 // stage A: the shard's header as it is uploaded
@@ -340,9 +341,11 @@ void ensure_dyn_smem(const void *fn, size_t smem)
 {
 	if (smem <= 64u * 1024u) return;
 	static std::mutex mu;
-	static std::map<const void *, size_t> have;
+	static std::map<std::pair<int, const void *>, size_t> have; // the attribute is per DEVICE and function (several devices in one process: mpcgpu_group, MUSCLE_GPU_DEVICES)
 	std::lock_guard<std::mutex> lk(mu);
-	size_t &h = have[fn];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+	size_t &h = have[std::make_pair(dev, fn)];
 	if (h >= smem) return;
 	if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess) h = smem;
 	else (void)hipGetLastError();
@@ -1801,7 +1804,11 @@ static int stage_a(mpcgpu_ctx *c, u64 np, const u32 *px, const u32 *py)
 	if (chain_on) {
 		size_t freeb = 0, totb = 0;
 		HIPCHK(c, hipMemGetInfo(&freeb, &totb));
-		const u64 fm_budget = std::min<u64>((u64)32 << 30, (u64)((freeb + c->d_fm.cap) * 0.25));
+		// (a quarter of what is free, 32 GB at most — and no more than MPCGPU_SCRATCH_GB where that is set: several contexts on one
+		// device, e.g. the eight of tests/test_gpu_parity.py::test_group_of_eight_contexts_config3_digests, each see the same free memory)
+		const char *scratch_set = getenv("MPCGPU_SCRATCH_GB");
+		const u64 fm_budget = std::min<u64>(std::min<u64>((u64)32 << 30, (scratch_set && *scratch_set) ? (u64)std::max(atoi(scratch_set), 1) << 30 : ~0ull),
+			(u64)((freeb + c->d_fm.cap) * 0.25));
 		for (u32 H = 1; H <= MPC_HMAX; ++H) {
 			const u64 waves = (u64)cus * (u32)occ_fbc_h((int)H, block, fbc_smem) * waves_per_block;
 			const u64 steps = fm_budget / (waves * H * 64 * 4);
@@ -3354,9 +3361,17 @@ int mpcgpu_get_list_sparse(mpcgpu_ctx *c, uint32_t q, uint32_t *nnz, uint32_t *o
 			inside = c->sa_b0 == 0 && c->sa_B == lx.size(); // (split into batches: the shard holds the last batch only)
 		}
 		if (!inside) {
-			const u32 x = c->ap_x[q], y = c->ap_y[q];
-			if (stage_a(c, 1, &x, &y)) return 1;
-			c->list_q0 = q;
+			// the whole chunk that holds q is staged again and stays resident (a caller that reads q = 0, 1, 2 ... in order pays one stage
+			// per 256 pairs, not one per pair: round-5 advisor finding); a chunk that stage A has to split falls back to the single pair
+			const u32 q0 = (q / 256u) * 256u, nq = (u32)std::min<size_t>(256u, c->ap_x.size() - q0);
+			const std::vector<u32> lx(c->ap_x.begin() + q0, c->ap_x.begin() + q0 + nq), ly(c->ap_y.begin() + q0, c->ap_y.begin() + q0 + nq);
+			if (stage_a(c, nq, lx.data(), ly.data())) return 1;
+			c->list_q0 = q0;
+			if (!(c->sa_b0 == 0 && c->sa_B == nq)) {
+				const u32 x = c->ap_x[q], y = c->ap_y[q];
+				if (stage_a(c, 1, &x, &y)) return 1;
+				c->list_q0 = q;
+			}
 		}
 		ql = q - c->list_q0;
 	}
@@ -3390,6 +3405,23 @@ int mpcgpu_relax_info(mpcgpu_ctx *c, char *buf, uint32_t buflen, int *is_fallbac
 		snprintf(buf, buflen, "%s", d.c_str());
 	}
 	if (is_fallback) *is_fallback = c->relax_fallback ? 1 : 0;
+	return 0;
+}
+
+int mpcgpu_store_info(mpcgpu_ctx *c, uint64_t out[6])
+{
+	if (!c) return 1;
+	if (!c->have_store) return fail(c, "mpcgpu_store_info: no store");
+	u64 packed_words = 0;
+	for (u64 k = 0; k < c->npairs; ++k) packed_words += rec_words(c->len[c->h_pair_x[k]], c->len[c->h_pair_y[k]], c->all_nnz[k]);
+	out[0] = c->have_pad ? c->var_total_blocks * 16 : 0;                 // block records (both orientations of every pair this store holds)
+	out[1] = (c->have_pad && c->win_ok) ? c->win_total_blocks * 16 : 0;  // window records
+	out[2] = packed_words * 4;                                           // packed records of all pairs
+	out[3] = c->total_entries;                                           // stored posteriors of all pairs
+	out[4] = c->h_vbase[c->own_k1] - c->h_vbase[c->own_k0];              // ... of the pairs this context relaxes
+	u32 held = 0;
+	for (u32 i = 0; i < c->n; ++i) held += (!c->partial || c->need[i]) ? 1u : 0u;
+	out[5] = held;                                                       // sequences whose records the store holds
 	return 0;
 }
 

@@ -296,3 +296,23 @@ def check_align_pairs_chunked(lib_path=None):
         assert res[q][0] == path and bits(res[q][1]) == bits(sc) and bits(res[q][2]) == bits(ea), q
         assert np.array_equal(sp[q][0], off) and np.array_equal(sp[q][1], val), (q, a, b)
     g.close()
+
+
+def check_full_alphabet(lib_path=None, n=5, length=64, seed=11):
+    """Stage A + relax on sequences that use 127 distinct seven-bit byte values: the compacted emission tables are then
+    (127 * 127 + 127) floats = 65 KB of LDS — beyond the 64 KB a kernel gets without asking (mpcgpu.cpp: ensure_dyn_smem, per device
+    and function: round-5 advisor finding) — against the oracle, bit for bit."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(1, 128, size=length)
+    seqs = []
+    for _ in range(n):
+        s = base.copy()
+        flip = rng.random(length) < 0.25
+        s[flip] = rng.integers(1, 128, size=int(flip.sum()))
+        seqs.append(bytes(s.astype(np.uint8)))
+    seqs[0] = bytes(range(1, 128))[:length] + seqs[0][length // 2:]  # every value 1..127 occurs somewhere
+    seqs[1] = bytes(range(127, 0, -1))[:127 - length] + seqs[1][:length // 2] if length < 127 else seqs[1]
+    assert len(set(b"".join(seqs))) >= 120
+    got = run_lib(seqs, lib_path=lib_path)
+    want = run_oracle(seqs)
+    assert_same(got, want, "127-letter alphabet")

@@ -219,6 +219,7 @@ struct hipDeviceProp_t { int multiProcessorCount; size_t totalGlobalMem; char na
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emu error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { if (d) *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
 {

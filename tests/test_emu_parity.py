@@ -306,6 +306,11 @@ def test_emu_set_seqs_takes_every_seven_bit_byte(emu):
     g.close()
 
 
+def test_emu_full_alphabet_stage(emu):
+    """the whole stage over ~127 distinct byte values (65 KB of emission tables in LDS) == the oracle"""
+    P.check_full_alphabet(emu)
+
+
 def test_emu_mega_then_letters_on_one_context(emu):
     """set_seqs drops the profiles: the same context goes back to letter emissions"""
     from muscle_amd._lib import MpcGpu
