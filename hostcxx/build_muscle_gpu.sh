@@ -5,8 +5,9 @@
 # of the reference is copied into the repo, and the combined (GPL-3.0) binary is git-ignored; it
 # travels to the GPU box as a built artefact.
 #
-#   reference objects  - consflat.o, alnalnsflat.o, alnmsasflat.o, buildpostflat.o, alignpairflat.o  (MPCFlat::ConsIter,
-#                        MPCFlat::AlignAlns, PProg::AlignMSAsFlat, MPCFlat::BuildPost and AlignPairFlat(_SparsePost) are ours)
+#   reference objects  - consflat.o, alnalnsflat.o, alnmsasflat.o, buildpostflat.o, alignpairflat.o, refineflat.o  (MPCFlat::ConsIter,
+#                        MPCFlat::AlignAlns, PProg::AlignMSAsFlat, MPCFlat::BuildPost, AlignPairFlat(_SparsePost) and
+#                        MPCFlat::RefineIter — each alone in its translation unit in the reference — are ours)
 #                      - calcposteriorflat.o's CalcPosterior symbol, weakened with objcopy so that
 #                        hostcxx/mpcflat_gpu.cpp's strong definition wins while CalcPostFlat and the
 #                        two vestigial virtuals in the same object stay available; likewise one member each of
@@ -39,7 +40,7 @@ objcopy --weaken-symbol=_ZN6UClust6SearchEjRNSt7__cxx1112basic_stringIcSt11char_
 objcopy --weaken-symbol=_ZN5PProg4Run2ERKSt6vectorIjSaIjEES4_ "$REFOBJ/pprog2.o" "$OUT/pprog2_weak.o"
 # MPCFlat::CalcPosteriors: ours (a plain loop: the work of all pairs happens inside the first CalcPosterior call); the rest of mpcflat.o stays
 objcopy --weaken-symbol=_ZN7MPCFlat14CalcPosteriorsEv "$REFOBJ/mpcflat.o" "$OUT/mpcflat_weak.o"
-OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' -e '/uclust\.o$' -e '/alignpairflat\.o$' -e '/pprog2\.o$' -e '/mpcflat\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$')
+OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' -e '/uclust\.o$' -e '/alignpairflat\.o$' -e '/pprog2\.o$' -e '/mpcflat\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$' -e '/refineflat\.o$')
 # The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
 # MPCGPU_LIBDIR/MPCGPU_LIBNAME pointing at the SIMT-emulator build of the same library sources
 # (tests/emu, test infrastructure) to check the host-side plumbing of this file without a GPU.

@@ -67,6 +67,7 @@ struct Batch
 	bool m_Materialise = false; // host copies of the stage-A matrices are needed (no relax follows)
 	bool m_OnHost = false;	// the CURRENT device matrices have been copied into the MySparseMx objects
 	uint m_ItersDone = 0;	// ConsIter calls since the batch started
+	unsigned long long m_Gen = 0;	// which StartBatch this is (process-wide count): what state derived from the batch is checked against
 	vector<float> m_EA;	// what calcposteriorflat.cpp:89 stores in m_DistMx
 // what the batch was computed from: a caller that re-runs InitSeqs on the same MPCFlat object (cmd_profseq does, with a
 // fresh MPCFlat at the same stack address per query) must get a new batch, not the previous one's numbers
@@ -358,7 +359,7 @@ bool TimingOn()
 						const double From = g_Mark[M_CONS_EXIT].load() != 0 ? At(M_CONS_EXIT) : At(M_POST_EXIT);
 						fprintf(stderr, "[muscle_gpu]   %8.3f  .. first AlignAlns: CalcJoinOrder, ProgressiveAlign's leaf MSAs                                  %7.3f s\n", At(M_ALN_ENTER), At(M_ALN_ENTER) - From);
 						const double In = (g_Nanos[T_ALN_PREP].load() + g_Nanos[T_ALN_LIB].load() + g_Nanos[T_ALN_POST].load())*1e-9;
-						fprintf(stderr, "[muscle_gpu]   %8.3f  first .. last AlignAlns: %.3f s inside the calls (rows above), between them ProgAln / RefineIter: rand(), Project, delete   %7.3f s\n",
+						fprintf(stderr, "[muscle_gpu]   %8.3f  first .. last AlignAlns / RefineIter (replaced): %.3f s inside them (rows above), between them ProgAln's bookkeeping   %7.3f s\n",
 						  At(M_ALN_EXIT), In, At(M_ALN_EXIT) - At(M_ALN_ENTER) - In);
 						fprintf(stderr, "[muscle_gpu]   %8.3f  .. exit handlers: SortMSA, InsertDupes, output                                                   %7.3f s\n", End, End - At(M_ALN_EXIT));
 						}
@@ -530,6 +531,8 @@ void SetMega(mpcgpu_ctx *Ctx, const vector<string> &Labels, const vector<uint32_
 // First CalcPosterior call of a run: the whole all-pairs stage A on the device.
 void StartBatch(MPCFlat &M, Batch &B, int SlotIndex)
 	{
+	static std::atomic<unsigned long long> s_Gen(0);
+	B.m_Gen = ++s_Gen;
 	Stopwatch SW(T_STAGE_A);
 	mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
 	mpcgpu_group *Group = g_Slots[SlotIndex].m_Group;
@@ -847,6 +850,179 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 		result->AddSequence(AlignedRow, true);
 		}
 	return result;
+	}
+
+// MPCFlat::RefineIter (refineflat.cpp:4-31; its own translation unit in the reference, not linked here) on POSITION -> COLUMN MAPS.
+// The reference draws a bipartition of the rows with rand(), projects m_MSA onto either part (MultiSequence::Project, project.cpp:16-67:
+// a new character matrix per part, all-gap columns dropped), aligns the two with AlignAlns and joins them along the path
+// (Sequence::AddGapsPath per row). At 1000 rows x 600 columns that is ~9 ms of host work around an 8 ms device join, 100 times:
+// profiles/r12d_align_timeline.log has 0.64 s between the AlignAlns calls + 0.29 s inside them on maps and the result MSA.
+// The alignment is carried here as what the device wants anyway — per row its sequence and Sequence::GetPosToCol (sequence.cpp:144-154):
+//   projection    = rank of a column among the columns any row of the part occupies;
+//   join          = column of MSA1 / MSA2 column c in the merged alignment, read off the path (B: both advance, X: MSA1, Y: MSA2);
+//   rows          = the rows of part 1 in ascending row order, then those of part 2 (refineflat.cpp:13-17, alnalnsflat.cpp:36-50),
+// O(residues) per round; m_MSA is rebuilt from the maps after every round (a character matrix filled once), so it is valid whenever
+// anybody looks. The rand() calls are the reference's, one per row, in row order; the numeric part is mpcgpu_align_alns_w as in
+// MPCFlat::AlignAlns above. State is kept per MPCFlat object and checked against m_MSA's address and the posterior batch it belongs to.
+namespace
+{
+struct RefineState
+	{
+	const MultiSequence *m_MSA = 0;
+	unsigned long long m_BatchGen = 0;
+	uint m_ColCount = 0;
+	vector<uint32_t> m_Seq;			// row -> index in m_MyInputSeqs
+	vector<vector<uint32_t> > m_Map;	// row -> position -> column
+	vector<string> m_Letters;		// row -> its residues (the non-gap characters of the row)
+	};
+std::map<const MPCFlat *, RefineState> g_Refine;	// (guarded by g_MapMu)
+}
+
+void MPCFlat::RefineIter()
+	{
+	const uint SeqCount = GetSeqCount();
+	asserta(m_MSA != 0);
+	asserta(m_MSA->GetSeqCount() == SeqCount);
+	const int SlotIndex = SlotIndexOf(this);
+	Slot &S = g_Slots[SlotIndex];
+	RefineState *St;
+	unsigned long long Gen;
+		{
+		std::lock_guard<std::mutex> Guard(g_MapMu);
+		St = &g_Refine[this];
+		}
+		{
+		std::lock_guard<std::mutex> Guard(S.m_Mu);
+		Gen = BatchOf(this).m_Gen;
+		}
+	if (St->m_MSA != m_MSA || St->m_BatchGen != Gen || SIZE(St->m_Seq) != SeqCount)
+		{
+// (first round of a run, or somebody else put another alignment into m_MSA: the maps are read off it)
+		St->m_MSA = m_MSA;
+		St->m_BatchGen = Gen;
+		St->m_ColCount = m_MSA->GetColCount();
+		St->m_Seq.resize(SeqCount);
+		St->m_Map.resize(SeqCount);
+		St->m_Letters.resize(SeqCount);
+		vector<uint> PosToCol;
+		for (uint i = 0; i < SeqCount; ++i)
+			{
+			const Sequence *Row = m_MSA->GetSequence(i);
+			const uint SMI = GetMyInputSeqIndex(Row->m_Label);
+			asserta(SMI != UINT_MAX);
+			St->m_Seq[i] = SMI;
+			Row->GetPosToCol(PosToCol);
+			asserta(SIZE(PosToCol) == GetSeqLength(SMI));
+			St->m_Map[i].assign(PosToCol.begin(), PosToCol.end());
+			string &L = St->m_Letters[i];
+			L.clear();
+			for (uint k = 0; k < SIZE(PosToCol); ++k)
+				L.push_back(Row->m_CharVec[PosToCol[k]]);
+			}
+		}
+
+// create two separate groups (refineflat.cpp:12-17: one rand() per row, in row order)
+	vector<uint> Rows1, Rows2;
+	for (uint SeqIndex = 0; SeqIndex < SeqCount; SeqIndex++)
+		if (rand()%2 == 0)
+			Rows1.push_back(SeqIndex);
+		else
+			Rows2.push_back(SeqIndex);
+	if (Rows1.empty() || Rows2.empty())
+		return;
+
+	if (S.m_StoreOwner != this)
+		Die("GPU posterior stage: RefineIter on an MPCFlat whose posteriors are not the ones on the device");
+	PhaseMark(M_ALN_ENTER, true);
+	struct ExitMark { ~ExitMark() { PhaseMark(M_ALN_EXIT, false); } } MarkAtExit;
+	Stopwatch SW(T_ALN_PREP);
+	const uint OldColCount = St->m_ColCount;
+// MultiSequence::Project (project.cpp:40-64): the columns that are not all gaps keep their order
+	vector<uint32_t> Rank1(OldColCount, 0), Rank2(OldColCount, 0);
+	auto Project = [&](const vector<uint> &Rows, vector<uint32_t> &Rank, vector<uint32_t> &Seqs, vector<uint32_t> &Map) -> uint
+		{
+		for (uint r : Rows)
+			for (uint32_t c : St->m_Map[r])
+				Rank[c] = 1;
+		uint n = 0;
+		for (uint c = 0; c < OldColCount; ++c)
+			{
+			const uint Occupied = Rank[c];
+			Rank[c] = n;
+			n += Occupied;
+			}
+		Seqs.clear(); Map.clear();
+		for (uint r : Rows)
+			{
+			Seqs.push_back(St->m_Seq[r]);
+			for (uint32_t c : St->m_Map[r])
+				Map.push_back(Rank[c]);
+			}
+		return n;
+		};
+	vector<uint32_t> Seqs1, Seqs2, Map1, Map2;
+	const uint ColCount1 = Project(Rows1, Rank1, Seqs1, Map1);
+	const uint ColCount2 = Project(Rows2, Rank2, Seqs2, Map2);
+// alnalnsflat.cpp:16-20, buildpostflat.cpp:41,52,74: the weights by ROW index in MSA1 / MSA2
+	if (SIZE(m_Weights) != SeqCount)
+		m_Weights.assign(SeqCount, 1.0f);
+	vector<float> W1(m_Weights.begin(), m_Weights.begin() + SIZE(Rows1)), W2(m_Weights.begin(), m_Weights.begin() + SIZE(Rows2));
+
+	string Path(ColCount1 + ColCount2, '?');
+	uint32_t PathLen = 0;
+	float Score = 0;
+	SW.Next(T_ALN_LIB);
+		{
+		std::lock_guard<std::mutex> Guard(S.m_Mu);
+		mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
+		GPUCHK(mpcgpu_align_alns_w(Ctx, SIZE(Seqs1), Seqs1.data(), SIZE(Seqs2), Seqs2.data(), ColCount1, ColCount2,
+		  Map1.data(), Map2.data(), W1.data(), W2.data(), &Path[0], &PathLen, &Score));
+		}
+	Path.resize(PathLen);
+	SW.Next(T_ALN_POST);
+// the join (alnalnsflat.cpp:36-50, Sequence::AddGapsPath sequence.cpp:115-140): column of either alignment's column in the merged one
+	vector<uint32_t> Lut1(ColCount1), Lut2(ColCount2);
+		{
+		uint i1 = 0, i2 = 0;
+		for (uint Col = 0; Col < PathLen; ++Col)
+			{
+			const char c = Path[Col];
+			if (c == 'B' || c == 'X')
+				{ asserta(i1 < ColCount1); Lut1[i1++] = Col; }
+			if (c == 'B' || c == 'Y')
+				{ asserta(i2 < ColCount2); Lut2[i2++] = Col; }
+			}
+		asserta(i1 == ColCount1 && i2 == ColCount2);
+		}
+	RefineState Next;
+	Next.m_BatchGen = Gen;
+	Next.m_ColCount = PathLen;
+	MultiSequence *Result = new MultiSequence();
+	auto Emit = [&](const vector<uint> &Rows, const vector<uint32_t> &Rank, const vector<uint32_t> &Lut)
+		{
+		for (uint r : Rows)
+			{
+			vector<uint32_t> &M = St->m_Map[r];
+			for (uint32_t &c : M)
+				c = Lut[Rank[c]];
+			Sequence *Row = NewSequence();
+			Row->m_Label = m_MSA->GetSequence(r)->m_Label;
+			Row->m_CharVec.assign(PathLen, '-');
+			const string &L = St->m_Letters[r];
+			for (uint k = 0; k < SIZE(M); ++k)
+				Row->m_CharVec[M[k]] = L[k];
+			Result->AddSequence(Row, true);
+			Next.m_Seq.push_back(St->m_Seq[r]);
+			Next.m_Map.push_back(std::move(M));
+			Next.m_Letters.push_back(std::move(St->m_Letters[r]));
+			}
+		};
+	Emit(Rows1, Rank1, Lut1);
+	Emit(Rows2, Rank2, Lut2);
+	delete m_MSA;
+	m_MSA = Result;
+	Next.m_MSA = m_MSA;
+	*St = std::move(Next);
 	}
 
 namespace

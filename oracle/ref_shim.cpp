@@ -208,6 +208,11 @@ void ref_mpc_cons_pairs(const uint *ks, uint count)
 	for (int i = 0; i < (int) count; ++i)
 		g_M->ConsPair(ks[i]);
 	}
+// the buffer swap of consflat.cpp:22 alone: what ref_mpc_cons_pairs wrote becomes the current store. For a STAGE-2 pin of a few pairs of
+// a store whose full ConsIter takes days: after ConsPair of iteration 1 for every pair that touches a small clique of sequences, the
+// swapped store holds the stage-1 matrices of exactly the pairs a ConsPair of two clique members reads (conspairflat.cpp:49-89: (X,Z)
+// and (Y,Z) for all Z) — the other pairs' objects are never looked at (tests/golden/make_golden.py big-stage2).
+void ref_mpc_swap_stores() { std::swap(g_M->m_ptrSparsePosts, g_M->m_ptrUpdatedSparsePosts); }
 uint ref_mpc_updated_nnz(uint k) { const MySparseMx &S = g_M->GetUpdatedSparsePost(k); return S.m_Offsets[S.m_LX]; }
 void ref_mpc_updated_sparse(uint k, uint *offsets, byte *values)
 	{

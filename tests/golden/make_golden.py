@@ -324,6 +324,78 @@ def _mpc_sampled_worker(args):
     return name, n, tot, len(ks), [tA, tB]
 
 
+def _clique_stage2(L, pairs, lens, clique, u32p, u8p):
+    """STAGE 2 (after two relax iterations) of the pairs among `clique`, from the compiled reference, without relaxing the whole store:
+    ConsPair of iteration 1 for every pair that touches the clique (what a second ConsPair of two clique members reads:
+    conspairflat.cpp:49-89), the buffer swap of consflat.cpp:22, ConsPair of iteration 2 for the pairs among the clique.
+    The store must be at stage 0. -> (ks, [sha256(offsets || values)], [nnz])."""
+    import ctypes as C
+    cs = set(int(c) for c in clique)
+    touch = np.array([k for k, (i, j) in enumerate(pairs) if i in cs or j in cs], np.uint32)
+    inner = np.array([k for k, (i, j) in enumerate(pairs) if i in cs and j in cs], np.uint32)
+    L.ref_mpc_updated_nnz.restype = C.c_uint
+    L.ref_mpc_cons_pairs(touch.ctypes.data_as(u32p), len(touch))
+    L.ref_mpc_swap_stores()
+    L.ref_mpc_cons_pairs(inner.ctypes.data_as(u32p), len(inner))
+    shas, nnzs = [], []
+    for k in inner:
+        i, j = pairs[int(k)]
+        nnz = L.ref_mpc_updated_nnz(int(k))
+        off = np.empty(lens[i] + 1, np.uint32)
+        val = np.empty(max(nnz, 1) * 2, np.uint32)
+        L.ref_mpc_updated_sparse(int(k), off.ctypes.data_as(u32p), val.ctypes.data_as(u8p))
+        shas.append(hashlib.sha256(off.tobytes() + val[:2 * nnz].tobytes()).digest())
+        nnzs.append(nnz)
+    return inner, shas, nnzs
+
+
+def _mpc_stage2_worker(args):
+    """Stage-2 pin at a size whose full relax takes days on the CPU: stage A of all pairs (the reference has to make its own stage 0),
+    then _clique_stage2 for `m` seeded sequences. check=True (small n): the same pairs after two FULL ConsIter must give the same
+    digests — the shortcut is checked against the thing it abbreviates (run in its own process: one MPCFlat per process)."""
+    name, n, m, threads, check = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import time
+    import _ref as R
+    from muscle_amd.synth import make_family, read_fasta
+    seqs = read_fasta(os.path.join(HERE, "rdrp_first1000.fa.gz"))[:n] if name.startswith("rdrp") else make_family(n, 60, seed=9)
+    R.init_hmm(False, 0)
+    L = R.lib()
+    arr = (C.c_char_p * len(seqs))(*[s.encode() for s in seqs])
+    if L.ref_mpc_begin(len(seqs), arr, threads) != 0:
+        raise RuntimeError("ref_mpc_begin may only be called once per process")
+    lens = [len(s) for s in seqs]
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    t0 = time.time()
+    L.ref_mpc_calc_posteriors()
+    tA = time.time() - t0
+    print("stage A: %.1f s" % tA, flush=True)
+    clique = np.sort(np.random.default_rng(20261001).choice(n, size=m, replace=False)).astype(np.uint32)
+    if check:
+        # two full iterations first, on a second look at the same store? No: one MPCFlat per process — the caller runs the full
+        # version in another process and compares (tests/test_oracle_vs_ref.py)
+        pass
+    t0 = time.time()
+    ks, shas, nnzs = _clique_stage2(L, pairs, lens, clique, R.u32p, R.u8p)
+    tB = time.time() - t0
+    print("stage 2 of %d pairs among %d sequences: %.1f s" % (len(ks), m, tB), flush=True)
+    d = {"n": np.int32(n), "clique": clique, "stage2_k": ks, "stage2_nnz": np.array(nnzs, np.uint32),
+         "stage2_sha": np.frombuffer(b"".join(shas), np.uint8).reshape(-1, 32),
+         "seqs_sha": np.array(hashlib.sha256("\n".join(seqs).encode()).hexdigest()),
+         "ref_seconds": np.array([tA, tB]), "ref_threads": np.int32(threads)}
+    if not check:
+        np.savez_compressed(os.path.join(HERE, "mpcbig_%s_stage2_clique.npz" % name), **d)
+    return d
+
+
+def gen_mpc_stage2(name, n, m, threads):
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        d = pool.map(_mpc_stage2_worker, [(name, n, m, threads, False)])[0]
+        print(name, n, "clique", d["clique"].tolist(), len(d["stage2_k"]), "pairs", d["ref_seconds"].tolist(), flush=True)
+
+
 def gen_mpc_sampled(name, n, nsample, threads):
     ctx = mp.get_context("spawn")
     with ctx.Pool(1) as pool:
@@ -523,6 +595,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if sys.argv[1:2] == ["big"]:  # python make_golden.py big <threads> <name> ...: digest-only BASELINE-size sets (CPU-hours)
         gen_mpc_big(sys.argv[3:], int(sys.argv[2]))
+        sys.exit(0)
+    if sys.argv[1:2] == ["big-stage2"]:  # python make_golden.py big-stage2 <threads> <n> [m]: rdrp prefix, stage 2 of the pairs among m seeded sequences
+        gen_mpc_stage2("rdrp%d" % int(sys.argv[3]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 6, int(sys.argv[2]))
         sys.exit(0)
     if sys.argv[1:2] == ["big-sampled"]:  # python make_golden.py big-sampled <threads> <n> [nsample]: rdrp prefix, stage A of all pairs + ConsPair of a sample
         gen_mpc_sampled("rdrp%d" % int(sys.argv[3]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 2048, int(sys.argv[2]))

@@ -73,3 +73,32 @@ def test_calc_aln_dense_random():
         sr, pr = R.calc_aln(P)
         assert po == pr and so == sr
         assert O.aln_score(P) == R.aln_score(P)
+
+
+def _full_two_iterations(args):
+    seqs, = args
+    import hashlib
+    stages, _ = R.mpc_run(seqs, iters=2, threads=2)
+    return [hashlib.sha256(o.tobytes() + v.tobytes()).digest() for o, v in stages[2]]
+
+
+def test_stage2_clique_shortcut_equals_two_full_iterations():
+    """tests/golden/make_golden.py big-stage2 (the stage-2 pin of rdrp-1000, whose full relax takes days on the CPU) relaxes only what
+    two ConsPair of a clique's pairs read: ConsPair of iteration 1 for every pair that touches the clique, the swap of consflat.cpp:22,
+    ConsPair of iteration 2 for the pairs among the clique. On 14 sequences the clique's stage-2 matrices must be those of two FULL
+    ConsIter of the same reference (each run in its own process: one MPCFlat per process)."""
+    import multiprocessing as mp
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as MG
+    n, m = 14, 4
+    seqs = make_family(n, 60, seed=9)
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        full = pool.map(_full_two_iterations, [(seqs,)])[0]
+    with ctx.Pool(1) as pool:
+        d = pool.map(MG._mpc_stage2_worker, [("synth", n, m, 2, True)])[0]
+    assert len(d["stage2_k"]) == m * (m - 1) // 2
+    for q, k in enumerate(d["stage2_k"]):
+        assert d["stage2_sha"][q].tobytes() == full[int(k)], (q, int(k))
