@@ -112,6 +112,14 @@ def real_data_leg(g, torch, run_stage, steps=1):
                   "compiled reference's: tests/golden/mpcbig_%s.npz" % (npairs, len(z["sample_k"]), name)) if err is None else err
     g.cons_iter(0, npairs)
     g.cons_commit()
+    name2 = D.stage2_fixture_for_fasta(path, n)
+    if name2 is not None and parity == "match":
+        # the second iteration too: the stage-2 matrices of the pairs among 6 seeded sequences (tests/golden/make_golden.py big-stage2)
+        err2 = D.compare_stage2_clique(D.load(name2), g)
+        if err2 is None:
+            detail += "; and the stage-2 matrices (two relax iterations) of the %d pairs among 6 seeded sequences: tests/golden/mpcbig_%s.npz" % (len(D.load(name2)["stage2_k"]), name2)
+        else:
+            parity, detail = "MISMATCH", err2
     g.synchronize()
     g.timers_reset()
     torch.cuda.synchronize()

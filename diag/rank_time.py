@@ -2,7 +2,7 @@
 pairs in `pieces` pieces, import of all shards + PARTIAL store build, relax on its pairs, commit), everything except the two
 exchanges. The other ranks' shards are computed beforehand on the same GPU (untimed) so that the imported store is the real one. With
 the 1-GPU step this gives the compute side of the scaling curve the 1-GPU box cannot measure.
-usage: python diag/rank_time.py [world] [N] [L] [rank] [pieces]      (MPCGPU_PARTITION=contiguous: the ranges of rounds 1-5)"""
+usage: python diag/rank_time.py [world] [N] [L] [rank] [pieces]"""
 import os
 import sys
 import time
@@ -22,7 +22,7 @@ world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 me = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-P = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+P = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 seqs = make_family(n, L, seed=1)
 lens = [len(s) for s in seqs]
 g = MpcGpu(0)

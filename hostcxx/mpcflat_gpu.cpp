@@ -225,12 +225,9 @@ const int g_SmallStoreDefault = setenv("MPCGPU_RELAX_SMALL_PAIRS", "40", 0);
 // threshold, or a trim), the kernel driver answers the invalidation by EVICTING the process's device queues and restoring them later:
 // every queue of the process stops for 10 - 30 ms (profiles/r10k). One thread's joins lose little to that; six threads
 // running joins side by side (PProg::Run2 below) freed such blocks all the time: 11.4 s for the run that takes 7.7 s on one thread and
-// 6.4 s with the memory kept (profiles/r11d). MUSCLE_GPU_MALLOC=default leaves the allocator alone.
+// 6.4 s with the memory kept (profiles/r11d); no cost to -align (profiles/r11i_align_malloc_ab.log).
 const int g_KeepFreedMemoryMapped = []
 	{
-	const char *e = getenv("MUSCLE_GPU_MALLOC");
-	if (e != 0 && strcmp(e, "default") == 0)
-		return 0;
 	mallopt(M_MMAP_THRESHOLD, 1 << 30);
 	mallopt(M_TRIM_THRESHOLD, 1 << 30);
 	return 1;

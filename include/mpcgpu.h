@@ -104,7 +104,7 @@ int mpcgpu_pair_position(mpcgpu_ctx *ctx, uint32_t x, uint32_t y, uint64_t *pos)
  * touches 2 of 4 groups, half of the store); any other world — g = world, rank i owns the triangle of group i and the blocks
  * {i, i + d}, d < g / 2, the antipodal blocks of an even g cut in two by rows. rects (capacity max_rects x 4 words) receives the
  * rectangles in rank order, rank_pos[world + 1] the positions where each rank's pairs begin: rank r owns [rank_pos[r],
- * rank_pos[r + 1]). *nrects == 0: no block cut (one rank, too few sequences, or MPCGPU_PARTITION=contiguous): InitPairs order,
+ * rank_pos[r + 1]). *nrects == 0: no block cut (one rank, too few sequences): InitPairs order,
  * contiguous ranges balanced by DP cells — the partition of rounds 1-5. Returns 0, or 2 when max_rects is too small. */
 int mpcgpu_plan_partition(uint32_t n, const uint32_t *lens, uint32_t world, uint32_t max_rects, uint32_t *rects,
                           uint32_t *nrects, uint64_t *rank_pos);

@@ -25,12 +25,6 @@
 #include "kernels_fb.h"
 
 #define MPC_CHAIN_MAX 16 // pairs per chain
-#ifdef MPC_EMU
-#include <cstdio>
-#define FBC_DBG(...) do { if (t == 0 && getenv("MPC_DBG")) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
-#else
-#define FBC_DBG(...)
-#endif
 #define MPC_CHAIN_TAB_WORDS 8
 #define MPC_CHAIN_TAB_BYTES (MPC_CHAIN_MAX * MPC_CHAIN_TAB_WORDS * 4) // per wave: {LY, base, pid, sy, total bits} per pair
 
@@ -102,7 +96,6 @@ __global__ void __launch_bounds__(256, (H == 8) ? 4 : 1) fb_chain_kernel(FbChain
 			MPC_WAVE_LDS_ORDER();
 			Vtot = (int)mpc_wave_first((u32)__shfl(incl, C - 1));
 		}
-		FBC_DBG("chain qi=%u first=%u C=%d LX=%d T=%d Vtot=%d\n", qi, first, C, LX, T, Vtot);
 		auto LYof = [&](int k) { return (int)tabw(k, 0); };
 		auto baseof = [&](int k) { return (int)tabw(k, 1); };
 		auto Yof = [&](int k) { return p.seq_code + p.seq_off[tabw(k, 3)]; };
@@ -212,7 +205,6 @@ __global__ void __launch_bounds__(256, (H == 8) ? 4 : 1) fb_chain_kernel(FbChain
 			}
 		}
 		MPC_WAVE_LDS_ORDER();
-		FBC_DBG("fwd done\n");
 
 		// ------------------------------------------------------------------ backward + posterior
 		// Row i uses the emissions of x_{i+1}=X[i] and y_{j+1}=Y[j] (bwdflat3.cpp:46,64).
@@ -351,6 +343,5 @@ __global__ void __launch_bounds__(256, (H == 8) ? 4 : 1) fb_chain_kernel(FbChain
 		}
 		if (t == 0)
 			p.cand_cnt[pidA] = ncA;
-		FBC_DBG("bwd done\n");
 	}
 }

@@ -242,18 +242,9 @@ struct PostRowsParams {
 	u32 *flags;
 	u32 count;
 	u32 long_min; // as in PostParams
-	u64 *prof;    // measurement only (MPCGPU_POST_PROFILE=1), else nullptr: clock ticks of workgroup 0 per phase, 8 slots
 };
 
 // phase clock of post_rows_kernel (workgroup 0, lane 0 only)
-#define MPC_POST_TICK(slot)                                                          \
-	do {                                                                             \
-		if (p.prof && blockIdx.x == 0 && t == 0) {                                   \
-			const u64 now_ = mpc_clock();                                            \
-			p.prof[slot] += now_ - tick_;                                            \
-			tick_ = now_;                                                            \
-		}                                                                            \
-	} while (0)
 
 __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 {
@@ -274,7 +265,6 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			continue;
 		}
 		if (t == 0) p.flags[pid] = 0u;
-		u64 tick_ = p.prof ? mpc_clock() : 0ull;
 		u64 *cand = p.cand + (u64)pid * p.capc;
 		u64 *sorted = (c <= p.sort_cap) ? s_sorted : (p.sort_scratch + (u64)blockIdx.x * p.sort_stride);
 		for (u32 q = t; q <= LX; q += 64) s_rend[q] = 0;
@@ -289,7 +279,6 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			atomicAdd(&s_rend[(u32)(v >> (32 + kshift))], 1u);
 		}
 		__syncthreads();
-		MPC_POST_TICK(0); // zeroing, probabilities, row histogram
 		// exclusive scan of the row counts (in place: s_rend[i] = first slot of row i)
 		{
 			u32 carry = 0;
@@ -313,7 +302,6 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			sorted[at] = ((v >> 32) & (u64)((1u << kshift) - 1u)) << 32 | (v & 0xffffffffull);
 		}
 		__syncthreads();
-		MPC_POST_TICK(1); // scan + scatter
 		// columns ascending inside each row (a lane per row; rows hold a handful of cells)
 		for (u32 i = t; i < LX; i += 64) {
 			const u32 b = i ? s_rend[i - 1] : 0u, e = s_rend[i];
@@ -325,7 +313,6 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			}
 		}
 		__syncthreads();
-		MPC_POST_TICK(2); // sort inside rows
 		// ---- EA score. PM is kept explicitly only up to column cmax, the right-most column any row has updated so far; right of
 		// it S(i,.) is flat (nothing stored there has been reached yet), PM[j] == PM[cmax]. Stored cells hug the alignment
 		// path, so a row updates the few columns between its first cell and that frontier instead of all LY of them.
@@ -423,7 +410,6 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 		const u32 mn = LX < LY ? LX : LY;
 		const float ea = score / (float)mn; // calcposteriorflat.cpp:89 (uint -> float, IEEE divide)
 		__syncthreads();
-		MPC_POST_TICK(3); // EA rows
 		// ---- sparsify (mysparsemx.cpp:115-152): keep P >= 0.01f, row-major rank among the kept
 		u32 kept = 0;
 		for (u32 q0 = 0; q0 < c; q0 += 64) {
@@ -469,7 +455,6 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 			base += __shfl(incl, 63);
 		}
 		__syncthreads();
-		MPC_POST_TICK(4); // kept entries out, row-major
 		// ---- column-major rank of every kept entry: counting sort on the column, rows ascending inside
 		for (u32 q = t; q < LY; q += 64) colcnt[q] = s_cend[q];
 		{
@@ -507,6 +492,5 @@ __global__ void __launch_bounds__(64) post_rows_kernel(PostRowsParams p)
 		for (u32 q = t; q < nnz; q += 64) tperm[csorted[q]] = q;
 		if (t == 0) { p.nnz[pid] = nnz; p.ea[pid] = ea; }
 		__syncthreads();
-		MPC_POST_TICK(5); // column-major ranks
 	}
 }

@@ -502,32 +502,10 @@ __global__ void __launch_bounds__(256) commit_kernel(StoreParams s, u64 e0, u64 
 	}
 }
 
-// commit for the record layout: the packed record of the pair and both orientations' records
-__global__ void __launch_bounds__(256) commit_pad_kernel(StoreParams s, u64 e0, u64 e1)
-{
-	const u64 last = e1;
-	for (u64 e = e0 + (u64)blockIdx.x * blockDim.x + threadIdx.x; e < last; e += (u64)gridDim.x * blockDim.x) {
-		const u64 k = mpc_find_pair(s.vbase, 0, s.npairs, e);
-		const u32 X = s.pair_x[k], Y = s.pair_y[k];
-		const u32 LX = s.seq_len[X], LY = s.seq_len[Y];
-		u32 *rec = s.packed + s.pbase[k];
-		const u32 idx = (u32)(e - s.vbase[k]);
-		u32 *ent = rec + LX + LY;
-		const u32 pb = __float_as_uint(s.vnext[e]);
-		ent[2 * (u64)idx] = pb;
-		// entry `pos` of a record = block pos / 2, slot pos % 2: its probability is dword block * 4 + slot
-		const bool nx = mpc_need(s, X), ny = mpc_need(s, Y); // a partial store holds the records of the needed sequences only
-		if (nx) { const u32 pf = s.pos_f[e]; s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, X, Y)] + (pf >> 1) * 4u + (pf & 1u)] = pb; }
-		if (ny) { const u32 pt = s.pos_t[e]; s.pad[4 * (u64)s.rec_off[mpc_rec_index(s.n, Y, X)] + (pt >> 1) * 4u + (pt & 1u)] = pb; }
-		if (s.win) { // the window copies of both orientations
-			if (nx) s.win[4 * ((u64)s.wrec_off[mpc_rec_index(s.n, X, Y)] + (LX + 1u + 3u) / 4u) + s.pos_wf[e]] = pb;
-			if (ny) s.win[4 * ((u64)s.wrec_off[mpc_rec_index(s.n, Y, X)] + (LY + 1u + 3u) / 4u) + s.pos_wt[e]] = pb;
-		}
-	}
-}
-
-// The same commit, one WAVE PER PAIR (round 6): the per-entry form above finds its pair by a binary search over vbase — 19 dependent
-// loads per thread at 499 500 pairs — and visits every entry even where nothing is to be written. Here a wave takes pair k of
+// The commit of the record layout — the packed record of the pair, both orientations' block records and window records — one WAVE PER
+// PAIR (round 6; the per-entry form of rounds 2-5, like commit_kernel above, found its pair by a binary search over vbase, 19
+// dependent loads per thread at 499 500 pairs, and visited every entry even where nothing was to be written: 24.2 -> 16.1 ms per
+// step on one GPU, 19.6 -> 7.0 ms on a rank of eight, profiles/r12c). A wave takes pair k of
 // [k0, k1) and walks its entries inside [e0, e1) (coalesced reads of vnext and the position arrays); a PARTIAL store skips the pairs
 // that touch none of its sequences and are not its own, and writes the packed record only for its own pairs [own0, own1) — the relax
 // kernel reads P_XY of its own pairs there; everyone else's packed values are refreshed from vnext when somebody asks for them

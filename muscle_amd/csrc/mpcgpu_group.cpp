@@ -293,8 +293,7 @@ int mpcgpu_plan_partition(uint32_t n, const uint32_t *lens, uint32_t world, uint
 	if (!lens || !nrects || !rank_pos || world == 0 || n < 2) return 1;
 	const std::vector<uint32_t> len(lens, lens + n);
 	std::vector<std::vector<PlanRect>> per_rank;
-	const char *mode = getenv("MPCGPU_PARTITION"); // "contiguous": the contiguous InitPairs ranges of rounds 1-5 (A/B, tests)
-	if ((mode && !strcmp(mode, "contiguous")) || !plan_blocks(len, world, per_rank)) {
+	if (!plan_blocks(len, world, per_rank)) {
 		std::vector<uint64_t> cuts;
 		shard_bounds(len, world, cuts);
 		*nrects = 0;

@@ -31,7 +31,7 @@ def pair_lengths(lens):
 
 def shard_bounds(lens, world):
     """Contiguous pair ranges balanced by DP cells sum (LX+1)(LY+1) in InitPairs order: the partition of rounds 1-5, still what
-    mpcgpu_plan_partition falls back to (one rank, too few sequences for groups, MPCGPU_PARTITION=contiguous).
+    mpcgpu_plan_partition falls back to (one rank, too few sequences for groups).
     Returns world+1 cut points; deterministic, identical on every rank."""
     lx, ly = pair_lengths(lens)
     w = np.cumsum((lx + 1) * (ly + 1))

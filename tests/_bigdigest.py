@@ -103,3 +103,24 @@ def compare_sample(z, g):
         if H.sha256(off.tobytes() + val.tobytes()).digest() != want[q].tobytes():
             bad.append(int(k))
     return None if not bad else "stage 1 sample: %d of %d sampled pairs differ, first = pair %d" % (len(bad), len(ks), bad[0])
+
+
+def stage2_fixture_for_fasta(path, n):
+    """the stage-2 pin of a few pairs of the rdrp prefix (tests/golden/make_golden.py big-stage2), or None"""
+    if os.path.basename(path) != "rdrp_first1000.fa.gz":
+        return None
+    name = "rdrp%d_stage2_clique" % n
+    return name if os.path.exists(os.path.join(GDIR, "mpcbig_%s.npz" % name)) else None
+
+
+def compare_stage2_clique(z, g):
+    """the library's CURRENT store (after TWO relax iterations + commits) against the compiled reference's stage-2 matrices of the
+    pairs among the fixture's clique of sequences -> None | text"""
+    import hashlib as H
+    ks, want = z["stage2_k"], z["stage2_sha"]
+    bad = []
+    for q, k in enumerate(ks):
+        (off, val), = g.get_sparse_range(int(k), int(k) + 1)
+        if H.sha256(off.tobytes() + val.tobytes()).digest() != want[q].tobytes():
+            bad.append(int(k))
+    return None if not bad else "stage 2 clique: %d of %d pairs differ, first = pair %d" % (len(bad), len(ks), bad[0])

@@ -554,7 +554,18 @@ def test_rdrp1000_sampled_reference_pin():
     assert D.compare_sample(z, g) is None
     info = g.relax_info()[0]
     assert "relax_band_kernel" in info, info
+    # round 6: the SECOND iteration at this size too — the stage-2 matrices of the 15 pairs among 6 seeded sequences, which the
+    # compiled reference reaches by relaxing only what those pairs read (tests/golden/make_golden.py big-stage2; the shortcut is
+    # checked against two full ConsIter in tests/test_oracle_vs_ref.py)
+    name2 = D.stage2_fixture_for_fasta(path, 1000)
+    if name2 is not None:
+        z2 = D.load(name2)
+        assert str(z2["seqs_sha"]) == str(z["seqs_sha"])
+        g.cons_iter()
+        g.cons_commit()
+        assert D.compare_stage2_clique(z2, g) is None
     g.close()
+    assert name2 is not None, "fixture tests/golden/mpcbig_rdrp1000_stage2_clique.npz not generated (the stage-0 / stage-1 pins above passed)"
 
 
 @pytest.mark.parametrize("nctx", [2, 3])

@@ -24,7 +24,7 @@ def isa(tmp_path_factory):
     # the listing `make -C muscle_amd/csrc asm` (__graft_entry__.build()) leaves, when it is newer than every source it was made from:
     # same compiler, same flags — a minute of compilation saved
     made = os.path.join(CSRC, "mpcgpu.gfx950.s")
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cpp"))] + [os.path.join(ROOT, "include", "mpcgpu.h"), os.path.join(CSRC, "Makefile")]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cpp", ".inc"))] + [os.path.join(ROOT, "include", "mpcgpu.h"), os.path.join(CSRC, "Makefile")]
     if os.path.exists(made) and os.path.getmtime(made) >= max(os.path.getmtime(f) for f in srcs):
         return open(made).read()
     out = tmp_path_factory.mktemp("isa") / "mpcgpu.gfx950.s"
@@ -57,7 +57,7 @@ def _walk(body):
 def test_default_relax_walk_has_no_spill_reloads(isa, kernel):
     """relax_band_kernel, the instantiation relax_band launches by default (kBandSlots cells per lane). A reload inside the walk is
     worse here than in relax_var_kernel: its wait is vmcnt(0), and the prefetch of the next step is in flight on the same counter."""
-    src = open(os.path.join(CSRC, "mpcgpu.cpp")).read()
+    src = open(os.path.join(CSRC, "mpcgpu_relax.inc")).read()  # (the host side of the relax: one of the files mpcgpu.cpp includes)
     assert re.search(r"kBandThreads = 1024, kBandSlots = 13;", src) and re.search(r"kBandSlotsWin = 15;", src), "default geometry of relax_band changed: update this test"
     body = _body(isa, kernel)
     merges = _walk(body)
