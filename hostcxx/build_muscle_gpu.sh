@@ -40,7 +40,9 @@ objcopy --weaken-symbol=_ZN6UClust6SearchEjRNSt7__cxx1112basic_stringIcSt11char_
 objcopy --weaken-symbol=_ZN5PProg4Run2ERKSt6vectorIjSaIjEES4_ "$REFOBJ/pprog2.o" "$OUT/pprog2_weak.o"
 # MPCFlat::CalcPosteriors: ours (a plain loop: the work of all pairs happens inside the first CalcPosterior call); the rest of mpcflat.o stays
 objcopy --weaken-symbol=_ZN7MPCFlat14CalcPosteriorsEv "$REFOBJ/mpcflat.o" "$OUT/mpcflat_weak.o"
-OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' -e '/uclust\.o$' -e '/alignpairflat\.o$' -e '/pprog2\.o$' -e '/mpcflat\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$' -e '/refineflat\.o$')
+# MPCFlat::ProgressiveAlign: ours (the joins of a guide-tree level in one library call); ProgAln, FreeProgMSAs, FreeSparsePosts of progalnflat.o stay
+objcopy --weaken-symbol=_ZN7MPCFlat16ProgressiveAlignEv "$REFOBJ/progalnflat.o" "$OUT/progalnflat_weak.o"
+OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' -e '/uclust\.o$' -e '/alignpairflat\.o$' -e '/pprog2\.o$' -e '/mpcflat\.o$' -e '/progalnflat\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$' -e '/refineflat\.o$')
 # The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
 # MPCGPU_LIBDIR/MPCGPU_LIBNAME pointing at the SIMT-emulator build of the same library sources
 # (tests/emu, test infrastructure) to check the host-side plumbing of this file without a GPU.
@@ -49,6 +51,6 @@ LIBNAME="${MPCGPU_LIBNAME:-mpcgpu}"
 BIN="${MPCGPU_BIN:-muscle_gpu}"
 # --wrap=rand: the reference's rand() (refineflat.cpp:14) gets a private copy of glibc's default
 # stream; the HIP runtime in the same process otherwise consumes it (hostcxx/rand_isolate.cpp)
-g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/super7_weak.o" "$OUT/uclust_weak.o" "$OUT/pprog2_weak.o" "$OUT/mpcflat_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
+g++ -O3 -fopenmp -pthread -Wl,--wrap=rand $OBJS "$OUT/calcposteriorflat_weak.o" "$OUT/super7_weak.o" "$OUT/uclust_weak.o" "$OUT/pprog2_weak.o" "$OUT/mpcflat_weak.o" "$OUT/progalnflat_weak.o" "$OUT/mpcflat_gpu.o" "$OUT/rand_isolate.o" \
   -L"$LIBDIR" -l"$LIBNAME" -Wl,-rpath,"$LIBDIR" -Wl,-rpath,'$ORIGIN/../../muscle_amd/csrc' -Wl,-rpath,/opt/rocm/lib -o "$OUT/$BIN"
 echo "built: $OUT/$BIN"

@@ -849,6 +849,168 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 	return result;
 	}
 
+// MPCFlat::ProgressiveAlign (progalnflat.cpp:72-100) with the joins of one guide-tree LEVEL in one library call. The reference walks
+// its N - 1 joins one after the other (ProgAln, progalnflat.cpp:41-70: AlignAlns of two MultiSequence objects, a new one for the
+// parent); a join needs only its two children, and at 1000 sequences ~990 of the 999 joins are one-wave kernels with a round trip
+// each. Here every node of the tree is carried as its rows' sequence indices and position -> column maps (what the device wants
+// anyway: see RefineIter below), the joins are grouped by their height in the tree — a join's children lie on lower levels — and a
+// level goes to mpcgpu_align_alns_batch: two launches for its small joins together. A parent's rows are MSA1's then MSA2's
+// (alnalnsflat.cpp:36-50), its columns come off the path (B: both advance, X: MSA1, Y: MSA2). Only the root becomes a MultiSequence.
+// Falls back to the reference's loop when a weight differs from 1.0f or an input sequence carries gap characters.
+void MPCFlat::ProgressiveAlign()
+	{
+	const uint SeqCount = m_MyInputSeqs->GetSeqCount();
+	const uint JoinCount = SeqCount - 1;
+	const uint NodeCount = SeqCount + JoinCount;
+	asserta(SIZE(m_JoinIndexes1) == JoinCount);
+	asserta(SIZE(m_JoinIndexes2) == JoinCount);
+	ValidateJoinOrder(m_JoinIndexes1, m_JoinIndexes2);
+
+	bool Plain = true;
+	for (uint i = 0; i < SIZE(m_Weights); ++i)
+		if (m_Weights[i] != 1.0f)
+			Plain = false;
+	for (uint i = 0; i < SeqCount && Plain; ++i)
+		{
+		const Sequence *Seq = m_MyInputSeqs->GetSequence(i);
+		for (char ch : Seq->m_CharVec)
+			if (ch == '-')
+				{ Plain = false; break; }
+		}
+	const int SlotIndex = SlotIndexOf(this);
+	Slot &S = g_Slots[SlotIndex];
+	if (!Plain || S.m_StoreOwner != this || JoinCount < 2)
+		{
+// the reference's own loop (progalnflat.cpp:78-99)
+		for (uint i = 0; i < SeqCount; ++i)
+			{
+			const Sequence *Seq = m_MyInputSeqs->GetSequence(i);
+			MultiSequence *MS = new MultiSequence;
+			MS->AddSequence(Seq, false);
+			m_ProgMSAs.push_back(MS);
+			}
+		for (uint JoinIndex = 0; JoinIndex < JoinCount; ++JoinIndex)
+			ProgAln(JoinIndex);
+		asserta(SIZE(m_ProgMSAs) == NodeCount);
+		m_MSA = m_ProgMSAs[NodeCount-1];
+		m_ProgMSAs[NodeCount-1] = 0;
+		FreeProgMSAs();
+		asserta(m_MSA != 0);
+		return;
+		}
+
+	struct Node
+		{
+		vector<uint32_t> m_Rows;		// sequence indices (m_MyInputSeqs), in row order
+		vector<vector<uint32_t> > m_Maps;	// per row: position -> column
+		uint m_ColCount = 0;
+		uint m_Level = 0;
+		};
+	vector<Node> Nodes(NodeCount);
+	for (uint i = 0; i < SeqCount; ++i)
+		{
+		const uint L = GetSeqLength(i);
+		Nodes[i].m_Rows.assign(1, i);
+		Nodes[i].m_Maps.resize(1);
+		Nodes[i].m_Maps[0].resize(L);
+		for (uint k = 0; k < L; ++k)
+			Nodes[i].m_Maps[0][k] = k;
+		Nodes[i].m_ColCount = L;
+		}
+	uint MaxLevel = 0;
+	for (uint j = 0; j < JoinCount; ++j)
+		{
+		const uint a = m_JoinIndexes1[j], b = m_JoinIndexes2[j];
+		asserta(a < SeqCount + j && b < SeqCount + j);
+		Nodes[SeqCount + j].m_Level = 1 + std::max(Nodes[a].m_Level, Nodes[b].m_Level);
+		MaxLevel = std::max(MaxLevel, Nodes[SeqCount + j].m_Level);
+		}
+	PhaseMark(M_ALN_ENTER, true);
+	struct ExitMark { ~ExitMark() { PhaseMark(M_ALN_EXIT, false); } } MarkAtExit;
+	for (uint Level = 1; Level <= MaxLevel; ++Level)
+		{
+		Stopwatch SW(T_ALN_PREP);
+		vector<uint> Joins;
+		for (uint j = 0; j < JoinCount; ++j)
+			if (Nodes[SeqCount + j].m_Level == Level)
+				Joins.push_back(j);
+		const uint nj = SIZE(Joins);
+		vector<uint32_t> N1(nj), N2(nj), C1(nj), C2(nj), Seqs, Maps;
+		uint32_t Stride = 1;
+		for (uint q = 0; q < nj; ++q)
+			{
+			const Node &A = Nodes[m_JoinIndexes1[Joins[q]]], &B = Nodes[m_JoinIndexes2[Joins[q]]];
+			N1[q] = SIZE(A.m_Rows); N2[q] = SIZE(B.m_Rows); C1[q] = A.m_ColCount; C2[q] = B.m_ColCount;
+			Stride = std::max(Stride, C1[q] + C2[q]);
+			Seqs.insert(Seqs.end(), A.m_Rows.begin(), A.m_Rows.end());
+			Seqs.insert(Seqs.end(), B.m_Rows.begin(), B.m_Rows.end());
+			for (const vector<uint32_t> &M : A.m_Maps) Maps.insert(Maps.end(), M.begin(), M.end());
+			for (const vector<uint32_t> &M : B.m_Maps) Maps.insert(Maps.end(), M.begin(), M.end());
+			}
+		vector<char> Paths((size_t) nj*Stride);
+		vector<uint32_t> PathLens(nj);
+		SW.Next(T_ALN_LIB);
+			{
+			std::lock_guard<std::mutex> Guard(S.m_Mu);
+			if (S.m_StoreOwner != this)
+				Die("GPU posterior stage: ProgressiveAlign on an MPCFlat whose posteriors are not the ones on the device");
+			mpcgpu_ctx *Ctx = GetCtx(SlotIndex);
+			GPUCHK(mpcgpu_align_alns_batch(Ctx, nj, N1.data(), N2.data(), C1.data(), C2.data(), Seqs.data(), Maps.data(), Stride,
+			  Paths.data(), PathLens.data(), 0));
+			}
+		SW.Next(T_ALN_POST);
+		for (uint q = 0; q < nj; ++q)
+			{
+			Node &A = Nodes[m_JoinIndexes1[Joins[q]]], &B = Nodes[m_JoinIndexes2[Joins[q]]], &P = Nodes[SeqCount + Joins[q]];
+			const char *Path = Paths.data() + (size_t) q*Stride;
+			const uint PathLen = PathLens[q];
+			vector<uint32_t> Lut1(A.m_ColCount), Lut2(B.m_ColCount);
+			uint i1 = 0, i2 = 0;
+			for (uint Col = 0; Col < PathLen; ++Col)
+				{
+				const char c = Path[Col];
+				if (c == 'B' || c == 'X')
+					{ asserta(i1 < A.m_ColCount); Lut1[i1++] = Col; }
+				if (c == 'B' || c == 'Y')
+					{ asserta(i2 < B.m_ColCount); Lut2[i2++] = Col; }
+				}
+			asserta(i1 == A.m_ColCount && i2 == B.m_ColCount);
+			P.m_ColCount = PathLen;
+			P.m_Rows = std::move(A.m_Rows);
+			P.m_Rows.insert(P.m_Rows.end(), B.m_Rows.begin(), B.m_Rows.end());
+			P.m_Maps = std::move(A.m_Maps);
+			for (vector<uint32_t> &M : P.m_Maps)
+				for (uint32_t &c : M)
+					c = Lut1[c];
+			for (vector<uint32_t> &M : B.m_Maps)
+				{
+				for (uint32_t &c : M)
+					c = Lut2[c];
+				P.m_Maps.push_back(std::move(M));
+				}
+			vector<uint32_t>().swap(B.m_Rows);
+			vector<vector<uint32_t> >().swap(B.m_Maps);
+			}
+		}
+// the root, as the MultiSequence the rest of MPCFlat::Run reads (Sequence::AddGapsPath, sequence.cpp:115-140, row by row in the reference)
+	const Node &Root = Nodes[NodeCount - 1];
+	asserta(SIZE(Root.m_Rows) == SeqCount);
+	MultiSequence *Result = new MultiSequence();
+	for (uint r = 0; r < SeqCount; ++r)
+		{
+		const Sequence *In = m_MyInputSeqs->GetSequence(Root.m_Rows[r]);
+		Sequence *Row = NewSequence();
+		Row->m_Label = In->m_Label;
+		Row->m_CharVec.assign(Root.m_ColCount, '-');
+		const vector<uint32_t> &M = Root.m_Maps[r];
+		asserta(SIZE(M) == SIZE(In->m_CharVec));
+		for (uint k = 0; k < SIZE(M); ++k)
+			Row->m_CharVec[M[k]] = In->m_CharVec[k];
+		Result->AddSequence(Row, true);
+		}
+	m_MSA = Result;
+	}
+
 // MPCFlat::RefineIter (refineflat.cpp:4-31; its own translation unit in the reference, not linked here) on POSITION -> COLUMN MAPS.
 // The reference draws a bipartition of the rows with rand(), projects m_MSA onto either part (MultiSequence::Project, project.cpp:16-67:
 // a new character matrix per part, all-gap columns dropped), aligns the two with AlignAlns and joins them along the path

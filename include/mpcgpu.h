@@ -220,6 +220,16 @@ int mpcgpu_align_alns_w(mpcgpu_ctx *ctx, uint32_t n1, const uint32_t *seq1, uint
                         uint32_t C1, uint32_t C2, const uint32_t *pos2col1, const uint32_t *pos2col2,
                         const float *w1, const float *w2, char *path, uint32_t *pathlen, float *score);
 
+/* mpcgpu_align_alns for a LIST of independent joins: the joins of one level of the guide tree MPCFlat::ProgressiveAlign walks
+ * (progalnflat.cpp:72-100 runs its N - 1 joins one after the other; a join needs only its two children). Join j aligns n1[j] rows
+ * with n2[j] rows, C1[j] x C2[j] columns; seqs holds the sequence indices of its rows, MSA1's then MSA2's, the joins back to back;
+ * pos2col likewise the rows' position -> column maps. All weights are 1.0f (what MPCFlat::Run sets, mpcflat.cpp:324).
+ * paths: njoins slots of path_stride bytes (>= C1[j] + C2[j]); scores may be NULL. The small joins — nearly all of a tree's — run
+ * in two launches together, the few large ones as mpcgpu_align_alns does; every matrix and path is the single call's. */
+int mpcgpu_align_alns_batch(mpcgpu_ctx *ctx, uint32_t njoins, const uint32_t *n1, const uint32_t *n2, const uint32_t *C1,
+                            const uint32_t *C2, const uint32_t *seqs, const uint32_t *pos2col, uint32_t path_stride,
+                            char *paths, uint32_t *pathlens, float *scores);
+
 /* MPCFlat::BuildPost alone (buildpostflat.cpp:18-106): the C1 x C2 matrix (row-major floats, host memory) that
  * mpcgpu_align_alns_w would align — for the callers of BuildPost outside MPCFlat::Run (profseq.cpp:33-49). Arguments as
  * for mpcgpu_align_alns_w (w1 / w2 may be NULL: all weights 1.0f). */

@@ -21,7 +21,7 @@ SYMBOLS = [
     "mpcgpu_cons_iter", "mpcgpu_cons_commit", "mpcgpu_cons_commit_range", "mpcgpu_get_ea", "mpcgpu_get_nnz", "mpcgpu_get_sparse",
     "mpcgpu_get_sparse_range", "mpcgpu_post_scores", "mpcgpu_calc_aln", "mpcgpu_align_alns", "mpcgpu_align_alns_w", "mpcgpu_build_post", "mpcgpu_get_last_post", "mpcgpu_align_msas", "mpcgpu_align_pairs", "mpcgpu_get_list_sparse", "mpcgpu_stage_a_info", "mpcgpu_set_seqs_registry", "mpcgpu_timers_reset", "mpcgpu_timers_enable", "mpcgpu_timers_get",
     "mpcgpu_work_get", "mpcgpu_synchronize", "mpcgpu_relax_info", "mpcgpu_shard_entries",
-    "mpcgpu_set_pair_order", "mpcgpu_pair_position", "mpcgpu_plan_partition", "mpcgpu_store_import_part", "mpcgpu_store_complete", "mpcgpu_store_info",
+    "mpcgpu_set_pair_order", "mpcgpu_pair_position", "mpcgpu_plan_partition", "mpcgpu_store_import_part", "mpcgpu_store_complete", "mpcgpu_store_info", "mpcgpu_align_alns_batch",
     "mpcgpu_group_create", "mpcgpu_group_destroy", "mpcgpu_group_last_error", "mpcgpu_group_size", "mpcgpu_group_ctx",
     "mpcgpu_group_transport", "mpcgpu_group_set_hmm", "mpcgpu_group_set_seqs", "mpcgpu_group_set_mega",
     "mpcgpu_group_calc_posteriors", "mpcgpu_group_cons_iter",
@@ -70,6 +70,7 @@ def load(lib_path=None):
     L.mpcgpu_store_import_part.argtypes = [vp, u32, vp, vp, vp, vp, vp, u64, u64]
     L.mpcgpu_store_complete.argtypes = [vp]
     L.mpcgpu_store_info.argtypes = [vp, vp]
+    L.mpcgpu_align_alns_batch.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp]
     L.mpcgpu_values_slice.argtypes = [vp, u64, u64, C.POINTER(u64), C.POINTER(u64)]
     L.mpcgpu_cons_iter.argtypes = [vp, u64, u64]
     L.mpcgpu_cons_commit.argtypes = [vp]
@@ -443,6 +444,24 @@ class MpcGpu:
         self._ck(self.L.mpcgpu_align_alns(self.h, len(s1), s1.ctypes.data, len(s2), s2.ctypes.data, C1, C2,
                                            m1.ctypes.data, m2.ctypes.data, path.ctypes.data, C.byref(n), C.byref(sc)))
         return path[:n.value].tobytes().decode(), float(np.float32(sc.value))
+
+    def align_alns_batch(self, joins):
+        """joins: list of (seq1, seq2, p2c1, p2c2, C1, C2) as align_alns takes them -> [(path, score)] (mpcgpu_align_alns_batch:
+        independent joins, the small ones in two launches together)"""
+        nj = len(joins)
+        n1 = np.array([len(j[0]) for j in joins], np.uint32)
+        n2 = np.array([len(j[1]) for j in joins], np.uint32)
+        C1 = np.array([j[4] for j in joins], np.uint32)
+        C2 = np.array([j[5] for j in joins], np.uint32)
+        seqs = np.concatenate([np.concatenate([np.asarray(j[0], np.uint32), np.asarray(j[1], np.uint32)]) for j in joins]).astype(np.uint32)
+        maps = np.concatenate([np.asarray(x, np.uint32) for j in joins for x in list(j[2]) + list(j[3])]).astype(np.uint32)
+        stride = int((C1 + C2).max())
+        paths = np.zeros(nj * stride, np.uint8)
+        plen = np.zeros(nj, np.uint32)
+        sc = np.zeros(nj, np.float32)
+        self._ck(self.L.mpcgpu_align_alns_batch(self.h, nj, n1.ctypes.data, n2.ctypes.data, C1.ctypes.data, C2.ctypes.data, seqs.ctypes.data,
+                                                 maps.ctypes.data, stride, paths.ctypes.data, plen.ctypes.data, sc.ctypes.data))
+        return [(paths[q * stride:q * stride + int(plen[q])].tobytes().decode(), float(sc[q])) for q in range(nj)]
 
     def align_pairs(self, seq1, seq2, sparse=False):
         """AlignPairFlat for a list of pairs of registered sequences -> [(path, score, ea)] (+ (off, val) per pair with sparse=True)"""

@@ -229,90 +229,112 @@ struct BuildPostRowsParams {
 	u32 *err;             // set to 1 when a chunk's entries exceed the list (the host then takes the general path)
 };
 
-template <int CH> // 64 * CH >= C2: columns a lane accumulates in registers
+// one output row (col1) of one join: the body of both kernels below
+template <int CH, class PARAMS> // 64 * CH >= C2: columns a lane accumulates in registers
+__device__ __forceinline__ void build_post_one_row(const PARAMS &p, u32 col1, u32 *lkey, float *lval)
+{
+	const u32 lane = threadIdx.x;
+	const u32 n = p.s.n;
+	const u32 npairs = p.n1 * p.n2;
+	const unsigned char *padb = (const unsigned char *)p.s.pad;
+	float acc[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) acc[c] = 0.0f; // buildpostflat.cpp:27-30
+	for (u32 ab0 = 0; ab0 < npairs; ab0 += 64u) {
+		const u32 ab = ab0 + lane;
+		const bool valid = ab < npairs;
+		const u32 a = valid ? ab / p.n2 : 0u, b = valid ? ab % p.n2 : 0u;
+		const u32 pos = valid ? p.c2p1[(u64)a * p.C1 + col1] : MPC_BPR_GAP;
+		const bool have = pos != MPC_BPR_GAP;
+		const u32 S = p.seq1[a], T = p.seq2[b];
+		const unsigned char *row0 = padb + 16 * ((u64)p.s.rec_off[mpc_rec_index(n, S, T)] + (have ? pos : 0u));
+		// pass 1: stored entries of the row (a block's second entry is real unless it repeats the first column or is the
+		// empty-row sentinel; a block's first entry is real unless the row is empty)
+		u32 cnt = 0;
+		if (have) {
+			const unsigned char *blk = row0;
+			for (;;) {
+				const MpcQuad v = *(const MpcQuad *)blk;
+				const u32 c0 = v.z & 0xffffu, dist = v.z >> 16;
+				cnt += (c0 != MPC_PAD_SENTINEL ? 1u : 0u) + ((v.w != c0 && v.w != MPC_PAD_SENTINEL) ? 1u : 0u);
+				if (dist == 0u) break;
+				blk += dist;
+			}
+		}
+		u32 incl = cnt;
+		for (int d = 1; d < 64; d <<= 1) {
+			const u32 o = __shfl_up(incl, d);
+			if (lane >= (u32)d) incl += o;
+		}
+		const u32 total = mpc_wave_first(__shfl(incl, 63));
+		if (total > MPC_BPR_CAP) { // not expected for the joins the host sends here; reported, not guessed
+			if (lane == 0) *p.err = 1u;
+			continue;
+		}
+		// pass 2: the entries, in lane order = (a, b) order, rows' entries in column order
+		if (have && cnt) {
+			u32 at = incl - cnt;
+			const u32 *m2 = p.p2c2 + p.off2[b];
+			const float w12 = p.w1 ? p.w1[a] * p.w2[b] : 1.0f; // w1*w2 rounded first: buildpostflat.cpp:74 / :96
+			const unsigned char *blk = row0;
+			for (;;) {
+				const MpcQuad v = *(const MpcQuad *)blk;
+				const u32 c0 = v.z & 0xffffu, dist = v.z >> 16;
+				if (c0 != MPC_PAD_SENTINEL) {
+					lkey[at] = m2[c0];
+					lval[at] = p.w1 ? w12 * __uint_as_float(v.x) : __uint_as_float(v.x);
+					++at;
+				}
+				if (v.w != c0 && v.w != MPC_PAD_SENTINEL) {
+					lkey[at] = m2[v.w];
+					lval[at] = p.w1 ? w12 * __uint_as_float(v.y) : __uint_as_float(v.y);
+					++at;
+				}
+				if (dist == 0u) break;
+				blk += dist;
+			}
+		}
+		MPC_WAVE_LDS_ORDER();
+		// the additions, strictly in list order
+		for (u32 e = 0; e < total; ++e) {
+			const u32 k = mpc_wave_first(lkey[e]);
+			const float v = lval[e];
+			const u32 ch = k >> 6;
+			const bool mine = (k & 63u) == lane;
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+				if (ch == (u32)c) acc[c] = mine ? acc[c] + v : acc[c]; // ch is wave-uniform: scalar branches
+		}
+		MPC_WAVE_LDS_ORDER();
+	}
+	float *out = p.post + (u64)col1 * p.C2;
+#pragma unroll
+	for (int c = 0; c < CH; ++c)
+		if ((u32)c * 64u + lane < p.C2) out[(u32)c * 64u + lane] = acc[c];
+}
+
+template <int CH>
 __global__ void __launch_bounds__(64) build_post_rows_kernel(BuildPostRowsParams p)
 {
 	MPC_DYN_SMEM(smem_raw); // 8 * MPC_BPR_CAP bytes: the list of one chunk of pairs
 	u32 *lkey = (u32 *)smem_raw;
 	float *lval = (float *)(smem_raw + 4 * MPC_BPR_CAP);
-	const u32 lane = threadIdx.x;
-	const u32 n = p.s.n;
-	const u32 npairs = p.n1 * p.n2;
-	const unsigned char *padb = (const unsigned char *)p.s.pad;
-	for (u32 col1 = blockIdx.x; col1 < p.C1; col1 += gridDim.x) {
-		float acc[CH];
-#pragma unroll
-		for (int c = 0; c < CH; ++c) acc[c] = 0.0f; // buildpostflat.cpp:27-30
-		for (u32 ab0 = 0; ab0 < npairs; ab0 += 64u) {
-			const u32 ab = ab0 + lane;
-			const bool valid = ab < npairs;
-			const u32 a = valid ? ab / p.n2 : 0u, b = valid ? ab % p.n2 : 0u;
-			const u32 pos = valid ? p.c2p1[(u64)a * p.C1 + col1] : MPC_BPR_GAP;
-			const bool have = pos != MPC_BPR_GAP;
-			const u32 S = p.seq1[a], T = p.seq2[b];
-			const unsigned char *row0 = padb + 16 * ((u64)p.s.rec_off[mpc_rec_index(n, S, T)] + (have ? pos : 0u));
-			// pass 1: stored entries of the row (a block's second entry is real unless it repeats the first column or is the
-			// empty-row sentinel; a block's first entry is real unless the row is empty)
-			u32 cnt = 0;
-			if (have) {
-				const unsigned char *blk = row0;
-				for (;;) {
-					const MpcQuad v = *(const MpcQuad *)blk;
-					const u32 c0 = v.z & 0xffffu, dist = v.z >> 16;
-					cnt += (c0 != MPC_PAD_SENTINEL ? 1u : 0u) + ((v.w != c0 && v.w != MPC_PAD_SENTINEL) ? 1u : 0u);
-					if (dist == 0u) break;
-					blk += dist;
-				}
-			}
-			u32 incl = cnt;
-			for (int d = 1; d < 64; d <<= 1) {
-				const u32 o = __shfl_up(incl, d);
-				if (lane >= (u32)d) incl += o;
-			}
-			const u32 total = mpc_wave_first(__shfl(incl, 63));
-			if (total > MPC_BPR_CAP) { // not expected for the joins the host sends here; reported, not guessed
-				if (lane == 0) *p.err = 1u;
-				continue;
-			}
-			// pass 2: the entries, in lane order = (a, b) order, rows' entries in column order
-			if (have && cnt) {
-				u32 at = incl - cnt;
-				const u32 *m2 = p.p2c2 + p.off2[b];
-				const float w12 = p.w1 ? p.w1[a] * p.w2[b] : 1.0f; // w1*w2 rounded first: buildpostflat.cpp:74 / :96
-				const unsigned char *blk = row0;
-				for (;;) {
-					const MpcQuad v = *(const MpcQuad *)blk;
-					const u32 c0 = v.z & 0xffffu, dist = v.z >> 16;
-					if (c0 != MPC_PAD_SENTINEL) {
-						lkey[at] = m2[c0];
-						lval[at] = p.w1 ? w12 * __uint_as_float(v.x) : __uint_as_float(v.x);
-						++at;
-					}
-					if (v.w != c0 && v.w != MPC_PAD_SENTINEL) {
-						lkey[at] = m2[v.w];
-						lval[at] = p.w1 ? w12 * __uint_as_float(v.y) : __uint_as_float(v.y);
-						++at;
-					}
-					if (dist == 0u) break;
-					blk += dist;
-				}
-			}
-			MPC_WAVE_LDS_ORDER();
-			// the additions, strictly in list order
-			for (u32 e = 0; e < total; ++e) {
-				const u32 k = mpc_wave_first(lkey[e]);
-				const float v = lval[e];
-				const u32 ch = k >> 6;
-				const bool mine = (k & 63u) == lane;
-#pragma unroll
-				for (int c = 0; c < CH; ++c)
-					if (ch == (u32)c) acc[c] = mine ? acc[c] + v : acc[c]; // ch is wave-uniform: scalar branches
-			}
-			MPC_WAVE_LDS_ORDER();
-		}
-		float *out = p.post + (u64)col1 * p.C2;
-#pragma unroll
-		for (int c = 0; c < CH; ++c)
-			if ((u32)c * 64u + lane < p.C2) out[(u32)c * 64u + lane] = acc[c];
+	for (u32 col1 = blockIdx.x; col1 < p.C1; col1 += gridDim.x) build_post_one_row<CH>(p, col1, lkey, lval);
+}
+
+// The same for a LIST of independent joins in one launch (mpcgpu_align_alns_batch: the joins of one level of a guide tree): workgroup
+// w builds row rows[2 w + 1] of join rows[2 w]; `batch` holds one parameter record per join (page-locked host memory, like the
+// joins' inputs). A join's matrix lies at its own place in the batch's buffer (BuildPostRowsParams::post).
+template <int CH>
+__global__ void __launch_bounds__(64) build_post_rows_batch_kernel(const BuildPostRowsParams *batch, const u32 *rows, u32 nrows)
+{
+	MPC_DYN_SMEM(smem_raw);
+	u32 *lkey = (u32 *)smem_raw;
+	float *lval = (float *)(smem_raw + 4 * MPC_BPR_CAP);
+	for (u32 w = blockIdx.x; w < nrows; w += gridDim.x) {
+		const u32 C2 = batch[rows[2 * w]].C2;
+		if (CH == 8 ? C2 > 512u : C2 <= 512u) continue; // (the launch with 8 columns per lane takes the joins up to 512 columns, the other the rest)
+		const BuildPostRowsParams p = batch[rows[2 * w]];
+		build_post_one_row<CH>(p, rows[2 * w + 1], lkey, lval);
 	}
 }

@@ -225,6 +225,11 @@ struct mpcgpu_ctx {
 	                          // right after a launch was measured at 24 ms on an otherwise idle device: profiles/r10k)
 	DevBuf d_ap_off;
 	DevBuf d_chain_first, d_chain_cnt; // fb_chain_kernel's work list (kernels_fbc.h)
+	// stage A's batch pipeline (mpcgpu_stage_a.inc): the index arrays of the NEXT batch (its sweeps are queued while this batch's sizes
+	// are on their way to the host), the stream those sizes come back on and the event behind the finishing kernel
+	DevBuf d_bx_n, d_by_n, d_order_n, d_chain_first_n, d_chain_cnt_n;
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_post = nullptr;
 	u64 sa_pairs = 0, sa_chained = 0, sa_chains = 0; // last stage A: pairs, pairs that ran in chains, chains
 	double aa_trace_t[5] = {0, 0, 0, 0, 0}; // MPCGPU_TRACE & 4: host seconds of mpcgpu_align_alns' phases
 	u64 aa_trace_n = 0;
@@ -634,7 +639,11 @@ void mpcgpu_destroy(mpcgpu_ctx *c)
 	c->h_ap.release();
 	c->d_ap_off.release();
 	c->d_chain_first.release(); c->d_chain_cnt.release();
+	c->d_bx_n.release(); c->d_by_n.release(); c->d_order_n.release(); c->d_chain_first_n.release(); c->d_chain_cnt_n.release();
+	c->d_rects.release(); c->d_need.release(); c->d_exp_klist.release(); c->d_exp_valbase.release();
 	c->d_tiles2.release();
+	if (c->ev_post) (void)hipEventDestroy(c->ev_post);
+	if (c->stream2) (void)hipStreamDestroy(c->stream2);
 	(void)hipStreamDestroy(c->stream);
 	delete c;
 }

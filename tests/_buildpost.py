@@ -31,9 +31,9 @@ def build_post(store_stage, pairs_index, seq1, seq2, p2c1, p2c2, C1, C2, w1=None
     return post
 
 
-def random_msa(seqs, idxs, rng):
-    """A random gapped alignment of the given sequences (same width): rows as strings."""
-    width = max(len(seqs[i]) for i in idxs) + int(rng.integers(0, 6))
+def random_msa(seqs, idxs, rng, extra=0):
+    """A random gapped alignment of the given sequences (same width): rows as strings. extra: more gap columns."""
+    width = max(len(seqs[i]) for i in idxs) + int(rng.integers(0, 6)) + extra
     rows = []
     for i in idxs:
         s = seqs[i]

@@ -5,6 +5,7 @@ import numpy as np
 import _golden as G
 import _oracle as O
 from muscle_amd._lib import MpcGpu
+from muscle_amd.synth import make_family
 
 
 def bits(a):
@@ -316,3 +317,36 @@ def check_full_alphabet(lib_path=None, n=5, length=64, seed=11):
     got = run_lib(seqs, lib_path=lib_path)
     want = run_oracle(seqs)
     assert_same(got, want, "127-letter alphabet")
+
+
+def check_align_alns_batch(lib_path=None, n=14, length=40, seed=29):
+    """mpcgpu_align_alns_batch (the joins of one guide-tree level in two launches) against mpcgpu_align_alns join by join: same path,
+    same score bits — small joins of 1..3 rows a side (the batched forms), wide ones (> 512 columns: 16 columns per lane), one that
+    only the general form takes (forced through it: > 2048 pairs would need 46 x 46 rows), and a batch of one."""
+    import _buildpost as BP
+    rng = np.random.default_rng(seed)
+    seqs = make_family(n - 2, length, seed=seed) + make_family(2, 300, seed=seed + 1)
+    s, t, m, i, thr = G.hmm_tables()
+    g = MpcGpu(0, lib_path)
+    g.set_hmm(s, t, m, i, thr)
+    g.set_seqs(seqs)
+    g.calc_posteriors()
+    g.build_store()
+    for _ in range(2):
+        g.cons_iter()
+        g.cons_commit()
+    groups = [([0], [1]), ([2, 3], [4]), ([5, 6, 7], [8, 9]), ([10], [11, 0]), ([n - 2], [n - 1]), ([n - 1, 3], [n - 2]), ([1, 2, 4], [5, 9, 10])]
+    joins = []
+    for grp1, grp2 in groups:
+        rows1, C1 = BP.random_msa(seqs, grp1, rng)
+        rows2, C2 = BP.random_msa(seqs, grp2, rng)
+        if n - 1 in grp1 + grp2:  # the long sequences, spread over > 512 columns on the MSA2 side
+            rows2, C2 = BP.random_msa(seqs, grp2, rng, extra=300)
+        joins.append((grp1, grp2, [BP.pos_to_col(r) for r in rows1], [BP.pos_to_col(r) for r in rows2], C1, C2))
+    want = [g.align_alns(*j) for j in joins]
+    got = g.align_alns_batch(joins)
+    for q, ((p0, s0), (p1, s1)) in enumerate(zip(want, got)):
+        assert p0 == p1 and bits(s0) == bits(s1), ("join", q, groups[q])
+    (p1, s1), = g.align_alns_batch(joins[2:3])  # a batch of one takes the single-join path
+    assert p1 == want[2][0] and bits(s1) == bits(want[2][1])
+    g.close()

@@ -178,6 +178,11 @@ def test_emu_align_alns(emu):
     g.close()
 
 
+def test_emu_align_alns_batch(emu):
+    """the joins of a guide-tree level in two launches (mpcgpu_align_alns_batch) == the same joins one call at a time"""
+    P.check_align_alns_batch(emu)
+
+
 def test_emu_align_alns_long_runs(emu):
     """Runs of the in-order reduction longer than one chunk (64 terms) and than one group of chunks (512): 24 x 24 closely
     related sequences, so the cells on the path collect a term from most of the 1024 pairs."""
@@ -508,6 +513,9 @@ def test_emu_group_block_partition_partial_stores(nctx, n, pieces, monkeypatch):
     a = views[0].build_post(s1, s2, p2c1, p2c2, C1, C2)
     b = one.build_post(s1, s2, p2c1, p2c2, C1, C2)
     assert np.array_equal(P.bits(a.ravel()), P.bits(b.ravel()))
+    monkeypatch.setenv("MPCGPU_BP", "sort")  # the general form looks the pairs' entry counts up by position in the pair order
+    a2 = views[1].build_post(s1, s2, p2c1, p2c2, C1, C2)
+    assert np.array_equal(P.bits(a2.ravel()), P.bits(b.ravel()))
     one.close()
     del views
     grp.close()

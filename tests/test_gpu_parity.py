@@ -652,6 +652,11 @@ def test_full_alphabet_stage_beyond_64k_of_lds():
     P.check_full_alphabet(None)
 
 
+def test_align_alns_batch():
+    """the joins of a guide-tree level in two launches (mpcgpu_align_alns_batch) == the same joins one call at a time"""
+    P.check_align_alns_batch(None)
+
+
 def test_group_rccl_loader_one_device():
     """librccl is dlopen()ed by the group layer on first use; a one-device communicator on request checks that the library is
     found and ncclCommInitAll / ncclCommDestroy work on this box (the N > 1 exchange itself needs N GPUs)."""
