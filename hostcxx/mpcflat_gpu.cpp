@@ -339,7 +339,11 @@ bool TimingOn()
 				fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  (inside the first call below that needed it)\n", "context creation, HIP init", g_CtxSeconds);
 				for (int i = 0; i < T_COUNT; ++i)
 					fprintf(stderr, "[muscle_gpu] %-28s %10.3f s  %8llu calls\n", Names[i], g_Nanos[i].load()*1e-9, g_Calls[i].load());
-				if (g_Mark[M_POST_ENTER].load() != 0)
+// (one MPCFlat::Run only: with the shrub workers of -super7 running many at once first-entered / last-left marks interleave)
+				const bool OneRun = g_Mark[M_POST_ENTER].load() != 0 && g_Mark[M_POST_ENTER].load() <= g_Mark[M_POST_EXIT].load() &&
+				  (g_Mark[M_CONS_ENTER].load() == 0 || (g_Mark[M_POST_EXIT].load() <= g_Mark[M_CONS_ENTER].load() && g_Mark[M_CONS_EXIT].load() <= std::max(g_Mark[M_ALN_ENTER].load(), g_Mark[M_CONS_EXIT].load()))) &&
+				  (g_Mark[M_ALN_ENTER].load() == 0 || g_Mark[M_CONS_EXIT].load() <= g_Mark[M_ALN_ENTER].load());
+				if (OneRun)
 					{
 					const double End = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_ProcessStart).count();
 					auto At = [](int m) { return g_Mark[m].load()*1e-9; };

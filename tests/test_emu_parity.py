@@ -472,7 +472,7 @@ def test_emu_group_of_contexts(nctx):
     grp.close()
 
 
-@pytest.mark.parametrize("nctx,n,pieces", [(3, 12, 2), (4, 16, 3), (8, 16, 2), (5, 20, 1)])
+@pytest.mark.parametrize("nctx,n,pieces", [(3, 12, 2), (4, 16, 3), (8, 16, 2)])
 def test_emu_group_block_partition_partial_stores(nctx, n, pieces, monkeypatch):
     """The block partition with real kernels: every context owns blocks of the pair triangle, enumerates the pairs
     block by block, runs stage A in pieces, imports the shards piece by piece and builds a PARTIAL store (the records of its
