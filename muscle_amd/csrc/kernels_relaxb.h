@@ -178,12 +178,19 @@ __global__ void __launch_bounds__(64) ovf_stats_kernel(StoreParams s, const u32 
 		if (!mpc_need(s, A)) continue; // a partial store: no records of this sequence
 		const u32 LA = win ? (s.seq_len[A] + 1u + 3u) / 4u : s.seq_len[A]; // blocks of the static part of a record
 		for (u32 b = t; b < nb1; b += 64) {
-			u32 sum = 0;
+			u32 sum = 0, umax = 0u, lmin = 0xffffffffu;
 			for (u32 Z = 0; Z < n; ++Z) {
 				const u64 r = mpc_rec_index(n, A, Z);
-				sum += ovf_off[r * nb1 + b] - (rstart[r] + LA);
+				const u32 pre = ovf_off[r * nb1 + b] - (rstart[r] + LA); // dynamic blocks of record (A,Z) before band b
+				sum += pre;
+				if (Z != A) { umax = pre > umax ? pre : umax; lmin = pre < lmin ? pre : lmin; } // (the record (A,A) is empty: it stages nothing)
 			}
 			ovf_sum[(u64)A * nb1 + b] = sum;
+			// round 6: the largest and the smallest prefix over Z — max_Z (pre(e1) - pre(e0)) <= umax(e1) - lmin(e0): an upper bound of a
+			// record's dynamic piece for ANY band range, within ~1.7x of the mean where the group-wise maxima below were 3.5x (window value
+			// areas), so that most tiles no longer need the exact walk over Z (band_fit_kernel)
+			ovf_sum[(u64)n * nb1 + (u64)A * nb1 + b] = umax;
+			ovf_sum[2ull * n * nb1 + (u64)A * nb1 + b] = lmin == 0xffffffffu ? 0u : lmin;
 		}
 		const u32 ng = (nb1 - 1u + MPC_RB_BG - 1u) / MPC_RB_BG; // groups of bands 0 .. nb1-2 (band nb1-1 is the end marker)
 		u32 carry = 0;
@@ -253,7 +260,8 @@ __device__ __forceinline__ RbTileStats rb_tile_stats(const StoreParams &s, const
 	const u32 rounded = rb_wave_sum(iy == 0u ? grnd : 0u);
 	r.slots = (rounded + tb.threads - 1u) / tb.threads;
 	// pieces: lane ix*8 speaks for X record ix, lane iy (ix == 0) for Y record iy
-	u32 first = 0, sum = 0, mxc = 0;
+	u32 first = 0, sum = 0, mxc = 0, mx2 = 0, my2 = 0;
+	const u64 N1 = (u64)n * tb.nb1; // ovf_sum / ysum are three tables back to back: sums, largest prefix, smallest prefix
 	r.xmask = rb_wave_sum((iy == 0u && ix < nx && g != 0u) ? 1u << ix : 0u);
 	if (iy == 0u && ix < nx && g != 0u) {
 		const u32 A = x0 + ix, LA = s.seq_len[A];
@@ -263,6 +271,8 @@ __device__ __forceinline__ RbTileStats rb_tile_stats(const StoreParams &s, const
 			first = a1 - a0;
 			sum = tb.ovf_sum[(u64)A * tb.nb1 + e1] - tb.ovf_sum[(u64)A * tb.nb1 + b0];
 			mxc = tb.ovf_maxc[(u64)A * tb.nb1 + e1] - tb.ovf_maxc[(u64)A * tb.nb1 + b0 / MPC_RB_BG * MPC_RB_BG];
+			const u32 hi2 = tb.ovf_sum[N1 + (u64)A * tb.nb1 + e1], lo2 = tb.ovf_sum[2 * N1 + (u64)A * tb.nb1 + b0];
+			mx2 = hi2 > lo2 ? hi2 - lo2 : 0u;
 		}
 	}
 	u32 fy = 0, sy = 0, my = 0;
@@ -273,11 +283,15 @@ __device__ __forceinline__ RbTileStats rb_tile_stats(const StoreParams &s, const
 		fy = tb.win ? (yhi + 1u - (ylo & ~3u) + 3u) / 4u : yhi - ylo;
 		sy = tb.ysum[(u64)A * tb.nb1 + e1] - tb.ysum[(u64)A * tb.nb1 + e0] + (tb.win ? n : 0u);
 		my = tb.ymaxc[(u64)A * tb.nb1 + e1] - tb.ymaxc[(u64)A * tb.nb1 + e0 / MPC_RB_BG * MPC_RB_BG] + (tb.win ? 1u : 0u);
+		const u32 hi2 = tb.ysum[N1 + (u64)A * tb.nb1 + e1], lo2 = tb.ysum[2 * N1 + (u64)A * tb.nb1 + e0];
+		my2 = (hi2 > lo2 ? hi2 - lo2 : 0u) + (tb.win ? 1u : 0u);
 	}
 	r.first = rb_wave_sum(first + fy);
 	const u32 tot = rb_wave_sum(sum + sy);
 	r.est = r.first + (tot + n - 1u) / n;
-	r.bound = r.first + rb_wave_sum(mxc + my);
+	const u32 bound_groups = r.first + rb_wave_sum(mxc + my);
+	const u32 bound_prefix = r.first + rb_wave_sum(mx2 + my2); // (ovf_stats_kernel: largest prefix at the range's end - smallest at its start)
+	r.bound = bound_prefix < bound_groups ? bound_prefix : bound_groups;
 	return r;
 }
 
@@ -453,12 +467,14 @@ __device__ __forceinline__ void rb_record(const u32 *seq_len, const u32 *tw, u32
 
 // out[t] = max over Z of the blocks tile list[t] stages at step Z (first pieces + overflow pieces): the exact LDS need of its
 // worst step. One wave per tile, lanes stride over Z.
-__global__ void __launch_bounds__(64) band_fit_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, const u32 *tiles, const u32 *list, u32 nlist, u32 *out, u32 win)
+// (round 6: four waves per workgroup take four CONSECUTIVE tiles of the list — the row bands of one super-tile follow each other, read the
+// same 16 sequences' table rows at neighbouring band entries, and one CU's L1 then serves what four CUs' used to fetch from L2)
+__global__ void __launch_bounds__(256) band_fit_kernel(StoreParams s, const u32 *ovf_off, u32 nb1, const u32 *tiles, const u32 *list, u32 nlist, u32 *out, u32 win)
 {
 	// lane = (Z parity, bound, record): the 16 records' band entries of one Z lie in two neighbourhoods of the tables (consecutive
 	// sequences), so a step of the loop touches a handful of cache lines — with lanes over Z every load was 64 lines
 	const u32 lane = threadIdx.x & 63u, n = s.n, li = lane & 15u, hi_bound = (lane >> 4) & 1u, par = lane >> 5;
-	for (u32 q = blockIdx.x; q < nlist; q += gridDim.x) {
+	for (u32 q = blockIdx.x * 4u + (threadIdx.x >> 6); q < nlist; q += gridDim.x * 4u) {
 		const u32 *tw = tiles + (u64)MPC_RB_TILE_WORDS * list[q];
 		u32 S, blk0, blocks, e0, e1, arow;
 		rb_record(s.seq_len, tw, li, win, &S, &blk0, &blocks, &e0, &e1, &arow);
@@ -468,13 +484,23 @@ __global__ void __launch_bounds__(64) band_fit_kernel(StoreParams s, const u32 *
 		const u32 *tab = wrec ? s.wv_off : ovf_off;
 		const u32 e = hi_bound ? e1 : e0;
 		u32 best = 0;
-		for (u32 Z = par; Z < n + par; Z += 2u) { // (every lane runs the same number of turns: the shuffles below are wave-wide)
-			const u32 Zc = Z < n ? Z : n - 1u;
-			const u32 v = tab[(mpc_rec_index(n, S, Zc)) * nb1 + e];
-			const u32 lo = __shfl(v, (int)(lane & ~16u)), hb = __shfl(v, (int)(lane | 16u));
-			u32 d = (e1 != e0) ? hb - lo + (wrec ? 1u : 0u) : 0u;
-			for (int k = 1; k < 16; k <<= 1) d += __shfl(d, (int)((lane & ~15u) | ((li + (u32)k) & 15u))); // sum over the 16 records (rotation inside the row)
-			best = d > best ? d : best;
+		// (every lane runs the same number of turns: the shuffles below are wave-wide. Four steps of Z per turn, their loads issued
+		// together: the walk is a chain of dependent table reads — 500 round trips to L2 per tile one at a time)
+		for (u32 Z0 = par; Z0 < n + par; Z0 += 8u) {
+			u32 v4[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const u32 Z = Z0 + 2u * (u32)u, Zc = Z < n ? Z : n - 1u;
+				v4[u] = tab[(mpc_rec_index(n, S, Zc)) * nb1 + e];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const u32 v = v4[u];
+				const u32 lo = __shfl(v, (int)(lane & ~16u)), hb = __shfl(v, (int)(lane | 16u));
+				u32 d = (e1 != e0) ? hb - lo + (wrec ? 1u : 0u) : 0u;
+				for (int k = 1; k < 16; k <<= 1) d += __shfl(d, (int)((lane & ~15u) | ((li + (u32)k) & 15u))); // sum over the 16 records (rotation inside the row)
+				best = d > best ? d : best;
+			}
 		}
 		for (int k = 32; k >= 1; k >>= 1) { const u32 o = __shfl(best, (int)(lane ^ (u32)k)); best = o > best ? o : best; }
 		if (lane == 0u) out[q] = first + best;
