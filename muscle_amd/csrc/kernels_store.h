@@ -536,15 +536,17 @@ __global__ void __launch_bounds__(64) commit_pairs_kernel(StoreParams s, u64 k0,
 	}
 }
 
-// packed P of the pairs OUTSIDE [own0, own1) from vnext (a partial store commits those lazily: commit_pairs_kernel)
-__global__ void __launch_bounds__(64) packed_refresh_kernel(StoreParams s, u64 own0, u64 own1)
+// packed P of the pairs [k0, k1) OUTSIDE [own0, own1), entries [e0, e1), from vnext: what commit_pairs_kernel left out when it
+// committed that range of entries lazily
+__global__ void __launch_bounds__(64) packed_refresh_kernel(StoreParams s, u64 k0, u64 k1, u64 e0, u64 e1, u64 own0, u64 own1)
 {
 	const u32 t = threadIdx.x;
-	for (u64 k = blockIdx.x; k < s.npairs; k += gridDim.x) {
+	for (u64 k = k0 + blockIdx.x; k < k1; k += gridDim.x) {
 		if (k >= own0 && k < own1) continue;
 		const u64 vb = s.vbase[k], ve = s.vbase[k + 1];
+		const u64 a = vb > e0 ? vb : e0, b = ve < e1 ? ve : e1;
 		u32 *ent = s.packed + s.pbase[k] + s.seq_len[s.pair_x[k]] + s.seq_len[s.pair_y[k]];
-		for (u64 e = vb + t; e < ve; e += 64) ent[2 * (e - vb)] = __float_as_uint(s.vnext[e]);
+		for (u64 e = a + t; e < b; e += 64) ent[2 * (e - vb)] = __float_as_uint(s.vnext[e]);
 	}
 }
 

@@ -130,6 +130,7 @@ struct mpcgpu_ctx {
 	// partial store (mpcgpu_store_import_part): the sequences whose records exist, and the positions this context relaxes
 	bool partial = false;
 	bool packed_stale = false; // commits since the import wrote the packed records of the own pairs only (refresh_packed)
+	std::vector<std::pair<u64, u64> > lazy_ranges; // ... for these ranges of entries [first, end), merged
 	std::vector<u8> need;
 	DevBuf d_need;
 	u64 own_k0 = 0, own_k1 = 0;
@@ -521,8 +522,17 @@ static int refresh_packed(mpcgpu_ctx *c)
 	if (!c->packed_stale) return 0;
 	StoreParams sp;
 	fill_store_params(c, sp);
-	MPC_LAUNCH(packed_refresh_kernel, (u32)std::min<u64>(std::max<u64>(c->npairs, 1), (u64)c->prop.multiProcessorCount * 64), 64, 0, c->stream, sp, c->own_k0, c->own_k1);
-	HIPCHK(c, hipGetLastError());
+	// exactly the ranges of entries that were committed since the last refresh (a caller that has committed its own slice only and
+	// asks for a foreign pair's matrix gets that pair's LAST committed values, not whatever the values array holds beyond them)
+	for (const std::pair<u64, u64> &r : c->lazy_ranges) {
+		const u64 ka = (u64)(std::upper_bound(c->h_vbase.begin(), c->h_vbase.end(), r.first) - c->h_vbase.begin()) - 1;
+		const u64 kb = std::min<u64>((u64)(std::lower_bound(c->h_vbase.begin(), c->h_vbase.end(), r.second) - c->h_vbase.begin()), c->npairs);
+		if (kb <= ka) continue;
+		MPC_LAUNCH(packed_refresh_kernel, (u32)std::min<u64>(kb - ka, (u64)c->prop.multiProcessorCount * 64), 64, 0, c->stream, sp, ka, kb, r.first, r.second,
+			c->own_k0, c->own_k1);
+		HIPCHK(c, hipGetLastError());
+	}
+	c->lazy_ranges.clear();
 	c->packed_stale = false;
 	return 0;
 }

@@ -521,6 +521,34 @@ def test_emu_group_block_partition_partial_stores(nctx, n, pieces, monkeypatch):
     grp.close()
 
 
+def test_emu_sharded_context_lazy_packed_values(emu):
+    """A context that relaxes a part of the pairs writes the packed matrices of ITS pairs at a commit and refreshes the others' from the
+    values array when somebody reads them — but only the ranges of entries that HAVE been committed: after a relax + a commit of the own
+    slice alone, a foreign pair's matrix must still be the stage-0 one, the own pairs' the relaxed ones."""
+    from muscle_amd._lib import MpcGpu
+    seqs = make_family(9, 30, seed=41)
+    want = P.run_oracle(seqs, iters=1)[0]
+    g = MpcGpu(0, emu)
+    g.set_hmm(*G.hmm_tables())
+    g.set_seqs(seqs)
+    npairs = g.npairs
+    g.calc_posteriors(0, npairs)
+    nb, ptr = g.shard_info()
+    buf = np.zeros(nb + 16, np.uint8)
+    g.shard_export(buf.ctypes.data)
+    k0, k1 = 5, 17  # this context's own range
+    g.store_import_part([0], [npairs], [nb], [0], buf.ctypes.data, k0, k1)
+    g.cons_iter(k0, k1)
+    first, count = g.values_slice(k0, k1)
+    g.cons_commit_range(first, count)
+    got = g.get_sparse_range()
+    for k in range(npairs):
+        o, v = got[k]
+        wo, wv = want[1][k] if k0 <= k < k1 else want[0][k]
+        assert np.array_equal(o, wo) and np.array_equal(v, wv), k
+    g.close()
+
+
 @pytest.mark.parametrize("n,nctx", [(3, 4), (2, 2), (4, 3)])
 def test_emu_group_more_contexts_than_work(n, nctx):
     """mpcgpu_group_* when shards are empty or tiny (more contexts than pairs; two sequences: no consistency stage)"""
