@@ -779,6 +779,8 @@ int mpcgpu_set_pair_order(mpcgpu_ctx *c, uint32_t nrects, const uint32_t *rects)
 	const u32 n = c->n;
 	c->have_shard = c->have_store = false;
 	c->partial = false;
+	if (c->order_rects.size() == 4 * (size_t)nrects && (nrects == 0 || !memcmp(c->order_rects.data(), rects, 16 * (size_t)nrects)))
+		return 0; // the order the context already has (mpcgpu_set_seqs leaves InitPairs order)
 	c->order_rects.clear(); c->order_base.clear(); c->ext2pos.clear();
 	u64 k = 0;
 	if (nrects == 0) { // back to MPCFlat::InitPairs order (mpcflat.cpp:145-155)

@@ -429,8 +429,13 @@ int mpcgpu_group_calc_posteriors(mpcgpu_group *g)
 		return gfail(g, "mpcgpu_group_calc_posteriors: no partition of %u sequences over %u ranks", g->n, R);
 	g->k0.assign(pos.begin(), pos.end() - 1);
 	g->k1.assign(pos.begin() + 1, pos.end());
-	for (uint32_t r = 0; r < R; ++r)
-		if (mpcgpu_set_pair_order(g->ctx[r], nrects, rects.data())) return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
+	{ // (every context enumerates its pairs in this order: on the ranks' own threads, side by side)
+		const int rc0 = per_rank(g, [&](uint32_t r) -> int {
+			if (mpcgpu_set_pair_order(g->ctx[r], nrects, rects.data())) return gfail(g, "rank %u: %s", r, mpcgpu_last_error(g->ctx[r]));
+			return 0;
+		});
+		if (rc0) return rc0;
+	}
 	if (R == 1) { // nothing to exchange
 		if (mpcgpu_calc_posteriors(g->ctx[0], g->k0[0], g->k1[0]) || mpcgpu_build_store(g->ctx[0]))
 			return gfail(g, "%s", mpcgpu_last_error(g->ctx[0]));
