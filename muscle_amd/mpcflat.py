@@ -253,34 +253,50 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
     if n >= 3:
         first, count = engine.values_slice(k0, k1)
         assert count == counts[rank], (count, counts)
-        voffs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        allv = exchange.buffer("values", int(voffs[-1]), torch.float32, owner=engine)
+        # the all-gather of the values runs IN PLACE in the library's values array (position order = rank order: every rank's slice is one
+        # segment): the array is wrapped as a tensor of the exchange's device (zero-copy; round 6 — rounds 2-5 copied the own slice out
+        # and the peers' slices in, 1.5 GB per iteration)
+        vptr, total_v = engine.values_info()
+        allv = _wrap(torch, vptr, total_v, exchange.device)
+        assert total_v == int(sum(counts)), (total_v, counts)
         for _ in range(iters):
             t0 = time.perf_counter()
             engine.cons_iter(k0, k1)
-            engine.values_export(first, count, allv.data_ptr() + 4 * int(voffs[rank]))  # (waits for the relax)
+            engine.synchronize()  # (the own slice is complete before it is sent)
             lap("relax", t0)
             t0 = time.perf_counter()
             works = exchange.start_gather_segments(allv, counts)
-            # my own slice is already in the store's values array: it is committed (library stream) while the peers' slices
-            # arrive (collective stream); theirs follow — every entry once, which equals one commit of everything
+            # my own slice is committed (library stream) while the peers' slices arrive (collective stream); theirs follow — every
+            # entry once, which equals one commit of everything
             engine.cons_commit_range(first, count)
-            got = exchange.finish_gather_segments(allv, counts, works)
+            exchange.finish_gather_segments(allv, counts, works)
             _sync(torch, exchange.device)
             lap("exchange_values", t0)
             t0 = time.perf_counter()
-            total_v = int(got.numel())
             if first:
-                engine.values_import(0, first, got.data_ptr())
                 engine.cons_commit_range(0, first)
             if first + count < total_v:
-                engine.values_import(first + count, total_v - first - count, got.data_ptr() + 4 * (first + count))
                 engine.cons_commit_range(first + count, total_v - first - count)
             engine.synchronize()
             lap("commit", t0)
     engine.synchronize()
     engine._exchange_seconds = ph.get("exchange_shards", 0.0) + ph.get("exchange_values", 0.0)
     return k0, k1
+
+
+def _wrap(torch, ptr, count, device):
+    """a float32 tensor over `count` floats at address `ptr` of the library's memory, without a copy: __cuda_array_interface__ on a GPU
+    (torch.as_tensor aliases it: diag/cai_probe.py), a ctypes buffer on the CPU (the emulator's "device" memory is host memory)."""
+    if count == 0:
+        return torch.empty(0, dtype=torch.float32, device=device)
+    if str(device).startswith("cuda"):
+        class _Mem:
+            pass
+        m = _Mem()
+        m.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4", "data": (int(ptr), False), "version": 2, "strides": None}
+        return torch.as_tensor(m, device=device)
+    import ctypes
+    return torch.frombuffer((ctypes.c_float * int(count)).from_address(int(ptr)), dtype=torch.float32)
 
 
 def _sync(torch, device):

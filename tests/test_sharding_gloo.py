@@ -110,6 +110,9 @@ class FakeEngine:
     def values_slice(self, k0, k1):
         return int(self.vbase[k0]), int(self.vbase[k1] - self.vbase[k0])
 
+    def values_info(self):
+        return self.values.ctypes.data, len(self.values)
+
     def cons_iter(self, k0, k1):
         self.iter = getattr(self, "iter", 0) + 1
         f, c = self.values_slice(k0, k1)
