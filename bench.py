@@ -495,7 +495,7 @@ def main():
                 "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "transport": "gloo (dry run)" if dry else "RCCL point-to-point (torch.distributed nccl backend), one process per GPU",
                 "partition": ("%d blocks of the pair triangle (mpcgpu_plan_partition), a rank's store holds the matrices of its blocks' sequences" % len(rects))
                              if len(rects) else "contiguous InitPairs ranges",
-                "stage_a_pieces": int(os.environ.get("MPC_PIECES", PIECES)),
+                "stage_a_pieces": str(os.environ.get("MPC_PIECES", PIECES)),
                 "pairs_per_rank": [int(pos[r + 1] - pos[r]) for r in range(world)],
                 "sequences_held_per_rank": [int(len(set(px[pos[r]:pos[r + 1]].tolist()) | set(py[pos[r]:pos[r + 1]].tolist()))) for r in range(world)],
                 "phase_ms_max_over_ranks": {k: max(pr.get(k, 0.0) for pr in per_rank) for k in phases},

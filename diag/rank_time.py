@@ -15,14 +15,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
 from muscle_amd._lib import MpcGpu  # noqa: E402
-from muscle_amd.mpcflat import piece_cuts, plan  # noqa: E402
+from muscle_amd.mpcflat import parse_pieces, piece_cuts, plan  # noqa: E402
 from muscle_amd.synth import make_family  # noqa: E402
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 400
 me = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-P = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+SPEC = sys.argv[5] if len(sys.argv) > 5 else "1"  # pieces: a count, or shares of the DP cells ("0.85,0.15")
+P = len(parse_pieces(SPEC))
 seqs = make_family(n, L, seed=1)
 lens = [len(s) for s in seqs]
 g = MpcGpu(0)
@@ -32,7 +33,7 @@ if os.environ.get("RANK_TIME_NO_TIMERS"):
 g.set_seqs(seqs)
 rects, pos, px, py = plan(g, lens, world)
 g.set_pair_order(rects)
-cuts = piece_cuts(lens, px, py, pos, P)
+cuts = piece_cuts(lens, px, py, pos, SPEC)
 need = len(set(px[pos[me]:pos[me + 1]].tolist()) | set(py[pos[me]:pos[me + 1]].tolist()))
 
 

@@ -66,16 +66,35 @@ def position_pairs(n, rects):
     return np.concatenate(xs).astype(np.int64), np.concatenate(ys).astype(np.int64)
 
 
+def parse_pieces(spec):
+    """MPC_PIECES: a count ("2": equal parts) or the parts' shares of the DP cells ("0.85,0.15": a large first piece, whose exchange the
+    small second one hides) -> list of shares that sum to 1."""
+    if isinstance(spec, (int, np.integer)):
+        return [1.0 / max(int(spec), 1)] * max(int(spec), 1)
+    if isinstance(spec, (list, tuple)):
+        f = [float(x) for x in spec]
+    else:
+        t = str(spec).strip()
+        if "," not in t and "." not in t:
+            return parse_pieces(int(t))
+        f = [float(x) for x in t.split(",") if x.strip()]
+    tot = sum(f)
+    return [x / tot for x in f] if f and tot > 0 else [1.0]
+
+
 def piece_cuts(lens, px, py, rank_pos, pieces):
-    """cut points [rank][piece]: every rank's position range in `pieces` parts of about equal DP cells sum (LX+1)(LY+1)."""
+    """cut points [rank][piece]: every rank's position range in parts by DP cells sum (LX+1)(LY+1): `pieces` equal parts, or parts
+    of the given shares (parse_pieces)."""
+    shares = parse_pieces(pieces)
+    edges = np.concatenate([[0.0], np.cumsum(shares)])
     lens = np.asarray(lens, np.int64)
     cum = np.concatenate([[0], np.cumsum((lens[px] + 1) * (lens[py] + 1))])
     out = []
     for r in range(len(rank_pos) - 1):
         a, b = rank_pos[r], rank_pos[r + 1]
         c = [a]
-        for p in range(1, pieces):
-            target = cum[a] + (cum[b] - cum[a]) * p // pieces
+        for p in range(1, len(shares)):
+            target = cum[a] + int((cum[b] - cum[a]) * float(edges[p]))
             c.append(int(min(max(a + np.searchsorted(cum[a:b + 1], target, side="left"), c[-1]), b)))
         c.append(b)
         out.append(c)
@@ -210,8 +229,9 @@ def run_stage(engine, lens, exchange=None, iters=CONSISTENCY_ITERS, torch_mod=No
     rects, pos, px, py = plan(engine, lens, world)
     engine.set_pair_order(rects)
     k0, k1 = pos[rank], pos[rank + 1]
-    P = max(int(pieces if pieces is not None else os.environ.get("MPC_PIECES", PIECES)), 1)
-    cuts = piece_cuts(lens, px, py, pos, P)
+    spec = pieces if pieces is not None else os.environ.get("MPC_PIECES", PIECES)
+    P = len(parse_pieces(spec))
+    cuts = piece_cuts(lens, px, py, pos, spec)
     # ---- stage A on my range, piece by piece; the all-gather of piece p (every rank's piece, each straight into its place in ONE
     # persistent gather buffer) travels while piece p + 1 is computed
     seg_k0, seg_k1, seg_bytes, seg_off = [], [], [], []
