@@ -381,6 +381,14 @@ def main():
             if pmc is not None and launched_kernel is not None and launched_kernel not in pmc.get("kernel", ""):
                 r["pmc_rejected"] = "committed PMC pass is of %r, this run launched %r" % (pmc.get("kernel"), launched_kernel)
                 pmc = None
+            if pmc is not None and world > 1:
+                # the committed counter passes are of the ONE-GPU launch; a rank of `world` launches its share of the tiles / pairs: the
+                # counters are scaled by that share (an approximation: the fractions are those of the one-GPU kernel unless the rank's
+                # tiles behave differently) and the record says so
+                pmc = dict(pmc)
+                pmc["hbm_bytes_per_launch"] = float(pmc["hbm_bytes_per_launch"]) * my_frac
+                pmc["sq_per_launch"] = {k: v * my_frac for k, v in pmc.get("sq_per_launch", {}).items()}
+                r["counters_scaled_from_one_gpu_pass"] = my_frac
             units_per_inst, cost_src = issue_cost_of(kernel_for_cost, cost_fallback)
             r["issue_cost"] = {"mean_valu_issue_cost": units_per_inst, "source": cost_src}
             r["clock"] = dict(zip(("hz", "source"), clock_of(pmc)))

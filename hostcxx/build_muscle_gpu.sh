@@ -40,8 +40,9 @@ objcopy --weaken-symbol=_ZN6UClust6SearchEjRNSt7__cxx1112basic_stringIcSt11char_
 objcopy --weaken-symbol=_ZN5PProg4Run2ERKSt6vectorIjSaIjEES4_ "$REFOBJ/pprog2.o" "$OUT/pprog2_weak.o"
 # MPCFlat::CalcPosteriors: ours (a plain loop: the work of all pairs happens inside the first CalcPosterior call); the rest of mpcflat.o stays
 objcopy --weaken-symbol=_ZN7MPCFlat14CalcPosteriorsEv "$REFOBJ/mpcflat.o" "$OUT/mpcflat_weak.o"
-# MPCFlat::ProgressiveAlign: ours (the joins of a guide-tree level in one library call); ProgAln, FreeProgMSAs, FreeSparsePosts of progalnflat.o stay
-objcopy --weaken-symbol=_ZN7MPCFlat16ProgressiveAlignEv "$REFOBJ/progalnflat.o" "$OUT/progalnflat_weak.o"
+# MPCFlat::ProgressiveAlign: ours (the joins of a guide-tree level in one library call); the reference's stays in the binary as
+# MPCFlat_ProgressiveAlign_ref (our fallback calls it); ProgAln, FreeProgMSAs, FreeSparsePosts of progalnflat.o stay as they are
+objcopy --redefine-sym _ZN7MPCFlat16ProgressiveAlignEv=MPCFlat_ProgressiveAlign_ref "$REFOBJ/progalnflat.o" "$OUT/progalnflat_weak.o"
 OBJS=$(ls "$REFOBJ"/*.o | grep -v -e '/super7\.o$' -e '/uclust\.o$' -e '/alignpairflat\.o$' -e '/pprog2\.o$' -e '/mpcflat\.o$' -e '/progalnflat\.o$' | grep -v -e '/consflat\.o$' -e '/alnalnsflat\.o$' -e '/alnmsasflat\.o$' -e '/calcposteriorflat\.o$' -e '/buildpostflat\.o$' -e '/refineflat\.o$')
 # The product links libmpcgpu.so. tests/test_dropin_emu.py re-runs this script with
 # MPCGPU_LIBDIR/MPCGPU_LIBNAME pointing at the SIMT-emulator build of the same library sources

@@ -860,7 +860,8 @@ MultiSequence *MPCFlat::AlignAlns(const MultiSequence &MSA1,
 // anyway: see RefineIter below), the joins are grouped by their height in the tree — a join's children lie on lower levels — and a
 // level goes to mpcgpu_align_alns_batch: two launches for its small joins together. A parent's rows are MSA1's then MSA2's
 // (alnalnsflat.cpp:36-50), its columns come off the path (B: both advance, X: MSA1, Y: MSA2). Only the root becomes a MultiSequence.
-// Falls back to the reference's loop when a weight differs from 1.0f or an input sequence carries gap characters.
+// Falls back to the reference's function when a weight differs from 1.0f or an input sequence carries gap characters.
+extern "C" void MPCFlat_ProgressiveAlign_ref(MPCFlat *This); // = the reference's MPCFlat::ProgressiveAlign, renamed at link time (a member function takes `this` first)
 void MPCFlat::ProgressiveAlign()
 	{
 	const uint SeqCount = m_MyInputSeqs->GetSeqCount();
@@ -885,21 +886,9 @@ void MPCFlat::ProgressiveAlign()
 	Slot &S = g_Slots[SlotIndex];
 	if (!Plain || S.m_StoreOwner != this || JoinCount < 2)
 		{
-// the reference's own loop (progalnflat.cpp:78-99)
-		for (uint i = 0; i < SeqCount; ++i)
-			{
-			const Sequence *Seq = m_MyInputSeqs->GetSequence(i);
-			MultiSequence *MS = new MultiSequence;
-			MS->AddSequence(Seq, false);
-			m_ProgMSAs.push_back(MS);
-			}
-		for (uint JoinIndex = 0; JoinIndex < JoinCount; ++JoinIndex)
-			ProgAln(JoinIndex);
-		asserta(SIZE(m_ProgMSAs) == NodeCount);
-		m_MSA = m_ProgMSAs[NodeCount-1];
-		m_ProgMSAs[NodeCount-1] = 0;
-		FreeProgMSAs();
-		asserta(m_MSA != 0);
+// the reference's own function (progalnflat.cpp:72-100), kept in the binary under another name (hostcxx/build_muscle_gpu.sh: objcopy
+// --redefine-sym on progalnflat.o): its joins go through MPCFlat::AlignAlns above, one after the other
+		MPCFlat_ProgressiveAlign_ref(this);
 		return;
 		}
 
