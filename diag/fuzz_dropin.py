@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "diag"))
-sys.argv, ARGV = sys.argv[:1], sys.argv  # (fuzz_parity reads its own arguments at import)
+ARGV = sys.argv
 import _msa  # noqa: E402
 from fuzz_parity import make_case  # noqa: E402
 from muscle_amd.hostinfo import usable_cores  # noqa: E402

@@ -24,9 +24,6 @@ import _parity as P  # noqa: E402
 from muscle_amd._lib import MpcGpu, MpcGroup  # noqa: E402
 from muscle_amd.synth import AMINO, make_family, read_fasta  # noqa: E402
 
-BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-GROUP = len(sys.argv) > 3 and sys.argv[3] == "group"
 RDRP = read_fasta(os.path.join(ROOT, "tests", "golden", "rdrp_first1000.fa.gz"))
 
 
@@ -97,6 +94,13 @@ def make_case(seed):
     return what, seqs, hmm, iters
 
 
+def mega_for(what, seqs, hmm, seed):
+    """structure profiles (Mega emissions: fwdflat_mega.cpp, bwdflat_mega.cpp) for a fifth of the amino-acid cases of str sequences"""
+    if hmm != "hmm_amino" or isinstance(seqs[0], bytes) or seed % 5 != 0 or any(c not in AMINO for s in seqs for c in s):
+        return None
+    return P.random_mega(seqs, seed, nfeat=int(np.random.default_rng(seed + 4).integers(2, 9)))
+
+
 def check_joins(seqs, hmm, seed):
     """random bipartitions of random subsets on random gapped rows: mpcgpu_align_alns against the restatement"""
     rng = np.random.default_rng(seed + 1)
@@ -157,17 +161,24 @@ def check_group(seqs, hmm, iters, want, seed):
 
 
 def main():
+    BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    GROUP = len(sys.argv) > 3 and sys.argv[3] == "group"
     t0 = time.time()
     seed, cases, joins, groups, failed = SEED0, 0, 0, 0, []
     kinds = {}
     while (time.time() - t0 < BUDGET) if BUDGET > 0 else (seed == SEED0):
         what, seqs, hmm, iters = make_case(seed)
         try:
-            info = {}
-            got = P.run_lib(seqs, iters=iters, hmm_name=hmm, info=info)
-            want = P.run_oracle(seqs, iters=iters, hmm_name=hmm)
+            mega = mega_for(what, seqs, hmm, seed)
+            if mega is not None:
+                what = "mega " + what
+            got = P.run_lib(seqs, iters=iters, hmm_name=hmm, mega=mega)
+            want = P.run_oracle(seqs, iters=iters, hmm_name=hmm, mega=mega)
             P.assert_same(got, want, what)
-            if GROUP:
+            if mega is not None:
+                pass
+            elif GROUP:
                 groups += check_group(seqs, hmm, iters, want, seed)
             else:
                 joins += check_joins(seqs, hmm, seed)

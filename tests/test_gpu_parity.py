@@ -328,6 +328,27 @@ def test_random_ragged_stores_against_the_oracle():
         P.assert_same(got, P.run_oracle(seqs), "fuzz case %d (%d sequences, lengths %s; %s)" % (case, len(seqs), [len(t) for t in seqs], info.get("relax_info", "")[-80:]))
 
 
+def test_fuzz_generator_slice_single_context_joins_and_groups():
+    """A slice of diag/fuzz_parity.py's seeded generator (tiny / long / low-complexity / identical / fragment / nucleotide / byte
+    sequences, rdrp picks, mixtures; 1..3 relax iterations): every stage against the oracle, random joins (BuildPost + CalcAlnFlat)
+    against the restatement, and the same cases as a group of 2..8 contexts — every rank, every stage. The long runs are in
+    profiles/r14c, r14d (2860 cases); MPCGPU_TEST_FUZZ_SEEDS widens this one (default 48 seeds: ~25 s on the GPU box)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diag"))
+    import fuzz_parity as F
+    joins = groups = 0
+    nseeds = int(os.environ.get("MPCGPU_TEST_FUZZ_SEEDS", "48"))
+    for seed in range(3000, 3000 + nseeds):
+        what, seqs, hmm, iters = F.make_case(seed)
+        got = P.run_lib(seqs, iters=iters, hmm_name=hmm)
+        want = P.run_oracle(seqs, iters=iters, hmm_name=hmm)
+        P.assert_same(got, want, "seed %d: %s" % (seed, what))
+        joins += F.check_joins(seqs, hmm, seed)
+        if seed % 3 == 0:
+            groups += F.check_group(seqs, hmm, iters, want, seed)
+    assert nseeds < 24 or (joins > 0 and groups > 0)
+
+
 def test_relax_cell_order_on_long_row_bands(monkeypatch):
     """the row-block cell order where a tile's band is the whole sequence (few pairs: 500 rows, the order's tables take 72 KB of the
     staging area) and where the tables do not fit (800 rows: the kernel falls back to the pair order by itself) — against the
