@@ -6,7 +6,8 @@ nucleotides, arbitrary seven-bit letters. A failure prints the case's seed (reru
 goes on; exit status 1 if any case failed. TEST INFRASTRUCTURE (imports the oracle).
 With `group`, every case also runs as a GROUP of 2..8 contexts on device 0 (mpcgpu_group_*: the block partition, partial stores, the two
 exchanges by peer copies) and every rank's stages are compared as well.
-usage: python diag/fuzz_parity.py [seconds] [first seed] [group]"""
+With `medium`: 65..200 sequences per case (families, ragged families, rdrp picks) — past the tile cutter's shortcut for few sequences.
+usage: python diag/fuzz_parity.py [seconds] [first seed] [group | medium | medium,group]"""
 import os
 import sys
 import time
@@ -24,6 +25,7 @@ import _parity as P  # noqa: E402
 from muscle_amd._lib import MpcGpu, MpcGroup  # noqa: E402
 from muscle_amd.synth import AMINO, make_family, read_fasta  # noqa: E402
 
+MEDIUM = False  # main(): the `medium` mode
 RDRP = read_fasta(os.path.join(ROOT, "tests", "golden", "rdrp_first1000.fa.gz"))
 
 
@@ -33,6 +35,19 @@ def make_case(seed):
     kind = int(rng.integers(0, 10))
     iters = int(rng.integers(1, 4))
     hmm = "hmm_amino"
+    if MEDIUM:  # more than 64 sequences: the tile cutter's search over shapes and targets instead of its few-sequences shortcut
+        n = int(rng.integers(65, 200))
+        if kind < 3:
+            seqs = [RDRP[i] for i in rng.choice(len(RDRP), size=min(n, 130), replace=False)]
+            return "medium rdrp n=%d" % len(seqs), seqs, hmm, min(iters, 2)
+        L = int(rng.integers(30, 260))
+        sub = float(rng.choice([0.1, 0.3, 0.6]))
+        seqs = make_family(n, L, seed=seed, p_del=float(rng.uniform(0, 0.1)), p_ins=float(rng.uniform(0, 0.1)), p_sub=sub)
+        if kind >= 7:  # ragged: a third of them fragments
+            for i in range(0, n, 3):
+                a, b = sorted(int(x) for x in rng.integers(0, len(seqs[i]) + 1, size=2))
+                seqs[i] = seqs[i][a:b] if b > a else seqs[i][:1]
+        return "medium family n=%d L=%d sub=%.1f%s" % (n, L, sub, " ragged" if kind >= 7 else ""), seqs, hmm, min(iters, 2)
     if kind == 0:  # a family, any divergence
         n, L = int(rng.integers(2, 49)), int(rng.integers(1, 400))
         sub = float(rng.choice([0.0, 0.02, 0.3, 0.6, 0.95]))
@@ -163,7 +178,9 @@ def check_group(seqs, hmm, iters, want, seed):
 def main():
     BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     SEED0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-    GROUP = len(sys.argv) > 3 and sys.argv[3] == "group"
+    GROUP = len(sys.argv) > 3 and "group" in sys.argv[3].split(",")
+    global MEDIUM
+    MEDIUM = len(sys.argv) > 3 and "medium" in sys.argv[3].split(",")
     t0 = time.time()
     seed, cases, joins, groups, failed = SEED0, 0, 0, 0, []
     kinds = {}
