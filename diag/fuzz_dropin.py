@@ -73,7 +73,7 @@ def super7_case(seed, rng, th, failed, opts_seen):
 
 
 def main():
-    th = usable_cores()
+    th = int(os.environ.get("FUZZ_THREADS", "0")) or usable_cores()  # -threads of both binaries
     t0 = time.time()
     seed, cases, skipped, failed = SEED0, 0, 0, []
     opts_seen = {}
